@@ -1,0 +1,167 @@
+// common.h — shared device helpers for the gfx950 kernels (wave64, NHWC activations).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+#define DS_F32 0
+#define DS_BF16 1
+#define DS_MAX_SRC 4
+
+// ---------------------------------------------------------------- error plumbing (host)
+void ds_set_error(const std::string& s);
+#define DS_CHECK(cond, msg)                                                            \
+  do {                                                                                 \
+    if (!(cond)) {                                                                     \
+      ds_set_error(std::string(__FILE__) + ":" + std::to_string(__LINE__) + ": " + (msg)); \
+      return 1;                                                                        \
+    }                                                                                  \
+  } while (0)
+#define DS_HIP(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      ds_set_error(std::string(__FILE__) + ":" + std::to_string(__LINE__) + ": " + #expr + " -> " + \
+                   hipGetErrorString(_e));                                             \
+      return 1;                                                                        \
+    }                                                                                  \
+  } while (0)
+#define DS_LAUNCH_CHECK() DS_HIP(hipGetLastError())
+
+// ---------------------------------------------------------------- scalar conversions
+__host__ __device__ inline float bf2f(bf16_t v) {
+  union { uint32_t u; float f; } c; c.u = ((uint32_t)v) << 16; return c.f;
+}
+__host__ __device__ inline bf16_t f2bf(float f) {  // round-to-nearest-even
+  union { uint32_t u; float f; } c; c.f = f;
+  uint32_t u = c.u;
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elt;
+template <> struct Elt<float> {
+  static constexpr int KV = 4;  // elements per 16 bytes
+  __device__ static inline float ld(const float* p) { return *p; }
+  __device__ static inline void st(float* p, float v) { *p = v; }
+};
+template <> struct Elt<bf16_t> {
+  static constexpr int KV = 8;
+  __device__ static inline float ld(const bf16_t* p) { return bf2f(*p); }
+  __device__ static inline void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 8 consecutive channels <-> 8 floats (the elementwise kernels' unit of work: C % 8 == 0 always).
+template <typename T> __device__ inline void load8(const T* p, float* f);
+template <> __device__ inline void load8<float>(const float* p, float* f) {
+  float4 a = *reinterpret_cast<const float4*>(p);
+  float4 b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+template <> __device__ inline void load8<bf16_t>(const bf16_t* p, float* f) {
+  uint4 u = *reinterpret_cast<const uint4*>(p);
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+template <typename T> __device__ inline void store8(T* p, const float* f);
+template <> __device__ inline void store8<float>(float* p, const float* f) {
+  *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+}
+template <> __device__ inline void store8<bf16_t>(bf16_t* p, const float* f) {
+  uint4 u;
+  u.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+  u.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+  u.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
+  u.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = u;
+}
+
+// SiLU / exp: the fp32 (parity) instantiations use the accurate ocml expf, bf16 the hardware v_exp_f32.
+template <typename T> __device__ inline float exp_t(float v);
+template <> __device__ inline float exp_t<float>(float v) { return expf(v); }
+template <> __device__ inline float exp_t<bf16_t>(float v) { return __expf(v); }
+template <typename T> __device__ inline float silu_t(float v) { return v / (1.0f + exp_t<T>(-v)); }
+
+// wave64 butterfly reductions (no LDS)
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- launcher prototypes (host)
+struct ConvArgs {
+  const void* x; long x_bs; int ldx;     // A operand: [B][M][ldx]; x_bs = batch stride (elements)
+  const void* w; long w_bs;              // Bt operand: [Cout][taps][Cin]; w_bs batch stride (0 = shared)
+  const float* bias;                     // [Cout] (mode 0) or [M] (mode 1) or null
+  const float* bias_b; int bias_b_ld;    // per-batch column bias [B][bias_b_ld] or null
+  int bias_mode;                         // 0 = along Cout, 1 = along rows (M)
+  const float* div_b;                    // per-batch divisor applied to the accumulator BEFORE bias (h / t), or null
+  const void* res; long res_bs; int ldr; // residual added before out_scale, or null
+  float out_scale;
+  void* y; long y_bs; int ldy;
+  int B, H, W;                           // taps==9: image H x W; taps==1: M = H*W rows
+  int Cin, Cout, taps;
+  int dtype;
+};
+int ds_launch_conv(const ConvArgs& a, hipStream_t st);
+
+// GroupNorm: stats -> per-(b,c) scale/shift -> apply(+SiLU)(+FIR resample)
+// ws layout: doubles [B][nblk][C][2] then floats scale[B][C], shift[B][C]
+long ds_gn_workspace_bytes(int B, int H, int W, int C);
+int ds_launch_gn_stats(const void* x, int ldx, int B, int H, int W, int C, int groups, float eps,
+                       const float* gamma, const float* beta, void* ws, float* scale, float* shift, int dtype,
+                       hipStream_t st);
+// mode: 0 none, 1 up, 2 down. scale/shift null => identity & no activation (pure FIR on x -> xr only).
+int ds_launch_gn_apply(const void* x, int ldx, const float* scale, const float* shift, int C, void* y, int ldy,
+                       void* xr, int ldxr, int B, int H, int W, int act, int mode, int dtype, hipStream_t st);
+int ds_launch_concat(const void* a, int lda, int Ca, const void* b, int ldb, int Cb, void* y, int ldy, long npix,
+                     int dtype, hipStream_t st);
+int ds_launch_softmax(const void* x, void* y, long rows, int L, int ld, int dtype, hipStream_t st);
+
+int ds_launch_stft_pack(const float* xt, const float* mix, void* y, int B, int S, long T, int n_fft, int hop,
+                        float exponent, float factor, int W, int Cpad, int shift, int dtype, const float* tab,
+                        hipStream_t st);
+int ds_launch_istft(const void* x, float* out, int B, int S, long T, int n_fft, int hop, float exponent, float factor,
+                    int W, int Cpad, int dtype, const float* tab, float* frames_ws, hipStream_t st);
+// tab: device float [3][n_fft] = cos(2 pi n/n_fft), sin(2 pi n/n_fft), hann[n]  (built by ds_build_stft_table)
+int ds_build_stft_table(int n_fft, float** dev_tab);
+
+struct SdeP { int kind; int ndim; float d_lambda, sigma_min, sigma_max; };
+int ds_launch_sde_prior(const SdeP& s, const float* y, const float* z, float* x, int B, int S, long T, hipStream_t st);
+int ds_launch_sde_corrector(const SdeP& s, float snr, const float* x, const float* t, const float* score,
+                            const float* z, float* xo, float* xm, int B, int S, long T, hipStream_t st);
+int ds_launch_sde_predictor(const SdeP& s, int N, const float* x, const float* t, const float* score, const float* z,
+                            float* xo, float* xm, int B, int S, long T, hipStream_t st);
+int ds_launch_normalize(const float* mix, float* out, float* mean, float* std, int B, long T, hipStream_t st);
+int ds_launch_scale_output(const float* mix, float* sep, int B, int S, long T, hipStream_t st);
+int ds_launch_randn(float* out, long n, uint64_t seed, uint64_t stream_id, hipStream_t st);
+int ds_launch_convert(const void* src, void* dst, long n, int sd, int dd, hipStream_t st);
+int ds_launch_fill(float* p, float v, long n, hipStream_t st);
+
+// time embedding: y[b][o] = sum_k act_in(x[b][k]) * W[o][k] + bias[o]   (fp32)
+int ds_launch_linear(const float* x, const float* W, const float* bias, float* y, int B, int K, int O, int silu_in,
+                     hipStream_t st);
+int ds_launch_fourier(const float* t, const float* Wf, float* emb, int B, int nf, hipStream_t st);

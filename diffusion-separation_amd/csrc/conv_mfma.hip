@@ -1,0 +1,259 @@
+// conv_mfma.hip — implicit-GEMM convolution / batched NT-GEMM on the gfx950 matrix cores.
+//
+// One kernel template covers every dense contraction on the hot path:
+//   * conv3x3 (pad 1)      layers.py:141-156  (ddpm_conv3x3)             TAPS = 9, spatial halo tile
+//   * conv1x1 / NIN        layers.py:112-119, 678-689                    TAPS = 1, rows = pixels
+//   * attention Q K^T, P V layerspp.py:83-87 (einsum)                    TAPS = 1, batched "weights"
+//
+//   Y[b, m, n] = ( sum_{tap,k} X[b, m (+) tap, k] * Wt[b?, n, tap, k] / div_b[b] + bias + res ) * out_scale
+//
+// Layout: X is NHWC with pixel stride ldx (k contiguous), Wt is [n][tap][k] (k contiguous) — both
+// operands are "K-major", so every MFMA fragment is one 16-byte LDS read:
+//   lane l -> row/col (l & 31), k-half h = l >> 5 reads bytes [(kb*2 + h)*16, +16) of its LDS row.
+//   bf16: those 8 values are exactly the A/B fragment of v_mfma_f32_32x32x16_bf16 (k = h*8 + j).
+//   f32 : the 4 values feed 4 x v_mfma_f32_32x32x2_f32 (k-slot h of MFMA s is channel kb*8 + h*4 + s);
+//         f32 MFMA is bit-for-bit an fmaf chain, so the parity path keeps exact fp32 products.
+// LDS rows are padded by 16 B (row stride 80 or 144 B): any 16 consecutive rows hit 16 distinct
+// 16-byte bank slots, so ds_read_b128 is conflict-free for the 32 consecutive pixels of a fragment.
+// Block = 256 threads = 4 waves (one per SIMD); wave tile = (32*WM) x (32*WN), fp32 accumulators.
+#include "common.h"
+
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<bf16_t> {
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
+                                                0);
+  }
+};
+
+struct ConvK {  // kernel-side copy of ConvArgs (typed by the template)
+  const void* x; long x_bs; int ldx;
+  const void* w; long w_bs;
+  const float* bias; const float* bias_b; int bias_b_ld; int bias_mode;
+  const float* div_b;
+  const void* res; long res_bs; int ldr;
+  float out_scale;
+  void* y; long y_bs; int ldy;
+  int H, W, Cin, Cout;
+  int tiles_x;
+};
+
+template <typename T, int TAPS, int TH, int TW, int BN, int WM, int WN, int KC>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
+  constexpr int KV = 16 / (int)sizeof(T);
+  constexpr int R = (TAPS == 9) ? 1 : 0;
+  constexpr int HW_ = TW + 2 * R, HH_ = TH + 2 * R, HP = HW_ * HH_;
+  constexpr int BM = TH * TW;
+  constexpr int ROWB = KC * (int)sizeof(T) + 16;
+  constexpr int NVEC = KC / KV;
+  constexpr int NKB = KC / (2 * KV);
+  constexpr int WAVES_N = BN / (32 * WN);
+  constexpr int WAVES_M = BM / (32 * WM);
+  static_assert(WAVES_M * WAVES_N == 4, "block is 4 waves");
+  static_assert(KC % (2 * KV) == 0, "KC must hold whole k-blocks");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  char* sB = smem + HP * ROWB;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l32 = lane & 31, h = lane >> 5;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int b = blockIdx.z;
+  const int n0 = blockIdx.y * BN;
+  int y0 = 0, x0 = 0;
+  long m0 = 0;
+  const long M = (long)p.H * p.W;
+  if (TAPS == 9) {
+    y0 = (blockIdx.x / p.tiles_x) * TH;
+    x0 = (blockIdx.x % p.tiles_x) * TW;
+  } else {
+    m0 = (long)blockIdx.x * BM;
+  }
+
+  const T* xb = reinterpret_cast<const T*>(p.x) + (long)b * p.x_bs;
+  const T* wb = reinterpret_cast<const T*>(p.w) + (long)b * p.w_bs;
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // per-lane LDS byte offsets of the fragment rows
+  int aoff[WM], boff[WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int pp = (wm * WM + i) * 32 + l32;
+    const int row = (TAPS == 9) ? ((pp / TW) * HW_ + (pp % TW)) : pp;
+    aoff[i] = row * ROWB + h * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < WN; ++j) boff[j] = ((wn * WN + j) * 32 + l32) * ROWB + h * 16;
+
+  for (int ci0 = 0; ci0 < p.Cin; ci0 += KC) {
+    __syncthreads();
+    // ---- stage the input (halo) tile chunk: HP pixels x KC channels
+    for (int i = tid; i < HP * NVEC; i += 256) {
+      const int pix = i / NVEC, v = i - pix * NVEC;
+      const int ci = ci0 + v * KV;
+      uint4 val = make_uint4(0u, 0u, 0u, 0u);
+      if (TAPS == 9) {
+        const int hy = pix / HW_, hx = pix - hy * HW_;
+        const int gy = y0 + hy - R, gx = x0 + hx - R;
+        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && ci < p.Cin)
+          val = *reinterpret_cast<const uint4*>(xb + ((long)gy * p.W + gx) * p.ldx + ci);
+      } else {
+        const long m = m0 + pix;
+        if (m < M && ci < p.Cin) val = *reinterpret_cast<const uint4*>(xb + m * p.ldx + ci);
+      }
+      *reinterpret_cast<uint4*>(sA + pix * ROWB + v * 16) = val;
+    }
+    // ---- stage the weight chunk: TAPS x BN rows x KC
+    for (int i = tid; i < TAPS * BN * NVEC; i += 256) {
+      const int row = i / NVEC, v = i - row * NVEC;
+      const int tap = row / BN, col = row - tap * BN;
+      const int co = n0 + col, ci = ci0 + v * KV;
+      uint4 val = make_uint4(0u, 0u, 0u, 0u);
+      if (co < p.Cout && ci < p.Cin)
+        val = *reinterpret_cast<const uint4*>(wb + ((long)co * TAPS + tap) * p.Cin + ci);
+      *reinterpret_cast<uint4*>(sB + row * ROWB + v * 16) = val;
+    }
+    __syncthreads();
+    // ---- MFMA over taps x k-blocks
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int toff = (TAPS == 9) ? ((tap / 3) * HW_ + (tap % 3)) * ROWB : 0;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        uint4 af[WM], bfr[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const uint4*>(sA + aoff[i] + toff + kb * 32);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          bfr[j] = *reinterpret_cast<const uint4*>(sB + boff[j] + tap * BN * ROWB + kb * 32);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
+      }
+    }
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h
+  const float dv = p.div_b ? (1.0f / p.div_b[b]) : 1.0f;
+  const bool has_div = p.div_b != nullptr;
+  T* yb = reinterpret_cast<T*>(p.y) + (long)b * p.y_bs;
+  const T* rb = p.res ? reinterpret_cast<const T*>(p.res) + (long)b * p.res_bs : nullptr;
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int co = n0 + (wn * WN + j) * 32 + l32;
+    const bool cok = co < p.Cout;
+    float cb = 0.f;
+    if (cok && p.bias_mode == 0) {
+      if (p.bias) cb += p.bias[co];
+      if (p.bias_b) cb += p.bias_b[(long)b * p.bias_b_ld + co];
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pp = (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        long m;
+        bool ok = cok;
+        if (TAPS == 9) {
+          const int gy = y0 + pp / TW, gx = x0 + pp % TW;
+          ok = ok && gy < p.H && gx < p.W;
+          m = (long)gy * p.W + gx;
+        } else {
+          m = m0 + pp;
+          ok = ok && m < M;
+        }
+        if (ok) {
+          float v = acc[i][j][r];
+          if (has_div) v = v / p.div_b[b];
+          v += cb;
+          if (p.bias_mode == 1 && p.bias) v += p.bias[m];
+          if (rb) v += Elt<T>::ld(rb + m * p.ldr + co);
+          v *= p.out_scale;
+          Elt<T>::st(yb + m * p.ldy + co, v);
+        }
+      }
+    }
+  }
+  (void)dv;
+}
+
+template <typename T, int TAPS, int TH, int TW, int BN, int WM, int WN, int KC>
+static int launch_cfg(const ConvArgs& a, hipStream_t st) {
+  constexpr int R = (TAPS == 9) ? 1 : 0;
+  constexpr int HP = (TW + 2 * R) * (TH + 2 * R);
+  constexpr int ROWB = KC * (int)sizeof(T) + 16;
+  constexpr int LDS = HP * ROWB + TAPS * BN * ROWB;
+  auto kern = conv_mfma_kernel<T, TAPS, TH, TW, BN, WM, WN, KC>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_done = true;
+  }
+  ConvK k;
+  k.x = a.x; k.x_bs = a.x_bs; k.ldx = a.ldx; k.w = a.w; k.w_bs = a.w_bs;
+  k.bias = a.bias; k.bias_b = a.bias_b; k.bias_b_ld = a.bias_b_ld; k.bias_mode = a.bias_mode; k.div_b = a.div_b;
+  k.res = a.res; k.res_bs = a.res_bs; k.ldr = a.ldr; k.out_scale = a.out_scale;
+  k.y = a.y; k.y_bs = a.y_bs; k.ldy = a.ldy;
+  k.H = a.H; k.W = a.W; k.Cin = a.Cin; k.Cout = a.Cout;
+  dim3 grid;
+  if (TAPS == 9) {
+    k.tiles_x = cdiv(a.W, TW);
+    grid.x = k.tiles_x * cdiv(a.H, TH);
+  } else {
+    k.tiles_x = 1;
+    grid.x = cdiv((long)a.H * a.W, TH * TW);
+  }
+  grid.y = cdiv(a.Cout, BN);
+  grid.z = a.B;
+  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, k);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+static int launch_typed(const ConvArgs& a, hipStream_t st) {
+  constexpr int KC9 = (sizeof(T) == 4) ? 16 : 32;
+  constexpr int KC1 = (sizeof(T) == 4) ? 32 : 64;
+  if (a.taps == 9) {
+    if (a.W >= 32 && a.H >= 8) {
+      if (a.Cout <= 32) return launch_cfg<T, 9, 8, 32, 32, 2, 1, KC9>(a, st);
+      return launch_cfg<T, 9, 8, 32, 64, 2, 2, KC9>(a, st);
+    }
+    return launch_cfg<T, 9, 8, 8, 64, 1, 1, KC9>(a, st);
+  }
+  const long M = (long)a.H * a.W;
+  if (M >= 1024) {
+    if (a.Cout <= 32) return launch_cfg<T, 1, 8, 32, 32, 2, 1, KC1>(a, st);
+    return launch_cfg<T, 1, 8, 32, 64, 2, 2, KC1>(a, st);
+  }
+  return launch_cfg<T, 1, 8, 8, 64, 1, 1, KC1>(a, st);
+}
+
+int ds_launch_conv(const ConvArgs& a, hipStream_t st) {
+  DS_CHECK(a.taps == 1 || a.taps == 9, "conv: taps must be 1 or 9");
+  DS_CHECK(a.Cin % 8 == 0 && a.ldx % 8 == 0, "conv: Cin and ldx must be multiples of 8");
+  DS_CHECK(a.B > 0 && a.H > 0 && a.W > 0 && a.Cout > 0, "conv: empty problem");
+  DS_CHECK(a.x && a.w && a.y, "conv: null pointer");
+  if (a.dtype == DS_F32) return launch_typed<float>(a, st);
+  if (a.dtype == DS_BF16) return launch_typed<bf16_t>(a, st);
+  DS_CHECK(false, "conv: unknown dtype");
+}

@@ -1,0 +1,996 @@
+// engine.hip — host side of the engine: architecture walk of NCSN++ (models/ncsnpp.py:106-308 ctor,
+// :319-478 forward), parameter table in reference state_dict order, weight repack, the workspace
+// arena, the per-NFE launch sequence (eager or hipGraph replay) and the PC sampler driver
+// (sdes/__init__.py:166-188).  Everything that touches data is a HIP kernel from the sibling files;
+// this file only sequences launches.
+#include <math.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/diffsep_hip.h"
+#include "common.h"
+
+// ------------------------------------------------------------------ error string
+static thread_local std::string g_err;
+void ds_set_error(const std::string& s) { g_err = s; }
+extern "C" const char* diffsep_last_error(void) { return g_err.c_str(); }
+extern "C" const char* diffsep_version(void) { return "diffsep-hip 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------ architecture description
+struct PRef { long off = -1; long numel = 0; };  // into the flat fp32 blob
+struct ParamInfo { std::string name; int ndim; int64_t shape[4]; long off; };
+
+enum ModKind { MK_FOURIER, MK_LINEAR, MK_CONV3, MK_RES, MK_ATTN, MK_COMBINE, MK_GN };
+
+struct Module {
+  ModKind kind;
+  int in_ch = 0, out_ch = 0;
+  bool up = false, down = false, has_conv2 = false;
+  int temb_off = 0;  // offset of this block's Dense_0 output inside the concatenated projection
+  // fp32 parameter references
+  PRef w0, b0;        // Fourier W / Linear / Conv (3x3 or 1x1) / GN gamma,beta
+  PRef gn0_w, gn0_b, conv0_w, conv0_b, dense_w, dense_b, gn1_w, gn1_b, conv1_w, conv1_b, conv2_w, conv2_b;
+  PRef nin_w[4], nin_b[4];
+  // packed (engine dtype) weight offsets in elements
+  long pk0 = -1, pk1 = -1, pk2 = -1, pk_nin[4] = {-1, -1, -1, -1};
+};
+
+struct Arch {
+  std::vector<Module> mods;
+  std::vector<ParamInfo> params;
+  PRef out_w, out_b;
+  long pk_out = -1;
+  long total = 0;       // floats in the blob
+  long pack_total = 0;  // elements in the packed weight buffer
+  int dense_total = 0;  // sum of out_ch over residual blocks
+  int chan_in = 0, chan_out = 0, cpad_in = 0, cpad_out = 0;
+};
+
+static int rup8(int c) { return (c + 7) & ~7; }
+
+struct ArchBuilder {
+  Arch& A;
+  explicit ArchBuilder(Arch& a) : A(a) {}
+  PRef add(const std::string& name, std::initializer_list<int64_t> shp) {
+    ParamInfo p;
+    p.name = name;
+    p.ndim = (int)shp.size();
+    long n = 1;
+    int i = 0;
+    for (auto s : shp) { p.shape[i++] = s; n *= s; }
+    for (; i < 4; ++i) p.shape[i] = 1;
+    p.off = A.total;
+    A.params.push_back(p);
+    PRef r;
+    r.off = A.total;
+    r.numel = n;
+    A.total += n;
+    return r;
+  }
+  long pack(long o, int taps, int cin) {
+    long r = A.pack_total;
+    A.pack_total += o * taps * (long)rup8(cin);
+    A.pack_total = (A.pack_total + 63) & ~63L;
+    return r;
+  }
+  std::string pfx() const { return "all_modules." + std::to_string(A.mods.size()) + "."; }
+  void fourier(int nf) {
+    Module m; m.kind = MK_FOURIER; m.out_ch = nf;
+    m.w0 = add(pfx() + "W", {nf});
+    A.mods.push_back(m);
+  }
+  void linear(int in, int out) {
+    Module m; m.kind = MK_LINEAR; m.in_ch = in; m.out_ch = out;
+    m.w0 = add(pfx() + "weight", {out, in});
+    m.b0 = add(pfx() + "bias", {out});
+    A.mods.push_back(m);
+  }
+  void conv3(int in, int out) {
+    Module m; m.kind = MK_CONV3; m.in_ch = in; m.out_ch = out;
+    m.w0 = add(pfx() + "weight", {out, in, 3, 3});
+    m.b0 = add(pfx() + "bias", {out});
+    m.pk0 = pack(out, 9, in);
+    A.mods.push_back(m);
+  }
+  void gn(int c) {
+    Module m; m.kind = MK_GN; m.in_ch = m.out_ch = c;
+    m.w0 = add(pfx() + "weight", {c});
+    m.b0 = add(pfx() + "bias", {c});
+    A.mods.push_back(m);
+  }
+  void res(int in, int out, bool up, bool down, int temb_dim) {
+    Module m; m.kind = MK_RES; m.in_ch = in; m.out_ch = out; m.up = up; m.down = down;
+    const std::string p = pfx();
+    m.gn0_w = add(p + "GroupNorm_0.weight", {in});
+    m.gn0_b = add(p + "GroupNorm_0.bias", {in});
+    m.conv0_w = add(p + "Conv_0.weight", {out, in, 3, 3});
+    m.conv0_b = add(p + "Conv_0.bias", {out});
+    m.dense_w = add(p + "Dense_0.weight", {out, temb_dim});
+    m.dense_b = add(p + "Dense_0.bias", {out});
+    m.gn1_w = add(p + "GroupNorm_1.weight", {out});
+    m.gn1_b = add(p + "GroupNorm_1.bias", {out});
+    m.conv1_w = add(p + "Conv_1.weight", {out, out, 3, 3});
+    m.conv1_b = add(p + "Conv_1.bias", {out});
+    m.has_conv2 = (in != out) || up || down;
+    if (m.has_conv2) {
+      m.conv2_w = add(p + "Conv_2.weight", {out, in, 1, 1});
+      m.conv2_b = add(p + "Conv_2.bias", {out});
+      m.pk2 = pack(out, 1, in);
+    }
+    m.pk0 = pack(out, 9, in);
+    m.pk1 = pack(out, 9, out);
+    m.temb_off = A.dense_total;
+    A.dense_total += out;
+    A.mods.push_back(m);
+  }
+  void attn(int c) {
+    Module m; m.kind = MK_ATTN; m.in_ch = m.out_ch = c;
+    const std::string p = pfx();
+    m.gn0_w = add(p + "GroupNorm_0.weight", {c});
+    m.gn0_b = add(p + "GroupNorm_0.bias", {c});
+    for (int i = 0; i < 4; ++i) {
+      m.nin_w[i] = add(p + "NIN_" + std::to_string(i) + ".W", {c, c});
+      m.nin_b[i] = add(p + "NIN_" + std::to_string(i) + ".b", {c});
+      m.pk_nin[i] = pack(c, 1, c);
+    }
+    A.mods.push_back(m);
+  }
+  void combine(int d1, int d2) {
+    Module m; m.kind = MK_COMBINE; m.in_ch = d1; m.out_ch = d2;
+    const std::string p = pfx();
+    m.w0 = add(p + "Conv_0.weight", {d2, d1, 1, 1});
+    m.b0 = add(p + "Conv_0.bias", {d2});
+    m.pk0 = pack(d2, 1, d1);
+    A.mods.push_back(m);
+  }
+};
+
+static int build_arch(const diffsep_model_config& c, Arch& A) {
+  DS_CHECK(c.nf >= 8 && c.nf % 8 == 0, "config: nf must be a positive multiple of 8");
+  DS_CHECK(c.num_sources >= 1 && c.num_sources <= 3, "config: num_sources must be 1..3");
+  DS_CHECK(c.n_levels >= 1 && c.n_levels <= 8, "config: n_levels must be 1..8");
+  DS_CHECK(c.num_res_blocks >= 1, "config: num_res_blocks");
+  DS_CHECK(c.n_fft % 2 == 0 && c.n_fft <= 512 && c.hop > 0, "config: n_fft must be even and <= 512");
+  A = Arch();
+  const int nf = c.nf, channels = 2 * c.num_sources + 2;
+  A.chan_in = channels;
+  A.chan_out = 2 * c.num_sources;
+  A.cpad_in = rup8(channels);
+  A.cpad_out = rup8(A.chan_out);
+  const int image_size = c.n_fft / 2 + 1;
+  ArchBuilder b(A);
+  // state_dict order: output_layer is registered before all_modules (ncsnpp.py:104-105 vs :308)
+  A.out_w = b.add("output_layer.weight", {A.chan_out, channels, 1, 1});
+  A.out_b = b.add("output_layer.bias", {A.chan_out});
+  A.pk_out = b.pack(A.chan_out, 1, channels);
+  b.fourier(nf);
+  b.linear(2 * nf, 4 * nf);
+  b.linear(4 * nf, 4 * nf);
+  b.conv3(channels, nf);
+  std::vector<int> hs_c{nf};
+  int in_ch = nf;
+  const int L = c.n_levels;
+  for (int i = 0; i < L; ++i) {
+    const int resl = image_size >> i;
+    for (int k = 0; k < c.num_res_blocks; ++k) {
+      const int out_ch = nf * c.ch_mult[i];
+      b.res(in_ch, out_ch, false, false, 4 * nf);
+      in_ch = out_ch;
+      if (resl == c.attn_resolution) b.attn(in_ch);
+      hs_c.push_back(in_ch);
+    }
+    if (i != L - 1) {
+      b.res(in_ch, in_ch, false, true, 4 * nf);
+      b.combine(channels, in_ch);
+      hs_c.push_back(in_ch);
+    }
+  }
+  in_ch = hs_c.back();
+  b.res(in_ch, in_ch, false, false, 4 * nf);
+  b.attn(in_ch);
+  b.res(in_ch, in_ch, false, false, 4 * nf);
+  for (int i = L - 1; i >= 0; --i) {
+    const int resl = image_size >> i;
+    for (int k = 0; k < c.num_res_blocks + 1; ++k) {
+      const int out_ch = nf * c.ch_mult[i];
+      const int skip = hs_c.back();
+      hs_c.pop_back();
+      b.res(in_ch + skip, out_ch, false, false, 4 * nf);
+      in_ch = out_ch;
+    }
+    if (resl == c.attn_resolution) b.attn(in_ch);
+    b.gn(in_ch);
+    b.conv3(in_ch, channels);
+    if (i != 0) b.res(in_ch, in_ch, true, false, 4 * nf);
+  }
+  DS_CHECK(hs_c.empty(), "internal: skip stack not empty");
+  return 0;
+}
+
+static diffsep_model_config g_tmp_cfg;
+static Arch g_tmp_arch;
+static bool g_tmp_valid = false;
+static int cached_arch(const diffsep_model_config* cfg, Arch** out) {
+  DS_CHECK(cfg != nullptr, "null config");
+  if (!g_tmp_valid || memcmp(&g_tmp_cfg, cfg, sizeof(*cfg)) != 0) {
+    g_tmp_valid = false;
+    if (build_arch(*cfg, g_tmp_arch)) return 1;
+    g_tmp_cfg = *cfg;
+    g_tmp_valid = true;
+  }
+  *out = &g_tmp_arch;
+  return 0;
+}
+
+extern "C" int32_t diffsep_param_count(const diffsep_model_config* cfg) {
+  Arch* a;
+  if (cached_arch(cfg, &a)) return -1;
+  return (int32_t)a->params.size();
+}
+extern "C" int64_t diffsep_param_total(const diffsep_model_config* cfg) {
+  Arch* a;
+  if (cached_arch(cfg, &a)) return -1;
+  return a->total;
+}
+extern "C" int32_t diffsep_param_info(const diffsep_model_config* cfg, int32_t idx, char* name, int32_t name_cap,
+                                      int64_t shape[4], int32_t* ndim, int64_t* offset) {
+  Arch* a;
+  if (cached_arch(cfg, &a)) return 1;
+  DS_CHECK(idx >= 0 && idx < (int)a->params.size(), "param index out of range");
+  const ParamInfo& p = a->params[idx];
+  if (name && name_cap > 0) {
+    strncpy(name, p.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (shape) for (int i = 0; i < 4; ++i) shape[i] = p.shape[i];
+  if (ndim) *ndim = p.ndim;
+  if (offset) *offset = p.off;
+  return 0;
+}
+extern "C" int32_t diffsep_num_frames(const diffsep_model_config* cfg, int64_t T) {
+  return 1 + (int32_t)((T + cfg->n_fft - cfg->hop) / cfg->hop);
+}
+extern "C" int32_t diffsep_padded_frames(const diffsep_model_config* cfg, int64_t T) {
+  const int F = diffsep_num_frames(cfg, T);
+  return 64 * ((F + 63) / 64);
+}
+
+// ------------------------------------------------------------------ weight repack kernel
+// dst[o][tap][i] (i < Ipad, zero padded) = src[o*so + i*si + tap*st]
+template <typename T>
+__global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ src, T* __restrict__ dst, int O, int I,
+                                                     int Ipad, int taps, long so, long si, long st) {
+  const long total = (long)O * taps * Ipad;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int i = (int)(idx % Ipad);
+    const long r = idx / Ipad;
+    const int tap = (int)(r % taps);
+    const int o = (int)(r / taps);
+    const float v = (i < I) ? src[o * so + i * si + tap * st] : 0.f;
+    Elt<T>::st(dst + idx, v);
+  }
+}
+
+// ------------------------------------------------------------------ engine
+struct Tn {  // NHWC view
+  void* p = nullptr;
+  int C = 0, ld = 0, H = 0, W = 0;
+};
+
+struct diffsep_engine {
+  diffsep_model_config cfg;
+  Arch arch;
+  int esz = 4;
+  float* d_blob = nullptr;
+  char* d_pack = nullptr;
+  float* d_dense_w = nullptr;
+  float* d_dense_b = nullptr;
+  float* d_tab = nullptr;
+  // arena
+  char* arena = nullptr;
+  size_t cap = 0, top = 0, fwd_base = 0;
+  bool dry = false;
+  int planB = -1;
+  long planT = -1;
+  // sampler state (inside the arena, below fwd_base)
+  float *st_x = nullptr, *st_xm = nullptr, *st_score = nullptr, *st_t = nullptr, *st_noise = nullptr,
+        *st_ts = nullptr, *st_mix = nullptr;
+  // graph of one NFE: (st_x, st_t, st_mix) -> st_score
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  bool graph_ok = false;
+  int use_graph = 1;
+  bool warmed = false;
+  int64_t weight_bytes = 0;
+  // work never runs on the legacy null stream (it cannot be captured): a NULL `stream` argument is
+  // mapped to this private stream, ordered against the null stream with events on both sides.
+  hipStream_t own = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+};
+
+struct StreamScope {
+  diffsep_engine* e; hipStream_t user; hipStream_t st;
+  StreamScope(diffsep_engine* e_, void* s) : e(e_), user((hipStream_t)s), st((hipStream_t)s) {
+    if (!user) {
+      st = e->own;
+      hipEventRecord(e->ev_in, nullptr);
+      hipStreamWaitEvent(st, e->ev_in, 0);
+    }
+  }
+  ~StreamScope() {
+    if (!user) {
+      hipEventRecord(e->ev_out, st);
+      hipStreamWaitEvent(nullptr, e->ev_out, 0);
+    }
+  }
+};
+
+static void* e_alloc(diffsep_engine* e, size_t bytes) {
+  const size_t a = (e->top + 255) & ~(size_t)255;
+  e->top = a + bytes;
+  if (e->dry) return (void*)(uintptr_t)(a + 256);  // fake non-null
+  return e->arena + a;
+}
+static Tn e_tensor(diffsep_engine* e, int B, int H, int W, int C) {
+  Tn t;
+  t.C = C; t.ld = C; t.H = H; t.W = W;
+  t.p = e_alloc(e, (size_t)B * H * W * C * e->esz);
+  return t;
+}
+static float* e_f32(diffsep_engine* e, size_t n) { return (float*)e_alloc(e, n * 4); }
+static const float* P(diffsep_engine* e, const PRef& r) { return e->d_blob + r.off; }
+static const void* PK(diffsep_engine* e, long off) { return e->d_pack + off * e->esz; }
+
+// ---- launch helpers (skip when dry)
+static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias, const float* bias_b, int bias_b_ld,
+                const Tn* res, float scale, const Tn& y, int Cout, int taps, int B, const float* div_b,
+                hipStream_t st) {
+  if (e->dry) return 0;
+  ConvArgs a;
+  a.x = x.p; a.x_bs = (long)x.H * x.W * x.ld; a.ldx = x.ld;
+  a.w = w; a.w_bs = 0;
+  a.bias = bias; a.bias_b = bias_b; a.bias_b_ld = bias_b_ld; a.bias_mode = 0; a.div_b = div_b;
+  a.res = res ? res->p : nullptr; a.res_bs = res ? (long)res->H * res->W * res->ld : 0; a.ldr = res ? res->ld : 0;
+  a.out_scale = scale;
+  a.y = y.p; a.y_bs = (long)y.H * y.W * y.ld; a.ldy = y.ld;
+  a.B = B; a.H = x.H; a.W = x.W; a.Cin = x.C; a.Cout = Cout; a.taps = taps; a.dtype = e->cfg.dtype;
+  return ds_launch_conv(a, st);
+}
+
+struct GnAff { float* scale; float* shift; };
+static int gn_stats(diffsep_engine* e, const Tn& x, const float* gamma, const float* beta, int B, GnAff& aff,
+                    hipStream_t st) {
+  void* ws = e_alloc(e, (size_t)ds_gn_workspace_bytes(B, x.H, x.W, x.C));
+  aff.scale = e_f32(e, (size_t)B * x.C);
+  aff.shift = e_f32(e, (size_t)B * x.C);
+  if (e->dry) return 0;
+  const int groups = (x.C / 4 < 32) ? x.C / 4 : 32;
+  return ds_launch_gn_stats(x.p, x.ld, B, x.H, x.W, x.C, groups, 1e-6f, gamma, beta, ws, aff.scale, aff.shift,
+                            e->cfg.dtype, st);
+}
+static int gn_apply(diffsep_engine* e, const Tn& x, const GnAff* aff, const Tn* y, const Tn* xr, int B, int act,
+                    int mode, hipStream_t st) {
+  if (e->dry) return 0;
+  return ds_launch_gn_apply(x.p, x.ld, aff ? aff->scale : nullptr, aff ? aff->shift : nullptr, x.C, y ? y->p : nullptr,
+                            y ? y->ld : 0, xr ? xr->p : nullptr, xr ? xr->ld : 0, B, x.H, x.W, act, mode, e->cfg.dtype,
+                            st);
+}
+
+static const float kInvSqrt2 = 0.70710678118654752440f;
+
+// ResnetBlockBigGANpp.forward  layerspp.py:291-323
+static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const float* temb_proj, int B, Tn& out,
+                     hipStream_t st) {
+  DS_CHECK(x.C == m.in_ch, "internal: resblock channel mismatch");
+  const int mode = m.up ? 1 : (m.down ? 2 : 0);
+  const int Ho = m.up ? 2 * x.H : (m.down ? x.H / 2 : x.H);
+  const int Wo = m.up ? 2 * x.W : (m.down ? x.W / 2 : x.W);
+  GnAff a0, a1;
+  if (gn_stats(e, x, P(e, m.gn0_w), P(e, m.gn0_b), B, a0, st)) return 1;
+  Tn h0 = e_tensor(e, B, Ho, Wo, m.in_ch);
+  Tn xr = x;
+  if (mode) xr = e_tensor(e, B, Ho, Wo, m.in_ch);
+  if (gn_apply(e, x, &a0, &h0, mode ? &xr : nullptr, B, 1, mode, st)) return 1;
+  Tn h1 = e_tensor(e, B, Ho, Wo, m.out_ch);
+  if (conv(e, h0, PK(e, m.pk0), P(e, m.conv0_b), temb_proj + m.temb_off, e->arch.dense_total, nullptr, 1.f, h1,
+           m.out_ch, 9, B, nullptr, st))
+    return 1;
+  if (gn_stats(e, h1, P(e, m.gn1_w), P(e, m.gn1_b), B, a1, st)) return 1;
+  Tn h2 = e_tensor(e, B, Ho, Wo, m.out_ch);
+  if (gn_apply(e, h1, &a1, &h2, nullptr, B, 1, 0, st)) return 1;
+  Tn skip = xr;
+  if (m.has_conv2) {
+    skip = e_tensor(e, B, Ho, Wo, m.out_ch);
+    if (conv(e, xr, PK(e, m.pk2), P(e, m.conv2_b), nullptr, 0, nullptr, 1.f, skip, m.out_ch, 1, B, nullptr, st))
+      return 1;
+  }
+  out = e_tensor(e, B, Ho, Wo, m.out_ch);
+  return conv(e, h2, PK(e, m.pk1), P(e, m.conv1_b), nullptr, 0, &skip, kInvSqrt2, out, m.out_ch, 9, B, nullptr, st);
+}
+
+// attention core shared with the unit entry point: o = softmax(q k^T C^-1/2) v
+static int attention_core(const void* q, const void* k, const void* vt, void* o, int B, int L, int C, int ldq, int ldo,
+                          void* scores, void* probs, int dtype, hipStream_t st) {
+  const int Lp = rup8(L);
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dtype = dtype; a.B = B; a.taps = 1; a.bias_mode = 0; a.out_scale = 1.f;
+  // scores[b, i, j] = sum_c q[b,i,c] k[b,j,c] * C^-0.5
+  a.x = q; a.x_bs = (long)L * ldq; a.ldx = ldq;
+  a.w = k; a.w_bs = (long)L * C;
+  a.y = scores; a.y_bs = (long)L * Lp; a.ldy = Lp;
+  a.H = 1; a.W = L; a.Cin = C; a.Cout = L;
+  a.out_scale = 1.0f / sqrtf((float)C);
+  if (ds_launch_conv(a, st)) return 1;
+  if (ds_launch_softmax(scores, probs, (long)B * L, L, Lp, dtype, st)) return 1;
+  // o[b, i, c] = sum_j P[b,i,j] vt[b,c,j]
+  a.x = probs; a.x_bs = (long)L * Lp; a.ldx = Lp;
+  a.w = vt; a.w_bs = (long)C * Lp;
+  a.y = o; a.y_bs = (long)L * ldo; a.ldy = ldo;
+  a.H = 1; a.W = L; a.Cin = Lp; a.Cout = C;
+  a.out_scale = 1.f;
+  return ds_launch_conv(a, st);
+}
+
+// AttnBlockpp.forward  layerspp.py:76-92
+static int attn_block(diffsep_engine* e, const Module& m, const Tn& x, int B, Tn& out, hipStream_t st) {
+  const int C = m.in_ch, L = x.H * x.W, Lp = rup8(L);
+  DS_CHECK(x.C == C, "internal: attention channel mismatch");
+  GnAff a0;
+  if (gn_stats(e, x, P(e, m.gn0_w), P(e, m.gn0_b), B, a0, st)) return 1;
+  Tn h = e_tensor(e, B, x.H, x.W, C);
+  if (gn_apply(e, x, &a0, &h, nullptr, B, 0, 0, st)) return 1;
+  Tn q = e_tensor(e, B, x.H, x.W, C), k = e_tensor(e, B, x.H, x.W, C);
+  if (conv(e, h, PK(e, m.pk_nin[0]), P(e, m.nin_b[0]), nullptr, 0, nullptr, 1.f, q, C, 1, B, nullptr, st)) return 1;
+  if (conv(e, h, PK(e, m.pk_nin[1]), P(e, m.nin_b[1]), nullptr, 0, nullptr, 1.f, k, C, 1, B, nullptr, st)) return 1;
+  // V^T[b, c, l] = sum_c' Wv[c', c] h[b, l, c'] + b[c]: A = packed Wv^T ([C][C]), Bt = h, bias along rows
+  void* vt = e_alloc(e, (size_t)B * C * Lp * e->esz);
+  void* scores = e_alloc(e, (size_t)B * L * Lp * e->esz);
+  void* probs = e_alloc(e, (size_t)B * L * Lp * e->esz);
+  Tn o = e_tensor(e, B, x.H, x.W, C);
+  out = e_tensor(e, B, x.H, x.W, C);
+  if (e->dry) return 0;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dtype = e->cfg.dtype; a.B = B; a.taps = 1; a.out_scale = 1.f;
+  a.x = PK(e, m.pk_nin[2]); a.x_bs = 0; a.ldx = C;
+  a.w = h.p; a.w_bs = (long)L * C;
+  a.bias = P(e, m.nin_b[2]); a.bias_mode = 1;
+  a.y = vt; a.y_bs = (long)C * Lp; a.ldy = Lp;
+  a.H = 1; a.W = C; a.Cin = C; a.Cout = L;
+  if (ds_launch_conv(a, st)) return 1;
+  if (attention_core(q.p, k.p, vt, o.p, B, L, C, C, C, scores, probs, e->cfg.dtype, st)) return 1;
+  return conv(e, o, PK(e, m.pk_nin[3]), P(e, m.nin_b[3]), nullptr, 0, &x, kInvSqrt2, out, C, 1, B, nullptr, st);
+}
+
+// NCSNpp.forward  ncsnpp.py:319-478.  x0: packed input AFTER 2x-1, [B,H,W,cpad_in]; y: [B,H,W,cpad_out]
+static int net_forward(diffsep_engine* e, const Tn& x0, const float* t, const Tn& y, int B, hipStream_t st) {
+  const Arch& A = e->arch;
+  const diffsep_model_config& c = e->cfg;
+  const int nf = c.nf;
+  size_t mi = 0;
+  // ---- time embedding (ncsnpp.py:324-343) and every block's Dense_0(act(temb)) (layerspp.py:311-312)
+  float* emb = e_f32(e, (size_t)B * 2 * nf);
+  float* t1 = e_f32(e, (size_t)B * 4 * nf);
+  float* temb = e_f32(e, (size_t)B * 4 * nf);
+  float* proj = e_f32(e, (size_t)B * A.dense_total);
+  const Module& mf = A.mods[mi++];
+  const Module& l1 = A.mods[mi++];
+  const Module& l2 = A.mods[mi++];
+  if (!e->dry) {
+    if (ds_launch_fourier(t, P(e, mf.w0), emb, B, nf, st)) return 1;
+    if (ds_launch_linear(emb, P(e, l1.w0), P(e, l1.b0), t1, B, 2 * nf, 4 * nf, 0, st)) return 1;
+    if (ds_launch_linear(t1, P(e, l2.w0), P(e, l2.b0), temb, B, 4 * nf, 4 * nf, 1, st)) return 1;
+    if (ds_launch_linear(temb, e->d_dense_w, e->d_dense_b, proj, B, 4 * nf, A.dense_total, 1, st)) return 1;
+  }
+  // ---- input conv
+  const Module& cin = A.mods[mi++];
+  std::vector<Tn> hs;
+  {
+    Tn h = e_tensor(e, B, x0.H, x0.W, nf);
+    if (conv(e, x0, PK(e, cin.pk0), P(e, cin.b0), nullptr, 0, nullptr, 1.f, h, nf, 9, B, nullptr, st)) return 1;
+    hs.push_back(h);
+  }
+  Tn pyr_in = x0;
+  const int L = c.n_levels;
+  Tn h;
+  for (int i = 0; i < L; ++i) {
+    for (int k = 0; k < c.num_res_blocks; ++k) {
+      if (res_block(e, A.mods[mi++], hs.back(), proj, B, h, st)) return 1;
+      if (h.H == c.attn_resolution) {
+        DS_CHECK(mi < A.mods.size() && A.mods[mi].kind == MK_ATTN, "attention placement mismatch (image height)");
+        Tn ha;
+        if (attn_block(e, A.mods[mi++], h, B, ha, st)) return 1;
+        h = ha;
+      }
+      hs.push_back(h);
+    }
+    if (i != L - 1) {
+      if (res_block(e, A.mods[mi++], hs.back(), proj, B, h, st)) return 1;
+      // input pyramid: FIR down, Combine = conv1x1(pyr) + h   (ncsnpp.py:383-386, layerspp.py:52-57)
+      Tn pd = e_tensor(e, B, pyr_in.H / 2, pyr_in.W / 2, pyr_in.C);
+      if (gn_apply(e, pyr_in, nullptr, nullptr, &pd, B, 0, 2, st)) return 1;
+      pyr_in = pd;
+      const Module& cm = A.mods[mi++];
+      DS_CHECK(cm.kind == MK_COMBINE, "internal: expected Combine");
+      Tn hc = e_tensor(e, B, h.H, h.W, h.C);
+      if (conv(e, pyr_in, PK(e, cm.pk0), P(e, cm.b0), nullptr, 0, &h, 1.f, hc, h.C, 1, B, nullptr, st)) return 1;
+      hs.push_back(hc);
+    }
+  }
+  h = hs.back();
+  Tn t2;
+  if (res_block(e, A.mods[mi++], h, proj, B, t2, st)) return 1;
+  if (attn_block(e, A.mods[mi++], t2, B, h, st)) return 1;
+  if (res_block(e, A.mods[mi++], h, proj, B, t2, st)) return 1;
+  h = t2;
+
+  Tn pyramid;
+  bool have_pyr = false;
+  for (int i = L - 1; i >= 0; --i) {
+    for (int k = 0; k < c.num_res_blocks + 1; ++k) {
+      const Tn s = hs.back();
+      hs.pop_back();
+      Tn cat = e_tensor(e, B, h.H, h.W, h.C + s.C);
+      if (!e->dry)
+        if (ds_launch_concat(h.p, h.ld, h.C, s.p, s.ld, s.C, cat.p, cat.ld, (long)B * h.H * h.W, c.dtype, st)) return 1;
+      if (res_block(e, A.mods[mi++], cat, proj, B, h, st)) return 1;
+    }
+    if (h.H == c.attn_resolution) {
+      DS_CHECK(mi < A.mods.size() && A.mods[mi].kind == MK_ATTN, "attention placement mismatch (image height)");
+      Tn ha;
+      if (attn_block(e, A.mods[mi++], h, B, ha, st)) return 1;
+      h = ha;
+    }
+    // output pyramid (ncsnpp.py:419-440): conv3x3(act(GN(h))) [+ FIR up of the previous pyramid]
+    const Module& g = A.mods[mi++];
+    const Module& cv = A.mods[mi++];
+    DS_CHECK(g.kind == MK_GN && cv.kind == MK_CONV3, "internal: expected pyramid GN + conv");
+    GnAff ga;
+    if (gn_stats(e, h, P(e, g.w0), P(e, g.b0), B, ga, st)) return 1;
+    Tn hn = e_tensor(e, B, h.H, h.W, h.C);
+    if (gn_apply(e, h, &ga, &hn, nullptr, B, 1, 0, st)) return 1;
+    Tn pnew = e_tensor(e, B, h.H, h.W, A.cpad_in);
+    if (have_pyr) {
+      Tn pu = e_tensor(e, B, h.H, h.W, A.cpad_in);
+      if (gn_apply(e, pyramid, nullptr, nullptr, &pu, B, 0, 1, st)) return 1;
+      if (conv(e, hn, PK(e, cv.pk0), P(e, cv.b0), nullptr, 0, &pu, 1.f, pnew, A.chan_in, 9, B, nullptr, st)) return 1;
+    } else {
+      if (conv(e, hn, PK(e, cv.pk0), P(e, cv.b0), nullptr, 0, nullptr, 1.f, pnew, A.chan_in, 9, B, nullptr, st))
+        return 1;
+    }
+    pyramid = pnew;
+    have_pyr = true;
+    if (i != 0) {
+      Tn hu;
+      if (res_block(e, A.mods[mi++], h, proj, B, hu, st)) return 1;
+      h = hu;
+    }
+  }
+  DS_CHECK(hs.empty() && mi == A.mods.size(), "internal: module walk did not consume all modules");
+  // h = pyramid / t ; out = output_layer(h)   (ncsnpp.py:472-477)
+  return conv(e, pyramid, PK(e, A.pk_out), P(e, A.out_b), nullptr, 0, nullptr, 1.f, y, A.chan_out, 1, B, t, st);
+}
+
+// ScoreModelNCSNpp.forward  score_models.py:126-138
+static int score_forward_impl(diffsep_engine* e, const float* xt, const float* t, const float* mix, float* out, int B,
+                              long T, hipStream_t st) {
+  const diffsep_model_config& c = e->cfg;
+  const int W = diffsep_padded_frames(&c, T), H = c.n_fft / 2 + 1, S = c.num_sources;
+  e->top = e->fwd_base;
+  Tn x0 = e_tensor(e, B, H, W, e->arch.cpad_in);
+  Tn y = e_tensor(e, B, H, W, e->arch.cpad_out);
+  const int F = diffsep_num_frames(&c, T);
+  float* frames = e_f32(e, (size_t)B * S * F * 512);
+  if (!e->dry)
+    if (ds_launch_stft_pack(xt, mix, x0.p, B, S, T, c.n_fft, c.hop, c.spec_abs_exponent, c.spec_factor, W,
+                            e->arch.cpad_in, 1, c.dtype, e->d_tab, st))
+      return 1;
+  if (net_forward(e, x0, t, y, B, st)) return 1;
+  if (!e->dry)
+    if (ds_launch_istft(y.p, out, B, S, T, c.n_fft, c.hop, c.spec_abs_exponent, c.spec_factor, W, e->arch.cpad_out,
+                        c.dtype, e->d_tab, frames, st))
+      return 1;
+  return 0;
+}
+
+static void drop_graph(diffsep_engine* e) {
+  if (e->gexec) hipGraphExecDestroy(e->gexec);
+  if (e->graph) hipGraphDestroy(e->graph);
+  e->gexec = nullptr;
+  e->graph = nullptr;
+  e->graph_ok = false;
+}
+
+// Size the arena for (B, T): sampler state + one forward's bump allocations.  kindW: if > 0 the
+// plan is for backbone_forward with that width (no STFT) — handled by the caller via T = -W.
+static int ensure_plan(diffsep_engine* e, int B, long T, hipStream_t st) {
+  if (e->planB == B && e->planT == T && e->arena) return 0;
+  DS_CHECK(B >= 1 && T >= 1, "empty batch or signal");
+  drop_graph(e);
+  const int S = e->cfg.num_sources;
+  const size_t nst = (size_t)B * S * T;
+  // state region
+  e->top = 0;
+  e->dry = true;
+  e_alloc(e, nst * 4); e_alloc(e, nst * 4); e_alloc(e, nst * 4); e_alloc(e, nst * 4);
+  e_alloc(e, (size_t)B * 4); e_alloc(e, (size_t)B * T * 4); e_alloc(e, 4096 * (size_t)B * 4);
+  e->fwd_base = (e->top + 255) & ~(size_t)255;
+  const int rc = score_forward_impl(e, nullptr, nullptr, nullptr, nullptr, B, T, st);
+  e->dry = false;
+  if (rc) return 1;
+  const size_t need = e->top + 4096;
+  if (need > e->cap) {
+    DS_HIP(hipStreamSynchronize(st));
+    if (e->arena) DS_HIP(hipFree(e->arena));
+    e->arena = nullptr;
+    e->cap = 0;
+    DS_HIP(hipMalloc((void**)&e->arena, need));
+    e->cap = need;
+  }
+  DS_HIP(hipMemsetAsync(e->arena, 0, e->cap, st));  // channel / K padding must read as zero
+  e->top = 0;
+  e->st_x = (float*)e_alloc(e, nst * 4);
+  e->st_xm = (float*)e_alloc(e, nst * 4);
+  e->st_score = (float*)e_alloc(e, nst * 4);
+  e->st_noise = (float*)e_alloc(e, nst * 4);
+  e->st_t = (float*)e_alloc(e, (size_t)B * 4);
+  e->st_mix = (float*)e_alloc(e, (size_t)B * T * 4);
+  e->st_ts = (float*)e_alloc(e, 4096 * (size_t)B * 4);
+  e->planB = B;
+  e->planT = T;
+  e->warmed = false;
+  return 0;
+}
+
+extern "C" int32_t diffsep_engine_create(const diffsep_model_config* cfg, const float* weights_host, int64_t n_floats,
+                                         diffsep_engine** out) {
+  DS_CHECK(cfg && weights_host && out, "engine_create: null argument");
+  DS_CHECK(cfg->dtype == DS_F32 || cfg->dtype == DS_BF16, "engine_create: dtype must be DIFFSEP_F32 or DIFFSEP_BF16");
+  diffsep_engine* e = new diffsep_engine();
+  e->cfg = *cfg;
+  if (build_arch(*cfg, e->arch)) { delete e; return 1; }
+  const Arch& A = e->arch;
+  if (n_floats != A.total) {
+    ds_set_error("engine_create: weight blob has " + std::to_string(n_floats) + " floats, expected " +
+                 std::to_string(A.total));
+    delete e;
+    return 1;
+  }
+  e->esz = cfg->dtype == DS_F32 ? 4 : 2;
+  DS_HIP(hipMalloc((void**)&e->d_blob, (size_t)A.total * 4));
+  DS_HIP(hipMemcpy(e->d_blob, weights_host, (size_t)A.total * 4, hipMemcpyHostToDevice));
+  DS_HIP(hipMalloc((void**)&e->d_pack, (size_t)A.pack_total * e->esz + 256));
+  DS_HIP(hipMemset(e->d_pack, 0, (size_t)A.pack_total * e->esz + 256));
+  DS_HIP(hipMalloc((void**)&e->d_dense_w, (size_t)A.dense_total * 4 * cfg->nf * 4));
+  DS_HIP(hipMalloc((void**)&e->d_dense_b, (size_t)A.dense_total * 4));
+  e->weight_bytes = (int64_t)A.total * 4 + (int64_t)A.pack_total * e->esz + (int64_t)A.dense_total * (4 * cfg->nf + 1) * 4;
+  if (ds_build_stft_table(cfg->n_fft, &e->d_tab)) { delete e; return 1; }
+  DS_HIP(hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
+  DS_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+  DS_HIP(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
+
+  auto repack = [&](const PRef& src, long pk, int O, int I, int taps, long so, long si, long stp) -> int {
+    const int Ipad = rup8(I);
+    const long total = (long)O * taps * Ipad;
+    long nb = (total + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (cfg->dtype == DS_F32)
+      hipLaunchKernelGGL(repack_kernel<float>, dim3(nb), dim3(256), 0, 0, e->d_blob + src.off,
+                         (float*)(e->d_pack) + pk, O, I, Ipad, taps, so, si, stp);
+    else
+      hipLaunchKernelGGL(repack_kernel<bf16_t>, dim3(nb), dim3(256), 0, 0, e->d_blob + src.off,
+                         (bf16_t*)(e->d_pack) + pk, O, I, Ipad, taps, so, si, stp);
+    DS_LAUNCH_CHECK();
+    return 0;
+  };
+  int rc = 0;
+  rc |= repack(A.out_w, A.pk_out, A.chan_out, A.chan_in, 1, A.chan_in, 1, 0);
+  for (const Module& m : A.mods) {
+    switch (m.kind) {
+      case MK_CONV3: rc |= repack(m.w0, m.pk0, m.out_ch, m.in_ch, 9, (long)m.in_ch * 9, 9, 1); break;
+      case MK_COMBINE: rc |= repack(m.w0, m.pk0, m.out_ch, m.in_ch, 1, m.in_ch, 1, 0); break;
+      case MK_RES:
+        rc |= repack(m.conv0_w, m.pk0, m.out_ch, m.in_ch, 9, (long)m.in_ch * 9, 9, 1);
+        rc |= repack(m.conv1_w, m.pk1, m.out_ch, m.out_ch, 9, (long)m.out_ch * 9, 9, 1);
+        if (m.has_conv2) rc |= repack(m.conv2_w, m.pk2, m.out_ch, m.in_ch, 1, m.in_ch, 1, 0);
+        // Dense_0 rows -> concatenated projection [dense_total][4 nf]
+        DS_HIP(hipMemcpy(e->d_dense_w + (size_t)m.temb_off * 4 * cfg->nf, e->d_blob + m.dense_w.off,
+                         (size_t)m.dense_w.numel * 4, hipMemcpyDeviceToDevice));
+        DS_HIP(hipMemcpy(e->d_dense_b + m.temb_off, e->d_blob + m.dense_b.off, (size_t)m.dense_b.numel * 4,
+                         hipMemcpyDeviceToDevice));
+        break;
+      case MK_ATTN:  // NIN.W is [in][out] (layers.py:678-689): packed as [out][in]
+        for (int i = 0; i < 4; ++i) rc |= repack(m.nin_w[i], m.pk_nin[i], m.in_ch, m.in_ch, 1, 1, m.in_ch, 0);
+        break;
+      default: break;
+    }
+  }
+  if (rc) { delete e; return 1; }
+  DS_HIP(hipDeviceSynchronize());
+  *out = e;
+  return 0;
+}
+
+extern "C" void diffsep_engine_destroy(diffsep_engine* e) {
+  if (!e) return;
+  drop_graph(e);
+  hipFree(e->d_blob); hipFree(e->d_pack); hipFree(e->d_dense_w); hipFree(e->d_dense_b); hipFree(e->d_tab);
+  if (e->arena) hipFree(e->arena);
+  if (e->own) hipStreamDestroy(e->own);
+  if (e->ev_in) hipEventDestroy(e->ev_in);
+  if (e->ev_out) hipEventDestroy(e->ev_out);
+  delete e;
+}
+extern "C" int64_t diffsep_engine_device_bytes(const diffsep_engine* e) { return e ? e->weight_bytes + (int64_t)e->cap : 0; }
+extern "C" int32_t diffsep_engine_set_graph(diffsep_engine* e, int32_t enable) {
+  DS_CHECK(e, "null engine");
+  e->use_graph = enable;
+  if (!enable) drop_graph(e);
+  return 0;
+}
+
+extern "C" int32_t diffsep_score_forward(diffsep_engine* e, const float* xt, const float* t, const float* mix,
+                                         float* out, int32_t B, int64_t T, void* stream) {
+  DS_CHECK(e && xt && t && mix && out, "score_forward: null argument");
+  StreamScope sc_(e, stream);
+  hipStream_t st = sc_.st;
+  if (ensure_plan(e, B, T, st)) return 1;
+  return score_forward_impl(e, xt, t, mix, out, B, T, st);
+}
+
+extern "C" int32_t diffsep_backbone_forward(diffsep_engine* e, const void* x, const float* t, void* y, int32_t B,
+                                            int32_t W, void* stream) {
+  DS_CHECK(e && x && t && y, "backbone_forward: null argument");
+  DS_CHECK(W >= 64 && W % 64 == 0, "backbone_forward: W must be a positive multiple of 64");
+  StreamScope sc_(e, stream);
+  hipStream_t st = sc_.st;
+  // plan sized through the equivalent signal length: F = W frames  <=>  T = (W-1)*hop - (n_fft-hop) + hop - 1
+  const long T = (long)(W - 1) * e->cfg.hop - (e->cfg.n_fft - e->cfg.hop) + e->cfg.hop - 1;
+  DS_CHECK(diffsep_padded_frames(&e->cfg, T) == W, "internal: width/length mapping");
+  if (ensure_plan(e, B, T, st)) return 1;
+  const int H = e->cfg.n_fft / 2 + 1;
+  e->top = e->fwd_base;
+  Tn xin; xin.p = (void*)x; xin.C = xin.ld = e->arch.cpad_in; xin.H = H; xin.W = W;
+  Tn x0 = e_tensor(e, B, H, W, e->arch.cpad_in);
+  float* sc = e_f32(e, (size_t)B * e->arch.cpad_in);
+  float* sh = e_f32(e, (size_t)B * e->arch.cpad_in);
+  if (ds_launch_fill(sc, 2.f, (long)B * e->arch.cpad_in, st)) return 1;
+  if (ds_launch_fill(sh, -1.f, (long)B * e->arch.cpad_in, st)) return 1;
+  GnAff aff{sc, sh};
+  if (gn_apply(e, xin, &aff, &x0, nullptr, B, 0, 0, st)) return 1;  // x = 2x - 1 (ncsnpp.py:347-349)
+  Tn yo; yo.p = y; yo.C = yo.ld = e->arch.cpad_out; yo.H = H; yo.W = W;
+  return net_forward(e, x0, t, yo, B, st);
+}
+
+// torch.linspace(start, end, n) in float32 (ATen RangeFactories: symmetric fill around the midpoint)
+static void linspace_f32(float start, float end, int n, float* out) {
+  if (n == 1) { out[0] = start; return; }
+  const float step = (end - start) / (float)(n - 1);
+  const int half = n / 2;
+  for (int i = 0; i < n; ++i) out[i] = (i < half) ? (start + step * (float)i) : (end - step * (float)(n - 1 - i));
+}
+
+__global__ void bcast_rows_kernel(const float* __restrict__ v, float* __restrict__ out, int N, int B) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < N * B) out[i] = v[i / B];
+}
+
+static int run_nfe(diffsep_engine* e, int B, long T, hipStream_t st) {
+  // one score evaluation on the resident state: (st_x, st_t, st_mix) -> st_score
+  if (e->use_graph && e->warmed) {
+    if (!e->graph_ok) {
+      DS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      const int rc = score_forward_impl(e, e->st_x, e->st_t, e->st_mix, e->st_score, B, T, st);
+      hipGraph_t g = nullptr;
+      const hipError_t ce = hipStreamEndCapture(st, &g);
+      if (rc || ce != hipSuccess || !g) {
+        if (g) hipGraphDestroy(g);
+        e->use_graph = 0;  // fall back to eager launches of the same kernels
+        if (rc) return 1;
+      } else {
+        e->graph = g;
+        DS_HIP(hipGraphInstantiate(&e->gexec, e->graph, nullptr, nullptr, 0));
+        e->graph_ok = true;
+      }
+    }
+    if (e->graph_ok) {
+      DS_HIP(hipGraphLaunch(e->gexec, st));
+      return 0;
+    }
+  }
+  const int rc = score_forward_impl(e, e->st_x, e->st_t, e->st_mix, e->st_score, B, T, st);
+  e->warmed = true;  // the first eager pass also sets the kernels' LDS attributes (not capturable)
+  return rc;
+}
+
+extern "C" int32_t diffsep_pc_sample(diffsep_engine* e, const diffsep_sde_config* sde, const diffsep_sampler_config* smp,
+                                     const float* mix_norm, float* out, int32_t B, int64_t T, const float* noise,
+                                     uint64_t seed, const float* timesteps_host, int32_t* nfe_out, void* stream) {
+  DS_CHECK(e && sde && smp && mix_norm && out, "pc_sample: null argument");
+  DS_CHECK(sde->kind == DIFFSEP_SDE_MIX, "pc_sample: only MixSDE runs on the device path in this build");
+  DS_CHECK(sde->ndim == e->cfg.num_sources, "pc_sample: sde.ndim != num_sources");
+  DS_CHECK(smp->N >= 1 && smp->N <= 4096, "pc_sample: N must be in [1,4096]");
+  DS_CHECK(smp->predictor == DIFFSEP_PRED_REVERSE_DIFFUSION || smp->predictor == DIFFSEP_PRED_NONE,
+           "pc_sample: predictor must be reverse_diffusion or none");
+  DS_CHECK(smp->corrector == DIFFSEP_CORR_ALD2 || smp->corrector == DIFFSEP_CORR_NONE,
+           "pc_sample: corrector must be ald2 or none");
+  StreamScope sc_(e, stream);
+  hipStream_t st = sc_.st;
+  const int S = e->cfg.num_sources, N = smp->N;
+  const int csteps = smp->corrector == DIFFSEP_CORR_ALD2 ? smp->corrector_steps : 0;
+  if (ensure_plan(e, B, T, st)) return 1;
+  const size_t nst = (size_t)B * S * T;
+  SdeP sp{sde->kind, sde->ndim, sde->d_lambda, sde->sigma_min, sde->sigma_max};
+  // time steps -> device rows [N][B]
+  std::vector<float> ts(N);
+  if (timesteps_host) for (int i = 0; i < N; ++i) ts[i] = timesteps_host[i];
+  else linspace_f32(1.0f, smp->eps, N, ts.data());
+  std::vector<float> rows((size_t)N * B);
+  for (int i = 0; i < N; ++i) for (int b = 0; b < B; ++b) rows[(size_t)i * B + b] = ts[i];
+  DS_HIP(hipMemcpyAsync(e->st_ts, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+  DS_HIP(hipStreamSynchronize(st));  // `rows` is pageable host memory about to go out of scope
+  DS_HIP(hipMemcpyAsync(e->st_mix, mix_norm, (size_t)B * T * 4, hipMemcpyDeviceToDevice, st));
+
+  long draw = 0;
+  auto next_noise = [&](const float** z) -> int {
+    if (noise) { *z = noise + (size_t)draw * nst; }
+    else {
+      if (ds_launch_randn(e->st_noise, (long)nst, seed, (uint64_t)draw, st)) return 1;
+      *z = e->st_noise;
+    }
+    ++draw;
+    return 0;
+  };
+  const float* z = nullptr;
+  if (next_noise(&z)) return 1;
+  if (ds_launch_sde_prior(sp, e->st_mix, z, e->st_x, B, S, T, st)) return 1;
+  DS_HIP(hipMemcpyAsync(e->st_xm, e->st_x, nst * 4, hipMemcpyDeviceToDevice, st));
+  int nfe = 0;
+  for (int i = 0; i < N; ++i) {
+    DS_HIP(hipMemcpyAsync(e->st_t, e->st_ts + (size_t)i * B, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    for (int k = 0; k < csteps; ++k) {
+      if (run_nfe(e, B, T, st)) return 1;
+      ++nfe;
+      if (next_noise(&z)) return 1;
+      if (ds_launch_sde_corrector(sp, smp->snr, e->st_x, e->st_t, e->st_score, z, e->st_x, e->st_xm, B, S, T, st))
+        return 1;
+    }
+    if (smp->predictor == DIFFSEP_PRED_REVERSE_DIFFUSION) {
+      if (run_nfe(e, B, T, st)) return 1;
+      ++nfe;
+      if (next_noise(&z)) return 1;
+      if (ds_launch_sde_predictor(sp, N, e->st_x, e->st_t, e->st_score, z, e->st_x, e->st_xm, B, S, T, st)) return 1;
+    } else {
+      DS_HIP(hipMemcpyAsync(e->st_xm, e->st_x, nst * 4, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  DS_HIP(hipMemcpyAsync(out, smp->denoise ? e->st_xm : e->st_x, nst * 4, hipMemcpyDeviceToDevice, st));
+  if (nfe_out) *nfe_out = N * (csteps + 1);
+  (void)nfe;
+  return 0;
+}
+
+// ------------------------------------------------------------------ unit entry points
+extern "C" int32_t diffsep_upfirdn2d(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx,
+                                     int32_t ldy, int32_t up, int32_t dtype, void* stream) {
+  DS_CHECK(x && y, "upfirdn2d: null pointer");
+  return ds_launch_gn_apply(x, ldx, nullptr, nullptr, C, nullptr, 0, y, ldy, B, H, W, 0, up ? 1 : 2, dtype,
+                            (hipStream_t)stream);
+}
+
+extern "C" int32_t diffsep_groupnorm_act(const void* x, const float* gamma, const float* beta, void* y, void* xr,
+                                         int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t ldy,
+                                         int32_t ldxr, int32_t groups, float eps, int32_t act, int32_t resample,
+                                         int32_t dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+  DS_CHECK(x && y && workspace, "groupnorm: null pointer");
+  const long wsb = (ds_gn_workspace_bytes(B, H, W, C) + 255) & ~255L;
+  DS_CHECK(workspace_bytes >= wsb + 2L * B * C * 4, "groupnorm: workspace too small");
+  float* scale = (float*)((char*)workspace + wsb);
+  float* shift = scale + (long)B * C;
+  hipStream_t st = (hipStream_t)stream;
+  if (ds_launch_gn_stats(x, ldx, B, H, W, C, groups, eps, gamma, beta, workspace, scale, shift, dtype, st)) return 1;
+  return ds_launch_gn_apply(x, ldx, scale, shift, C, y, ldy, xr, ldxr, B, H, W, act, resample, dtype, st);
+}
+
+extern "C" int32_t diffsep_conv2d(const void* x, const void* w, const float* bias, const float* bias_b, const void* res,
+                                  void* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                                  int32_t ldx, int32_t ldr, int32_t ldy, float out_scale, int32_t dtype, void* stream) {
+  DS_CHECK(ksize == 1 || ksize == 3, "conv2d: ksize must be 1 or 3");
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.x_bs = (long)H * W * ldx; a.ldx = ldx;
+  a.w = w; a.w_bs = 0;
+  a.bias = bias; a.bias_b = bias_b; a.bias_b_ld = Cout; a.bias_mode = 0;
+  a.res = res; a.res_bs = (long)H * W * ldr; a.ldr = ldr;
+  a.out_scale = out_scale;
+  a.y = y; a.y_bs = (long)H * W * ldy; a.ldy = ldy;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.taps = ksize == 3 ? 9 : 1; a.dtype = dtype;
+  return ds_launch_conv(a, (hipStream_t)stream);
+}
+
+extern "C" int32_t diffsep_attention(const void* q, const void* k, const void* vt, void* o, int32_t B, int32_t L,
+                                     int32_t C, int32_t ld, int32_t dtype, void* workspace, int64_t workspace_bytes,
+                                     void* stream) {
+  DS_CHECK(q && k && vt && o && workspace, "attention: null pointer");
+  DS_CHECK(ld == C, "attention: q/k must be dense [B,L,C] (ld == C)");
+  const int Lp = rup8(L), esz = dtype == DS_F32 ? 4 : 2;
+  const long one = (((long)B * L * Lp * esz) + 255) & ~255L;
+  DS_CHECK(workspace_bytes >= 2 * one, "attention: workspace too small");
+  return attention_core(q, k, vt, o, B, L, C, ld, ld, workspace, (char*)workspace + one, dtype, (hipStream_t)stream);
+}
+
+static float* g_tab = nullptr;
+static int g_tab_n = 0;
+static int unit_tab(int n_fft, float** tab) {
+  if (g_tab_n != n_fft) {
+    if (g_tab) hipFree(g_tab);
+    g_tab = nullptr;
+    g_tab_n = 0;
+    if (ds_build_stft_table(n_fft, &g_tab)) return 1;
+    g_tab_n = n_fft;
+  }
+  *tab = g_tab;
+  return 0;
+}
+
+extern "C" int32_t diffsep_stft_pack(const float* xt, const float* mix, void* y, int32_t B, int32_t S, int64_t T,
+                                     int32_t n_fft, int32_t hop, float exponent, float factor, int32_t W, int32_t Cpad,
+                                     int32_t centered_shift, int32_t dtype, void* stream) {
+  DS_CHECK(xt && mix && y, "stft_pack: null pointer");
+  float* tab;
+  if (unit_tab(n_fft, &tab)) return 1;
+  return ds_launch_stft_pack(xt, mix, y, B, S, T, n_fft, hop, exponent, factor, W, Cpad, centered_shift, dtype, tab,
+                             (hipStream_t)stream);
+}
+
+extern "C" int32_t diffsep_istft_unpack(const void* x, float* out, int32_t B, int32_t S, int64_t T, int32_t n_fft,
+                                        int32_t hop, float exponent, float factor, int32_t W, int32_t Cpad,
+                                        int32_t dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+  DS_CHECK(x && out && workspace, "istft_unpack: null pointer");
+  const int F = 1 + (int)((T + n_fft - hop) / hop);
+  DS_CHECK(workspace_bytes >= (int64_t)B * S * F * 512 * 4, "istft_unpack: workspace too small");
+  float* tab;
+  if (unit_tab(n_fft, &tab)) return 1;
+  return ds_launch_istft(x, out, B, S, T, n_fft, hop, exponent, factor, W, Cpad, dtype, tab, (float*)workspace,
+                         (hipStream_t)stream);
+}
+
+static SdeP to_sdep(const diffsep_sde_config* s) { return SdeP{s->kind, s->ndim, s->d_lambda, s->sigma_min, s->sigma_max}; }
+
+extern "C" int32_t diffsep_sde_prior(const diffsep_sde_config* sde, const float* y, const float* z, float* x, int32_t B,
+                                     int32_t S, int64_t T, void* stream) {
+  DS_CHECK(sde && y && z && x, "sde_prior: null pointer");
+  return ds_launch_sde_prior(to_sdep(sde), y, z, x, B, S, T, (hipStream_t)stream);
+}
+extern "C" int32_t diffsep_sde_corrector_update(const diffsep_sde_config* sde, float snr, const float* x, const float* t,
+                                                const float* score, const float* z, float* x_out, float* x_mean_out,
+                                                int32_t B, int32_t S, int64_t T, void* stream) {
+  DS_CHECK(sde && x && t && score && x_out, "sde_corrector_update: null pointer");
+  return ds_launch_sde_corrector(to_sdep(sde), snr, x, t, score, z, x_out, x_mean_out, B, S, T, (hipStream_t)stream);
+}
+extern "C" int32_t diffsep_sde_predictor_update(const diffsep_sde_config* sde, int32_t N, const float* x, const float* t,
+                                                const float* score, const float* z, float* x_out, float* x_mean_out,
+                                                int32_t B, int32_t S, int64_t T, void* stream) {
+  DS_CHECK(sde && x && t && score && x_out, "sde_predictor_update: null pointer");
+  return ds_launch_sde_predictor(to_sdep(sde), N, x, t, score, z, x_out, x_mean_out, B, S, T, (hipStream_t)stream);
+}
+extern "C" int32_t diffsep_normalize_batch(const float* mix, float* mix_norm, float* mean, float* std, int32_t B,
+                                           int64_t T, void* stream) {
+  DS_CHECK(mix && mix_norm, "normalize_batch: null pointer");
+  return ds_launch_normalize(mix, mix_norm, mean, std, B, T, (hipStream_t)stream);
+}
+extern "C" int32_t diffsep_scale_output(const float* mix, float* sep, int32_t B, int32_t S, int64_t T, void* stream) {
+  DS_CHECK(mix && sep, "scale_output: null pointer");
+  return ds_launch_scale_output(mix, sep, B, S, T, (hipStream_t)stream);
+}
+extern "C" int32_t diffsep_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream) {
+  DS_CHECK(out, "randn: null pointer");
+  return ds_launch_randn(out, n, seed, stream_id, (hipStream_t)stream);
+}
+extern "C" int32_t diffsep_convert(const void* src, void* dst, int64_t n, int32_t sd, int32_t dd, void* stream) {
+  DS_CHECK(src && dst, "convert: null pointer");
+  return ds_launch_convert(src, dst, n, sd, dd, (hipStream_t)stream);
+}

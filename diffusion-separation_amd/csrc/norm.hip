@@ -1,0 +1,319 @@
+// norm.hip — HBM-bound NHWC kernels around the convolutions:
+//   GroupNorm statistics (fp64 accumulation, wave shuffles + LDS), per-(b,c) scale/shift,
+//   apply + SiLU (+ the [1,3,3,1] FIR x2 up / down resampling of BOTH act(GN(x)) and raw x in one read),
+//   channel concat, row softmax.
+// Reference semantics: nn.GroupNorm(min(C/4,32), C, eps=1e-6) + SiLU  layerspp.py:264-266,292,313;
+// upsample_2d / downsample_2d  up_or_down_sampling.py:206-273 (closed forms: SURVEY.md §8a-15).
+#include "common.h"
+
+// ------------------------------------------------------------------ GroupNorm statistics
+// grid (nblk, B); each block reduces `ppb` pixels of one batch entry for all C channels.
+// Thread t owns channel group cg = t % (C/8) and pixel lane pl = t / (C/8): consecutive threads read
+// consecutive 16/32-byte channel vectors of one pixel -> fully coalesced rows.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int ldx, long bs, long npix, int C,
+                                                       long ppb, double* __restrict__ part) {
+  __shared__ double sh[4096];  // [npl][C][2], npl*C <= 2048
+  const int ncg = C >> 3;
+  const int npl = 256 / ncg;
+  const int tid = threadIdx.x;
+  const int cg = tid % ncg, pl = tid / ncg;
+  const int b = blockIdx.y;
+  const long p0 = (long)blockIdx.x * ppb;
+  long p1 = p0 + ppb;
+  if (p1 > npix) p1 = npix;
+  double s[8], ss[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.0; ss[j] = 0.0; }
+  if (pl < npl) {
+    const T* xb = x + (long)b * bs + cg * 8;
+    for (long p = p0 + pl; p < p1; p += npl) {
+      float f[8];
+      load8<T>(xb + p * ldx, f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const double d = (double)f[j];
+        s[j] += d;
+        ss[j] = fma(d, d, ss[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sh[((pl * C) + cg * 8 + j) * 2 + 0] = s[j];
+      sh[((pl * C) + cg * 8 + j) * 2 + 1] = ss[j];
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    double a = 0.0, q = 0.0;
+    for (int l = 0; l < npl; ++l) {
+      a += sh[(l * C + c) * 2 + 0];
+      q += sh[(l * C + c) * 2 + 1];
+    }
+    double* o = part + (((long)b * gridDim.x + blockIdx.x) * C + c) * 2;
+    o[0] = a;
+    o[1] = q;
+  }
+}
+
+// grid (B): fold block partials -> group mean / rstd -> per-channel scale & shift:
+//   y = x * scale + shift,  scale = rstd * gamma, shift = beta - mean * scale.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ part, int nblk, int C, int groups,
+                                                          double count, float eps, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ scale,
+                                                          float* __restrict__ shift) {
+  __shared__ double cs[1024], cq[1024];
+  __shared__ float gm[256], gr[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int c = tid; c < C; c += 256) {
+    double a = 0.0, q = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+      const double* o = part + (((long)b * nblk + k) * C + c) * 2;
+      a += o[0];
+      q += o[1];
+    }
+    cs[c] = a;
+    cq[c] = q;
+  }
+  __syncthreads();
+  const int cpg = C / groups;
+  for (int g = tid; g < groups; g += 256) {
+    double a = 0.0, q = 0.0;
+    for (int j = 0; j < cpg; ++j) {
+      a += cs[g * cpg + j];
+      q += cq[g * cpg + j];
+    }
+    const double mean = a / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    gm[g] = (float)mean;
+    gr[g] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cpg;
+    const float sc = gr[g] * (gamma ? gamma[c] : 1.f);
+    scale[(long)b * C + c] = sc;
+    shift[(long)b * C + c] = (beta ? beta[c] : 0.f) - gm[g] * sc;
+  }
+}
+
+long ds_gn_workspace_bytes(int B, int H, int W, int C) {
+  const long npix = (long)H * W;
+  long nblk = cdiv(npix, 64);
+  if (nblk > 64) nblk = 64;
+  return (long)B * nblk * C * 2 * 8 + 256;
+}
+
+int ds_launch_gn_stats(const void* x, int ldx, int B, int H, int W, int C, int groups, float eps, const float* gamma,
+                       const float* beta, void* ws, float* scale, float* shift, int dtype, hipStream_t st) {
+  DS_CHECK(C % 8 == 0 && C <= 1024 && C >= 8, "groupnorm: C must be a multiple of 8 in [8,1024]");
+  DS_CHECK(groups > 0 && groups <= 256 && C % groups == 0, "groupnorm: bad group count");
+  DS_CHECK((C >> 3) <= 256, "groupnorm: C too large");
+  const long npix = (long)H * W;
+  long nblk = cdiv(npix, 64);
+  if (nblk > 64) nblk = 64;
+  const long ppb = (npix + nblk - 1) / nblk;
+  double* part = reinterpret_cast<double*>(ws);
+  dim3 grid((unsigned)nblk, (unsigned)B);
+  if (dtype == DS_F32)
+    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, npix * ldx, npix, C, ppb,
+                       part);
+  else
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, npix * ldx, npix, C,
+                       ppb, part);
+  DS_LAUNCH_CHECK();
+  const double count = (double)npix * (double)(C / groups);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, part, (int)nblk, C, groups, count, eps, gamma, beta,
+                     scale, shift);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ apply (+SiLU) (+FIR resample)
+// One thread = one OUTPUT pixel x 8 channels.  MODE 0: same size; 1: FIR x2 up; 2: FIR x2 down.
+//   down: y[m]    = (x[2m-1] + 3x[2m] + 3x[2m+1] + x[2m+2]) / 8   per axis, zeros outside
+//   up:   y[2m]   = x[m-1]/4 + 3x[m]/4 ;  y[2m+1] = 3x[m]/4 + x[m+1]/4
+// The activation is applied BEFORE resampling (layerspp.py:292-299) and out-of-image taps are zero.
+template <typename T, int MODE, bool AFFINE>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int ldx,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int C, T* __restrict__ y,
+                                                       int ldy, T* __restrict__ xr, int ldxr, int B, int H, int W,
+                                                       int act) {
+  const int Ho = MODE == 1 ? 2 * H : (MODE == 2 ? H / 2 : H);
+  const int Wo = MODE == 1 ? 2 * W : (MODE == 2 ? W / 2 : W);
+  const int ncg = C >> 3;
+  const long total = (long)B * Ho * Wo * ncg;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cg = (int)(i % ncg);
+    long r = i / ncg;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    float sc[8], sf[8];
+    if (AFFINE) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sc[j] = scale[(long)b * C + cg * 8 + j];
+        sf[j] = shift[(long)b * C + cg * 8 + j];
+      }
+    }
+    const T* xb = x + (long)b * H * W * ldx + cg * 8;
+    float ah[8], ax[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ah[j] = 0.f; ax[j] = 0.f; }
+    if (MODE == 0) {
+      float f[8];
+      load8<T>(xb + ((long)oy * W + ox) * ldx, f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = f[j] * sc[j] + sf[j];
+        ah[j] = act ? silu_t<T>(v) : v;
+      }
+    } else {
+      constexpr int NT = MODE == 2 ? 4 : 2;
+      int iy0, ix0;
+      float wy[4], wx[4];
+      if (MODE == 2) {
+        iy0 = 2 * oy - 1; ix0 = 2 * ox - 1;
+        wy[0] = wx[0] = 0.125f; wy[1] = wx[1] = 0.375f; wy[2] = wx[2] = 0.375f; wy[3] = wx[3] = 0.125f;
+      } else {
+        const int ay = oy & 1, axp = ox & 1;
+        iy0 = (oy >> 1) - 1 + ay; ix0 = (ox >> 1) - 1 + axp;
+        wy[0] = ay ? 0.75f : 0.25f; wy[1] = ay ? 0.25f : 0.75f;
+        wx[0] = axp ? 0.75f : 0.25f; wx[1] = axp ? 0.25f : 0.75f;
+        wy[2] = wy[3] = wx[2] = wx[3] = 0.f;
+      }
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        const int iy = iy0 + a;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+          const int ix = ix0 + c;
+          if (ix < 0 || ix >= W) continue;
+          const float wgt = wy[a] * wx[c];
+          float f[8];
+          load8<T>(xb + ((long)iy * W + ix) * ldx, f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            ax[j] += wgt * f[j];
+            if (AFFINE) {
+              float v = f[j] * sc[j] + sf[j];
+              v = act ? silu_t<T>(v) : v;
+              ah[j] += wgt * v;
+            }
+          }
+        }
+      }
+    }
+    const long opix = ((long)b * Ho + oy) * Wo + ox;
+    if (AFFINE) store8<T>(y + opix * ldy + cg * 8, ah);
+    if (MODE != 0 && xr) store8<T>(xr + opix * ldxr + cg * 8, ax);
+  }
+}
+
+template <typename T>
+static int gn_apply_typed(const void* x, int ldx, const float* scale, const float* shift, int C, void* y, int ldy,
+                          void* xr, int ldxr, int B, int H, int W, int act, int mode, hipStream_t st) {
+  const int Ho = mode == 1 ? 2 * H : (mode == 2 ? H / 2 : H);
+  const int Wo = mode == 1 ? 2 * W : (mode == 2 ? W / 2 : W);
+  const long total = (long)B * Ho * Wo * (C >> 3);
+  long nb = (total + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  if (nb < 1) nb = 1;
+  const bool aff = scale != nullptr;
+#define GA(M, A)                                                                                                    \
+  hipLaunchKernelGGL((gn_apply_kernel<T, M, A>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)x, ldx, scale, shift, \
+                     C, (T*)y, ldy, (T*)xr, ldxr, B, H, W, act)
+  if (mode == 0) { if (aff) GA(0, true); else GA(0, false); }
+  else if (mode == 1) { if (aff) GA(1, true); else GA(1, false); }
+  else { if (aff) GA(2, true); else GA(2, false); }
+#undef GA
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+
+int ds_launch_gn_apply(const void* x, int ldx, const float* scale, const float* shift, int C, void* y, int ldy,
+                       void* xr, int ldxr, int B, int H, int W, int act, int mode, int dtype, hipStream_t st) {
+  DS_CHECK(C % 8 == 0, "gn_apply: C must be a multiple of 8");
+  DS_CHECK(mode >= 0 && mode <= 2, "gn_apply: bad resample mode");
+  DS_CHECK(mode != 2 || (H % 2 == 0 && W % 2 == 0), "gn_apply: FIR down needs even H, W");
+  DS_CHECK(scale != nullptr || (mode != 0 && xr != nullptr), "gn_apply: nothing to do");
+  if (dtype == DS_F32) return gn_apply_typed<float>(x, ldx, scale, shift, C, y, ldy, xr, ldxr, B, H, W, act, mode, st);
+  return gn_apply_typed<bf16_t>(x, ldx, scale, shift, C, y, ldy, xr, ldxr, B, H, W, act, mode, st);
+}
+
+// ------------------------------------------------------------------ channel concat  cat([a, b], dim=C)
+template <typename T>
+__global__ __launch_bounds__(256) void concat_kernel(const T* __restrict__ a, int lda, int Ca, const T* __restrict__ b,
+                                                     int ldb, int Cb, T* __restrict__ y, int ldy, long npix) {
+  const int ncg = (Ca + Cb) >> 3, nca = Ca >> 3;
+  const long total = npix * ncg;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cg = (int)(i % ncg);
+    const long p = i / ncg;
+    const T* src = cg < nca ? a + p * lda + cg * 8 : b + p * ldb + (cg - nca) * 8;
+    T* dst = y + p * ldy + cg * 8;
+    if (sizeof(T) == 4) {
+      reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<const uint4*>(src)[0];
+      reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<const uint4*>(src)[1];
+    } else {
+      reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<const uint4*>(src)[0];
+    }
+  }
+}
+
+int ds_launch_concat(const void* a, int lda, int Ca, const void* b, int ldb, int Cb, void* y, int ldy, long npix,
+                     int dtype, hipStream_t st) {
+  DS_CHECK(Ca % 8 == 0 && Cb % 8 == 0, "concat: channels must be multiples of 8");
+  const long total = npix * ((Ca + Cb) >> 3);
+  long nb = (total + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  if (nb < 1) nb = 1;
+  if (dtype == DS_F32)
+    hipLaunchKernelGGL(concat_kernel<float>, dim3((unsigned)nb), dim3(256), 0, st, (const float*)a, lda, Ca,
+                       (const float*)b, ldb, Cb, (float*)y, ldy, npix);
+  else
+    hipLaunchKernelGGL(concat_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, st, (const bf16_t*)a, lda, Ca,
+                       (const bf16_t*)b, ldb, Cb, (bf16_t*)y, ldy, npix);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ row softmax (one wave per row)
+// y[r, j] = exp(x[r,j] - max) / sum for j < L; columns [L, ld) are written as 0 (K padding of P V).
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int L,
+                                                      int ld) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xr = x + row * ld;
+  T* yr = y + row * ld;
+  float mx = -INFINITY;
+  for (int j = lane; j < L; j += 64) mx = fmaxf(mx, Elt<T>::ld(xr + j));
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < L; j += 64) sum += exp_t<T>(Elt<T>::ld(xr + j) - mx);
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  for (int j = lane; j < ld; j += 64) {
+    float v = 0.f;
+    if (j < L) v = exp_t<T>(Elt<T>::ld(xr + j) - mx) * inv;
+    Elt<T>::st(yr + j, v);
+  }
+}
+
+int ds_launch_softmax(const void* x, void* y, long rows, int L, int ld, int dtype, hipStream_t st) {
+  DS_CHECK(L > 0 && ld >= L, "softmax: bad sizes");
+  const unsigned nb = (unsigned)((rows + 3) / 4);
+  if (dtype == DS_F32)
+    hipLaunchKernelGGL(softmax_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, (float*)y, rows, L, ld);
+  else
+    hipLaunchKernelGGL(softmax_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, rows, L, ld);
+  DS_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,312 @@
+// sde.hip — the predictor–corrector state updates of the reverse-diffusion sampler, time-domain
+// helpers and the time embedding (all fp32, HBM-bound, one thread = one time index x all sources).
+//
+// MixSDE matrices are all of the form  M = a*A + p*P  with A = 11^T/S, P = I - A  (sdes/sdes.py:242-248),
+// so M @ v = a*mean_s(v) + p*(v - mean_s(v)) for any number of sources — no [B,S,S] matmul needed.
+//   ev1 = smin^2 (r^{2t} - 1),  ev2 = smin^2 (r^{2t} - e^{-2 lambda t}) / (1 + lambda/ln r)   sdes.py:296-309
+//   L   = sqrt(ev1) A + sqrt(ev2) P                                                      sdes.py:315-320
+//   g(t)= smin r^t sqrt(2 ln r);  G = g sqrt(dt), dt = 1/N (quirk Q1)                     sdes.py:275-284, 93-107
+#include "common.h"
+
+struct MixCoef { float a, p; };  // sqrt(ev1), sqrt(ev2)
+
+__device__ inline void mix_eig(const SdeP& s, float t, float& ev1, float& ev2) {
+  const float r = s.sigma_max / s.sigma_min;
+  const float logsig = logf(r);
+  const float mult = s.sigma_min * s.sigma_min;
+  const float srp = powf(r, 2.0f * t);
+  ev1 = mult * (srp - 1.0f);
+  const float ex = expf(-2.0f * s.d_lambda * t);
+  const float denom = 1.0f + s.d_lambda / logsig;
+  ev2 = mult * (srp - ex) / denom;
+}
+
+// x_T = c*y + L(T=1) @ z          MixSDE.prior_sampling  sdes.py:334-346 (c = 0.5 hard-coded for S = 2: quirk Q2)
+__global__ __launch_bounds__(256) void sde_prior_kernel(SdeP s, const float* __restrict__ y,
+                                                        const float* __restrict__ z, float* __restrict__ x, int S,
+                                                        long T) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= T) return;
+  float ev1, ev2;
+  mix_eig(s, 1.0f, ev1, ev2);
+  const float a = sqrtf(ev1), p = sqrtf(ev2);
+  const float c = (S == 2) ? 0.5f : 1.0f / (float)S;
+  const float m = c * y[(long)b * T + t];
+  float zz[DS_MAX_SRC], mz = 0.f;
+  for (int i = 0; i < S; ++i) { zz[i] = z[((long)b * S + i) * T + t]; mz += zz[i]; }
+  mz /= (float)S;
+  for (int i = 0; i < S; ++i) x[((long)b * S + i) * T + t] = m + (a * mz + p * (zz[i] - mz));
+}
+
+// ald2 corrector step given score g:  x_mean = x + 2 snr^2 L L g ;  x = x_mean + (2 snr L) z
+// sdes/correctors.py:115-126
+__global__ __launch_bounds__(256) void sde_corrector_kernel(SdeP s, float snr, const float* __restrict__ x,
+                                                            const float* __restrict__ tt,
+                                                            const float* __restrict__ score,
+                                                            const float* __restrict__ z, float* __restrict__ xo,
+                                                            float* __restrict__ xm, int S, long T) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= T) return;
+  float ev1, ev2;
+  mix_eig(s, tt[b], ev1, ev2);
+  const float a = sqrtf(ev1), p = sqrtf(ev2);
+  const float step = 2.0f * snr * snr;
+  float g[DS_MAX_SRC], n[DS_MAX_SRC], mg = 0.f, mn = 0.f;
+  for (int i = 0; i < S; ++i) {
+    g[i] = score[((long)b * S + i) * T + t];
+    n[i] = z ? z[((long)b * S + i) * T + t] : 0.f;
+    mg += g[i];
+    mn += n[i];
+  }
+  mg /= (float)S;
+  mn /= (float)S;
+  for (int i = 0; i < S; ++i) {
+    // L @ (L @ g), evaluated as two applications like the reference does
+    const float u = a * mg + p * (g[i] - mg);        // (L g)_i ; mean_s(L g) = a * mg
+    const float llg = a * (a * mg) + p * (u - a * mg);
+    const long o = ((long)b * S + i) * T + t;
+    const float mean = x[o] + step * llg;
+    const float a2 = 2.0f * snr * a, p2 = 2.0f * snr * p;
+    if (xm) xm[o] = mean;
+    xo[o] = mean + (a2 * mn + p2 * (n[i] - mn));
+  }
+}
+
+// reverse-diffusion predictor given score:  f = -lambda P x dt ; rev_f = f - G^2 score ;
+// x_mean = x - rev_f ; x = x_mean + G z          sdes/predictors.py:60-66, sdes/sdes.py:163-171
+__global__ __launch_bounds__(256) void sde_predictor_kernel(SdeP s, int N, const float* __restrict__ x,
+                                                            const float* __restrict__ tt,
+                                                            const float* __restrict__ score,
+                                                            const float* __restrict__ z, float* __restrict__ xo,
+                                                            float* __restrict__ xm, int S, long T) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= T) return;
+  const float r = s.sigma_max / s.sigma_min;
+  const float dt = 1.0f / (float)N;
+  const float sigma = s.sigma_min * powf(r, tt[b]);
+  const float diffusion = sigma * sqrtf(2.0f * logf(r));
+  const float G = diffusion * sqrtf(dt);
+  float xv[DS_MAX_SRC], mx = 0.f;
+  for (int i = 0; i < S; ++i) { xv[i] = x[((long)b * S + i) * T + t]; mx += xv[i]; }
+  mx /= (float)S;
+  for (int i = 0; i < S; ++i) {
+    const long o = ((long)b * S + i) * T + t;
+    const float drift = -s.d_lambda * (xv[i] - mx);
+    const float f = drift * dt;
+    const float rev_f = f - G * G * score[o];
+    const float mean = xv[i] - rev_f;
+    if (xm) xm[o] = mean;
+    xo[o] = mean + G * (z ? z[o] : 0.f);
+  }
+}
+
+int ds_launch_sde_prior(const SdeP& s, const float* y, const float* z, float* x, int B, int S, long T, hipStream_t st) {
+  DS_CHECK(s.kind == 0, "sde: only MixSDE is implemented on the device path");
+  DS_CHECK(S >= 1 && S <= DS_MAX_SRC, "sde: too many sources");
+  hipLaunchKernelGGL(sde_prior_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, s, y, z, x, S, T);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+int ds_launch_sde_corrector(const SdeP& s, float snr, const float* x, const float* t, const float* score,
+                            const float* z, float* xo, float* xm, int B, int S, long T, hipStream_t st) {
+  DS_CHECK(s.kind == 0, "sde: only MixSDE is implemented on the device path");
+  DS_CHECK(S >= 1 && S <= DS_MAX_SRC, "sde: too many sources");
+  hipLaunchKernelGGL(sde_corrector_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, s, snr, x, t, score, z, xo, xm, S,
+                     T);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+int ds_launch_sde_predictor(const SdeP& s, int N, const float* x, const float* t, const float* score, const float* z,
+                            float* xo, float* xm, int B, int S, long T, hipStream_t st) {
+  DS_CHECK(s.kind == 0, "sde: only MixSDE is implemented on the device path");
+  DS_CHECK(S >= 1 && S <= DS_MAX_SRC && N >= 1, "sde: bad arguments");
+  hipLaunchKernelGGL(sde_predictor_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, s, N, x, t, score, z, xo, xm, S, T);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ block reductions (fp64)
+__device__ inline double block_sum_d(double v, double* sh) {
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int i = 0; i < nw; ++i) r += sh[i];
+  return r;
+}
+
+// normalize_batch  pl_model.py:81-88: (mix - mean) / clamp(std_unbiased, 1e-5) over (chan=1, time)
+__global__ __launch_bounds__(1024) void normalize_kernel(const float* __restrict__ mix, float* __restrict__ out,
+                                                         float* __restrict__ mean_o, float* __restrict__ std_o,
+                                                         long T) {
+  __shared__ double sh[16];
+  const int b = blockIdx.x;
+  const float* m = mix + (long)b * T;
+  double s = 0.0;
+  for (long i = threadIdx.x; i < T; i += blockDim.x) s += (double)m[i];
+  const double mean = block_sum_d(s, sh) / (double)T;
+  double q = 0.0;
+  for (long i = threadIdx.x; i < T; i += blockDim.x) {
+    const double d = (double)m[i] - mean;
+    q += d * d;
+  }
+  const double var = block_sum_d(q, sh) / (double)(T > 1 ? T - 1 : 1);
+  float sd = (float)sqrt(var);
+  if (sd < 1e-5f) sd = 1e-5f;
+  const float mu = (float)mean;
+  for (long i = threadIdx.x; i < T; i += blockDim.x) out[(long)b * T + i] = (m[i] - mu) / sd;
+  if (threadIdx.x == 0) {
+    if (mean_o) mean_o[b] = mu;
+    if (std_o) std_o[b] = sd;
+  }
+}
+int ds_launch_normalize(const float* mix, float* out, float* mean, float* std, int B, long T, hipStream_t st) {
+  hipLaunchKernelGGL(normalize_kernel, dim3(B), dim3(1024), 0, st, mix, out, mean, std, T);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+
+// scale_output  separate.py:73-78: alpha = sum(mix*sep) / sum(sep^2 + 1e-10); sep *= alpha
+__global__ __launch_bounds__(1024) void scale_output_kernel(const float* __restrict__ mix, float* __restrict__ sep,
+                                                            int S, long T) {
+  __shared__ double sh[16];
+  const int s = blockIdx.x, b = blockIdx.y;
+  const float* m = mix + (long)b * T;
+  float* x = sep + ((long)b * S + s) * T;
+  double num = 0.0, den = 0.0;
+  for (long i = threadIdx.x; i < T; i += blockDim.x) {
+    const double v = (double)x[i];
+    num += (double)m[i] * v;
+    den += v * v + 1e-10;
+  }
+  num = block_sum_d(num, sh);
+  den = block_sum_d(den, sh);
+  const float alpha = (float)(num / den);
+  for (long i = threadIdx.x; i < T; i += blockDim.x) x[i] = alpha * x[i];
+}
+int ds_launch_scale_output(const float* mix, float* sep, int B, int S, long T, hipStream_t st) {
+  hipLaunchKernelGGL(scale_output_kernel, dim3(S, B), dim3(1024), 0, st, mix, sep, S, T);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 + Box–Muller
+__device__ inline void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, long n, uint64_t seed, uint64_t sid) {
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;  // one thread = 4 outputs
+  if (q * 4 >= n) return;
+  uint32_t c0 = (uint32_t)q, c1 = (uint32_t)((uint64_t)q >> 32), c2 = (uint32_t)sid, c3 = (uint32_t)(sid >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u1 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u3 = ((float)(c3 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+  float v[4];
+  sincosf(6.28318530718f * u1, &v[1], &v[0]);
+  sincosf(6.28318530718f * u3, &v[3], &v[2]);
+  v[0] *= r0; v[1] *= r0; v[2] *= r1; v[3] *= r1;
+  for (int j = 0; j < 4; ++j)
+    if (q * 4 + j < n) out[q * 4 + j] = v[j];
+}
+int ds_launch_randn(float* out, long n, uint64_t seed, uint64_t stream_id, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(randn_kernel, dim3(cdiv((n + 3) / 4, 256)), dim3(256), 0, st, out, n, seed, stream_id);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ dtype conversion / fill
+template <typename SRC, typename DST>
+__global__ __launch_bounds__(256) void convert_kernel(const SRC* __restrict__ s, DST* __restrict__ d, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    Elt<DST>::st(d + i, Elt<SRC>::ld(s + i));
+}
+int ds_launch_convert(const void* src, void* dst, long n, int sd, int dd, hipStream_t st) {
+  if (n <= 0) return 0;
+  long nb = (n + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  if (sd == DS_F32 && dd == DS_F32)
+    hipLaunchKernelGGL((convert_kernel<float, float>), dim3(nb), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+  else if (sd == DS_F32 && dd == DS_BF16)
+    hipLaunchKernelGGL((convert_kernel<float, bf16_t>), dim3(nb), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
+  else if (sd == DS_BF16 && dd == DS_F32)
+    hipLaunchKernelGGL((convert_kernel<bf16_t, float>), dim3(nb), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
+  else
+    hipLaunchKernelGGL((convert_kernel<bf16_t, bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst,
+                       n);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+__global__ __launch_bounds__(256) void fill_kernel(float* p, float v, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
+}
+int ds_launch_fill(float* p, float v, long n, hipStream_t st) {
+  if (n <= 0) return 0;
+  long nb = (n + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(fill_kernel, dim3(nb), dim3(256), 0, st, p, v, n);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ time embedding
+// GaussianFourierProjection(log t): cat(sin, cos)(((log t * W) * 2) * pi)      layerspp.py:32-41, ncsnpp.py:327
+__global__ __launch_bounds__(256) void fourier_kernel(const float* __restrict__ t, const float* __restrict__ Wf,
+                                                      float* __restrict__ emb, int nf) {
+  const int b = blockIdx.x;
+  const float lt = logf(t[b]);
+  for (int j = threadIdx.x; j < nf; j += 256) {
+    const float xp = ((lt * Wf[j]) * 2.0f) * 3.14159265358979323846f;
+    emb[(long)b * 2 * nf + j] = sinf(xp);
+    emb[(long)b * 2 * nf + nf + j] = cosf(xp);
+  }
+}
+int ds_launch_fourier(const float* t, const float* Wf, float* emb, int B, int nf, hipStream_t st) {
+  hipLaunchKernelGGL(fourier_kernel, dim3(B), dim3(256), 0, st, t, Wf, emb, nf);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+// y[b][o] = sum_k act(x[b][k]) W[o][k] + bias[o]; one wave per output (nn.Linear: ncsnpp.py:339-343, layerspp.py:311-312)
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, float* __restrict__ y, int K,
+                                                     int O, int silu_in) {
+  const int lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  if (o >= O) return;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    float v = x[(long)b * K + k];
+    if (silu_in) v = silu_t<float>(v);
+    acc = fmaf(v, W[(long)o * K + k], acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) y[(long)b * O + o] = acc + (bias ? bias[o] : 0.f);
+}
+int ds_launch_linear(const float* x, const float* W, const float* bias, float* y, int B, int K, int O, int silu_in,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(linear_kernel, dim3(cdiv(O, 4), B), dim3(256), 0, st, x, W, bias, y, K, O, silu_in);
+  DS_LAUNCH_CHECK();
+  return 0;
+}

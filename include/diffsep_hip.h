@@ -1,0 +1,215 @@
+/*
+ * diffsep_hip.h — C-ABI of the MI355X-native reverse-diffusion separation engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of fakufaku/diffusion-separation:
+ *   separate.py / evaluate.py -> DiffSepModel.get_pc_sampler -> sdes.get_pc_sampler
+ *   -> {ald2 corrector, reverse_diffusion predictor} -> ScoreModelNCSNpp (STFT -> NCSN++ -> iSTFT).
+ * The reference has no C-ABI/FFI of its own on this path: its plug points are
+ * Python call signatures.  Each entry point below cites the reference interface it replaces
+ * (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - plain C types, raw DEVICE pointers (e.g. torch.Tensor.data_ptr()), sizes as int / int64_t;
+ *   - every function returns 0 on success, non-zero on failure; diffsep_last_error() returns a
+ *     thread-local message; no C++ exception crosses this boundary;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is
+ *     asynchronous on it, the caller synchronises;
+ *   - waveforms are float32 [B, S, T] / [B, 1, T] contiguous, exactly as the reference passes them;
+ *   - image-like activations at the unit-op level are NHWC ("pixel-major") with an explicit pixel
+ *     stride `ld` (elements): element (b,h,w,c) lives at ((b*H + h)*W + w)*ld + c.  dtype is
+ *     DIFFSEP_F32 or DIFFSEP_BF16 (raw bfloat16 bits), C and ld multiples of 8;
+ *   - an engine handle is bound to the device that was current at creation, owns the repacked
+ *     weights + workspace, and is not thread-safe (the reference is one Python thread per process
+ *     per GPU: evaluate_mp.py:339,510-513).
+ */
+#ifndef DIFFSEP_HIP_H
+#define DIFFSEP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIFFSEP_F32 0
+#define DIFFSEP_BF16 1
+
+#define DIFFSEP_SDE_MIX 0      /* sdes/sdes.py:180-349  MixSDE      */
+#define DIFFSEP_SDE_PRIORMIX 1 /* sdes/sdes.py:352-590  PriorMixSDE */
+
+#define DIFFSEP_PRED_REVERSE_DIFFUSION 0 /* sdes/predictors.py:55-66 */
+#define DIFFSEP_PRED_EULER_MARUYAMA 1    /* sdes/predictors.py:39-52 */
+#define DIFFSEP_PRED_NONE 2              /* sdes/predictors.py:69-77 */
+
+#define DIFFSEP_CORR_ALD2 0 /* sdes/correctors.py:94-128  */
+#define DIFFSEP_CORR_NONE 1 /* sdes/correctors.py:131-141 */
+
+typedef struct diffsep_engine diffsep_engine; /* opaque */
+
+/* Hyper-parameters of ScoreModelNCSNpp + its NCSNpp backbone.
+ * Replaces: models/score_models.py:11-39 (ctor kwargs), models/ncsnpp.py:45-70 (ctor defaults),
+ * config/model/default.yaml:14-31. */
+typedef struct {
+  int32_t nf;               /* backbone_args.nf (64 default.yaml:25; 128 icassp-separation.yaml:16) */
+  int32_t num_sources;      /* S; backbone in = 2S+2, out = 2S (score_models.py:24-26) */
+  int32_t n_levels;         /* len(ch_mult) = 7 */
+  int32_t ch_mult[8];       /* (1,1,2,2,2,2,2) */
+  int32_t num_res_blocks;   /* 2 */
+  int32_t attn_resolution;  /* 16 (tested against the frequency axis, ncsnpp.py:367,415) */
+  int32_t n_fft;            /* 510 -> image height n_fft/2+1 = 256 */
+  int32_t hop;              /* 128 */
+  float spec_abs_exponent;  /* 0.5 */
+  float spec_factor;        /* 0.33 (0.15 published) */
+  int32_t dtype;            /* DIFFSEP_F32 (parity) or DIFFSEP_BF16 (throughput) activations/weights */
+} diffsep_model_config;
+
+/* sdes/sdes.py:217-240 (MixSDE ctor), :397-450 (PriorMixSDE ctor). */
+typedef struct {
+  int32_t kind; /* DIFFSEP_SDE_* */
+  int32_t ndim; /* number of sources */
+  float d_lambda, sigma_min, sigma_max;
+} diffsep_sde_config;
+
+/* sdes/__init__.py:132-145 (get_pc_sampler kwargs) + pl_model.py:687-701. */
+typedef struct {
+  int32_t N;               /* reverse steps */
+  int32_t corrector_steps; /* n_steps of the corrector */
+  float snr;               /* corrector step size */
+  float eps;               /* t_eps: last time step */
+  int32_t denoise;         /* return x_mean of the last predictor step */
+  int32_t predictor;       /* DIFFSEP_PRED_* */
+  int32_t corrector;       /* DIFFSEP_CORR_* */
+} diffsep_sampler_config;
+
+const char* diffsep_last_error(void);
+const char* diffsep_version(void);
+
+/* ---- parameter table: the canonical weight order is the reference state_dict order of
+ * ScoreModelNCSNpp.backbone (models/ncsnpp.py:106-308: all_modules.{i}.*, then output_layer.*,
+ * see SURVEY.md Appendix A).  The host assembles one flat float32 blob in this order. ---- */
+int32_t diffsep_param_count(const diffsep_model_config* cfg);
+/* name: e.g. "all_modules.4.Conv_0.weight"; shape: up to 4 dims (reference layout, e.g. OIHW);
+ * offset: position (in floats) inside the flat blob. */
+int32_t diffsep_param_info(const diffsep_model_config* cfg, int32_t idx, char* name, int32_t name_cap,
+                           int64_t shape[4], int32_t* ndim, int64_t* offset);
+int64_t diffsep_param_total(const diffsep_model_config* cfg);
+
+/* Create from HOST weights (EMA already applied by the caller: pl_model.py:655-660).
+ * Replaces DiffSepModel.__init__/load_from_checkpoint + .to(device) (separate.py:44-48). */
+int32_t diffsep_engine_create(const diffsep_model_config* cfg, const float* weights_host, int64_t n_floats,
+                              diffsep_engine** out);
+void diffsep_engine_destroy(diffsep_engine* e);
+/* bytes of device memory currently held (weights + workspace). */
+int64_t diffsep_engine_device_bytes(const diffsep_engine* e);
+/* frames F = 1 + (T + n_fft - hop)/hop and padded width W = 64*ceil(F/64) for T samples
+ * (score_models.py:83-91,107-112). Pure host arithmetic. */
+int32_t diffsep_num_frames(const diffsep_model_config* cfg, int64_t T);
+int32_t diffsep_padded_frames(const diffsep_model_config* cfg, int64_t T);
+
+/* score_fn(x, t, mix): DiffSepModel.forward (pl_model.py:407-409) -> ScoreModelNCSNpp.forward
+ * (models/score_models.py:126-138).  xt [B,S,T], t [B], mix [B,1,T], out [B,S,T]; all device f32. */
+int32_t diffsep_score_forward(diffsep_engine* e, const float* xt, const float* t, const float* mix, float* out,
+                              int32_t B, int64_t T, void* stream);
+
+/* backbone only: NCSNpp.forward (models/ncsnpp.py:319-478) on an already-packed NHWC input
+ * x [B,256,W,Cpad] (dtype of the engine, BEFORE the 2x-1 of ncsnpp.py:347-349), t [B] f32;
+ * y [B,256,W,Cpad_out].  Used by parity tests to isolate the network from the STFT front end. */
+int32_t diffsep_backbone_forward(diffsep_engine* e, const void* x, const float* t, void* y, int32_t B, int32_t W,
+                                 void* stream);
+
+/* The whole sampler: sdes.get_pc_sampler(...)() (sdes/__init__.py:132-190) as called from
+ * DiffSepModel.get_pc_sampler (pl_model.py:687-711) with score_fn = the engine.
+ *   mix_norm [B,1,T] : output of normalize_batch (pl_model.py:81-88);
+ *   out      [B,S,T] : x_mean of the last predictor step if denoise else x (sdes/__init__.py:183);
+ *   noise            : NULL -> on-device Philox N(0,1) draws keyed by `seed`; otherwise
+ *                      [1 + N*(corrector_steps+1)][B][S][T] float32 draws consumed in the
+ *                      reference's RNG order: prior, then per step corrector
+ *                      draw(s), predictor draw;
+ *   timesteps        : NULL -> torch.linspace(T=1, eps, N) semantics (sdes/__init__.py:175);
+ *                      otherwise N+1 HOST floats for the scheduled sampler
+ *                      (sdes/__init__.py:91-111; dt is still 1/N — reference quirk Q1);
+ *   nfe_out          : N*(corrector_steps+1) (sdes/__init__.py:184), may be NULL. */
+int32_t diffsep_pc_sample(diffsep_engine* e, const diffsep_sde_config* sde, const diffsep_sampler_config* smp,
+                          const float* mix_norm, float* out, int32_t B, int64_t T, const float* noise,
+                          uint64_t seed, const float* timesteps_host, int32_t* nfe_out, void* stream);
+
+/* Use hipGraph replay of the per-NFE launch sequence inside diffsep_pc_sample (default 1). */
+int32_t diffsep_engine_set_graph(diffsep_engine* e, int32_t enable);
+
+/* ------------------------------------------------------------------ unit entry points
+ * (used by the parity tests; the engine calls the same launchers internally). */
+
+/* upfirdn2d with the [1,3,3,1] FIR, factor 2: upsample_2d / downsample_2d
+ * (models/ncsnpp_utils/up_or_down_sampling.py:206-273; native op op/upfirdn2d.cpp:12-23,
+ * op/upfirdn2d_kernel.cu:107-207).  up!=0: [B,H,W,C] -> [B,2H,2W,C]; else -> [B,H/2,W/2,C]. */
+int32_t diffsep_upfirdn2d(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx,
+                          int32_t ldy, int32_t up, int32_t dtype, void* stream);
+
+/* y = act(GroupNorm(x)) with G = min(C/4,32), eps, affine (layerspp.py:264-266,292,313);
+ * act: 0 none (attention GN, layerspp.py:78) / 1 SiLU.  resample: 0 none / 1 FIR up / 2 FIR down
+ * applied to act(GN(x)) (layerspp.py:294-299); xr (nullable) receives the same resampling of raw x. */
+int32_t diffsep_groupnorm_act(const void* x, const float* gamma, const float* beta, void* y, void* xr, int32_t B,
+                              int32_t H, int32_t W, int32_t C, int32_t ldx, int32_t ldy, int32_t ldxr,
+                              int32_t groups, float eps, int32_t act, int32_t resample, int32_t dtype,
+                              void* workspace, int64_t workspace_bytes, void* stream);
+
+/* 3x3 (pad 1) or 1x1 convolution, NHWC, implicit GEMM on MFMA:
+ * y = (conv(x, w) + bias[co] + bias_b[b,co] + res) * out_scale     (layers.py:112-119,141-156;
+ * the fused terms are layerspp.py:306-323).  w: [Cout][taps][Cin] in `dtype` (taps = ky*3+kx). */
+int32_t diffsep_conv2d(const void* x, const void* w, const float* bias, const float* bias_b, const void* res,
+                       void* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                       int32_t ldx, int32_t ldr, int32_t ldy, float out_scale, int32_t dtype, void* stream);
+
+/* AttnBlockpp core (layerspp.py:83-87): o = softmax(q k^T * C^-0.5) v over L = H*W tokens.
+ * q,k [B,L,C] (ld), vt [B,C,Lp] (V transposed, Lp = L rounded up to 8), o [B,L,C];
+ * ws >= B*L*Lp*(2*elt) bytes.  QK^T and PV run on MFMA. */
+int32_t diffsep_attention(const void* q, const void* k, const void* vt, void* o, int32_t B, int32_t L, int32_t C,
+                          int32_t ld, int32_t dtype, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* pre_process (score_models.py:107-116) + the 2x-1 of ncsnpp.py:347-349: cat(xt, mix) -> right pad
+ * n_fft-hop -> STFT(n_fft, hop, periodic Hann, center, zero pad) -> |z|^e e^{j angle} * factor ->
+ * [re x S+1 | im x S+1] channels -> zero-pad frames to W (then 2x-1).
+ * xt [B,S,T], mix [B,1,T] f32 -> y [B, n_fft/2+1, W, Cpad] (dtype), Cpad = roundup(2S+2, 8).
+ * centered_shift != 0 applies 2x-1 (what the engine does); 0 leaves the packed spectrogram. */
+int32_t diffsep_stft_pack(const float* xt, const float* mix, void* y, int32_t B, int32_t S, int64_t T,
+                          int32_t n_fft, int32_t hop, float exponent, float factor, int32_t W, int32_t Cpad,
+                          int32_t centered_shift, int32_t dtype, void* stream);
+
+/* post_process (score_models.py:118-124): unpad frames -> channels to complex -> z/|factor| ->
+ * |z|^(1/e) e^{j angle} -> iSTFT -> crop to T.  x [B,256,W,Cpad] (first 2S channels used) -> out [B,S,T];
+ * ws >= B*S*F*512*4 bytes. */
+int32_t diffsep_istft_unpack(const void* x, float* out, int32_t B, int32_t S, int64_t T, int32_t n_fft,
+                             int32_t hop, float exponent, float factor, int32_t W, int32_t Cpad, int32_t dtype,
+                             void* workspace, int64_t workspace_bytes, void* stream);
+
+/* MixSDE.prior_sampling (sdes/sdes.py:334-346): x_T = 0.5*y (bcast) + L(T) @ z. */
+int32_t diffsep_sde_prior(const diffsep_sde_config* sde, const float* y, const float* z, float* x, int32_t B,
+                          int32_t S, int64_t T, void* stream);
+/* AnnealedLangevinDynamics2.update_fn body for one step given the score
+ * (sdes/correctors.py:115-126). t [B] device. */
+int32_t diffsep_sde_corrector_update(const diffsep_sde_config* sde, float snr, const float* x, const float* t,
+                                     const float* score, const float* z, float* x_out, float* x_mean_out,
+                                     int32_t B, int32_t S, int64_t T, void* stream);
+/* ReverseDiffusionPredictor.update_fn given the score (sdes/predictors.py:60-66 ->
+ * sdes/sdes.py:163-171,93-107,275-284); dt = 1/N. */
+int32_t diffsep_sde_predictor_update(const diffsep_sde_config* sde, int32_t N, const float* x, const float* t,
+                                     const float* score, const float* z, float* x_out, float* x_mean_out,
+                                     int32_t B, int32_t S, int64_t T, void* stream);
+
+/* normalize_batch (pl_model.py:81-88): per-utterance mean / unbiased std (clamped 1e-5) over (1,T).
+ * mix [B,1,T] -> mix_norm; mean,std [B] (nullable). */
+int32_t diffsep_normalize_batch(const float* mix, float* mix_norm, float* mean, float* std, int32_t B, int64_t T,
+                                void* stream);
+/* scale_output (separate.py:73-78): alpha = <mix,sep>/sum(sep^2+1e-10); sep*alpha, in place. */
+int32_t diffsep_scale_output(const float* mix, float* sep, int32_t B, int32_t S, int64_t T, void* stream);
+
+/* on-device standard normal draws (Philox4x32-10 + Box-Muller); used when noise == NULL. */
+int32_t diffsep_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+
+/* float32 <-> engine dtype conversion helper for the tests (n elements). */
+int32_t diffsep_convert(const void* src, void* dst, int64_t n, int32_t src_dtype, int32_t dst_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFSEP_HIP_H */

@@ -1,0 +1,154 @@
+"""Pin the CPU oracle (oracle/diffsep_oracle.py) against outputs of the reference itself
+(tests/golden/golden_ref.npz, produced by tests/golden/gen_golden.py).  CPU only."""
+import numpy as np
+import torch
+
+import diffsep_oracle as O
+from diffsep_amd import synth
+
+torch.set_grad_enabled(False)
+
+
+def rel_rms(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)) / (np.sqrt(np.mean(b ** 2)) + 1e-30))
+
+
+def weights(cfg, seed):
+    return O.to_torch(synth.synth_state_dict(O.param_table(cfg), seed))
+
+
+def test_param_table_matches_reference_state_dict(golden):
+    _, meta = golden
+    for key, cfg in (("param_table_nf16_S2", O.default_config(16, 2)), ("param_table_nf16_S3", O.default_config(16, 3)),
+                     ("param_table_nf64_S2", O.default_config(64, 2)), ("param_table_nf128_S2", O.default_config(128, 2))):
+        mine = [[n, list(s)] for n, s in O.param_table(cfg)]
+        assert mine == meta[key], key
+    n64 = sum(int(np.prod(s)) for _, s in O.param_table(O.default_config(64, 2)))
+    assert n64 == meta["param_count_nf64_S2"] == 16456390  # SURVEY.md §5 / BASELINE.md
+    assert meta["param_count_nf128_S2"] == 65623366
+
+
+def test_fir_resampling(golden):
+    g, _ = golden
+    x = torch.from_numpy(synth.synth_noise("g1.x", (2, 8, 6, 10)))
+    assert np.abs(O.fir_up2(x).numpy() - g["g1_up"]).max() < 1e-6
+    assert np.abs(O.fir_down2(x).numpy() - g["g1_down"]).max() < 1e-6
+
+
+def _block_weights(names_shapes, seed):
+    return O.to_torch(synth.synth_state_dict(names_shapes, seed))
+
+
+def test_resblocks_and_attention(golden):
+    g, _ = golden
+    temb = torch.from_numpy(synth.synth_noise("g4.temb", (2, 32)))
+    for tag, cout, up, down in (("plain", 16, False, False), ("widen", 24, False, False), ("up", 16, True, False),
+                                ("down", 16, False, True)):
+        cin = 16
+        tbl = [("GroupNorm_0.weight", (cin,)), ("GroupNorm_0.bias", (cin,)), ("Conv_0.weight", (cout, cin, 3, 3)),
+               ("Conv_0.bias", (cout,)), ("Dense_0.weight", (cout, 32)), ("Dense_0.bias", (cout,)),
+               ("GroupNorm_1.weight", (cout,)), ("GroupNorm_1.bias", (cout,)), ("Conv_1.weight", (cout, cout, 3, 3)),
+               ("Conv_1.bias", (cout,))]
+        if cin != cout or up or down:
+            tbl += [("Conv_2.weight", (cout, cin, 1, 1)), ("Conv_2.bias", (cout,))]
+        p = _block_weights(tbl, 4)
+        x = torch.from_numpy(synth.synth_noise("g4.x." + tag, (2, cin, 8, 12)))
+        y = O._res_block(p, "", x, temb, up=up, down=down)
+        assert rel_rms(y.numpy(), g["g4_" + tag]) < 2e-6, tag
+    for tag, hw in (("16x16", (16, 16)), ("4x4", (4, 4))):
+        tbl = [("GroupNorm_0.weight", (16,)), ("GroupNorm_0.bias", (16,))]
+        for k in range(4):
+            tbl += [(f"NIN_{k}.W", (16, 16)), (f"NIN_{k}.b", (16,))]
+        p = _block_weights(tbl, 5)
+        x = torch.from_numpy(synth.synth_noise("g5.x." + tag, (2, 16) + hw))
+        assert rel_rms(O._attn_block(p, "", x).numpy(), g["g5_" + tag]) < 2e-6, tag
+
+
+def test_frame_counts_are_exact(golden):
+    _, meta = golden
+    cfg = O.default_config(16, 2)
+    for T, (F, W) in meta["frames"].items():
+        T = int(T)
+        assert O.num_frames(cfg, T) == F
+        assert 64 * ((F + 63) // 64) == W
+    assert meta["frames"]["32000"] == [253, 256] and meta["frames"]["4000"] == [35, 64]
+
+
+def test_pre_post_process(golden):
+    g, _ = golden
+    cfg = O.default_config(16, 2)
+    x = torch.from_numpy(synth.synth_noise("g6.x.4000", (1, 3, 4000))) * 0.3
+    spec, T, n_pad = O.pre_process(cfg, x)
+    assert spec.shape == (1, 6, 256, 64) and n_pad == 29
+    assert rel_rms(spec.numpy(), g["g6_pre_4000"]) < 1e-6
+    y = torch.from_numpy(synth.synth_noise("g6.y.4000", (1, 4, 256, 64))) * 0.2
+    assert rel_rms(O.post_process(cfg, y, T, n_pad).numpy(), g["g6_post_4000"]) < 1e-6
+    for T in (31999, 32000, 32001):
+        x = torch.from_numpy(synth.synth_noise(f"g6.x.{T}", (1, 3, T))) * 0.3
+        spec, _, n_pad = O.pre_process(cfg, x)
+        F = spec.shape[-1] - n_pad
+        assert rel_rms(spec[..., [0, 1, F // 2, F - 2, F - 1]].numpy(), g[f"g6_pre_{T}_frames"]) < 1e-6
+
+
+def test_score_model_forward(golden):
+    g, _ = golden
+    cfg = O.default_config(16, 2)
+    p = weights(cfg, 7)
+    T = 4000
+    xt = torch.from_numpy(synth.synth_noise("g7.xt", (2, 2, T))) * 0.5
+    mix = torch.from_numpy(synth.synth_noise("g7.mix", (2, 1, T))) * 0.5
+    t = torch.tensor([0.7, 0.05])
+    assert rel_rms(O.score_forward(p, cfg, xt, t, mix).numpy(), g["g7_score"]) < 2e-5
+    xb = torch.from_numpy(synth.synth_noise("g7.xb", (1, 6, 256, 64))) * 0.3
+    assert rel_rms(O.ncsnpp_forward(p, cfg, xb, torch.tensor([0.4])).numpy(), g["g7_backbone"]) < 2e-5
+    cfg3 = O.default_config(16, 3)
+    p3 = weights(cfg3, 7)
+    xt3 = torch.from_numpy(synth.synth_noise("g7.xt3", (1, 3, T))) * 0.5
+    mix3 = torch.from_numpy(synth.synth_noise("g7.mix3", (1, 1, T))) * 0.5
+    assert rel_rms(O.score_forward(p3, cfg3, xt3, torch.tensor([0.3]), mix3).numpy(), g["g7_score_S3"]) < 2e-5
+
+
+def test_sde_tables(golden):
+    g, _ = golden
+    cfg = O.default_config()
+    ts = torch.linspace(1.0, 0.03, 30)
+    assert np.array_equal(ts.numpy(), g["g8_timesteps"])
+    ev1, ev2 = O.cov_eigval(cfg, ts)
+    np.testing.assert_allclose(ev1.numpy(), g["g8_ev1"], rtol=2e-6)
+    np.testing.assert_allclose(ev2.numpy(), g["g8_ev2"], rtol=2e-6)
+    np.testing.assert_allclose(O.mix_std(cfg, ts, 2).numpy(), g["g8_std"], rtol=2e-6, atol=1e-9)
+    # SURVEY.md Appendix B known answers (float64 probe of the reference)
+    assert abs(float(ev1[0]) - 2.475e-01) < 1e-6 and abs(float(ev2[0]) - 1.337663e-01) < 1e-6
+    L1 = O.mix_std(cfg, torch.tensor([1.0]), 2)[0]
+    assert abs(float(L1[0, 0]) - 0.4316172) < 1e-6 and abs(float(L1[0, 1]) - 0.0658765) < 1e-6
+
+
+def test_pc_sampler_and_separate(golden):
+    g, meta = golden
+    cfg = O.default_config(16, 2)
+    p = weights(cfg, 7)
+    B, S, T, N, cs = 2, 2, 4000, 3, 1
+    mix = torch.from_numpy(synth.synth_batch(B, T=T)[0])
+    mix_norm, _, _ = O.normalize_batch(mix)
+    assert rel_rms(mix_norm.numpy(), g["g10_mix_norm"]) < 1e-6
+    draws = [torch.from_numpy(synth.synth_noise(f"g9.z{i}", (B, S, T))) for i in range(1 + N * (cs + 1))]
+    assert rel_rms(O.prior_sampling(cfg, mix_norm, draws[0]).numpy(), g["g9_prior"]) < 1e-6
+    sep, nfe = O.pc_sampler(p, cfg, mix_norm, draws, N=N, corrector_steps=cs, snr=0.5, eps=0.03, denoise=True)
+    assert nfe == meta["g9_nfe"] == 6
+    assert rel_rms(sep.numpy(), g["g9_sep"]) < 1e-4
+    sep2, _ = O.pc_sampler(p, cfg, mix_norm, draws, N=N, corrector_steps=cs, snr=0.5, eps=0.03, denoise=False)
+    assert rel_rms(sep2.numpy(), g["g9_sep_nodenoise"]) < 1e-4
+    # isolated updates
+    x0 = torch.from_numpy(synth.synth_noise("g9.x0", (B, S, T))) * 0.5
+    tv = torch.tensor([0.8, 0.2])
+    sc = O.score_forward(p, cfg, x0, tv, mix_norm)
+    xc, xcm = O.corrector_ald2(cfg, x0, tv, sc, draws[1], 0.5)
+    xp, xpm = O.predictor_reverse_diffusion(cfg, x0, tv, sc, draws[2], N)
+    for a, k in ((xc, "g9_corr_x"), (xcm, "g9_corr_mean"), (xp, "g9_pred_x"), (xpm, "g9_pred_mean")):
+        assert rel_rms(a.numpy(), g[k]) < 2e-5, k
+    # separate.separate() on utterance 0 (N=2) and scale_output
+    d1 = [torch.from_numpy(synth.synth_noise(f"g10.z{i}", (1, S, T))) for i in range(5)]
+    out, _ = O.separate(p, cfg, mix[:1], d1, N=2, corrector_steps=1, snr=0.5, eps=0.03, denoise=True)
+    assert rel_rms(out.numpy(), g["g10_separate"]) < 1e-4
+    assert rel_rms(O.scale_output(mix, torch.from_numpy(g["g9_sep"])).numpy(), g["g10_scale_output"]) < 1e-6
