@@ -1,0 +1,102 @@
+"""ctypes binding of libdiffsep_hip.so (include/diffsep_hip.h).  No fallback: if the HIP library
+is missing or a call fails, this raises — the product path never routes around the GPU code."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libdiffsep_hip.so")
+
+F32, BF16 = 0, 1
+SDE_MIX, SDE_PRIORMIX = 0, 1
+PRED_REVERSE_DIFFUSION, PRED_EULER_MARUYAMA, PRED_NONE = 0, 1, 2
+CORR_ALD2, CORR_NONE = 0, 1
+
+
+class ModelConfig(C.Structure):
+    _fields_ = [("nf", C.c_int32), ("num_sources", C.c_int32), ("n_levels", C.c_int32), ("ch_mult", C.c_int32 * 8),
+                ("num_res_blocks", C.c_int32), ("attn_resolution", C.c_int32), ("n_fft", C.c_int32),
+                ("hop", C.c_int32), ("spec_abs_exponent", C.c_float), ("spec_factor", C.c_float),
+                ("dtype", C.c_int32)]
+
+
+class SdeConfig(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("ndim", C.c_int32), ("d_lambda", C.c_float), ("sigma_min", C.c_float),
+                ("sigma_max", C.c_float)]
+
+
+class SamplerConfig(C.Structure):
+    _fields_ = [("N", C.c_int32), ("corrector_steps", C.c_int32), ("snr", C.c_float), ("eps", C.c_float),
+                ("denoise", C.c_int32), ("predictor", C.c_int32), ("corrector", C.c_int32)]
+
+
+class DiffsepError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_P, _I, _L, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
+_SIGS = {
+    "diffsep_last_error": (C.c_char_p, []),
+    "diffsep_version": (C.c_char_p, []),
+    "diffsep_param_count": (_I, [C.POINTER(ModelConfig)]),
+    "diffsep_param_info": (_I, [C.POINTER(ModelConfig), _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(_I),
+                                C.POINTER(_L)]),
+    "diffsep_param_total": (_L, [C.POINTER(ModelConfig)]),
+    "diffsep_engine_create": (_I, [C.POINTER(ModelConfig), _P, _L, C.POINTER(_P)]),
+    "diffsep_engine_destroy": (None, [_P]),
+    "diffsep_engine_device_bytes": (_L, [_P]),
+    "diffsep_num_frames": (_I, [C.POINTER(ModelConfig), _L]),
+    "diffsep_padded_frames": (_I, [C.POINTER(ModelConfig), _L]),
+    "diffsep_score_forward": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
+    "diffsep_backbone_forward": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "diffsep_pc_sample": (_I, [_P, C.POINTER(SdeConfig), C.POINTER(SamplerConfig), _P, _P, _I, _L, _P, _U64, _P,
+                               C.POINTER(_I), _P]),
+    "diffsep_engine_set_graph": (_I, [_P, _I]),
+    "diffsep_upfirdn2d": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "diffsep_groupnorm_act": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _L, _P]),
+    "diffsep_conv2d": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "diffsep_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
+    "diffsep_stft_pack": (_I, [_P, _P, _P, _I, _I, _L, _I, _I, _F, _F, _I, _I, _I, _I, _P]),
+    "diffsep_istft_unpack": (_I, [_P, _P, _I, _I, _L, _I, _I, _F, _F, _I, _I, _I, _P, _L, _P]),
+    "diffsep_sde_prior": (_I, [C.POINTER(SdeConfig), _P, _P, _P, _I, _I, _L, _P]),
+    "diffsep_sde_corrector_update": (_I, [C.POINTER(SdeConfig), _F, _P, _P, _P, _P, _P, _P, _I, _I, _L, _P]),
+    "diffsep_sde_predictor_update": (_I, [C.POINTER(SdeConfig), _I, _P, _P, _P, _P, _P, _P, _I, _I, _L, _P]),
+    "diffsep_normalize_batch": (_I, [_P, _P, _P, _P, _I, _L, _P]),
+    "diffsep_scale_output": (_I, [_P, _P, _I, _I, _L, _P]),
+    "diffsep_randn": (_I, [_P, _L, _U64, _U64, _P]),
+    "diffsep_convert": (_I, [_P, _P, _L, _I, _I, _P]),
+}
+EXPORTS = tuple(_SIGS.keys())
+
+
+def lib():
+    """Load (once) and return the HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DiffsepError(f"{LIB_PATH} not found: build it with __graft_entry__.build() or "
+                               "`make -C diffusion-separation_amd/csrc` (hipcc, gfx950). There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise DiffsepError(lib().diffsep_last_error().decode("utf-8", "replace"))
+
+
+def model_config(nf=64, num_sources=2, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, attn_resolution=16,
+                 n_fft=510, hop=128, spec_abs_exponent=0.5, spec_factor=0.33, dtype=F32):
+    c = ModelConfig()
+    c.nf, c.num_sources, c.n_levels = nf, num_sources, len(ch_mult)
+    for i, m in enumerate(ch_mult):
+        c.ch_mult[i] = m
+    c.num_res_blocks, c.attn_resolution, c.n_fft, c.hop = num_res_blocks, attn_resolution, n_fft, hop
+    c.spec_abs_exponent, c.spec_factor, c.dtype = spec_abs_exponent, spec_factor, dtype
+    return c

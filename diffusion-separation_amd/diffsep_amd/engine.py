@@ -1,0 +1,147 @@
+"""Engine: the Python handle on one device-resident NCSN++ score model + PC sampler.
+
+PyTorch is used for device memory (tensor.data_ptr()), streams and nothing else: every FLOP of
+the path runs in libdiffsep_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import F32, BF16, check, lib
+
+
+def _stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def param_table(cfg):
+    """[(name, shape, offset)] in the canonical (reference state_dict) order."""
+    l = lib()
+    n = l.diffsep_param_count(C.byref(cfg))
+    if n < 0:
+        check(1)
+    out = []
+    name = C.create_string_buffer(256)
+    shape = (C.c_int64 * 4)()
+    ndim = C.c_int32()
+    off = C.c_int64()
+    for i in range(n):
+        check(l.diffsep_param_info(C.byref(cfg), i, name, 256, shape, C.byref(ndim), C.byref(off)))
+        out.append((name.value.decode(), tuple(int(shape[k]) for k in range(ndim.value)), int(off.value)))
+    return out
+
+
+def pack_state_dict(cfg, state, prefix=""):
+    """Flatten {name: array/tensor} into the float32 blob the engine expects. Missing keys raise."""
+    total = lib().diffsep_param_total(C.byref(cfg))
+    blob = np.empty(total, dtype=np.float32)
+    for name, shape, off in param_table(cfg):
+        key = prefix + name
+        if key not in state:
+            raise KeyError(f"checkpoint is missing parameter '{key}'")
+        v = state[key]
+        v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+        if tuple(v.shape) != shape:
+            raise ValueError(f"parameter '{key}' has shape {tuple(v.shape)}, expected {shape}")
+        blob[off:off + v.size] = v.astype(np.float32, copy=False).reshape(-1)
+    return blob
+
+
+class Engine:
+    """Owns the repacked weights and workspace on the current CUDA(HIP) device."""
+
+    def __init__(self, cfg, weights_blob, device=None):
+        if not torch.cuda.is_available():
+            raise _lib.DiffsepError("no GPU visible: the separation engine has no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.cfg = cfg
+        blob = np.ascontiguousarray(weights_blob, dtype=np.float32)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().diffsep_engine_create(C.byref(cfg), blob.ctypes.data_as(C.c_void_p), blob.size,
+                                              C.byref(self._h)))
+        self.S = cfg.num_sources
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().diffsep_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def dtype(self):
+        return self.cfg.dtype
+
+    def device_bytes(self):
+        return int(lib().diffsep_engine_device_bytes(self._h))
+
+    def set_graph(self, enable):
+        check(lib().diffsep_engine_set_graph(self._h, int(bool(enable))))
+
+    def padded_frames(self, T):
+        return int(lib().diffsep_padded_frames(C.byref(self.cfg), T))
+
+    def _f32(self, t):
+        assert t.is_cuda and t.dtype == torch.float32, "device float32 tensor expected"
+        return t.contiguous()
+
+    def score(self, xt, t, mix):
+        """score_fn(x, t, mix) -> [B,S,T]   (DiffSepModel.forward / ScoreModelNCSNpp.forward)."""
+        xt, t, mix = self._f32(xt), self._f32(t), self._f32(mix)
+        B, S, T = xt.shape
+        assert S == self.S and mix.shape == (B, 1, T) and t.shape == (B,)
+        out = torch.empty_like(xt)
+        with torch.cuda.device(self.device):
+            check(lib().diffsep_score_forward(self._h, _ptr(xt), _ptr(t), _ptr(mix), _ptr(out), B, T,
+                                              _stream_ptr(self.device)))
+        return out
+
+    def backbone(self, x_nhwc, t):
+        """NCSNpp.forward on a packed NHWC input [B,256,W,Cpad] (engine dtype storage)."""
+        B, H, W, Cp = x_nhwc.shape
+        t = self._f32(t)
+        cout = ((2 * self.S + 7) // 8) * 8
+        y = torch.zeros((B, H, W, cout), dtype=x_nhwc.dtype, device=x_nhwc.device)
+        with torch.cuda.device(self.device):
+            check(lib().diffsep_backbone_forward(self._h, _ptr(x_nhwc.contiguous()), _ptr(t), _ptr(y), B, W,
+                                                 _stream_ptr(self.device)))
+        return y
+
+    def pc_sample(self, mix_norm, sde, N=30, corrector_steps=1, snr=0.5, eps=0.03, denoise=True,
+                  predictor="reverse_diffusion", corrector="ald2", noise=None, seed=0, timesteps=None):
+        """The whole sampler (sdes.get_pc_sampler(...)()).  sde: dict(kind, ndim, d_lambda, sigma_min, sigma_max)."""
+        mix_norm = self._f32(mix_norm)
+        B, one, T = mix_norm.shape
+        assert one == 1
+        sc = _lib.SdeConfig(sde.get("kind", _lib.SDE_MIX), sde["ndim"], sde["d_lambda"], sde["sigma_min"],
+                            sde["sigma_max"])
+        pred = {"reverse_diffusion": _lib.PRED_REVERSE_DIFFUSION, "none": _lib.PRED_NONE}[predictor]
+        corr = {"ald2": _lib.CORR_ALD2, "none": _lib.CORR_NONE}[corrector]
+        sm = _lib.SamplerConfig(N, corrector_steps, snr, eps, int(bool(denoise)), pred, corr)
+        out = torch.empty((B, self.S, T), dtype=torch.float32, device=mix_norm.device)
+        if noise is not None:
+            noise = self._f32(noise)
+            ncs = corrector_steps if corrector == "ald2" else 0
+            npred = 1 if predictor == "reverse_diffusion" else 0
+            assert noise.shape == (1 + N * (ncs + npred), B, self.S, T), "noise must be [draws,B,S,T]"
+        ts = None
+        if timesteps is not None:
+            ts = np.ascontiguousarray(timesteps, dtype=np.float32)
+            assert ts.size >= N
+        nfe = C.c_int32()
+        with torch.cuda.device(self.device):
+            check(lib().diffsep_pc_sample(self._h, C.byref(sc), C.byref(sm), _ptr(mix_norm), _ptr(out), B, T,
+                                          _ptr(noise), seed, ts.ctypes.data_as(C.c_void_p) if ts is not None else None,
+                                          C.byref(nfe), _stream_ptr(self.device)))
+        return out, int(nfe.value)

@@ -1,0 +1,149 @@
+"""Unit-op wrappers over the C-ABI (parity tests call the kernels through these).
+Activations are NHWC torch tensors on the GPU; bf16 is torch.bfloat16 storage."""
+import ctypes as C
+
+import torch
+
+from ._lib import F32, BF16, SdeConfig, SDE_MIX, check, lib
+from .engine import _ptr, _stream_ptr
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("float32 or bfloat16 expected")
+
+
+def to_nhwc(x, cpad=None):
+    """NCHW torch tensor -> contiguous NHWC (optionally zero-padded to cpad channels)."""
+    y = x.permute(0, 2, 3, 1).contiguous()
+    if cpad is not None and cpad > y.shape[-1]:
+        y = torch.nn.functional.pad(y, (0, cpad - y.shape[-1]))
+    return y.contiguous()
+
+
+def to_nchw(y, c=None):
+    y = y.permute(0, 3, 1, 2)
+    return (y if c is None else y[:, :c]).contiguous()
+
+
+def pack_conv_weight(w, dtype):
+    """OIHW float32 -> [O][taps][Ipad] in `dtype` (Ipad = roundup(I, 8))."""
+    O, I, kh, kw = w.shape
+    wp = w.permute(0, 2, 3, 1).reshape(O, kh * kw, I)
+    ipad = (I + 7) // 8 * 8
+    if ipad != I:
+        wp = torch.nn.functional.pad(wp, (0, ipad - I))
+    return wp.contiguous().to(dtype)
+
+
+def upfirdn2d(x, up):
+    B, H, W, Cc = x.shape
+    Ho, Wo = (2 * H, 2 * W) if up else (H // 2, W // 2)
+    y = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    check(lib().diffsep_upfirdn2d(_ptr(x), _ptr(y), B, H, W, Cc, Cc, Cc, int(up), _dt(x), _stream_ptr()))
+    return y
+
+
+def groupnorm_act(x, gamma, beta, groups, eps=1e-6, act=1, resample=0, want_xr=False):
+    B, H, W, Cc = x.shape
+    Ho, Wo = {0: (H, W), 1: (2 * H, 2 * W), 2: (H // 2, W // 2)}[resample]
+    y = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    xr = torch.empty_like(y) if want_xr else None
+    ws = torch.empty(B * 64 * Cc * 16 + 2 * B * Cc * 4 + 4096, dtype=torch.uint8, device=x.device)
+    check(lib().diffsep_groupnorm_act(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(xr), B, H, W, Cc, Cc, Cc, Cc,
+                                      groups, eps, act, resample, _dt(x), _ptr(ws), ws.numel(), _stream_ptr()))
+    return (y, xr) if want_xr else y
+
+
+def conv2d(x, wpacked, bias, cout, ksize, bias_b=None, res=None, out_scale=1.0, cout_pad=None):
+    B, H, W, Cin = x.shape
+    cp = cout if cout_pad is None else cout_pad
+    y = torch.zeros((B, H, W, cp), dtype=x.dtype, device=x.device)
+    check(lib().diffsep_conv2d(_ptr(x), _ptr(wpacked), _ptr(bias), _ptr(bias_b), _ptr(res), _ptr(y), B, H, W, Cin,
+                               cout, ksize, Cin, res.shape[-1] if res is not None else 0, cp, out_scale, _dt(x),
+                               _stream_ptr()))
+    return y
+
+
+def attention(q, k, vt):
+    B, L, Cc = q.shape
+    Lp = (L + 7) // 8 * 8
+    assert vt.shape == (B, Cc, Lp)
+    o = torch.empty_like(q)
+    ws = torch.empty(2 * (B * L * Lp * q.element_size() + 256), dtype=torch.uint8, device=q.device)
+    check(lib().diffsep_attention(_ptr(q), _ptr(k), _ptr(vt), _ptr(o), B, L, Cc, Cc, _dt(q), _ptr(ws), ws.numel(),
+                                  _stream_ptr()))
+    return o
+
+
+def stft_pack(xt, mix, W, cpad, n_fft=510, hop=128, exponent=0.5, factor=0.33, shift=False, dtype=torch.float32):
+    B, S, T = xt.shape
+    y = torch.empty((B, n_fft // 2 + 1, W, cpad), dtype=dtype, device=xt.device)
+    check(lib().diffsep_stft_pack(_ptr(xt), _ptr(mix), _ptr(y), B, S, T, n_fft, hop, exponent, factor, W, cpad,
+                                  int(shift), F32 if dtype == torch.float32 else BF16, _stream_ptr()))
+    return y
+
+
+def istft_unpack(x, S, T, n_fft=510, hop=128, exponent=0.5, factor=0.33):
+    B, H, W, cpad = x.shape
+    F_ = 1 + (T + n_fft - hop) // hop
+    out = torch.empty((B, S, T), dtype=torch.float32, device=x.device)
+    ws = torch.empty(B * S * F_ * 512, dtype=torch.float32, device=x.device)
+    check(lib().diffsep_istft_unpack(_ptr(x), _ptr(out), B, S, T, n_fft, hop, exponent, factor, W, cpad, _dt(x),
+                                     _ptr(ws), ws.numel() * 4, _stream_ptr()))
+    return out
+
+
+def _sde(s):
+    return SdeConfig(s.get("kind", SDE_MIX), s["ndim"], s["d_lambda"], s["sigma_min"], s["sigma_max"])
+
+
+def sde_prior(sde, y, z):
+    B, S, T = z.shape
+    x = torch.empty_like(z)
+    sc = _sde(sde)
+    check(lib().diffsep_sde_prior(C.byref(sc), _ptr(y), _ptr(z), _ptr(x), B, S, T, _stream_ptr()))
+    return x
+
+
+def sde_corrector_update(sde, snr, x, t, score, z):
+    B, S, T = x.shape
+    xo, xm = torch.empty_like(x), torch.empty_like(x)
+    sc = _sde(sde)
+    check(lib().diffsep_sde_corrector_update(C.byref(sc), snr, _ptr(x), _ptr(t), _ptr(score), _ptr(z), _ptr(xo),
+                                             _ptr(xm), B, S, T, _stream_ptr()))
+    return xo, xm
+
+
+def sde_predictor_update(sde, N, x, t, score, z):
+    B, S, T = x.shape
+    xo, xm = torch.empty_like(x), torch.empty_like(x)
+    sc = _sde(sde)
+    check(lib().diffsep_sde_predictor_update(C.byref(sc), N, _ptr(x), _ptr(t), _ptr(score), _ptr(z), _ptr(xo),
+                                             _ptr(xm), B, S, T, _stream_ptr()))
+    return xo, xm
+
+
+def normalize_batch(mix):
+    B, _, T = mix.shape
+    out = torch.empty_like(mix)
+    mean = torch.empty(B, dtype=torch.float32, device=mix.device)
+    std = torch.empty(B, dtype=torch.float32, device=mix.device)
+    check(lib().diffsep_normalize_batch(_ptr(mix), _ptr(out), _ptr(mean), _ptr(std), B, T, _stream_ptr()))
+    return out, mean.view(B, 1, 1), std.view(B, 1, 1)
+
+
+def scale_output(mix, sep):
+    B, S, T = sep.shape
+    out = sep.clone()
+    check(lib().diffsep_scale_output(_ptr(mix), _ptr(out), B, S, T, _stream_ptr()))
+    return out
+
+
+def randn(n, seed, stream_id, device="cuda"):
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    check(lib().diffsep_randn(_ptr(out), n, seed, stream_id, _stream_ptr()))
+    return out

@@ -1,0 +1,86 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU, exports every
+symbol include/diffsep_hip.h declares, and its parameter table / frame arithmetic (pure host code)
+agree with the oracle and therefore with the reference.  No compute call is made here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import diffsep_oracle as O
+from diffsep_amd import _lib
+from diffsep_amd.engine import pack_state_dict, param_table
+from diffsep_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_header_symbols():
+    l = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "diffsep_hip.h")).read()
+    declared = set(re.findall(r"\b(diffsep_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    for name in sorted(declared):
+        assert hasattr(l, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert b"gfx950" in l.diffsep_version()
+
+
+@pytest.mark.parametrize("nf,S", [(16, 2), (16, 3), (64, 2), (128, 2)])
+def test_param_table_is_reference_state_dict_order(golden, nf, S):
+    _, meta = golden
+    cfg = _lib.model_config(nf=nf, num_sources=S)
+    mine = [[n, list(s)] for n, s, _ in param_table(cfg)]
+    assert mine == meta[f"param_table_nf{nf}_S{S}"]
+    assert mine == [[n, list(s)] for n, s in O.param_table(O.default_config(nf, S))]
+    offs = [o for _, _, o in param_table(cfg)]
+    sizes = [int(np.prod(s)) for _, s, _ in param_table(cfg)]
+    assert offs == list(np.cumsum([0] + sizes[:-1]))
+    assert _lib.lib().diffsep_param_total(C.byref(cfg)) == sum(sizes)
+
+
+def test_frame_arithmetic_is_bit_exact(golden):
+    _, meta = golden
+    cfg = _lib.model_config()
+    l = _lib.lib()
+    for T, (F, W) in meta["frames"].items():
+        assert l.diffsep_num_frames(C.byref(cfg), int(T)) == F
+        assert l.diffsep_padded_frames(C.byref(cfg), int(T)) == W
+    for T in (1, 127, 128, 129, 382, 383, 48000, 64000, 64001):
+        F = 1 + (T + 382) // 128
+        assert l.diffsep_num_frames(C.byref(cfg), T) == F
+        assert l.diffsep_padded_frames(C.byref(cfg), T) == 64 * ((F + 63) // 64)
+
+
+def test_pack_state_dict_roundtrip_and_errors():
+    cfg = _lib.model_config(nf=16)
+    table = [(n, s) for n, s, _ in param_table(cfg)]
+    sd = synth.synth_state_dict(table, 3)
+    blob = pack_state_dict(cfg, sd)
+    for n, s, off in param_table(cfg):
+        assert np.array_equal(blob[off:off + sd[n].size], sd[n].reshape(-1))
+    bad = dict(sd)
+    bad.pop("all_modules.3.weight")
+    with pytest.raises(KeyError):
+        pack_state_dict(cfg, bad)
+    bad = dict(sd)
+    bad["all_modules.3.weight"] = bad["all_modules.3.weight"][:, :, :1]
+    with pytest.raises(ValueError):
+        pack_state_dict(cfg, bad)
+
+
+def test_bad_config_reports_error_without_gpu():
+    cfg = _lib.model_config(nf=12)  # not a multiple of 8
+    assert _lib.lib().diffsep_param_count(C.byref(cfg)) < 0
+    assert b"nf" in _lib.lib().diffsep_last_error()
+
+
+def test_engine_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from diffsep_amd.engine import Engine
+    cfg = _lib.model_config(nf=16)
+    with pytest.raises(_lib.DiffsepError):
+        Engine(cfg, np.zeros(10, np.float32))
