@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — separated utterances/s of the reverse-diffusion hot path on N MI355X of one node.
+
+A "step" = one full pass of the hot path over one resident batch per GPU:
+    normalize_batch -> PC sampler (N=30 reverse steps, 1 ald2 corrector step => 60 network
+    evaluations, on-device Philox noise) -> scale_output [-> RCCL gather of the waveforms to rank 0]
+on B=16 synthetic 4 s / 8 kHz 2-speaker mixtures per GPU (BASELINE.json configs[1]), NCSN++ nf=64
+with random-init weights (no checkpoint can be downloaded here), bf16 activations/weights with fp32
+accumulation.  Utterances shard embarrassingly: every rank owns its own 16 utterances (weak
+scaling) and the only collective is the result gather.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     — the dominant kernel (3x3 implicit-GEMM conv on MFMA, 8x32 pixel x 64 cout tile):
+                 algorithmic FLOPs of its launches / their summed durations, measured with HIP events
+                 on the launch stream in one extra, untimed pass of the same step right after the
+                 timed region (diffsep_engine_profile_begin/end).
+  cpu_baseline — the CPU oracle (torch fp32, this repo's restatement of the reference path) timed on
+                 the host cores for a bounded number of network evaluations and scaled to utt/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "diffusion-separation_amd"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+GFLOP_PER_NFE = {64: 133.83, 128: 532.89}  # SURVEY.md §8d, per utterance at W=256 (probe-counted 2*MAC)
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # MI355X_MICROARCH.md: dense MFMA peaks
+
+
+def cpu_baseline(nf, T, budget_s=12.0, max_nfe=12):
+    """Time the oracle's score evaluation (the 99 % of the path) on the host cores."""
+    import diffsep_oracle as O
+    from diffsep_amd import synth
+    torch.set_grad_enabled(False)
+    cfg = O.default_config(nf, 2)
+    p = O.to_torch(synth.synth_state_dict(O.param_table(cfg), 7))
+    mix = torch.from_numpy(synth.synth_batch(1, T=T)[0])
+    mix_norm, _, _ = O.normalize_batch(mix)
+    xt = O.prior_sampling(cfg, mix_norm, torch.from_numpy(synth.synth_noise("cpu.z", (1, 2, T))))
+    t = torch.tensor([0.5])
+    O.score_forward(p, cfg, xt, t, mix_norm)  # warm-up (oneDNN primitive creation)
+    n, t0 = 0, time.perf_counter()
+    while n < max_nfe and (time.perf_counter() - t0 < budget_s or n < 2):
+        O.score_forward(p, cfg, xt, t, mix_norm)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return dt, n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="utterances per GPU")
+    ap.add_argument("--nf", type=int, default=64)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--samples", type=int, default=32000, help="samples per utterance (4 s at 8 kHz)")
+    ap.add_argument("-N", type=int, default=30)
+    ap.add_argument("--corrector-steps", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from diffsep_amd import _lib, ops, synth
+    from diffsep_amd.engine import Engine, pack_state_dict, param_table
+    torch.set_grad_enabled(False)
+
+    B, T, S = args.batch, args.samples, 2
+    dt_flag = _lib.BF16 if args.dtype == "bf16" else _lib.F32
+    cfg = _lib.model_config(nf=args.nf, num_sources=S, dtype=dt_flag)
+    sd = synth.synth_state_dict([(n, s) for n, s, _ in param_table(cfg)], 7)
+    eng = Engine(cfg, pack_state_dict(cfg, sd))
+    if args.no_graph:
+        eng.set_graph(False)
+    sde = dict(ndim=S, d_lambda=2.0, sigma_min=0.05, sigma_max=0.5)
+    mix = torch.from_numpy(synth.synth_batch(B, T=T, start=rank * B)[0]).cuda()  # resident before timing
+    gathered = [torch.empty((B, S, T), dtype=torch.float32, device="cuda") for _ in range(world)] if rank == 0 else None
+
+    stream = torch.cuda.Stream()
+
+    def step(i):
+        mix_norm, _, _ = ops.normalize_batch(mix)
+        sep, nfe = eng.pc_sample(mix_norm, sde, N=args.N, corrector_steps=args.corrector_steps, snr=0.5, eps=0.03,
+                                 denoise=True, seed=1000 + i)
+        out = ops.scale_output(mix, sep)
+        if world > 1:
+            dist.gather(out, gathered, dst=0)  # RCCL over xGMI: the only collective on the path
+        return out, nfe
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        for i in range(args.warmup):
+            out, nfe = step(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out, nfe = step(args.warmup + i)
+        fence()
+        elapsed = time.perf_counter() - t0
+        finite = bool(torch.isfinite(out).all())
+
+        roof = None
+        if not args.no_roofline and rank == 0:
+            eng.profile_begin()
+            step(10_000)
+            prof = eng.profile_end()
+            fl, ms, n = prof["conv3x3_8x32xN64"]
+            tot_ms = sum(v[1] for v in prof.values())
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            peak = PEAK_TFLOPS[args.dtype]
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_conv3x3.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get(f"hbm_bytes_per_launch_{args.dtype}_B{B}")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "mfma", "kernel": "conv_mfma_kernel<%s,9,8,32,64,2,2>" % args.dtype,
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": traffic, "launches": n, "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
+                    "flops_per_launch": fl / max(n, 1),
+                    "all_mfma_kernels_ms": round(tot_ms, 2),
+                    "all_mfma_kernels_tflops": round(sum(v[0] for v in prof.values()) / (tot_ms * 1e-3) / 1e12, 2)}
+
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        utt = B * world * args.steps
+        value = utt / elapsed
+        res = {
+            "metric": "separated utterances/sec (4 s, 8 kHz, 2-spk, N=30 PC steps)",
+            "value": round(value, 4), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs[1]: 2-spk N=%d PC sampler (+%d ald2 corrector step), batch=%d x %.1f s @ 8 kHz "
+                                   "per GPU, NCSN++ nf=%d random-init, %d NFE/step" %
+                                   (args.N, args.corrector_steps, B, T / 8000.0, args.nf, nfe),
+                       "batch_per_gpu": B, "samples": T, "N": args.N, "corrector_steps": args.corrector_steps,
+                       "nf": args.nf, "sharding": "utterances/%d" % world, "graph": not args.no_graph},
+            "realtime_factor": round(value * T / 8000.0, 2),
+            "nfe_per_s": round(value * nfe, 1),
+            "model_tflops": round(value * nfe * GFLOP_PER_NFE.get(args.nf, float("nan")) * (T / 32000.0) / 1e3, 2),
+            "finite": finite,
+            "device_bytes": eng.device_bytes(),
+        }
+        if roof is not None:
+            res["roofline"] = roof
+        if not args.no_cpu_baseline and world == 1:
+            t_nfe, n = cpu_baseline(args.nf, T)
+            res["cpu_baseline"] = {"value": round(1.0 / (t_nfe * nfe), 5), "unit": "utterances/s",
+                                   "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": "%d score evaluations (STFT->NCSN++ nf=%d->iSTFT) of the fp32 torch-CPU oracle at "
+                                             "B=1, T=%d: %.3f s each; x%d NFE per utterance" % (n, args.nf, T, t_nfe, nfe)}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

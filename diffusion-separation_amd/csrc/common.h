@@ -127,6 +127,7 @@ struct ConvArgs {
   int dtype;
 };
 int ds_launch_conv(const ConvArgs& a, hipStream_t st);
+int ds_conv_config_id(const ConvArgs& a);
 
 // GroupNorm: stats -> per-(b,c) scale/shift -> apply(+SiLU)(+FIR resample)
 // ws layout: doubles [B][nblk][C][2] then floats scale[B][C], shift[B][C]

@@ -248,6 +248,17 @@ static int launch_typed(const ConvArgs& a, hipStream_t st) {
   return launch_cfg<T, 1, 8, 8, 64, 1, 1, KC1>(a, st);
 }
 
+// Which instantiation ds_launch_conv picks (profiling label): 0/1/2 = 3x3 {8x32xBN64, 8x32xBN32, 8x8xBN64},
+// 3/4/5 = the same tiles for 1x1 / GEMM.
+int ds_conv_config_id(const ConvArgs& a) {
+  if (a.taps == 9) {
+    if (a.W >= 32 && a.H >= 8) return a.Cout <= 32 ? 1 : 0;
+    return 2;
+  }
+  if ((long)a.H * a.W >= 1024) return a.Cout <= 32 ? 4 : 3;
+  return 5;
+}
+
 int ds_launch_conv(const ConvArgs& a, hipStream_t st) {
   DS_CHECK(a.taps == 1 || a.taps == 9, "conv: taps must be 1 or 9");
   DS_CHECK(a.Cin % 8 == 0 && a.ldx % 8 == 0, "conv: Cin and ldx must be multiples of 8");

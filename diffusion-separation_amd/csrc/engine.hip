@@ -308,7 +308,31 @@ struct diffsep_engine {
   // mapped to this private stream, ordered against the null stream with events on both sides.
   hipStream_t own = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  // optional per-launch timing of the MFMA kernels (HIP events on the launch stream)
+  bool prof = false;
+  struct ProfRec { hipEvent_t a, b; double flops; int cls; };
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> ev_pool;
 };
+#define DS_NCLS 6
+static hipEvent_t prof_event(diffsep_engine* e) {
+  if (!e->ev_pool.empty()) { hipEvent_t v = e->ev_pool.back(); e->ev_pool.pop_back(); return v; }
+  hipEvent_t v = nullptr;
+  hipEventCreate(&v);
+  return v;
+}
+static int conv_launch_prof(diffsep_engine* e, const ConvArgs& a, hipStream_t st) {
+  if (!e->prof) return ds_launch_conv(a, st);
+  diffsep_engine::ProfRec r;
+  r.a = prof_event(e); r.b = prof_event(e);
+  r.flops = 2.0 * a.taps * (double)a.Cin * a.Cout * (double)a.H * a.W * a.B;
+  r.cls = ds_conv_config_id(a);
+  hipEventRecord(r.a, st);
+  const int rc = ds_launch_conv(a, st);
+  hipEventRecord(r.b, st);
+  e->prof_recs.push_back(r);
+  return rc;
+}
 
 struct StreamScope {
   diffsep_engine* e; hipStream_t user; hipStream_t st;
@@ -356,7 +380,7 @@ static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias
   a.out_scale = scale;
   a.y = y.p; a.y_bs = (long)y.H * y.W * y.ld; a.ldy = y.ld;
   a.B = B; a.H = x.H; a.W = x.W; a.Cin = x.C; a.Cout = Cout; a.taps = taps; a.dtype = e->cfg.dtype;
-  return ds_launch_conv(a, st);
+  return conv_launch_prof(e, a, st);
 }
 
 struct GnAff { float* scale; float* shift; };
@@ -732,6 +756,34 @@ extern "C" int32_t diffsep_engine_set_graph(diffsep_engine* e, int32_t enable) {
   return 0;
 }
 
+// Per-launch timing of the MFMA contraction kernels inside the real launch sequence: between
+// profile_begin and profile_end every conv/GEMM launch is bracketed by HIP events on its stream
+// (graph replay is bypassed meanwhile).  Arrays have 6 entries: 3x3 {8x32xBN64, 8x32xBN32, 8x8xBN64},
+// then the same three tiles for 1x1/GEMM.  flops = algorithmic 2*taps*Cin*Cout*H*W*B (unpadded).
+extern "C" int32_t diffsep_engine_profile_begin(diffsep_engine* e) {
+  DS_CHECK(e, "null engine");
+  e->prof = true;
+  e->prof_recs.clear();
+  return 0;
+}
+extern "C" int32_t diffsep_engine_profile_end(diffsep_engine* e, double* flops, double* ms, int64_t* launches) {
+  DS_CHECK(e && flops && ms && launches, "profile_end: null argument");
+  DS_HIP(hipDeviceSynchronize());
+  for (int i = 0; i < DS_NCLS; ++i) { flops[i] = 0; ms[i] = 0; launches[i] = 0; }
+  for (auto& r : e->prof_recs) {
+    float t = 0.f;
+    hipEventElapsedTime(&t, r.a, r.b);
+    flops[r.cls] += r.flops;
+    ms[r.cls] += t;
+    launches[r.cls] += 1;
+    e->ev_pool.push_back(r.a);
+    e->ev_pool.push_back(r.b);
+  }
+  e->prof_recs.clear();
+  e->prof = false;
+  return 0;
+}
+
 extern "C" int32_t diffsep_score_forward(diffsep_engine* e, const float* xt, const float* t, const float* mix,
                                          float* out, int32_t B, int64_t T, void* stream) {
   DS_CHECK(e && xt && t && mix && out, "score_forward: null argument");
@@ -780,7 +832,7 @@ __global__ void bcast_rows_kernel(const float* __restrict__ v, float* __restrict
 
 static int run_nfe(diffsep_engine* e, int B, long T, hipStream_t st) {
   // one score evaluation on the resident state: (st_x, st_t, st_mix) -> st_score
-  if (e->use_graph && e->warmed) {
+  if (e->use_graph && e->warmed && !e->prof) {
     if (!e->graph_ok) {
       DS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
       const int rc = score_forward_impl(e, e->st_x, e->st_t, e->st_mix, e->st_score, B, T, st);

@@ -89,6 +89,18 @@ class Engine:
     def set_graph(self, enable):
         check(lib().diffsep_engine_set_graph(self._h, int(bool(enable))))
 
+    CONV_CLASSES = ("conv3x3_8x32xN64", "conv3x3_8x32xN32", "conv3x3_8x8xN64", "gemm1x1_256xN64", "gemm1x1_256xN32",
+                    "gemm1x1_64xN64")
+
+    def profile_begin(self):
+        check(lib().diffsep_engine_profile_begin(self._h))
+
+    def profile_end(self):
+        """{class: (algorithmic flops, milliseconds, launches)} of the MFMA kernels since profile_begin."""
+        fl, ms, n = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_int64 * 6)()
+        check(lib().diffsep_engine_profile_end(self._h, fl, ms, n))
+        return {k: (fl[i], ms[i], int(n[i])) for i, k in enumerate(self.CONV_CLASSES)}
+
     def padded_frames(self, T):
         return int(lib().diffsep_padded_frames(C.byref(self.cfg), T))
 
