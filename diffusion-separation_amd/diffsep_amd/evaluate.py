@@ -1,0 +1,141 @@
+"""evaluate.py — the sampler + timing part of the reference's evaluate.py / evaluate_mp.py
+(evaluate.py:322-443, evaluate_mp.py:154-326,495-528) on the HIP engine, one rank per GPU.
+
+    python -m diffsep_amd.evaluate --synthetic 32 --synthetic-weights 64 -o out/            (1 GPU)
+    python -m torch.distributed.run --nproc-per-node 8 -m diffsep_amd.evaluate ...          (8 GPUs)
+
+Utterances are sharded over ranks in contiguous ranges (evaluate_mp.py:495-503); each rank separates its
+share, records {batch_idx, si_sdr, nfe, runtime, len_s} per utterance (evaluate.py:394-405; runtime is
+measured WITH a device sync, unlike evaluate.py:374-376) and rank 0 gathers everything (RCCL) and writes
+results.json + results_summary.json.  Dataset: --dataset-dir ROOT with WSJ0-mix style sub-folders
+mix/, s1/, s2/ (datasets/wsj0_mix.py:64-92) or --synthetic N speech-like mixtures.  SI-SDR (scale-invariant
+SDR with the best source permutation) is computed in the normalised domain like evaluate.py:360,382.
+"""
+import argparse
+import itertools
+import json
+import os
+import time
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+
+from . import synth, wavio
+from .dist_utils import gather_objects, shard_range
+from .pl_model import DiffSepModel, cfg_get, default_config
+
+
+def si_sdr_pit(est, ref):
+    """est, ref [S,T] -> (best mean SI-SDR dB, per-source list) over source permutations (zero_mean=False)."""
+    S = ref.shape[0]
+    best, best_vals = None, None
+    for perm in itertools.permutations(range(S)):
+        e = est[list(perm)]
+        a = (e * ref).sum(-1, keepdim=True) / (ref * ref).sum(-1, keepdim=True).clamp(min=1e-20)
+        num = ((a * ref) ** 2).sum(-1)
+        den = ((e - a * ref) ** 2).sum(-1).clamp(min=1e-20)
+        v = 10 * torch.log10(num / den)
+        if best is None or float(v.mean()) > best:
+            best, best_vals = float(v.mean()), [float(x) for x in v]
+    return best, best_vals
+
+
+def load_dataset(args, fs):
+    if args.dataset_dir:
+        root = Path(args.dataset_dir)
+        names = sorted(p.name for p in (root / "mix").glob("*.wav"))
+        if args.limit:
+            names = names[: args.limit]
+
+        def get(i):
+            mix, _ = wavio.load(root / "mix" / names[i])
+            tgt = torch.cat([wavio.load(root / f"s{k + 1}" / names[i])[0][:1] for k in range(args.n_speakers)], 0)
+            return mix[:1], tgt
+        return len(names), get
+    n = args.synthetic
+
+    def get(i):
+        mix, tgt = synth.synth_mixture(i, T=args.samples, fs=fs, n_src=args.n_speakers)
+        return torch.from_numpy(mix), torch.from_numpy(tgt)
+    return n, get
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("ckpt", nargs="?", default=None)
+    ap.add_argument("--synthetic-weights", type=int, default=0, metavar="NF")
+    ap.add_argument("--dataset-dir", type=str, default=None)
+    ap.add_argument("--synthetic", type=int, default=0, help="number of synthetic mixtures")
+    ap.add_argument("--samples", type=int, default=32000)
+    ap.add_argument("--n-speakers", type=int, default=2)
+    ap.add_argument("-l", "--limit", type=int, default=None)
+    ap.add_argument("-N", type=int, default=None)
+    ap.add_argument("--snr", type=float, default=None)
+    ap.add_argument("--corrector-steps", type=int, default=None)
+    ap.add_argument("--schedule", type=str, default=None)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("-o", "--output-dir", type=Path, default=Path("results"))
+    ap.add_argument("--save-wav", action="store_true")
+    args = ap.parse_args(argv)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("No GPU visible: this build has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.synthetic_weights or args.ckpt is None:
+        model = DiffSepModel(default_config(nf=args.synthetic_weights or 64, n_speakers=args.n_speakers), dtype=args.dtype)
+    else:
+        model = DiffSepModel.load_from_checkpoint(args.ckpt, dtype=args.dtype)
+    fs = cfg_get(model.config, "model.fs", 8000)
+    N = cfg_get(model.config, "model.sampler.N", 30) if args.N is None else args.N
+    cs = cfg_get(model.config, "model.sampler.corrector_steps", 1) if args.corrector_steps is None else args.corrector_steps
+    snr = cfg_get(model.config, "model.sampler.snr", 0.5) if args.snr is None else args.snr
+
+    n, get = load_dataset(args, fs)
+    lo, hi = shard_range(n, world, rank)
+    records = []
+    for i in range(lo, hi):
+        mix, tgt = get(i)
+        mix, tgt = mix[None].cuda(), tgt[None].cuda()
+        (mix_n, tgt_n), *_ = model.normalize_batch((mix, tgt))
+        sampler = model.get_pc_sampler("reverse_diffusion", "ald2", mix_n, N=N, corrector_steps=cs, snr=snr,
+                                       denoise=True, intermediate=False, schedule=args.schedule)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        est, nfe, *_ = sampler()
+        torch.cuda.synchronize()
+        runtime = time.perf_counter() - t0
+        sdr, per = si_sdr_pit(est[0], tgt_n[0])
+        records.append({"batch_idx": i, "si_sdr": sdr, "si_sdr_per_source": per, "nfe": int(nfe), "runtime": runtime,
+                        "len_s": mix.shape[-1] / fs})
+        if args.save_wav:
+            d = args.output_dir / "wav"
+            d.mkdir(parents=True, exist_ok=True)
+            for k in range(est.shape[1]):
+                wavio.save(d / f"{i:05d}_s{k}.wav", est[0, k:k + 1].cpu() * 0.1, fs)
+    allrec = gather_objects(records)
+    if rank == 0:
+        flat = sorted([r for part in allrec for r in part], key=lambda r: r["batch_idx"])
+        args.output_dir.mkdir(parents=True, exist_ok=True)
+        with open(args.output_dir / "results.json", "w") as f:
+            json.dump(flat, f, indent=1)
+        tot_rt = sum(r["runtime"] for r in flat)
+        summary = {"n": len(flat), "si_sdr": sum(r["si_sdr"] for r in flat) / max(len(flat), 1),
+                   "runtime": tot_rt / max(len(flat), 1), "nfe": flat[0]["nfe"] if flat else 0,
+                   "rtf": tot_rt / max(sum(r["len_s"] for r in flat), 1e-9), "world_size": world}
+        with open(args.output_dir / "results_summary.json", "w") as f:
+            json.dump(summary, f, indent=1)
+        print(json.dumps(summary))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,150 @@
+"""DiffSepModel — inference members of the reference LightningModule (pl_model.py:95-759) re-hosted on
+the HIP engine: checkpoint loading incl. the EMA swap (pl_model.py:642-670), normalize_batch (:81-92),
+forward = score_fn (:407-409), get_pc_sampler (:687-759), separate (:148-164).  Training members are out
+of scope."""
+import math
+
+import torch
+
+from . import ops, sdes
+from .engine import param_table
+from .score_models import ScoreModelNCSNpp
+from .sdes import MixSDE
+
+
+def cfg_get(cfg, path, default=None):
+    """Read 'a.b.c' from dicts / attribute objects / OmegaConf nodes alike."""
+    cur = cfg
+    for k in path.split("."):
+        if cur is None:
+            return default
+        if isinstance(cur, dict):
+            cur = cur.get(k, None)
+        else:
+            try:
+                cur = cur[k]
+            except Exception:
+                cur = getattr(cur, k, None)
+    return default if cur is None else cur
+
+
+def normalize_batch(batch):
+    """pl_model.py:81-88: mix [B,1,T] -> zero mean / unit (unbiased) std per utterance, std clamped at 1e-5.
+    The reduction + scaling of the mixture run in the HIP kernel; the optional target only reuses mean/std."""
+    mix, tgt = batch
+    if mix.shape[1] != 1:
+        raise ValueError("normalize_batch expects a single-channel mixture [B,1,T]")
+    mix_n, mean, std = ops.normalize_batch(mix.contiguous().float())
+    if tgt is not None:
+        tgt = (tgt - mean) / std
+    return (mix_n, tgt), mean, std
+
+
+def denormalize_batch(x, mean, std):
+    return x * std + mean
+
+
+def default_config(nf=64, n_speakers=2, fs=8000, spec_factor=0.33):
+    """config/model/default.yaml restated as a plain dict (values only)."""
+    return {"model": {
+        "n_speakers": n_speakers, "fs": fs, "t_eps": 0.03,
+        "score_model": {"num_sources": n_speakers,
+                        "stft_args": {"n_fft": 510, "hop_length": 128, "center": True, "pad_mode": "constant"},
+                        "backbone_args": {"nf": nf}, "transform": "exponent", "spec_abs_exponent": 0.5,
+                        "spec_factor": spec_factor, "spec_trans_learnable": False},
+        "sde": {"ndim": n_speakers, "d_lambda": 2.0, "sigma_min": 0.05, "sigma_max": 0.5, "N": 30},
+        "sampler": {"N": 30, "snr": 0.5, "corrector_steps": 1}}}
+
+
+class DiffSepModel:
+    def __init__(self, config, dtype="bf16", device=None, init_seed=0):
+        self.config = config
+        sm = dict(cfg_get(config, "model.score_model"))
+        sm.pop("_target_", None)
+        sm["stft_args"] = dict(sm["stft_args"])
+        sm["backbone_args"] = {k: v for k, v in dict(sm["backbone_args"]).items()}
+        self.score_model = ScoreModelNCSNpp(dtype=dtype, device=device, init_seed=init_seed, **sm)
+        sd = dict(cfg_get(config, "model.sde"))
+        target = sd.pop("_target_", "sdes.sdes.MixSDE")
+        if not str(target).endswith("MixSDE") or str(target).endswith("PriorMixSDE"):
+            raise NotImplementedError(f"SDE '{target}' is not on the accelerated path yet (MixSDE only)")
+        self.sde = MixSDE(**sd)
+        self.t_eps = cfg_get(config, "model.t_eps", 0.03)
+        self.t_max = self.sde.T
+        self.normalize_batch = normalize_batch
+        self.denormalize_batch = denormalize_batch
+
+    # ---- checkpoint ----------------------------------------------------------------------
+    @classmethod
+    def load_from_checkpoint(cls, path, dtype="bf16", device=None, use_ema=True):
+        """Lightning .ckpt / HF checkpoint.pt: {'state_dict', 'hyper_parameters': {'config'}, 'ema'}
+        (pl_model.py:100,642-673).  Inference runs on the EMA shadow weights (pl_model.py:655-660)."""
+        ckpt = torch.load(str(path), map_location="cpu", weights_only=False)
+        config = ckpt["hyper_parameters"]["config"]
+        model = cls(config, dtype=dtype, device=device)
+        state = {k[len("score_model."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("score_model.")}
+        ema = ckpt.get("ema", None) if use_ema else None
+        if ema is not None:
+            shadow = ema["shadow_params"]
+            names = ["backbone." + n for n, _, _ in param_table(model.score_model.cfg)]
+            if len(shadow) == len(names) - 1:  # torch_ema tracks requires_grad params only: frozen Fourier W skipped
+                names = [n for n in names if not n.endswith("all_modules.0.W")]
+            if len(shadow) != len(names):
+                raise ValueError(f"EMA has {len(shadow)} shadow params, model has {len(names)} parameters")
+            for n, v in zip(names, shadow):
+                if tuple(v.shape) != tuple(state[n].shape):
+                    raise ValueError(f"EMA shadow parameter for '{n}' has shape {tuple(v.shape)}")
+                state[n] = v
+        model.score_model.load_state_dict(state)
+        return model
+
+    def to(self, device):
+        self.score_model.to(device)
+        return self
+
+    def eval(self, no_ema=False):
+        return self
+
+    def engine(self):
+        return self.score_model.engine()
+
+    # ---- score function --------------------------------------------------------------------
+    def forward(self, xt, time, mix):
+        return self.score_model(xt, time, mix)
+
+    __call__ = forward
+
+    # ---- sampler factory (pl_model.py:687-759) ---------------------------------------------
+    def get_pc_sampler(self, predictor_name, corrector_name, y, N=None, minibatch=None, schedule=None, **kwargs):
+        sde = self.sde.copy()
+        sde.N = self.sde.N if N is None else N
+        kwargs = {"eps": self.t_eps, **kwargs}
+
+        def make(y_part):
+            if schedule is None:
+                return sdes.get_pc_sampler(predictor_name, corrector_name, sde=sde, score_fn=self, y=y_part, **kwargs)
+            return sdes.get_pc_scheduled_sampler(predictor_name, corrector_name, sde=sde, score_fn=self, y=y_part,
+                                                 schedule=schedule, **kwargs)
+
+        if minibatch is None:
+            return make(y)
+
+        def batched_sampling_fn():
+            samples, ns, inter = [], [], []
+            for i in range(int(math.ceil(y.shape[0] / minibatch))):
+                sample, n, *other = make(y[i * minibatch:(i + 1) * minibatch])()
+                samples.append(sample)
+                ns.append(n)
+                if other:
+                    inter.append(other[0])
+            samples = torch.cat(samples, dim=0)
+            return (samples, ns, inter) if inter else (samples, ns)
+
+        return batched_sampling_fn
+
+    def separate(self, mix, **kwargs):
+        (mix_n, _), mean, std = self.normalize_batch((mix, None))
+        skw = dict(cfg_get(self.config, "model.sampler", {}))
+        skw.update(kwargs)
+        est, *others = self.get_pc_sampler("reverse_diffusion", "ald2", mix_n, **skw)()
+        return self.denormalize_batch(est, mean, std)

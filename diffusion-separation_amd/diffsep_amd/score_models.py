@@ -1,0 +1,84 @@
+"""ScoreModelNCSNpp with the reference constructor and forward contract
+(models/score_models.py:10-138), backed by the HIP engine: forward(xt, time_cond, mix) runs
+STFT -> NCSN++ -> iSTFT entirely in libdiffsep_hip.so.
+
+A drop-in for hydra configs: `_target_: diffsep_amd.score_models.ScoreModelNCSNpp` accepts the same
+kwargs as `models.score_models.ScoreModelNCSNpp`; weights arrive through load_state_dict() with the
+reference's key layout (backbone.all_modules.{i}...., backbone.output_layer.*).
+"""
+import numpy as np
+import torch
+
+from . import _lib, synth
+from .engine import Engine, pack_state_dict, param_table
+
+
+class ScoreModelNCSNpp:
+    def __init__(self, num_sources, stft_args, backbone_args, transform="exponent", spec_abs_exponent=0.5,
+                 spec_factor=3.0, spec_trans_learnable=False, dtype="bf16", device=None, init_seed=0):
+        if transform != "exponent":
+            raise NotImplementedError("only transform='exponent' runs on the accelerated path")
+        if spec_trans_learnable:
+            raise NotImplementedError("spec_trans_learnable is a training feature")
+        if not stft_args.get("center", True) or stft_args.get("pad_mode", "constant") != "constant":
+            raise NotImplementedError("STFT must be center=True, pad_mode='constant' (config/model/default.yaml:21-22)")
+        ba = {k: v for k, v in dict(backbone_args).items() if k != "_target_"}
+        self.num_sources = num_sources
+        self.stft_args = dict(stft_args)
+        self.spec_abs_exponent, self.spec_factor = spec_abs_exponent, spec_factor
+        self.cfg = _lib.model_config(
+            nf=ba.get("nf", 128), num_sources=num_sources, ch_mult=tuple(ba.get("ch_mult", (1, 1, 2, 2, 2, 2, 2))),
+            num_res_blocks=ba.get("num_res_blocks", 2), attn_resolution=tuple(ba.get("attn_resolutions", (16,)))[0],
+            n_fft=stft_args["n_fft"], hop=stft_args["hop_length"], spec_abs_exponent=abs(spec_abs_exponent),
+            spec_factor=spec_factor, dtype={"bf16": _lib.BF16, "f32": _lib.F32, "fp32": _lib.F32}[dtype])
+        self.device = device
+        self._engine = None
+        # random init like the reference constructor (no checkpoint yet): synthetic variance-scaling weights
+        self._state = synth.synth_state_dict([(n, s) for n, s, _ in param_table(self.cfg)], init_seed)
+
+    # ---- weights ---------------------------------------------------------------------------
+    def param_names(self):
+        return ["backbone." + n for n, _, _ in param_table(self.cfg)]
+
+    def load_state_dict(self, state, strict=True):
+        """Keys as in the reference ('backbone.all_modules.3.weight', ...); STFT window buffers are ignored."""
+        new = {}
+        for n, shape, _ in param_table(self.cfg):
+            k = "backbone." + n
+            if k not in state:
+                if strict:
+                    raise KeyError(f"missing key '{k}'")
+                new[n] = self._state[n]
+                continue
+            v = state[k]
+            v = v.detach().cpu().float().numpy() if isinstance(v, torch.Tensor) else np.asarray(v, np.float32)
+            if tuple(v.shape) != shape:
+                raise ValueError(f"size mismatch for '{k}': {tuple(v.shape)} vs {shape}")
+            new[n] = v
+        self._state = new
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+        return self
+
+    def state_dict(self):
+        return {"backbone." + n: torch.from_numpy(np.array(v)) for n, v in self._state.items()}
+
+    def to(self, device):
+        self.device = device
+        return self
+
+    def eval(self):
+        return self
+
+    def engine(self):
+        """The device-resident engine (created lazily on the current / configured device)."""
+        if self._engine is None:
+            self._engine = Engine(self.cfg, pack_state_dict(self.cfg, self._state), device=self.device)
+        return self._engine
+
+    # ---- reference forward ---------------------------------------------------------------
+    def forward(self, xt, time_cond, mix):
+        return self.engine().score(xt, time_cond, mix)
+
+    __call__ = forward

@@ -1,0 +1,88 @@
+"""Sampler factories with the reference signatures (sdes/__init__.py:46-190).
+
+get_pc_sampler(...) returns a closure `pc_sampler() -> (x, nfe[, intermediates])`.  When score_fn is an
+engine-backed model and the request is the default path (reverse_diffusion + ald2/none, no
+intermediates) the whole loop runs as ONE engine call (hipGraph-replayed network evaluations, fused
+update kernels, on-device Philox noise seeded from torch's generator); otherwise the generic
+step-by-step loop below runs the same kernels through the predictor / corrector objects.
+"""
+import math
+
+import torch
+
+from .correctors import Corrector, CorrectorRegistry
+from .predictors import Predictor, PredictorRegistry, ReverseDiffusionPredictor
+from .sdes import MixSDE, SDERegistry
+
+__all__ = ["PredictorRegistry", "CorrectorRegistry", "SDERegistry", "Predictor", "Corrector", "MixSDE",
+           "get_pc_sampler", "get_pc_scheduled_sampler"]
+
+
+def _timesteps(sde, eps, schedule, device):
+    """None -> linspace(T, eps, N) (sdes/__init__.py:175); scheduled samplers use N+1 points
+    (sdes/__init__.py:91-111) but still step with dt = 1/N (reference quirk Q1)."""
+    if schedule is None:
+        return torch.linspace(sde.T, eps, sde.N, device=device)
+    if schedule == "linear":
+        return torch.linspace(sde.T, eps, sde.N + 1, device=device)
+    if schedule == "log":
+        return torch.logspace(math.log10(sde.T), math.log10(eps), sde.N + 1, base=10, device=device)
+    if schedule == "revlog":
+        return torch.logspace(math.log10(eps), math.log10(sde.T), sde.N + 1, base=10, device=device).flip(dims=(0,))
+    raise NotImplementedError(f"Schedule '{schedule}' does not exist")
+
+
+def _engine_of(score_fn):
+    eng = getattr(score_fn, "engine", None)
+    return eng() if callable(eng) else eng
+
+
+def _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, denoise, eps, snr, corrector_steps,
+                  probability_flow, intermediate, schedule):
+    predictor = PredictorRegistry.get_by_name(predictor_name)(sde, score_fn, probability_flow=probability_flow)
+    corrector = CorrectorRegistry.get_by_name(corrector_name)(sde, score_fn, snr=snr, n_steps=corrector_steps)
+    eng = _engine_of(score_fn)
+    fused = (eng is not None and not intermediate and true_mean is None and not probability_flow
+             and predictor_name in ("reverse_diffusion", "none") and corrector_name in ("ald2", "none")
+             and isinstance(sde, MixSDE))
+
+    def pc_sampler():
+        with torch.no_grad():
+            ns = sde.N * (corrector.n_steps + 1)
+            if fused:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # torch.manual_seed() governs reproducibility
+                ts = None if schedule is None else _timesteps(sde, eps, schedule, "cpu").numpy()
+                x, _ = eng.pc_sample(y, sde.engine_config(), N=sde.N, corrector_steps=corrector.n_steps, snr=snr,
+                                     eps=eps, denoise=denoise, predictor=predictor_name, corrector=corrector_name,
+                                     seed=seed, timesteps=ts)
+                return x, ns
+            im = []
+            xt = sde.prior_sampling((true_mean if true_mean is not None else y).shape,
+                                    true_mean if true_mean is not None else y)
+            ts = _timesteps(sde, eps, schedule, y.device)
+            xt_mean = xt
+            for i in range(sde.N):
+                vec_t = torch.ones(y.shape[0], device=y.device) * ts[i]
+                xt, xt_mean = corrector.update_fn(xt, vec_t, y)
+                if intermediate:
+                    im.append((xt, xt_mean))
+                xt, xt_mean = predictor.update_fn(xt, vec_t, y)
+            res = xt_mean if denoise else xt
+            return (res, ns, im) if intermediate else (res, ns)
+
+    return pc_sampler
+
+
+def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean=None, denoise=True, eps=3e-2, snr=0.1,
+                   corrector_steps=1, probability_flow=False, intermediate=False, **kwargs):
+    """Reference: sdes/__init__.py:132-190."""
+    return _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, denoise, eps, snr,
+                         corrector_steps, probability_flow, intermediate, None)
+
+
+def get_pc_scheduled_sampler(predictor_name, corrector_name, sde, score_fn, y, denoise=True, true_mean=None, eps=3e-2,
+                             snr=0.1, corrector_steps=1, probability_flow=False, intermediate=False,
+                             schedule="linear", **kwargs):
+    """Reference: sdes/__init__.py:46-129."""
+    return _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, denoise, eps, snr,
+                         corrector_steps, probability_flow, intermediate, schedule)

@@ -1,0 +1,47 @@
+"""Correctors (reference sdes/correctors.py): registry names 'ald2' and 'none' on the accelerated path."""
+import abc
+
+import torch
+
+from .. import ops
+from ..registry import Registry
+from .sdes import MixSDE
+
+CorrectorRegistry = Registry("Corrector")
+
+
+class Corrector(abc.ABC):
+    def __init__(self, sde, score_fn, snr, n_steps):
+        self.sde, self.score_fn, self.snr, self.n_steps = sde, score_fn, snr, n_steps
+
+    @abc.abstractmethod
+    def update_fn(self, x, t, *args, **kwargs):
+        ...
+
+
+@CorrectorRegistry.register("ald2")
+class AnnealedLangevinDynamics2(Corrector):
+    """n_steps x { x_mean = x + 2 snr^2 L L score ; x = x_mean + 2 snr L z }  (sdes/correctors.py:109-128)."""
+
+    def __init__(self, sde, score_fn, snr, n_steps):
+        super().__init__(sde, score_fn, snr, n_steps)
+        if not isinstance(sde, MixSDE):
+            raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+
+    def update_fn(self, x, t, *args, **kwargs):
+        x_mean = x
+        for _ in range(self.n_steps):
+            score = self.score_fn(x, t, *args)
+            z = torch.randn_like(x)
+            x, x_mean = ops.sde_corrector_update(self.sde.engine_config(), self.snr, x.contiguous(), t.contiguous(),
+                                                 score, z)
+        return x, x_mean
+
+
+@CorrectorRegistry.register("none")
+class NoneCorrector(Corrector):
+    def __init__(self, *args, **kwargs):
+        self.snr, self.n_steps = 0, 0
+
+    def update_fn(self, x, t, *args, **kwargs):
+        return x, x

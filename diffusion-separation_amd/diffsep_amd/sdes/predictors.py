@@ -1,0 +1,41 @@
+"""Predictors (reference sdes/predictors.py): same registry names, constructor and update_fn contract
+`update_fn(x, t, *args) -> (x, x_mean)`; the update itself is one fused HIP kernel."""
+import abc
+
+import torch
+
+from .. import ops
+from ..registry import Registry
+
+PredictorRegistry = Registry("Predictor")
+
+
+class Predictor(abc.ABC):
+    def __init__(self, sde, score_fn, probability_flow=False):
+        self.sde, self.score_fn, self.probability_flow = sde, score_fn, probability_flow
+        if probability_flow:
+            raise NotImplementedError("probability_flow sampling is outside the accelerated path")
+
+    @abc.abstractmethod
+    def update_fn(self, x, t, *args, **kwargs):
+        ...
+
+
+@PredictorRegistry.register("reverse_diffusion")
+class ReverseDiffusionPredictor(Predictor):
+    """x_mean = x - (f - G^2 score), x = x_mean + G z with f = -lambda P x / N, G = g(t)/sqrt(N)
+    (sdes/predictors.py:60-66; the step is always 1/N — reference quirk Q1)."""
+
+    def update_fn(self, x, t, *args, **kwargs):
+        score = self.score_fn(x, t, *args)
+        z = torch.randn_like(x)
+        return ops.sde_predictor_update(self.sde.engine_config(), self.sde.N, x.contiguous(), t.contiguous(), score, z)
+
+
+@PredictorRegistry.register("none")
+class NonePredictor(Predictor):
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def update_fn(self, x, t, *args, **kwargs):
+        return x, x

@@ -1,0 +1,61 @@
+"""SDE objects of the hot path.  Mirrors the constructor / attribute surface of the reference's
+sdes/sdes.py (MixSDE :180-349) that the sampler touches; all tensor arithmetic is delegated to the
+HIP kernels (csrc/sde.hip) through the C-ABI."""
+import math
+
+import torch
+
+from .. import _lib, ops
+from ..registry import Registry
+
+SDERegistry = Registry("SDE")
+
+
+class SDE:
+    """Base: holds N (number of discretisation steps) — reference sdes/sdes.py:43-52."""
+
+    def __init__(self, N):
+        self.N = N
+
+    @property
+    def T(self):
+        raise NotImplementedError
+
+    def copy(self):
+        raise NotImplementedError
+
+
+@SDERegistry.register("mix")
+class MixSDE(SDE):
+    """dx = -lambda P x dt + g(t) dw with the source-mixing structure of sdes/sdes.py:217-349."""
+
+    def __init__(self, ndim, d_lambda, sigma_min, sigma_max, N=1000):
+        super().__init__(N)
+        self.ndim, self.d_lambda, self.sigma_min, self.sigma_max = ndim, d_lambda, sigma_min, sigma_max
+        self.ratiosig = sigma_max / sigma_min
+        self.logsig = math.log(self.ratiosig)
+
+    @property
+    def T(self):
+        return 1.0
+
+    def copy(self):
+        return MixSDE(self.ndim, self.d_lambda, self.sigma_min, self.sigma_max, N=self.N)
+
+    def engine_config(self):
+        return dict(kind=_lib.SDE_MIX, ndim=self.ndim, d_lambda=self.d_lambda, sigma_min=self.sigma_min,
+                    sigma_max=self.sigma_max)
+
+    def _cov_eigval(self, t):
+        """sdes/sdes.py:296-309 (tiny [B] host-side tensors; the kernels recompute these in registers)."""
+        mult = self.sigma_min ** 2
+        srp = self.ratiosig ** (2 * t)
+        ev1 = mult * (srp - 1)
+        ev2 = mult * (srp - torch.exp(-2.0 * self.d_lambda * t)) / (1.0 + self.d_lambda / self.logsig)
+        return ev1, ev2
+
+    def prior_sampling(self, shape, y):
+        """x_T = 0.5 y + L(T) z   (sdes/sdes.py:334-346); z from torch's generator like the reference."""
+        B, _, T = y.shape
+        z = torch.randn((B, self.ndim, T), dtype=y.dtype, device=y.device)
+        return ops.sde_prior(self.engine_config(), y.contiguous(), z)

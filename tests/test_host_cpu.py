@@ -1,0 +1,119 @@
+"""Host-side logic that needs no GPU: registries, config access, wav I/O, checkpoint -> weight mapping with
+the EMA swap, utterance sharding and the multi-rank result gather (gloo, world_size 2)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from diffsep_amd import dist_utils, synth, wavio
+from diffsep_amd.engine import param_table
+from diffsep_amd.pl_model import DiffSepModel, cfg_get, default_config
+from diffsep_amd.sdes import CorrectorRegistry, PredictorRegistry, SDERegistry, MixSDE
+
+
+def test_registries_expose_reference_names():
+    assert {"reverse_diffusion", "none"} <= set(PredictorRegistry.get_all_names())
+    assert {"ald2", "none"} <= set(CorrectorRegistry.get_all_names())
+    assert SDERegistry.get_by_name("mix") is MixSDE
+    with pytest.raises(ValueError):
+        PredictorRegistry.get_by_name("nope")
+
+
+def test_cfg_get_on_dicts_and_objects():
+    cfg = default_config(nf=16)
+    assert cfg_get(cfg, "model.sampler.N") == 30 and cfg_get(cfg, "model.missing.x", 7) == 7
+
+    class O:
+        pass
+    o = O(); o.model = O(); o.model.fs = 16000
+    assert cfg_get(o, "model.fs") == 16000
+
+
+def test_mixsde_copy_and_eigenvalues():
+    s = MixSDE(2, 2.0, 0.05, 0.5, N=30)
+    c = s.copy(); c.N = 7
+    assert s.N == 30 and c.N == 7 and c.T == 1.0
+    ev1, ev2 = s._cov_eigval(torch.tensor([1.0]))
+    assert abs(float(ev1) - 0.2475) < 1e-6 and abs(float(ev2) - 0.1337663) < 1e-6
+
+
+def test_wav_roundtrip(tmp_path):
+    x = torch.from_numpy(synth.synth_mixture(0, T=4000)[0])
+    wavio.save(tmp_path / "a.wav", x, 8000)
+    y, sr = wavio.load(tmp_path / "a.wav")
+    assert sr == 8000 and y.shape == x.shape and float((x - y).abs().max()) < 1.0 / 16384
+    wavio.save(tmp_path / "b.wav", x, 8000, bits=32)
+    z, _ = wavio.load(tmp_path / "b.wav")
+    assert torch.equal(z, x)
+    with pytest.raises(ValueError):
+        (tmp_path / "c.wav").write_bytes(b"not a wav file at all")
+        wavio.load(tmp_path / "c.wav")
+
+
+def test_checkpoint_loader_applies_ema(tmp_path):
+    cfg = default_config(nf=16)
+    m = DiffSepModel(cfg)
+    names = [n for n, _, _ in param_table(m.score_model.cfg)]
+    raw = synth.synth_state_dict([(n, s) for n, s, _ in param_table(m.score_model.cfg)], 1)
+    ema = synth.synth_state_dict([(n, s) for n, s, _ in param_table(m.score_model.cfg)], 2)
+    sd = {"score_model.backbone." + n: torch.from_numpy(v) for n, v in raw.items()}
+    sd["score_model.stft.window"] = torch.hann_window(510)
+    shadow = [torch.from_numpy(ema[n]) for n in names if not n.endswith("all_modules.0.W")]  # torch_ema skips frozen W
+    torch.save({"state_dict": sd, "hyper_parameters": {"config": cfg}, "ema": {"shadow_params": shadow}},
+               tmp_path / "m.ckpt")
+    m2 = DiffSepModel.load_from_checkpoint(tmp_path / "m.ckpt")
+    st = m2.score_model._state
+    assert np.array_equal(st["all_modules.0.W"], raw["all_modules.0.W"])  # frozen Fourier weights: no EMA
+    assert np.array_equal(st["all_modules.3.weight"], ema["all_modules.3.weight"])
+    assert np.array_equal(st["output_layer.bias"], ema["output_layer.bias"])
+    m3 = DiffSepModel.load_from_checkpoint(tmp_path / "m.ckpt", use_ema=False)
+    assert np.array_equal(m3.score_model._state["all_modules.3.weight"], raw["all_modules.3.weight"])
+    with pytest.raises(KeyError):
+        m.score_model.load_state_dict({})
+
+
+def test_shard_range_matches_reference_partition():
+    # evaluate_mp.py:495-503: floor(n/workers) per worker, last one takes the remainder
+    for n, w in ((3000, 8), (10, 3), (7, 7), (5, 8), (0, 2)):
+        rs = [dist_utils.shard_range(n, w, r) for r in range(w)]
+        assert rs[0][0] == 0 and rs[-1][1] == n
+        assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+        assert all(e - s == n // w for s, e in rs[:-1])
+    parts = dist_utils.length_balanced_order([5, 1, 9, 3, 7, 2], 2)
+    assert sorted(parts[0] + parts[1]) == list(range(6))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = dist_utils.shard_range(5, world, rank)
+    local = [torch.full((2, 100 + 10 * i), float(i)) for i in range(lo, hi)]  # variable-length "waveforms"
+    out = dist_utils.gather_waveforms(local, None, device=torch.device("cpu"))
+    objs = dist_utils.gather_objects([{"batch_idx": i} for i in range(lo, hi)])
+    if rank == 0:
+        q.put(([(tuple(o.shape), float(o[0, 0])) for o in out], objs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_across_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, objs = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [((2, 100 + 10 * i), float(i)) for i in range(5)]
+    assert [r["batch_idx"] for part in objs for r in part] == list(range(5))
