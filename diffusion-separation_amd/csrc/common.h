@@ -114,7 +114,11 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // ---------------------------------------------------------------- launcher prototypes (host)
 struct ConvArgs {
   const void* x; long x_bs; int ldx;     // A operand: [B][M][ldx]; x_bs = batch stride (elements)
+  const void* x2; long x2_bs; int ldx2;  // optional second A source: channels [C1, Cin) come from x2 (concat in place)
+  int C1;                                // channels taken from x when x2 != null
   const void* w; long w_bs;              // Bt operand: [Cout][taps][Cin]; w_bs batch stride (0 = shared)
+  const float* gn_scale;                 // optional fused GroupNorm-apply on A: f(x) = act(x*scale[b,c] + shift[b,c])
+  const float* gn_shift; int gn_act;     //   scale/shift are [B][Cin] fp32; gn_act: 0 none, 1 SiLU
   const float* bias;                     // [Cout] (mode 0) or [M] (mode 1) or null
   const float* bias_b; int bias_b_ld;    // per-batch column bias [B][bias_b_ld] or null
   int bias_mode;                         // 0 = along Cout, 1 = along rows (M)
@@ -132,9 +136,10 @@ int ds_conv_config_id(const ConvArgs& a);
 // GroupNorm: stats -> per-(b,c) scale/shift -> apply(+SiLU)(+FIR resample)
 // ws layout: doubles [B][nblk][C][2] then floats scale[B][C], shift[B][C]
 long ds_gn_workspace_bytes(int B, int H, int W, int C);
-int ds_launch_gn_stats(const void* x, int ldx, int B, int H, int W, int C, int groups, float eps,
-                       const float* gamma, const float* beta, void* ws, float* scale, float* shift, int dtype,
-                       hipStream_t st);
+// x2 != null: channels [C1, C) are read from x2 (pixel stride ldx2) — statistics of cat([x, x2]) in place.
+int ds_launch_gn_stats(const void* x, int ldx, const void* x2, int ldx2, int C1, int B, int H, int W, int C, int groups,
+                       float eps, const float* gamma, const float* beta, void* ws, float* scale, float* shift,
+                       int dtype, hipStream_t st);
 // mode: 0 none, 1 up, 2 down. scale/shift null => identity & no activation (pure FIR on x -> xr only).
 int ds_launch_gn_apply(const void* x, int ldx, const float* scale, const float* shift, int C, void* y, int ldy,
                        void* xr, int ldxr, int B, int H, int W, int act, int mode, int dtype, hipStream_t st);

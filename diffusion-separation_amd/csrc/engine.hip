@@ -274,10 +274,17 @@ __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ s
 }
 
 // ------------------------------------------------------------------ engine
-struct Tn {  // NHWC view
+struct Tn {  // NHWC view; optionally the in-place channel concat of two tensors (C1 channels from p, rest from p2)
   void* p = nullptr;
   int C = 0, ld = 0, H = 0, W = 0;
+  void* p2 = nullptr;
+  int C1 = 0, ld2 = 0;
 };
+static Tn cat_view(const Tn& a, const Tn& b) {
+  Tn t = a;
+  t.C = a.C + b.C; t.C1 = a.C; t.p2 = b.p; t.ld2 = b.ld;
+  return t;
+}
 
 struct diffsep_engine {
   diffsep_model_config cfg;
@@ -368,12 +375,16 @@ static const float* P(diffsep_engine* e, const PRef& r) { return e->d_blob + r.o
 static const void* PK(diffsep_engine* e, long off) { return e->d_pack + off * e->esz; }
 
 // ---- launch helpers (skip when dry)
+struct GnAff { float* scale; float* shift; };
 static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias, const float* bias_b, int bias_b_ld,
                 const Tn* res, float scale, const Tn& y, int Cout, int taps, int B, const float* div_b,
-                hipStream_t st) {
+                hipStream_t st, const GnAff* gn = nullptr, int gn_act = 0) {
   if (e->dry) return 0;
   ConvArgs a;
+  memset(&a, 0, sizeof(a));
   a.x = x.p; a.x_bs = (long)x.H * x.W * x.ld; a.ldx = x.ld;
+  a.x2 = x.p2; a.x2_bs = (long)x.H * x.W * x.ld2; a.ldx2 = x.ld2; a.C1 = x.C1;
+  a.gn_scale = gn ? gn->scale : nullptr; a.gn_shift = gn ? gn->shift : nullptr; a.gn_act = gn_act;
   a.w = w; a.w_bs = 0;
   a.bias = bias; a.bias_b = bias_b; a.bias_b_ld = bias_b_ld; a.bias_mode = 0; a.div_b = div_b;
   a.res = res ? res->p : nullptr; a.res_bs = res ? (long)res->H * res->W * res->ld : 0; a.ldr = res ? res->ld : 0;
@@ -383,7 +394,6 @@ static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias
   return conv_launch_prof(e, a, st);
 }
 
-struct GnAff { float* scale; float* shift; };
 static int gn_stats(diffsep_engine* e, const Tn& x, const float* gamma, const float* beta, int B, GnAff& aff,
                     hipStream_t st) {
   void* ws = e_alloc(e, (size_t)ds_gn_workspace_bytes(B, x.H, x.W, x.C));
@@ -391,8 +401,8 @@ static int gn_stats(diffsep_engine* e, const Tn& x, const float* gamma, const fl
   aff.shift = e_f32(e, (size_t)B * x.C);
   if (e->dry) return 0;
   const int groups = (x.C / 4 < 32) ? x.C / 4 : 32;
-  return ds_launch_gn_stats(x.p, x.ld, B, x.H, x.W, x.C, groups, 1e-6f, gamma, beta, ws, aff.scale, aff.shift,
-                            e->cfg.dtype, st);
+  return ds_launch_gn_stats(x.p, x.ld, x.p2, x.ld2, x.C1, B, x.H, x.W, x.C, groups, 1e-6f, gamma, beta, ws, aff.scale,
+                            aff.shift, e->cfg.dtype, st);
 }
 static int gn_apply(diffsep_engine* e, const Tn& x, const GnAff* aff, const Tn* y, const Tn* xr, int B, int act,
                     int mode, hipStream_t st) {
@@ -404,7 +414,8 @@ static int gn_apply(diffsep_engine* e, const Tn& x, const GnAff* aff, const Tn* 
 
 static const float kInvSqrt2 = 0.70710678118654752440f;
 
-// ResnetBlockBigGANpp.forward  layerspp.py:291-323
+// ResnetBlockBigGANpp.forward  layerspp.py:291-323.  act(GN(.)) is never materialised for the plain blocks:
+// both 3x3 convs apply it while staging their input tile; x may be an in-place concat view.
 static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const float* temb_proj, int B, Tn& out,
                      hipStream_t st) {
   DS_CHECK(x.C == m.in_ch, "internal: resblock channel mismatch");
@@ -413,25 +424,33 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
   const int Wo = m.up ? 2 * x.W : (m.down ? x.W / 2 : x.W);
   GnAff a0, a1;
   if (gn_stats(e, x, P(e, m.gn0_w), P(e, m.gn0_b), B, a0, st)) return 1;
-  Tn h0 = e_tensor(e, B, Ho, Wo, m.in_ch);
-  Tn xr = x;
-  if (mode) xr = e_tensor(e, B, Ho, Wo, m.in_ch);
-  if (gn_apply(e, x, &a0, &h0, mode ? &xr : nullptr, B, 1, mode, st)) return 1;
   Tn h1 = e_tensor(e, B, Ho, Wo, m.out_ch);
-  if (conv(e, h0, PK(e, m.pk0), P(e, m.conv0_b), temb_proj + m.temb_off, e->arch.dense_total, nullptr, 1.f, h1,
-           m.out_ch, 9, B, nullptr, st))
-    return 1;
+  Tn xr = x;
+  if (mode) {
+    DS_CHECK(x.p2 == nullptr, "internal: resampling block on a concat view");
+    Tn h0 = e_tensor(e, B, Ho, Wo, m.in_ch);
+    xr = e_tensor(e, B, Ho, Wo, m.in_ch);
+    if (gn_apply(e, x, &a0, &h0, &xr, B, 1, mode, st)) return 1;
+    if (conv(e, h0, PK(e, m.pk0), P(e, m.conv0_b), temb_proj + m.temb_off, e->arch.dense_total, nullptr, 1.f, h1,
+             m.out_ch, 9, B, nullptr, st))
+      return 1;
+  } else {
+    if (conv(e, x, PK(e, m.pk0), P(e, m.conv0_b), temb_proj + m.temb_off, e->arch.dense_total, nullptr, 1.f, h1,
+             m.out_ch, 9, B, nullptr, st, &a0, 1))
+      return 1;
+  }
   if (gn_stats(e, h1, P(e, m.gn1_w), P(e, m.gn1_b), B, a1, st)) return 1;
-  Tn h2 = e_tensor(e, B, Ho, Wo, m.out_ch);
-  if (gn_apply(e, h1, &a1, &h2, nullptr, B, 1, 0, st)) return 1;
   Tn skip = xr;
   if (m.has_conv2) {
     skip = e_tensor(e, B, Ho, Wo, m.out_ch);
     if (conv(e, xr, PK(e, m.pk2), P(e, m.conv2_b), nullptr, 0, nullptr, 1.f, skip, m.out_ch, 1, B, nullptr, st))
       return 1;
+  } else {
+    DS_CHECK(xr.p2 == nullptr, "internal: identity skip on a concat view");
   }
   out = e_tensor(e, B, Ho, Wo, m.out_ch);
-  return conv(e, h2, PK(e, m.pk1), P(e, m.conv1_b), nullptr, 0, &skip, kInvSqrt2, out, m.out_ch, 9, B, nullptr, st);
+  return conv(e, h1, PK(e, m.pk1), P(e, m.conv1_b), nullptr, 0, &skip, kInvSqrt2, out, m.out_ch, 9, B, nullptr, st,
+              &a1, 1);
 }
 
 // attention core shared with the unit entry point: o = softmax(q k^T C^-1/2) v
@@ -557,10 +576,10 @@ static int net_forward(diffsep_engine* e, const Tn& x0, const float* t, const Tn
     for (int k = 0; k < c.num_res_blocks + 1; ++k) {
       const Tn s = hs.back();
       hs.pop_back();
-      Tn cat = e_tensor(e, B, h.H, h.W, h.C + s.C);
-      if (!e->dry)
-        if (ds_launch_concat(h.p, h.ld, h.C, s.p, s.ld, s.C, cat.p, cat.ld, (long)B * h.H * h.W, c.dtype, st)) return 1;
-      if (res_block(e, A.mods[mi++], cat, proj, B, h, st)) return 1;
+      const Tn cat = cat_view(h, s);  // torch.cat([h, hs.pop()], dim=1) read in place (ncsnpp.py:411)
+      Tn hn2;
+      if (res_block(e, A.mods[mi++], cat, proj, B, hn2, st)) return 1;
+      h = hn2;
     }
     if (h.H == c.attn_resolution) {
       DS_CHECK(mi < A.mods.size() && A.mods[mi].kind == MK_ATTN, "attention placement mismatch (image height)");
@@ -574,15 +593,14 @@ static int net_forward(diffsep_engine* e, const Tn& x0, const float* t, const Tn
     DS_CHECK(g.kind == MK_GN && cv.kind == MK_CONV3, "internal: expected pyramid GN + conv");
     GnAff ga;
     if (gn_stats(e, h, P(e, g.w0), P(e, g.b0), B, ga, st)) return 1;
-    Tn hn = e_tensor(e, B, h.H, h.W, h.C);
-    if (gn_apply(e, h, &ga, &hn, nullptr, B, 1, 0, st)) return 1;
     Tn pnew = e_tensor(e, B, h.H, h.W, A.cpad_in);
     if (have_pyr) {
       Tn pu = e_tensor(e, B, h.H, h.W, A.cpad_in);
       if (gn_apply(e, pyramid, nullptr, nullptr, &pu, B, 0, 1, st)) return 1;
-      if (conv(e, hn, PK(e, cv.pk0), P(e, cv.b0), nullptr, 0, &pu, 1.f, pnew, A.chan_in, 9, B, nullptr, st)) return 1;
+      if (conv(e, h, PK(e, cv.pk0), P(e, cv.b0), nullptr, 0, &pu, 1.f, pnew, A.chan_in, 9, B, nullptr, st, &ga, 1))
+        return 1;
     } else {
-      if (conv(e, hn, PK(e, cv.pk0), P(e, cv.b0), nullptr, 0, nullptr, 1.f, pnew, A.chan_in, 9, B, nullptr, st))
+      if (conv(e, h, PK(e, cv.pk0), P(e, cv.b0), nullptr, 0, nullptr, 1.f, pnew, A.chan_in, 9, B, nullptr, st, &ga, 1))
         return 1;
     }
     pyramid = pnew;
@@ -943,7 +961,8 @@ extern "C" int32_t diffsep_groupnorm_act(const void* x, const float* gamma, cons
   float* scale = (float*)((char*)workspace + wsb);
   float* shift = scale + (long)B * C;
   hipStream_t st = (hipStream_t)stream;
-  if (ds_launch_gn_stats(x, ldx, B, H, W, C, groups, eps, gamma, beta, workspace, scale, shift, dtype, st)) return 1;
+  if (ds_launch_gn_stats(x, ldx, nullptr, 0, C, B, H, W, C, groups, eps, gamma, beta, workspace, scale, shift, dtype, st))
+    return 1;
   return ds_launch_gn_apply(x, ldx, scale, shift, C, y, ldy, xr, ldxr, B, H, W, act, resample, dtype, st);
 }
 
@@ -954,6 +973,36 @@ extern "C" int32_t diffsep_conv2d(const void* x, const void* w, const float* bia
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.x_bs = (long)H * W * ldx; a.ldx = ldx;
+  a.w = w; a.w_bs = 0;
+  a.bias = bias; a.bias_b = bias_b; a.bias_b_ld = Cout; a.bias_mode = 0;
+  a.res = res; a.res_bs = (long)H * W * ldr; a.ldr = ldr;
+  a.out_scale = out_scale;
+  a.y = y; a.y_bs = (long)H * W * ldy; a.ldy = ldy;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.taps = ksize == 3 ? 9 : 1; a.dtype = dtype;
+  return ds_launch_conv(a, (hipStream_t)stream);
+}
+
+extern "C" int32_t diffsep_groupnorm_stats(const void* x, const void* x2, int32_t C1, const float* gamma,
+                                           const float* beta, float* scale, float* shift, int32_t B, int32_t H,
+                                           int32_t W, int32_t C, int32_t ldx, int32_t ldx2, int32_t groups, float eps,
+                                           int32_t dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+  DS_CHECK(x && scale && shift && workspace, "groupnorm_stats: null pointer");
+  DS_CHECK(workspace_bytes >= ds_gn_workspace_bytes(B, H, W, C), "groupnorm_stats: workspace too small");
+  return ds_launch_gn_stats(x, ldx, x2, ldx2, x2 ? C1 : C, B, H, W, C, groups, eps, gamma, beta, workspace, scale, shift,
+                            dtype, (hipStream_t)stream);
+}
+
+extern "C" int32_t diffsep_conv2d_fused(const void* x, const void* x2, int32_t C1, const float* gn_scale,
+                                        const float* gn_shift, int32_t gn_act, const void* w, const float* bias,
+                                        const float* bias_b, const void* res, void* y, int32_t B, int32_t H, int32_t W,
+                                        int32_t Cin, int32_t Cout, int32_t ksize, int32_t ldx, int32_t ldx2,
+                                        int32_t ldr, int32_t ldy, float out_scale, int32_t dtype, void* stream) {
+  DS_CHECK(ksize == 1 || ksize == 3, "conv2d: ksize must be 1 or 3");
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.x_bs = (long)H * W * ldx; a.ldx = ldx;
+  a.x2 = x2; a.x2_bs = (long)H * W * ldx2; a.ldx2 = ldx2; a.C1 = C1;
+  a.gn_scale = gn_scale; a.gn_shift = gn_shift; a.gn_act = gn_act;
   a.w = w; a.w_bs = 0;
   a.bias = bias; a.bias_b = bias_b; a.bias_b_ld = Cout; a.bias_mode = 0;
   a.res = res; a.res_bs = (long)H * W * ldr; a.ldr = ldr;

@@ -11,8 +11,9 @@
 // Thread t owns channel group cg = t % (C/8) and pixel lane pl = t / (C/8): consecutive threads read
 // consecutive 16/32-byte channel vectors of one pixel -> fully coalesced rows.
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int ldx, long bs, long npix, int C,
-                                                       long ppb, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ x2,
+                                                       int ldx2, int C1, long npix, int C, long ppb,
+                                                       double* __restrict__ part) {
   __shared__ double sh[4096];  // [npl][C][2], npl*C <= 2048
   const int ncg = C >> 3;
   const int npl = 256 / ncg;
@@ -26,10 +27,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.0; ss[j] = 0.0; }
   if (pl < npl) {
-    const T* xb = x + (long)b * bs + cg * 8;
+    const bool second = x2 != nullptr && cg * 8 >= C1;
+    const int ld = second ? ldx2 : ldx;
+    const T* xb = second ? x2 + (long)b * npix * ldx2 + (cg * 8 - C1) : x + (long)b * npix * ldx + cg * 8;
     for (long p = p0 + pl; p < p1; p += npl) {
       float f[8];
-      load8<T>(xb + p * ldx, f);
+      load8<T>(xb + p * ld, f);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const double d = (double)f[j];
@@ -105,8 +108,10 @@ long ds_gn_workspace_bytes(int B, int H, int W, int C) {
   return (long)B * nblk * C * 2 * 8 + 256;
 }
 
-int ds_launch_gn_stats(const void* x, int ldx, int B, int H, int W, int C, int groups, float eps, const float* gamma,
-                       const float* beta, void* ws, float* scale, float* shift, int dtype, hipStream_t st) {
+int ds_launch_gn_stats(const void* x, int ldx, const void* x2, int ldx2, int C1, int B, int H, int W, int C, int groups,
+                       float eps, const float* gamma, const float* beta, void* ws, float* scale, float* shift,
+                       int dtype, hipStream_t st) {
+  DS_CHECK(!x2 || (C1 % 8 == 0 && C1 > 0 && C1 < C), "groupnorm: bad concat split");
   DS_CHECK(C % 8 == 0 && C <= 1024 && C >= 8, "groupnorm: C must be a multiple of 8 in [8,1024]");
   DS_CHECK(groups > 0 && groups <= 256 && C % groups == 0, "groupnorm: bad group count");
   DS_CHECK((C >> 3) <= 256, "groupnorm: C too large");
@@ -117,11 +122,11 @@ int ds_launch_gn_stats(const void* x, int ldx, int B, int H, int W, int C, int g
   double* part = reinterpret_cast<double*>(ws);
   dim3 grid((unsigned)nblk, (unsigned)B);
   if (dtype == DS_F32)
-    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, npix * ldx, npix, C, ppb,
-                       part);
+    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ldx, (const float*)x2, ldx2,
+                       C1, npix, C, ppb, part);
   else
-    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, npix * ldx, npix, C,
-                       ppb, part);
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)x2, ldx2,
+                       C1, npix, C, ppb, part);
   DS_LAUNCH_CHECK();
   const double count = (double)npix * (double)(C / groups);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, part, (int)nblk, C, groups, count, eps, gamma, beta,

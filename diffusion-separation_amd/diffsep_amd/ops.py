@@ -68,6 +68,33 @@ def conv2d(x, wpacked, bias, cout, ksize, bias_b=None, res=None, out_scale=1.0, 
     return y
 
 
+def groupnorm_stats(x, gamma, beta, groups, eps=1e-6, x2=None):
+    """scale, shift [B,C] fp32 of GroupNorm over x (or over cat([x, x2], channel) read in place)."""
+    B, H, W, C1 = x.shape
+    Cc = C1 + (x2.shape[-1] if x2 is not None else 0)
+    scale = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+    shift = torch.empty_like(scale)
+    ws = torch.empty(B * 64 * Cc * 16 + 4096, dtype=torch.uint8, device=x.device)
+    check(lib().diffsep_groupnorm_stats(_ptr(x), _ptr(x2), C1, _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift), B, H,
+                                        W, Cc, C1, x2.shape[-1] if x2 is not None else 0, groups, eps, _dt(x), _ptr(ws),
+                                        ws.numel(), _stream_ptr()))
+    return scale, shift
+
+
+def conv2d_fused(x, wpacked, bias, cout, ksize, x2=None, gn=None, gn_act=1, bias_b=None, res=None, out_scale=1.0,
+                 cout_pad=None):
+    B, H, W, C1 = x.shape
+    Cin = C1 + (x2.shape[-1] if x2 is not None else 0)
+    cp = cout if cout_pad is None else cout_pad
+    y = torch.zeros((B, H, W, cp), dtype=x.dtype, device=x.device)
+    sc, sh = gn if gn is not None else (None, None)
+    check(lib().diffsep_conv2d_fused(_ptr(x), _ptr(x2), C1, _ptr(sc), _ptr(sh), gn_act, _ptr(wpacked), _ptr(bias),
+                                     _ptr(bias_b), _ptr(res), _ptr(y), B, H, W, Cin, cout, ksize, C1,
+                                     x2.shape[-1] if x2 is not None else 0, res.shape[-1] if res is not None else 0, cp,
+                                     out_scale, _dt(x), _stream_ptr()))
+    return y
+
+
 def attention(q, k, vt):
     B, L, Cc = q.shape
     Lp = (L + 7) // 8 * 8

@@ -167,6 +167,22 @@ int32_t diffsep_conv2d(const void* x, const void* w, const float* bias, const fl
                        void* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                        int32_t ldx, int32_t ldr, int32_t ldy, float out_scale, int32_t dtype, void* stream);
 
+/* GroupNorm statistics only: per-(b,c) scale = rstd*gamma, shift = beta - mean*scale ([B][C] fp32), optionally
+ * over the in-place channel concat cat([x, x2]) (x holds C1 channels).  The convolutions consume them. */
+int32_t diffsep_groupnorm_stats(const void* x, const void* x2, int32_t C1, const float* gamma, const float* beta,
+                                float* scale, float* shift, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx,
+                                int32_t ldx2, int32_t groups, float eps, int32_t dtype, void* workspace,
+                                int64_t workspace_bytes, void* stream);
+
+/* diffsep_conv2d with the producer-side fusions the engine uses: the input may be cat([x, x2], C) read in
+ * place (ncsnpp.py:411) and act(GroupNorm(.)) (layerspp.py:292,313) is applied to it on the fly from
+ * per-(b,c) scale/shift (gn_act: 0 none, 1 SiLU); zero padding is applied AFTER the activation. */
+int32_t diffsep_conv2d_fused(const void* x, const void* x2, int32_t C1, const float* gn_scale, const float* gn_shift,
+                             int32_t gn_act, const void* w, const float* bias, const float* bias_b, const void* res,
+                             void* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
+                             int32_t ldx, int32_t ldx2, int32_t ldr, int32_t ldy, float out_scale, int32_t dtype,
+                             void* stream);
+
 /* AttnBlockpp core (layerspp.py:83-87): o = softmax(q k^T * C^-0.5) v over L = H*W tokens.
  * q,k [B,L,C] (ld), vt [B,C,Lp] (V transposed, Lp = L rounded up to 8), o [B,L,C];
  * ws >= B*L*Lp*(2*elt) bytes.  QK^T and PV run on MFMA. */

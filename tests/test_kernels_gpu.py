@@ -64,6 +64,34 @@ def test_conv1x1(dtype, tol, B, Cin, Cout, H, W):
     assert rel_rms(ops.to_nchw(y.float(), Cout), ref) < tol
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("C1,C2,Cout,H,W,k", [(64, 64, 64, 16, 64, 3), (128, 64, 64, 16, 32, 3), (16, 16, 24, 8, 8, 3),
+                                             (128, 128, 128, 4, 4, 3), (64, 64, 64, 16, 64, 1), (64, 0, 64, 24, 64, 3)])
+def test_conv_with_fused_groupnorm_silu_and_concat(dtype, tol, C1, C2, Cout, H, W, k):
+    # conv(silu(GN(cat([a, b])))) with the concat read in place and act(GN(.)) applied while staging:
+    # the reference computes it as three separate ops (ncsnpp.py:411, layerspp.py:292-306)
+    B = 2
+    a = rnd(f"cf.a{C1}{H}", (B, C1, H, W), 1.3) + 0.2
+    bt = rnd(f"cf.b{C2}{H}", (B, C2, H, W), 0.7) - 0.1 if C2 else None
+    C = C1 + C2
+    w = rnd(f"cf.w{C}{Cout}{k}", (Cout, C, k, k), 1.0 / math.sqrt(k * k * C))
+    bias = rnd(f"cf.bias{Cout}", (Cout,), 0.1)
+    g, be = 1.0 + rnd(f"cf.g{C}", (C,), 0.2), rnd(f"cf.be{C}", (C,), 0.1)
+    groups = min(C // 4, 32)
+    ar, br = a.to(dtype).float(), (bt.to(dtype).float() if C2 else None)
+    xcat = torch.cat([ar, br], 1) if C2 else ar
+    hn = F.silu(F.group_norm(xcat, groups, g, be, eps=1e-6))
+    if dtype == torch.bfloat16:
+        hn = hn.to(dtype).float()  # the kernel rounds act(GN(x)) to bf16 before the MFMA
+    ref = F.conv2d(hn, w, bias, padding=k // 2)
+    xa = ops.to_nhwc(a).to(DEV, dtype)
+    xb = ops.to_nhwc(bt).to(DEV, dtype) if C2 else None
+    sc, sh = ops.groupnorm_stats(xa, g.to(DEV), be.to(DEV), groups, 1e-6, x2=xb)
+    y = ops.conv2d_fused(xa, ops.pack_conv_weight(w, dtype).to(DEV), bias.to(DEV), Cout, k, x2=xb, gn=(sc, sh),
+                         gn_act=1)
+    assert rel_rms(ops.to_nchw(y.float()), ref) < tol
+
+
 def test_conv_f32_is_exact_fmaf_chain_on_integers():
     # small-integer operands: every product and partial sum is exactly representable, so the
     # MFMA result must be bit-identical to the CPU result regardless of summation order.
