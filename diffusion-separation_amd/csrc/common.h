@@ -126,12 +126,14 @@ struct ConvArgs {
   const void* res; long res_bs; int ldr; // residual added before out_scale, or null
   float out_scale;
   void* y; long y_bs; int ldy;
+  double* stats_out;                     // optional [B][ds_conv_tiles][Cout][2] per-tile (sum, sumsq) of the output
   int B, H, W;                           // taps==9: image H x W; taps==1: M = H*W rows
   int Cin, Cout, taps;
   int dtype;
 };
 int ds_launch_conv(const ConvArgs& a, hipStream_t st);
 int ds_conv_config_id(const ConvArgs& a);
+int ds_conv_tiles(const ConvArgs& a);
 
 // GroupNorm: stats -> per-(b,c) scale/shift -> apply(+SiLU)(+FIR resample)
 // ws layout: doubles [B][nblk][C][2] then floats scale[B][C], shift[B][C]
@@ -140,6 +142,10 @@ long ds_gn_workspace_bytes(int B, int H, int W, int C);
 int ds_launch_gn_stats(const void* x, int ldx, const void* x2, int ldx2, int C1, int B, int H, int W, int C, int groups,
                        float eps, const float* gamma, const float* beta, void* ws, float* scale, float* shift,
                        int dtype, hipStream_t st);
+// scale/shift from per-tile channel partials written by the conv epilogue (two sources = concat view)
+int ds_launch_gn_finalize_parts(const double* p1, int nt1, int C1, const double* p2, int nt2, int C2, int B, long npix,
+                                int groups, float eps, const float* gamma, const float* beta, float* scale,
+                                float* shift, hipStream_t st);
 // mode: 0 none, 1 up, 2 down. scale/shift null => identity & no activation (pure FIR on x -> xr only).
 int ds_launch_gn_apply(const void* x, int ldx, const float* scale, const float* shift, int C, void* y, int ldy,
                        void* xr, int ldxr, int B, int H, int W, int act, int mode, int dtype, hipStream_t st);

@@ -87,6 +87,7 @@ struct ConvK {  // kernel-side copy of ConvArgs (typed by the template)
   const void* res; long res_bs; int ldr;
   float out_scale;
   void* y; long y_bs; int ldy;
+  double* stats;  // optional [B][gridDim.x][Cout][2]: per-tile sum / sum of squares of the OUTPUT channels
   int H, W, Cin, Cout;
   int tiles_x;
 };
@@ -211,12 +212,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
       pa[k] = make_uint4(0u, 0u, 0u, 0u);
+#ifndef ABL_NOLOAD
       if (apix[k] >= 0 && ch_ok) pa[k] = *reinterpret_cast<const uint4*>(src + (long)apix[k] * ld);
+#endif
     }
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
       pb[k] = make_uint4(0u, 0u, 0u, 0u);
+#ifndef ABL_NOLOADB
       if (bsrc[k] >= 0 && ch_ok) pb[k] = *reinterpret_cast<const uint4*>(wb + bsrc[k] + ci);
+#endif
     }
     if (has_gn && ch_ok) {
 #pragma unroll
@@ -260,7 +265,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
-          for (int j = 0; j < WN; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
+          for (int j = 0; j < WN; ++j) {
+#ifndef ABL_NOMFMA
+            Mma<T>::run(af[i], bfr[j], acc[i][j]);
+#else
+            acc[i][j][0] += __uint_as_float(af[i].x ^ bfr[j].y);
+#endif
+          }
       }
     }
   }
@@ -286,44 +297,74 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
   const int cout8 = (p.Cout + 7) & ~7;
   const float dvs = p.div_b ? p.div_b[b] : 1.0f;
   constexpr int NCG = BN / 8;
-  for (int i = tid; i < BM * NCG; i += 256) {
-    const int pp = i / NCG, cg = i - pp * NCG;
-    const int co = n0 + cg * 8;
-    if (co >= cout8) continue;
-    long m;
-    if (TAPS == 9) {
-      const int gy = y0 + pp / TW, gx = x0 + pp % TW;
-      if (gy >= p.H || gx >= p.W) continue;
-      m = (long)gy * p.W + gx;
-    } else {
-      m = m0 + pp;
-      if (m >= M) continue;
+  static_assert(256 % NCG == 0, "a thread keeps one cout group across the epilogue loop");
+  const int cg = tid % NCG;
+  const int co = n0 + cg * 8;
+  float bv[8];  // per-thread column bias (conv bias + per-batch temb bias), loaded once
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float t = 0.f;
+    const int c = co + j;
+    if (p.bias_mode == 0 && c < p.Cout) {
+      if (p.bias) t += p.bias[c];
+      if (p.bias_b) t += p.bias_b[(long)b * p.bias_b_ld + c];
     }
-    float v[8];
-    const float4 a0 = *reinterpret_cast<const float4*>(smem + pp * OROW + cg * 32);
-    const float4 a1 = *reinterpret_cast<const float4*>(smem + pp * OROW + cg * 32 + 16);
-    v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-    float rv[8];
-    if (rb) load8<T>(rb + m * p.ldr + co, rv);
+    bv[j] = t;
+  }
+  float ssum[8], ssq[8];  // GroupNorm statistics of what this thread writes (consumed by the next GN)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+  if (co < cout8) {
+    for (int pp = tid / NCG; pp < BM; pp += 256 / NCG) {
+      long m;
+      if (TAPS == 9) {
+        const int gy = y0 + pp / TW, gx = x0 + pp % TW;
+        if (gy >= p.H || gx >= p.W) continue;
+        m = (long)gy * p.W + gx;
+      } else {
+        m = m0 + pp;
+        if (m >= M) continue;
+      }
+      float v[8];
+      const float4 a0 = *reinterpret_cast<const float4*>(smem + pp * OROW + cg * 32);
+      const float4 a1 = *reinterpret_cast<const float4*>(smem + pp * OROW + cg * 32 + 16);
+      v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+      float rv[8];
+      if (rb) load8<T>(rb + m * p.ldr + co, rv);
+      const float rowb = (p.bias_mode == 1 && p.bias) ? p.bias[m] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = v[j];
+        if (p.div_b) t = t / dvs;
+        t = (co + j < p.Cout) ? t + bv[j] + rowb : 0.f;
+        if (rb) t += rv[j];
+        v[j] = t * p.out_scale;
+        ssum[j] += v[j];
+        ssq[j] = fmaf(v[j], v[j], ssq[j]);
+      }
+      store8<T>(yb + m * p.ldy + co, v);
+    }
+  }
+  if (p.stats) {  // block-reduce the per-thread partials: 256/NCG threads share a cout group
+    __syncthreads();
+    float* sr = reinterpret_cast<float*>(smem);  // [256/NCG][BN][2]
+    const int r = tid / NCG;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float t = v[j];
-      if (p.div_b) t = t / dvs;
-      const int c = co + j;
-      if (c < p.Cout) {
-        if (p.bias_mode == 0) {
-          if (p.bias) t += p.bias[c];
-          if (p.bias_b) t += p.bias_b[(long)b * p.bias_b_ld + c];
-        } else if (p.bias) {
-          t += p.bias[m];
-        }
-      } else {
-        t = 0.f;
-      }
-      if (rb) t += rv[j];
-      v[j] = t * p.out_scale;
+      sr[(r * BN + cg * 8 + j) * 2 + 0] = ssum[j];
+      sr[(r * BN + cg * 8 + j) * 2 + 1] = ssq[j];
     }
-    store8<T>(yb + m * p.ldy + co, v);
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.Cout) {
+      double a = 0.0, q = 0.0;
+      for (int rr = 0; rr < 256 / NCG; ++rr) {
+        a += (double)sr[(rr * BN + tid) * 2 + 0];
+        q += (double)sr[(rr * BN + tid) * 2 + 1];
+      }
+      double* o = p.stats + (((long)b * gridDim.x + blockIdx.x) * p.Cout + n0 + tid) * 2;
+      o[0] = a;
+      o[1] = q;
+    }
   }
   (void)so;
 }
@@ -345,7 +386,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   k.gn_scale = a.gn_scale; k.gn_shift = a.gn_shift; k.gn_act = a.gn_act;
   k.bias = a.bias; k.bias_b = a.bias_b; k.bias_b_ld = a.bias_b_ld; k.bias_mode = a.bias_mode; k.div_b = a.div_b;
   k.res = a.res; k.res_bs = a.res_bs; k.ldr = a.ldr; k.out_scale = a.out_scale;
-  k.y = a.y; k.y_bs = a.y_bs; k.ldy = a.ldy;
+  k.y = a.y; k.y_bs = a.y_bs; k.ldy = a.ldy; k.stats = a.stats_out;
   k.H = a.H; k.W = a.W; k.Cin = a.Cin; k.Cout = a.Cout;
   dim3 grid;
   if (TAPS == 9) {
@@ -374,6 +415,15 @@ static int launch_typed(const ConvArgs& a, hipStream_t st) {
     case 4: return launch_cfg<T, 1, 8, 32, 32, 2, 1, KC1>(a, st);
     default: return launch_cfg<T, 1, 8, 8, 64, 1, 1, KC1>(a, st);
   }
+}
+
+// grid.x of the launch = number of output tiles per image (the stride of the statistics partials)
+int ds_conv_tiles(const ConvArgs& a) {
+  const int id = ds_conv_config_id(a);
+  if (id <= 1) return cdiv(a.W, 32) * cdiv(a.H, 8);
+  if (id == 2) return cdiv(a.W, 8) * cdiv(a.H, 8);
+  const long M = (long)a.H * a.W;
+  return id == 5 ? cdiv(M, 64) : cdiv(M, 256);
 }
 
 // Which instantiation ds_launch_conv picks (profiling label): 0/1/2 = 3x3 {8x32xBN64, 8x32xBN32, 8x8xBN64},

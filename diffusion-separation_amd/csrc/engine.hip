@@ -279,10 +279,14 @@ struct Tn {  // NHWC view; optionally the in-place channel concat of two tensors
   int C = 0, ld = 0, H = 0, W = 0;
   void* p2 = nullptr;
   int C1 = 0, ld2 = 0;
+  // per-tile channel statistics written by the producing conv ([B][nt][C][2] doubles), or null
+  double* st = nullptr; int nt = 0;
+  double* st2 = nullptr; int nt2 = 0;
 };
 static Tn cat_view(const Tn& a, const Tn& b) {
   Tn t = a;
   t.C = a.C + b.C; t.C1 = a.C; t.p2 = b.p; t.ld2 = b.ld;
+  t.st2 = b.st; t.nt2 = b.nt;
   return t;
 }
 
@@ -377,11 +381,17 @@ static const void* PK(diffsep_engine* e, long off) { return e->d_pack + off * e-
 // ---- launch helpers (skip when dry)
 struct GnAff { float* scale; float* shift; };
 static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias, const float* bias_b, int bias_b_ld,
-                const Tn* res, float scale, const Tn& y, int Cout, int taps, int B, const float* div_b,
-                hipStream_t st, const GnAff* gn = nullptr, int gn_act = 0) {
-  if (e->dry) return 0;
+                const Tn* res, float scale, Tn& y, int Cout, int taps, int B, const float* div_b,
+                hipStream_t st, const GnAff* gn = nullptr, int gn_act = 0, bool want_stats = false) {
   ConvArgs a;
   memset(&a, 0, sizeof(a));
+  a.B = B; a.H = x.H; a.W = x.W; a.Cin = x.C; a.Cout = Cout; a.taps = taps; a.dtype = e->cfg.dtype;
+  if (want_stats) {  // the consumer's GroupNorm reads these partials instead of re-reading the tensor
+    y.nt = ds_conv_tiles(a);
+    y.st = (double*)e_alloc(e, (size_t)B * y.nt * Cout * 2 * sizeof(double));
+    a.stats_out = y.st;
+  }
+  if (e->dry) return 0;
   a.x = x.p; a.x_bs = (long)x.H * x.W * x.ld; a.ldx = x.ld;
   a.x2 = x.p2; a.x2_bs = (long)x.H * x.W * x.ld2; a.ldx2 = x.ld2; a.C1 = x.C1;
   a.gn_scale = gn ? gn->scale : nullptr; a.gn_shift = gn ? gn->shift : nullptr; a.gn_act = gn_act;
@@ -390,17 +400,21 @@ static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias
   a.res = res ? res->p : nullptr; a.res_bs = res ? (long)res->H * res->W * res->ld : 0; a.ldr = res ? res->ld : 0;
   a.out_scale = scale;
   a.y = y.p; a.y_bs = (long)y.H * y.W * y.ld; a.ldy = y.ld;
-  a.B = B; a.H = x.H; a.W = x.W; a.Cin = x.C; a.Cout = Cout; a.taps = taps; a.dtype = e->cfg.dtype;
   return conv_launch_prof(e, a, st);
 }
 
 static int gn_stats(diffsep_engine* e, const Tn& x, const float* gamma, const float* beta, int B, GnAff& aff,
                     hipStream_t st) {
-  void* ws = e_alloc(e, (size_t)ds_gn_workspace_bytes(B, x.H, x.W, x.C));
   aff.scale = e_f32(e, (size_t)B * x.C);
   aff.shift = e_f32(e, (size_t)B * x.C);
-  if (e->dry) return 0;
   const int groups = (x.C / 4 < 32) ? x.C / 4 : 32;
+  if (x.st && (!x.p2 || x.st2)) {  // statistics came with the tensor(s): finalize only
+    if (e->dry) return 0;
+    return ds_launch_gn_finalize_parts(x.st, x.nt, x.p2 ? x.C1 : x.C, x.st2, x.nt2, x.p2 ? x.C - x.C1 : 0, B,
+                                       (long)x.H * x.W, groups, 1e-6f, gamma, beta, aff.scale, aff.shift, st);
+  }
+  void* ws = e_alloc(e, (size_t)ds_gn_workspace_bytes(B, x.H, x.W, x.C));
+  if (e->dry) return 0;
   return ds_launch_gn_stats(x.p, x.ld, x.p2, x.ld2, x.C1, B, x.H, x.W, x.C, groups, 1e-6f, gamma, beta, ws, aff.scale,
                             aff.shift, e->cfg.dtype, st);
 }
@@ -432,11 +446,11 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
     xr = e_tensor(e, B, Ho, Wo, m.in_ch);
     if (gn_apply(e, x, &a0, &h0, &xr, B, 1, mode, st)) return 1;
     if (conv(e, h0, PK(e, m.pk0), P(e, m.conv0_b), temb_proj + m.temb_off, e->arch.dense_total, nullptr, 1.f, h1,
-             m.out_ch, 9, B, nullptr, st))
+             m.out_ch, 9, B, nullptr, st, nullptr, 0, true))
       return 1;
   } else {
     if (conv(e, x, PK(e, m.pk0), P(e, m.conv0_b), temb_proj + m.temb_off, e->arch.dense_total, nullptr, 1.f, h1,
-             m.out_ch, 9, B, nullptr, st, &a0, 1))
+             m.out_ch, 9, B, nullptr, st, &a0, 1, true))
       return 1;
   }
   if (gn_stats(e, h1, P(e, m.gn1_w), P(e, m.gn1_b), B, a1, st)) return 1;
@@ -450,7 +464,7 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
   }
   out = e_tensor(e, B, Ho, Wo, m.out_ch);
   return conv(e, h1, PK(e, m.pk1), P(e, m.conv1_b), nullptr, 0, &skip, kInvSqrt2, out, m.out_ch, 9, B, nullptr, st,
-              &a1, 1);
+              &a1, 1, true);
 }
 
 // attention core shared with the unit entry point: o = softmax(q k^T C^-1/2) v
@@ -505,7 +519,8 @@ static int attn_block(diffsep_engine* e, const Module& m, const Tn& x, int B, Tn
   a.H = 1; a.W = C; a.Cin = C; a.Cout = L;
   if (ds_launch_conv(a, st)) return 1;
   if (attention_core(q.p, k.p, vt, o.p, B, L, C, C, C, scores, probs, e->cfg.dtype, st)) return 1;
-  return conv(e, o, PK(e, m.pk_nin[3]), P(e, m.nin_b[3]), nullptr, 0, &x, kInvSqrt2, out, C, 1, B, nullptr, st);
+  return conv(e, o, PK(e, m.pk_nin[3]), P(e, m.nin_b[3]), nullptr, 0, &x, kInvSqrt2, out, C, 1, B, nullptr, st, nullptr,
+              0, true);
 }
 
 // NCSNpp.forward  ncsnpp.py:319-478.  x0: packed input AFTER 2x-1, [B,H,W,cpad_in]; y: [B,H,W,cpad_out]
@@ -533,7 +548,8 @@ static int net_forward(diffsep_engine* e, const Tn& x0, const float* t, const Tn
   std::vector<Tn> hs;
   {
     Tn h = e_tensor(e, B, x0.H, x0.W, nf);
-    if (conv(e, x0, PK(e, cin.pk0), P(e, cin.b0), nullptr, 0, nullptr, 1.f, h, nf, 9, B, nullptr, st)) return 1;
+    if (conv(e, x0, PK(e, cin.pk0), P(e, cin.b0), nullptr, 0, nullptr, 1.f, h, nf, 9, B, nullptr, st, nullptr, 0, true))
+      return 1;
     hs.push_back(h);
   }
   Tn pyr_in = x0;
@@ -559,7 +575,8 @@ static int net_forward(diffsep_engine* e, const Tn& x0, const float* t, const Tn
       const Module& cm = A.mods[mi++];
       DS_CHECK(cm.kind == MK_COMBINE, "internal: expected Combine");
       Tn hc = e_tensor(e, B, h.H, h.W, h.C);
-      if (conv(e, pyr_in, PK(e, cm.pk0), P(e, cm.b0), nullptr, 0, &h, 1.f, hc, h.C, 1, B, nullptr, st)) return 1;
+      if (conv(e, pyr_in, PK(e, cm.pk0), P(e, cm.b0), nullptr, 0, &h, 1.f, hc, h.C, 1, B, nullptr, st, nullptr, 0, true))
+        return 1;
       hs.push_back(hc);
     }
   }
@@ -613,7 +630,8 @@ static int net_forward(diffsep_engine* e, const Tn& x0, const float* t, const Tn
   }
   DS_CHECK(hs.empty() && mi == A.mods.size(), "internal: module walk did not consume all modules");
   // h = pyramid / t ; out = output_layer(h)   (ncsnpp.py:472-477)
-  return conv(e, pyramid, PK(e, A.pk_out), P(e, A.out_b), nullptr, 0, nullptr, 1.f, y, A.chan_out, 1, B, t, st);
+  Tn yy = y;
+  return conv(e, pyramid, PK(e, A.pk_out), P(e, A.out_b), nullptr, 0, nullptr, 1.f, yy, A.chan_out, 1, B, t, st);
 }
 
 // ScoreModelNCSNpp.forward  score_models.py:126-138

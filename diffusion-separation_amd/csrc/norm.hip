@@ -101,6 +101,76 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
   }
 }
 
+// GroupNorm scale/shift from the per-tile channel partials the conv epilogue wrote (no extra pass over the
+// activation).  grid (B); threads split (channel, tile-slice); two partial sources = in-place concat.
+__global__ __launch_bounds__(256) void gn_finalize_parts_kernel(const double* __restrict__ p1, int nt1, int C1,
+                                                                const double* __restrict__ p2, int nt2, int C2,
+                                                                int groups, double count, float eps,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double cs[1024], cq[1024];
+  __shared__ float gm[256], gr[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int C = C1 + C2;
+  const int Cw = C < 256 ? C : 256;
+  const int nsl = 256 / Cw;
+  const int cl = tid % Cw, sl = tid / Cw;
+  if (sl < nsl) {
+    for (int c = cl; c < C; c += Cw) {
+      const bool second = c >= C1;
+      const double* src = second ? p2 : p1;
+      const int nt = second ? nt2 : nt1, Cs = second ? C2 : C1, cc = second ? c - C1 : c;
+      double a = 0.0, q = 0.0;
+#pragma unroll 4
+      for (int t = sl; t < nt; t += nsl) {
+        const double* o = src + (((long)b * nt + t) * Cs + cc) * 2;
+        a += o[0];
+        q += o[1];
+      }
+      cs[sl * C + c] = a;
+      cq[sl * C + c] = q;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    double a = 0.0, q = 0.0;
+    for (int s = 0; s < nsl; ++s) { a += cs[s * C + c]; q += cq[s * C + c]; }
+    cs[c] = a;  // slot (0, c) is read by this thread only: no hazard with the other threads' reads
+    cq[c] = q;
+  }
+  __syncthreads();
+  const int cpg = C / groups;
+  for (int g = tid; g < groups; g += 256) {
+    double a = 0.0, q = 0.0;
+    for (int j = 0; j < cpg; ++j) { a += cs[g * cpg + j]; q += cq[g * cpg + j]; }
+    const double mean = a / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    gm[g] = (float)mean;
+    gr[g] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cpg;
+    const float sc = gr[g] * (gamma ? gamma[c] : 1.f);
+    scale[(long)b * C + c] = sc;
+    shift[(long)b * C + c] = (beta ? beta[c] : 0.f) - gm[g] * sc;
+  }
+}
+
+int ds_launch_gn_finalize_parts(const double* p1, int nt1, int C1, const double* p2, int nt2, int C2, int B, long npix,
+                                int groups, float eps, const float* gamma, const float* beta, float* scale,
+                                float* shift, hipStream_t st) {
+  const int C = C1 + C2;
+  DS_CHECK(C <= 1024 && C % groups == 0 && groups <= 256, "groupnorm(parts): unsupported channel / group count");
+  const double count = (double)npix * (double)(C / groups);
+  hipLaunchKernelGGL(gn_finalize_parts_kernel, dim3(B), dim3(256), 0, st, p1, nt1, C1, p2, nt2, C2, groups, count, eps,
+                     gamma, beta, scale, shift);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+
 long ds_gn_workspace_bytes(int B, int H, int W, int C) {
   const long npix = (long)H * W;
   long nblk = cdiv(npix, 64);

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libdiffsep_hip.so")
+LIB_PATH = os.environ.get("DIFFSEP_LIB", os.path.join(os.path.dirname(_HERE), "libdiffsep_hip.so"))
 
 F32, BF16 = 0, 1
 SDE_MIX, SDE_PRIORMIX = 0, 1
