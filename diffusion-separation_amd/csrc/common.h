@@ -153,12 +153,14 @@ int ds_launch_concat(const void* a, int lda, int Ca, const void* b, int ldb, int
                      int dtype, hipStream_t st);
 int ds_launch_softmax(const void* x, void* y, long rows, int L, int ld, int dtype, hipStream_t st);
 
+long ds_stft_workspace_bytes(int B, int S, long T, int n_fft, int hop);
+long ds_istft_workspace_bytes(int B, int S, long T, int n_fft, int hop);
 int ds_launch_stft_pack(const float* xt, const float* mix, void* y, int B, int S, long T, int n_fft, int hop,
                         float exponent, float factor, int W, int Cpad, int shift, int dtype, const float* tab,
-                        hipStream_t st);
+                        float* ws, hipStream_t st);
 int ds_launch_istft(const void* x, float* out, int B, int S, long T, int n_fft, int hop, float exponent, float factor,
-                    int W, int Cpad, int dtype, const float* tab, float* frames_ws, hipStream_t st);
-// tab: device float [3][n_fft] = cos(2 pi n/n_fft), sin(2 pi n/n_fft), hann[n]  (built by ds_build_stft_table)
+                    int W, int Cpad, int dtype, const float* tab, float* ws, hipStream_t st);
+// tab: device floats: cos | sin | hann (n_fft each), then the [512][512] forward and inverse(+window) DFT matrices
 int ds_build_stft_table(int n_fft, float** dev_tab);
 
 struct SdeP { int kind; int ndim; float d_lambda, sigma_min, sigma_max; };

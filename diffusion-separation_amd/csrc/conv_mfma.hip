@@ -212,16 +212,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
       pa[k] = make_uint4(0u, 0u, 0u, 0u);
-#ifndef ABL_NOLOAD
       if (apix[k] >= 0 && ch_ok) pa[k] = *reinterpret_cast<const uint4*>(src + (long)apix[k] * ld);
-#endif
     }
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
       pb[k] = make_uint4(0u, 0u, 0u, 0u);
-#ifndef ABL_NOLOADB
       if (bsrc[k] >= 0 && ch_ok) pb[k] = *reinterpret_cast<const uint4*>(wb + bsrc[k] + ci);
-#endif
     }
     if (has_gn && ch_ok) {
 #pragma unroll
@@ -265,13 +261,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
-          for (int j = 0; j < WN; ++j) {
-#ifndef ABL_NOMFMA
-            Mma<T>::run(af[i], bfr[j], acc[i][j]);
-#else
-            acc[i][j][0] += __uint_as_float(af[i].x ^ bfr[j].y);
-#endif
-          }
+          for (int j = 0; j < WN; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
       }
     }
   }

@@ -642,11 +642,11 @@ static int score_forward_impl(diffsep_engine* e, const float* xt, const float* t
   e->top = e->fwd_base;
   Tn x0 = e_tensor(e, B, H, W, e->arch.cpad_in);
   Tn y = e_tensor(e, B, H, W, e->arch.cpad_out);
-  const int F = diffsep_num_frames(&c, T);
-  float* frames = e_f32(e, (size_t)B * S * F * 512);
+  float* ws_f = (float*)e_alloc(e, (size_t)ds_stft_workspace_bytes(B, S, T, c.n_fft, c.hop));
+  float* frames = (float*)e_alloc(e, (size_t)ds_istft_workspace_bytes(B, S, T, c.n_fft, c.hop));
   if (!e->dry)
     if (ds_launch_stft_pack(xt, mix, x0.p, B, S, T, c.n_fft, c.hop, c.spec_abs_exponent, c.spec_factor, W,
-                            e->arch.cpad_in, 1, c.dtype, e->d_tab, st))
+                            e->arch.cpad_in, 1, c.dtype, e->d_tab, ws_f, st))
       return 1;
   if (net_forward(e, x0, t, y, B, st)) return 1;
   if (!e->dry)
@@ -1057,20 +1057,21 @@ static int unit_tab(int n_fft, float** tab) {
 
 extern "C" int32_t diffsep_stft_pack(const float* xt, const float* mix, void* y, int32_t B, int32_t S, int64_t T,
                                      int32_t n_fft, int32_t hop, float exponent, float factor, int32_t W, int32_t Cpad,
-                                     int32_t centered_shift, int32_t dtype, void* stream) {
-  DS_CHECK(xt && mix && y, "stft_pack: null pointer");
+                                     int32_t centered_shift, int32_t dtype, void* workspace, int64_t workspace_bytes,
+                                     void* stream) {
+  DS_CHECK(xt && mix && y && workspace, "stft_pack: null pointer");
+  DS_CHECK(workspace_bytes >= ds_stft_workspace_bytes(B, S, T, n_fft, hop), "stft_pack: workspace too small");
   float* tab;
   if (unit_tab(n_fft, &tab)) return 1;
   return ds_launch_stft_pack(xt, mix, y, B, S, T, n_fft, hop, exponent, factor, W, Cpad, centered_shift, dtype, tab,
-                             (hipStream_t)stream);
+                             (float*)workspace, (hipStream_t)stream);
 }
 
 extern "C" int32_t diffsep_istft_unpack(const void* x, float* out, int32_t B, int32_t S, int64_t T, int32_t n_fft,
                                         int32_t hop, float exponent, float factor, int32_t W, int32_t Cpad,
                                         int32_t dtype, void* workspace, int64_t workspace_bytes, void* stream) {
   DS_CHECK(x && out && workspace, "istft_unpack: null pointer");
-  const int F = 1 + (int)((T + n_fft - hop) / hop);
-  DS_CHECK(workspace_bytes >= (int64_t)B * S * F * 512 * 4, "istft_unpack: workspace too small");
+  DS_CHECK(workspace_bytes >= ds_istft_workspace_bytes(B, S, T, n_fft, hop), "istft_unpack: workspace too small");
   float* tab;
   if (unit_tab(n_fft, &tab)) return 1;
   return ds_launch_istft(x, out, B, S, T, n_fft, hop, exponent, factor, W, Cpad, dtype, tab, (float*)workspace,

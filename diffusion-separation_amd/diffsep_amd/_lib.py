@@ -62,7 +62,7 @@ _SIGS = {
     "diffsep_conv2d_fused": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F,
                                   _I, _P]),
     "diffsep_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
-    "diffsep_stft_pack": (_I, [_P, _P, _P, _I, _I, _L, _I, _I, _F, _F, _I, _I, _I, _I, _P]),
+    "diffsep_stft_pack": (_I, [_P, _P, _P, _I, _I, _L, _I, _I, _F, _F, _I, _I, _I, _I, _P, _L, _P]),
     "diffsep_istft_unpack": (_I, [_P, _P, _I, _I, _L, _I, _I, _F, _F, _I, _I, _I, _P, _L, _P]),
     "diffsep_sde_prior": (_I, [C.POINTER(SdeConfig), _P, _P, _P, _I, _I, _L, _P]),
     "diffsep_sde_corrector_update": (_I, [C.POINTER(SdeConfig), _F, _P, _P, _P, _P, _P, _P, _I, _I, _L, _P]),

@@ -109,8 +109,11 @@ def attention(q, k, vt):
 def stft_pack(xt, mix, W, cpad, n_fft=510, hop=128, exponent=0.5, factor=0.33, shift=False, dtype=torch.float32):
     B, S, T = xt.shape
     y = torch.empty((B, n_fft // 2 + 1, W, cpad), dtype=dtype, device=xt.device)
+    F_ = 1 + (T + n_fft - hop) // hop
+    ws = torch.empty(2 * ((B * (S + 1) * F_ + 8) * 512 + 64), dtype=torch.float32, device=xt.device)
     check(lib().diffsep_stft_pack(_ptr(xt), _ptr(mix), _ptr(y), B, S, T, n_fft, hop, exponent, factor, W, cpad,
-                                  int(shift), F32 if dtype == torch.float32 else BF16, _stream_ptr()))
+                                  int(shift), F32 if dtype == torch.float32 else BF16, _ptr(ws), ws.numel() * 4,
+                                  _stream_ptr()))
     return y
 
 
@@ -118,7 +121,7 @@ def istft_unpack(x, S, T, n_fft=510, hop=128, exponent=0.5, factor=0.33):
     B, H, W, cpad = x.shape
     F_ = 1 + (T + n_fft - hop) // hop
     out = torch.empty((B, S, T), dtype=torch.float32, device=x.device)
-    ws = torch.empty(B * S * F_ * 512, dtype=torch.float32, device=x.device)
+    ws = torch.empty(2 * (B * S * F_ * 512 + 64), dtype=torch.float32, device=x.device)
     check(lib().diffsep_istft_unpack(_ptr(x), _ptr(out), B, S, T, n_fft, hop, exponent, factor, W, cpad, _dt(x),
                                      _ptr(ws), ws.numel() * 4, _stream_ptr()))
     return out

@@ -193,14 +193,16 @@ int32_t diffsep_attention(const void* q, const void* k, const void* vt, void* o,
  * n_fft-hop -> STFT(n_fft, hop, periodic Hann, center, zero pad) -> |z|^e e^{j angle} * factor ->
  * [re x S+1 | im x S+1] channels -> zero-pad frames to W (then 2x-1).
  * xt [B,S,T], mix [B,1,T] f32 -> y [B, n_fft/2+1, W, Cpad] (dtype), Cpad = roundup(2S+2, 8).
- * centered_shift != 0 applies 2x-1 (what the engine does); 0 leaves the packed spectrogram. */
+ * centered_shift != 0 applies 2x-1 (what the engine does); 0 leaves the packed spectrogram.
+ * ws >= 2*((B*(S+1)*F + 8)*512*4 + 256) bytes (windowed frames + transposed spectrum of the DFT GEMM). */
 int32_t diffsep_stft_pack(const float* xt, const float* mix, void* y, int32_t B, int32_t S, int64_t T,
                           int32_t n_fft, int32_t hop, float exponent, float factor, int32_t W, int32_t Cpad,
-                          int32_t centered_shift, int32_t dtype, void* stream);
+                          int32_t centered_shift, int32_t dtype, void* workspace, int64_t workspace_bytes,
+                          void* stream);
 
 /* post_process (score_models.py:118-124): unpad frames -> channels to complex -> z/|factor| ->
  * |z|^(1/e) e^{j angle} -> iSTFT -> crop to T.  x [B,256,W,Cpad] (first 2S channels used) -> out [B,S,T];
- * ws >= B*S*F*512*4 bytes. */
+ * ws >= 2*(B*S*F*512*4 + 256) bytes (decompressed bins + inverse-DFT frames). */
 int32_t diffsep_istft_unpack(const void* x, float* out, int32_t B, int32_t S, int64_t T, int32_t n_fft,
                              int32_t hop, float exponent, float factor, int32_t W, int32_t Cpad, int32_t dtype,
                              void* workspace, int64_t workspace_bytes, void* stream);
