@@ -38,7 +38,17 @@ void ds_set_error(const std::string& s);
 __host__ __device__ inline float bf2f(bf16_t v) {
   union { uint32_t u; float f; } c; c.u = ((uint32_t)v) << 16; return c.f;
 }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two floats -> packed bf16x2 (RNE): one v_cvt_pk_bf16_f32 on gfx950
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 __host__ __device__ inline bf16_t f2bf(float f) {  // round-to-nearest-even
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
+#endif
   union { uint32_t u; float f; } c; c.f = f;
   uint32_t u = c.u;
   if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
@@ -79,10 +89,10 @@ template <> __device__ inline void store8<float>(float* p, const float* f) {
 }
 template <> __device__ inline void store8<bf16_t>(bf16_t* p, const float* f) {
   uint4 u;
-  u.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
-  u.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
-  u.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
-  u.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+  u.x = pack_bf16x2(f[0], f[1]);
+  u.y = pack_bf16x2(f[2], f[3]);
+  u.z = pack_bf16x2(f[4], f[5]);
+  u.w = pack_bf16x2(f[6], f[7]);
   *reinterpret_cast<uint4*>(p) = u;
 }
 
@@ -90,7 +100,10 @@ template <> __device__ inline void store8<bf16_t>(bf16_t* p, const float* f) {
 template <typename T> __device__ inline float exp_t(float v);
 template <> __device__ inline float exp_t<float>(float v) { return expf(v); }
 template <> __device__ inline float exp_t<bf16_t>(float v) { return __expf(v); }
-template <typename T> __device__ inline float silu_t(float v) { return v / (1.0f + exp_t<T>(-v)); }
+template <typename T> __device__ inline float silu_t(float v);
+template <> __device__ inline float silu_t<float>(float v) { return v / (1.0f + expf(-v)); }
+// bf16 mode: v_exp_f32 + v_rcp_f32 (1 ulp) instead of the 11-instruction IEEE division
+template <> __device__ inline float silu_t<bf16_t>(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // wave64 butterfly reductions (no LDS)
 __device__ inline float wave_sum(float v) {

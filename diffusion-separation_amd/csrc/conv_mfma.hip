@@ -69,10 +69,10 @@ template <> struct GnVec<bf16_t> {
       f[j] = act ? silu_t<bf16_t>(v) : v;
     }
     uint4 o;
-    o.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
-    o.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
-    o.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
-    o.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+    o.x = pack_bf16x2(f[0], f[1]);
+    o.y = pack_bf16x2(f[2], f[3]);
+    o.z = pack_bf16x2(f[4], f[5]);
+    o.w = pack_bf16x2(f[6], f[7]);
     return o;
   }
 };

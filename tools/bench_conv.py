@@ -22,9 +22,12 @@ SHAPES = [  # (ksize, Cin, Cout, H, W, count per forward)
 def main():
     dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    sel = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else None
     B = 16
     tot_t = tot_f = 0.0
-    for k, ci, co, H, W, cnt in SHAPES:
+    for idx, (k, ci, co, H, W, cnt) in enumerate(SHAPES):
+        if sel is not None and idx not in sel:
+            continue
         x = torch.randn(B, H, W, ci, device="cuda").to(dt)
         w = (torch.randn(co, k * k, ci, device="cuda") / (k * k * ci) ** 0.5).to(dt)
         b = torch.randn(co, device="cuda")
