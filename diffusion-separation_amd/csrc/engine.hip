@@ -4,6 +4,7 @@
 // (sdes/__init__.py:166-188).  Everything that touches data is a HIP kernel from the sibling files;
 // this file only sequences launches.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -319,6 +320,12 @@ struct diffsep_engine {
   // mapped to this private stream, ordered against the null stream with events on both sides.
   hipStream_t own = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  // independent branches of the network (1x1 skip convolutions, the output pyramid) run on two side
+  // streams, forked / joined with events (captured into the graph as parallel branches)
+  hipStream_t sideA = nullptr, sideB = nullptr;
+  std::vector<hipEvent_t> fj_events;
+  size_t fj_i = 0;
+  int use_side = 0;  // measured on MI355X: parallel graph branches cost ~5 % here (DIFFSEP_SIDE=1|2|3 enables them)
   // optional per-launch timing of the MFMA kernels (HIP events on the launch stream)
   bool prof = false;
   struct ProfRec { hipEvent_t a, b; double flops; int cls; };
@@ -326,6 +333,21 @@ struct diffsep_engine {
   std::vector<hipEvent_t> ev_pool;
 };
 #define DS_NCLS 6
+static hipEvent_t fj_event(diffsep_engine* e) {
+  if (e->fj_i == e->fj_events.size()) {
+    hipEvent_t v = nullptr;
+    hipEventCreateWithFlags(&v, hipEventDisableTiming);
+    e->fj_events.push_back(v);
+  }
+  return e->fj_events[e->fj_i++];
+}
+// make `to` wait for everything issued so far on `from`
+static int stream_dep(diffsep_engine* e, hipStream_t from, hipStream_t to) {
+  hipEvent_t ev = fj_event(e);
+  DS_HIP(hipEventRecord(ev, from));
+  DS_HIP(hipStreamWaitEvent(to, ev, 0));
+  return 0;
+}
 static hipEvent_t prof_event(diffsep_engine* e) {
   if (!e->ev_pool.empty()) { hipEvent_t v = e->ev_pool.back(); e->ev_pool.pop_back(); return v; }
   hipEvent_t v = nullptr;
@@ -439,13 +461,27 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
   GnAff a0, a1;
   if (gn_stats(e, x, P(e, m.gn0_w), P(e, m.gn0_b), B, a0, st)) return 1;
   Tn h1 = e_tensor(e, B, Ho, Wo, m.out_ch);
-  Tn xr = x;
+  Tn xr = x, h0m;
   if (mode) {
     DS_CHECK(x.p2 == nullptr, "internal: resampling block on a concat view");
-    Tn h0 = e_tensor(e, B, Ho, Wo, m.in_ch);
+    h0m = e_tensor(e, B, Ho, Wo, m.in_ch);
     xr = e_tensor(e, B, Ho, Wo, m.in_ch);
-    if (gn_apply(e, x, &a0, &h0, &xr, B, 1, mode, st)) return 1;
-    if (conv(e, h0, PK(e, m.pk0), P(e, m.conv0_b), temb_proj + m.temb_off, e->arch.dense_total, nullptr, 1.f, h1,
+    if (gn_apply(e, x, &a0, &h0m, &xr, B, 1, mode, st)) return 1;
+  }
+  // the 1x1 skip convolution only needs the (resampled) block input: run it beside conv0 -> GN1
+  Tn skip = xr;
+  const bool side = m.has_conv2 && !e->dry && (e->use_side & 1);
+  if (m.has_conv2) {
+    skip = e_tensor(e, B, Ho, Wo, m.out_ch);
+    hipStream_t s2 = side ? e->sideA : st;
+    if (side && stream_dep(e, st, s2)) return 1;
+    if (conv(e, xr, PK(e, m.pk2), P(e, m.conv2_b), nullptr, 0, nullptr, 1.f, skip, m.out_ch, 1, B, nullptr, s2))
+      return 1;
+  } else {
+    DS_CHECK(xr.p2 == nullptr, "internal: identity skip on a concat view");
+  }
+  if (mode) {
+    if (conv(e, h0m, PK(e, m.pk0), P(e, m.conv0_b), temb_proj + m.temb_off, e->arch.dense_total, nullptr, 1.f, h1,
              m.out_ch, 9, B, nullptr, st, nullptr, 0, true))
       return 1;
   } else {
@@ -454,14 +490,7 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
       return 1;
   }
   if (gn_stats(e, h1, P(e, m.gn1_w), P(e, m.gn1_b), B, a1, st)) return 1;
-  Tn skip = xr;
-  if (m.has_conv2) {
-    skip = e_tensor(e, B, Ho, Wo, m.out_ch);
-    if (conv(e, xr, PK(e, m.pk2), P(e, m.conv2_b), nullptr, 0, nullptr, 1.f, skip, m.out_ch, 1, B, nullptr, st))
-      return 1;
-  } else {
-    DS_CHECK(xr.p2 == nullptr, "internal: identity skip on a concat view");
-  }
+  if (side && stream_dep(e, e->sideA, st)) return 1;
   out = e_tensor(e, B, Ho, Wo, m.out_ch);
   return conv(e, h1, PK(e, m.pk1), P(e, m.conv1_b), nullptr, 0, &skip, kInvSqrt2, out, m.out_ch, 9, B, nullptr, st,
               &a1, 1, true);
@@ -608,16 +637,20 @@ static int net_forward(diffsep_engine* e, const Tn& x0, const float* t, const Tn
     const Module& g = A.mods[mi++];
     const Module& cv = A.mods[mi++];
     DS_CHECK(g.kind == MK_GN && cv.kind == MK_CONV3, "internal: expected pyramid GN + conv");
+    // the pyramid chain only depends on h of each level: it runs on its own stream beside the up path
+    const bool sideb = !e->dry && (e->use_side & 2);
+    hipStream_t sp = sideb ? e->sideB : st;
+    if (sideb && stream_dep(e, st, sp)) return 1;
     GnAff ga;
-    if (gn_stats(e, h, P(e, g.w0), P(e, g.b0), B, ga, st)) return 1;
+    if (gn_stats(e, h, P(e, g.w0), P(e, g.b0), B, ga, sp)) return 1;
     Tn pnew = e_tensor(e, B, h.H, h.W, A.cpad_in);
     if (have_pyr) {
       Tn pu = e_tensor(e, B, h.H, h.W, A.cpad_in);
-      if (gn_apply(e, pyramid, nullptr, nullptr, &pu, B, 0, 1, st)) return 1;
-      if (conv(e, h, PK(e, cv.pk0), P(e, cv.b0), nullptr, 0, &pu, 1.f, pnew, A.chan_in, 9, B, nullptr, st, &ga, 1))
+      if (gn_apply(e, pyramid, nullptr, nullptr, &pu, B, 0, 1, sp)) return 1;
+      if (conv(e, h, PK(e, cv.pk0), P(e, cv.b0), nullptr, 0, &pu, 1.f, pnew, A.chan_in, 9, B, nullptr, sp, &ga, 1))
         return 1;
     } else {
-      if (conv(e, h, PK(e, cv.pk0), P(e, cv.b0), nullptr, 0, nullptr, 1.f, pnew, A.chan_in, 9, B, nullptr, st, &ga, 1))
+      if (conv(e, h, PK(e, cv.pk0), P(e, cv.b0), nullptr, 0, nullptr, 1.f, pnew, A.chan_in, 9, B, nullptr, sp, &ga, 1))
         return 1;
     }
     pyramid = pnew;
@@ -630,6 +663,7 @@ static int net_forward(diffsep_engine* e, const Tn& x0, const float* t, const Tn
   }
   DS_CHECK(hs.empty() && mi == A.mods.size(), "internal: module walk did not consume all modules");
   // h = pyramid / t ; out = output_layer(h)   (ncsnpp.py:472-477)
+  if (!e->dry && (e->use_side & 2) && stream_dep(e, e->sideB, st)) return 1;
   Tn yy = y;
   return conv(e, pyramid, PK(e, A.pk_out), P(e, A.out_b), nullptr, 0, nullptr, 1.f, yy, A.chan_out, 1, B, t, st);
 }
@@ -640,6 +674,7 @@ static int score_forward_impl(diffsep_engine* e, const float* xt, const float* t
   const diffsep_model_config& c = e->cfg;
   const int W = diffsep_padded_frames(&c, T), H = c.n_fft / 2 + 1, S = c.num_sources;
   e->top = e->fwd_base;
+  e->fj_i = 0;
   Tn x0 = e_tensor(e, B, H, W, e->arch.cpad_in);
   Tn y = e_tensor(e, B, H, W, e->arch.cpad_out);
   float* ws_f = (float*)e_alloc(e, (size_t)ds_stft_workspace_bytes(B, S, T, c.n_fft, c.hop));
@@ -729,6 +764,9 @@ extern "C" int32_t diffsep_engine_create(const diffsep_model_config* cfg, const 
   e->weight_bytes = (int64_t)A.total * 4 + (int64_t)A.pack_total * e->esz + (int64_t)A.dense_total * (4 * cfg->nf + 1) * 4;
   if (ds_build_stft_table(cfg->n_fft, &e->d_tab)) { delete e; return 1; }
   DS_HIP(hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
+  if (const char* sv = getenv("DIFFSEP_SIDE")) e->use_side = atoi(sv);
+  DS_HIP(hipStreamCreateWithFlags(&e->sideA, hipStreamNonBlocking));
+  DS_HIP(hipStreamCreateWithFlags(&e->sideB, hipStreamNonBlocking));
   DS_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
   DS_HIP(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
 
@@ -780,6 +818,9 @@ extern "C" void diffsep_engine_destroy(diffsep_engine* e) {
   hipFree(e->d_blob); hipFree(e->d_pack); hipFree(e->d_dense_w); hipFree(e->d_dense_b); hipFree(e->d_tab);
   if (e->arena) hipFree(e->arena);
   if (e->own) hipStreamDestroy(e->own);
+  if (e->sideA) hipStreamDestroy(e->sideA);
+  if (e->sideB) hipStreamDestroy(e->sideB);
+  for (auto v : e->fj_events) hipEventDestroy(v);
   if (e->ev_in) hipEventDestroy(e->ev_in);
   if (e->ev_out) hipEventDestroy(e->ev_out);
   delete e;
@@ -841,6 +882,7 @@ extern "C" int32_t diffsep_backbone_forward(diffsep_engine* e, const void* x, co
   if (ensure_plan(e, B, T, st)) return 1;
   const int H = e->cfg.n_fft / 2 + 1;
   e->top = e->fwd_base;
+  e->fj_i = 0;
   Tn xin; xin.p = (void*)x; xin.C = xin.ld = e->arch.cpad_in; xin.H = H; xin.W = W;
   Tn x0 = e_tensor(e, B, H, W, e->arch.cpad_in);
   float* sc = e_f32(e, (size_t)B * e->arch.cpad_in);
