@@ -25,7 +25,25 @@
 // current chunk and written to LDS after it (issue-early / write-late), so HBM/L2 latency hides
 // under the matrix work.  Epilogue: accumulators go through LDS (fp32) and leave as 16-byte,
 // channel-contiguous stores with coalesced residual reads.
+#include <stdlib.h>
+
 #include "common.h"
+
+#ifdef CONV_TIMING  // profiling build only (tools/conv_timing.sh): per-phase cycle totals of wave 0 of every block
+__device__ unsigned long long g_conv_dbg[8];
+#define CT_DECL unsigned long long ct_prev = clock64(), ct_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#define CT_MARK(i) { unsigned long long ct_now = clock64(); ct_acc[i] += ct_now - ct_prev; ct_prev = ct_now; }
+#define CT_FLUSH if (threadIdx.x == 0) { for (int q = 0; q < 7; ++q) atomicAdd(&g_conv_dbg[q], ct_acc[q]); atomicAdd(&g_conv_dbg[7], 1ull); }
+extern "C" int diffsep_debug_read(unsigned long long* out, int reset) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_dbg), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_conv_dbg), z, sizeof(z)); }
+  return 0;
+}
+#else
+#define CT_DECL
+#define CT_MARK(i)
+#define CT_FLUSH
+#endif
 
 template <typename T> struct Mma;
 template <> struct Mma<float> {
@@ -77,6 +95,29 @@ template <> struct GnVec<bf16_t> {
   }
 };
 
+// 8 channels held as raw 16-byte vectors -> floats
+template <typename T> __device__ inline void unpack8(const uint4* u, float* f);
+template <> __device__ inline void unpack8<float>(const uint4* u, float* f) {
+  f[0] = __uint_as_float(u[0].x); f[1] = __uint_as_float(u[0].y); f[2] = __uint_as_float(u[0].z);
+  f[3] = __uint_as_float(u[0].w); f[4] = __uint_as_float(u[1].x); f[5] = __uint_as_float(u[1].y);
+  f[6] = __uint_as_float(u[1].z); f[7] = __uint_as_float(u[1].w);
+}
+template <> __device__ inline void unpack8<bf16_t>(const uint4* u, float* f) {
+  f[0] = __uint_as_float(u[0].x << 16); f[1] = __uint_as_float(u[0].x & 0xffff0000u);
+  f[2] = __uint_as_float(u[0].y << 16); f[3] = __uint_as_float(u[0].y & 0xffff0000u);
+  f[4] = __uint_as_float(u[0].z << 16); f[5] = __uint_as_float(u[0].z & 0xffff0000u);
+  f[6] = __uint_as_float(u[0].w << 16); f[7] = __uint_as_float(u[0].w & 0xffff0000u);
+}
+
+template <typename T> __device__ inline void pack8(const float* f, uint4* u);
+template <> __device__ inline void pack8<float>(const float* f, uint4* u) {
+  u[0] = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+  u[1] = make_uint4(__float_as_uint(f[4]), __float_as_uint(f[5]), __float_as_uint(f[6]), __float_as_uint(f[7]));
+}
+template <> __device__ inline void pack8<bf16_t>(const float* f, uint4* u) {
+  u[0] = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+}
+
 struct ConvK {  // kernel-side copy of ConvArgs (typed by the template)
   const void* x; long x_bs; int ldx; int C1;
   const void* x2; long x2_bs; int ldx2;
@@ -92,7 +133,7 @@ struct ConvK {  // kernel-side copy of ConvArgs (typed by the template)
   int tiles_x;
 };
 
-template <typename T, int TAPS, int TH, int TW, int BN, int KC>
+template <typename T, int TAPS, int TH, int TW, int BN, int KC, int EP = 1>
 struct ConvGeom {
   static constexpr int KV = 16 / (int)sizeof(T);
   static constexpr int R = (TAPS == 9) ? 1 : 0;
@@ -105,15 +146,36 @@ struct ConvGeom {
   static constexpr int NB = (TAPS * BN * NVEC + 255) / 256;
   static constexpr int OROW = BN * 4 + 16;  // fp32 output staging row pitch
   static constexpr int LDS_STAGE = HP * ROWB + TAPS * BN * ROWB;
-  static constexpr int LDS_OUT = BM * OROW;
+  static constexpr int LDS_OUT = (BM / EP) * OROW;  // the epilogue streams the tile out in EP passes
   static constexpr int LDS = LDS_STAGE > LDS_OUT ? LDS_STAGE : LDS_OUT;
 };
 
-template <typename T, int TAPS, int TH, int TW, int BN, int WM, int WN, int KC>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
-  using G = ConvGeom<T, TAPS, TH, TW, BN, KC>;
+// ---- buffer addressing (SRSRC): a wave-uniform descriptor + a 32-bit per-lane byte offset + a uniform
+// scalar offset.  Lanes that must not touch memory get an offset >= num_records: the hardware returns 0 for
+// such loads and drops such stores, so the halo zero padding, ragged tiles and channel tails cost no
+// branches, no exec masking and no zero-initialisation.  The per-lane offsets are loop invariant: inside the
+// K loop a load is ONE instruction (the chunk's channel offset travels in the scalar offset).
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+#define DS_OOB 0x80000000u
+__device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ inline uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ inline void buf_store16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const uint4& d) {
+  u32x4_t v = {d.x, d.y, d.z, d.w};
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
+}
+
+template <typename T, int TAPS, int TH, int TW, int BN, int WM, int WN, int KC, int EP = 1, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
+  using G = ConvGeom<T, TAPS, TH, TW, BN, KC, EP>;
+  static_assert(EP == 1 || (WM % EP == 0), "epilogue passes split the wave's M blocks");
   constexpr int KV = G::KV, R = G::R, HW_ = G::HW_, HP = G::HP, BM = G::BM, ROWB = G::ROWB, NVEC = G::NVEC,
                 NKB = G::NKB, NA = G::NA, NB = G::NB, OROW = G::OROW;
+  constexpr int ESZ = (int)sizeof(T);
   constexpr int WAVES_N = BN / (32 * WN);
   constexpr int WAVES_M = BM / (32 * WM);
   static_assert(WAVES_M * WAVES_N == 4, "block is 4 waves");
@@ -132,52 +194,62 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
   const int b = blockIdx.z;
   const int n0 = blockIdx.y * BN;
   int y0 = 0, x0 = 0;
-  long m0 = 0;
-  const long M = (long)p.H * p.W;
+  int m0 = 0;
+  const int M = p.H * p.W;
   if (TAPS == 9) {
     y0 = (blockIdx.x / p.tiles_x) * TH;
     x0 = (blockIdx.x % p.tiles_x) * TW;
   } else {
-    m0 = (long)blockIdx.x * BM;
+    m0 = blockIdx.x * BM;
   }
 
-  const T* xb1 = reinterpret_cast<const T*>(p.x) + (long)b * p.x_bs;
-  const T* xb2 = p.x2 ? reinterpret_cast<const T*>(p.x2) + (long)b * p.x2_bs : nullptr;
-  const T* wb = reinterpret_cast<const T*>(p.w) + (long)b * p.w_bs;
   const bool has_gn = p.gn_scale != nullptr;
+  const int C1 = p.C1, C2 = p.Cin - p.C1;
+  const __amdgpu_buffer_rsrc_t rx1 =
+      make_rsrc(reinterpret_cast<const T*>(p.x) + (long)b * p.x_bs, (unsigned)M * p.ldx * ESZ);
+  const __amdgpu_buffer_rsrc_t rx2 = make_rsrc(
+      p.x2 ? reinterpret_cast<const T*>(p.x2) + (long)b * p.x2_bs : reinterpret_cast<const T*>(p.x), (unsigned)M * (p.x2 ? p.ldx2 : p.ldx) * ESZ);
+  const __amdgpu_buffer_rsrc_t rw =
+      make_rsrc(reinterpret_cast<const T*>(p.w) + (long)b * p.w_bs, (unsigned)p.Cout * TAPS * p.Cin * ESZ);
 
-  // ---- per-thread staging descriptors (chunk independent)
+  // ---- per-thread staging descriptors.  Vector i = tid + 256 k of a stage: row (pixel / weight row)
+  // row0 + k*RPS, 16-byte slot tid % NVEC: LDS offsets are linear in k (immediates), global byte offsets
+  // are computed once (pixels: one per source because the pixel strides differ).
+  constexpr int RPS = 256 / NVEC;  // rows covered by one pass of the block
+  constexpr bool B_TAPSTEP = (RPS % BN == 0);
+  static_assert(B_TAPSTEP || (TAPS == 1 && BN % RPS == 0), "weight rows must be linear in the pass index");
   const int vch = (tid % NVEC) * KV;  // channel offset of this thread's vectors inside a chunk
-  int apix[NA];                       // pixel index inside the image (or -1: outside / unused)
-  int alds[NA];                       // LDS byte offset of the vector
+  const int row0 = tid / NVEC;
+  const int lds0 = row0 * ROWB + (tid % NVEC) * 16;  // + k * RPS * ROWB
+  auto a_in = [&](int k) { return row0 + k * RPS < HP; };
+  auto b_in = [&](int k) { return row0 + k * RPS < TAPS * BN; };
+  unsigned voa1[NA], voa2[NA];  // byte offsets of the thread's halo vectors in source 1 / 2 (DS_OOB: zero)
+  bool aval[NA];
 #pragma unroll
   for (int k = 0; k < NA; ++k) {
-    const int i = tid + k * 256;
-    const int pix = i / NVEC;
-    apix[k] = -1;
-    alds[k] = (i < HP * NVEC) ? pix * ROWB + (i - pix * NVEC) * 16 : -1;
-    if (i < HP * NVEC) {
+    int pixi = -1;
+    if (a_in(k)) {
+      const int pix = row0 + k * RPS;
       if (TAPS == 9) {
         const int hy = pix / HW_, hx = pix - hy * HW_;
         const int gy = y0 + hy - R, gx = x0 + hx - R;
-        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) apix[k] = gy * p.W + gx;
+        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) pixi = gy * p.W + gx;
       } else {
-        const long m = m0 + pix;
-        if (m < M) apix[k] = (int)m;
+        if (m0 + pix < M) pixi = m0 + pix;
       }
     }
+    aval[k] = pixi >= 0;
+    voa1[k] = pixi >= 0 ? (unsigned)(pixi * p.ldx + vch) * ESZ : DS_OOB;
+    voa2[k] = pixi >= 0 ? (unsigned)(pixi * p.ldx2 + vch) * ESZ : DS_OOB;
   }
-  int bsrc[NB];  // element offset of (co, tap, 0) in the weight tensor (or -1)
-  int blds[NB];
+  const int bco0 = n0 + (B_TAPSTEP ? row0 % BN : row0);                  // cout of pass 0
+  const int boff0 = (bco0 * TAPS + (B_TAPSTEP ? row0 / BN : 0)) * p.Cin;   // element offset of its weight row
+  const int bstep = B_TAPSTEP ? (RPS / BN) * p.Cin : RPS * TAPS * p.Cin;   // per pass
+  unsigned vob[NB];
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
-    const int i = tid + k * 256;
-    const int row = i / NVEC;
-    const int tap = row / BN, col = row - tap * BN;
-    const int co = n0 + col;
-    const bool in = i < TAPS * BN * NVEC;
-    blds[k] = in ? row * ROWB + (i - row * NVEC) * 16 : -1;
-    bsrc[k] = (in && co < p.Cout) ? (co * TAPS + tap) * p.Cin : -1;
+    const bool ok = b_in(k) && (B_TAPSTEP ? bco0 : bco0 + k * RPS) < p.Cout;
+    vob[k] = ok ? (unsigned)(boff0 + k * bstep + vch) * ESZ : DS_OOB;
   }
 
   f32x16 acc[WM][WN];
@@ -201,52 +273,75 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
 
   uint4 pa[NA], pb[NB];
   float gsc[KV], gsh[KV];
-  bool ch_ok = false;
+  bool ch_ok = true;
 
-  auto load_chunk = [&](int ci0) {
-    const int ci = ci0 + vch;
-    ch_ok = ci < p.Cin;
-    const bool second = xb2 != nullptr && ci >= p.C1;
-    const T* src = second ? xb2 + (ci - p.C1) : xb1 + ci;
-    const int ld = second ? p.ldx2 : p.ldx;
+  // K is walked source by source so that a chunk never straddles the concat seam: chunks [0, nch1) read
+  // channels of x, chunks [nch1, nch) channels of x2 (weights follow the concatenated channel index).
+  const int nch1 = (C1 + KC - 1) / KC;
+  const int nch = nch1 + (C2 + KC - 1) / KC;
+  auto load_chunk = [&](int c) {
+    const bool second = c >= nch1;
+    const int cb = (second ? c - nch1 : c) * KC;        // channel offset inside the source
+    const int width = (second ? C2 : C1) - cb;           // channels left in the source (>= 1)
+    const int wb = second ? C1 + cb : cb;                // channel offset inside the weights / GN tables
+    ch_ok = vch < width;
+    const unsigned so = (unsigned)cb * ESZ, sw = (unsigned)wb * ESZ;
+    if (width >= KC) {  // uniform fast path: every lane's offsets are the precomputed ones
+      if (!second) {
 #pragma unroll
-    for (int k = 0; k < NA; ++k) {
-      pa[k] = make_uint4(0u, 0u, 0u, 0u);
-      if (apix[k] >= 0 && ch_ok) pa[k] = *reinterpret_cast<const uint4*>(src + (long)apix[k] * ld);
+        for (int k = 0; k < NA; ++k) pa[k] = buf_load16(rx1, voa1[k], so);
+      } else {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) pa[k] = buf_load16(rx2, voa2[k], so);
+      }
+#pragma unroll
+      for (int k = 0; k < NB; ++k) pb[k] = buf_load16(rw, vob[k], sw);
+    } else {  // channel tail of a source: lanes past the end read zeros
+      if (!second) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) pa[k] = buf_load16(rx1, ch_ok ? voa1[k] : DS_OOB, so);
+      } else {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) pa[k] = buf_load16(rx2, ch_ok ? voa2[k] : DS_OOB, so);
+      }
+#pragma unroll
+      for (int k = 0; k < NB; ++k) pb[k] = buf_load16(rw, ch_ok ? vob[k] : DS_OOB, sw);
     }
+    if (has_gn && ch_ok) {  // KV consecutive floats each: 16-byte vector loads
+      const float4* ps = reinterpret_cast<const float4*>(p.gn_scale + (long)b * p.Cin + wb + vch);
+      const float4* ph = reinterpret_cast<const float4*>(p.gn_shift + (long)b * p.Cin + wb + vch);
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      pb[k] = make_uint4(0u, 0u, 0u, 0u);
-      if (bsrc[k] >= 0 && ch_ok) pb[k] = *reinterpret_cast<const uint4*>(wb + bsrc[k] + ci);
-    }
-    if (has_gn && ch_ok) {
-#pragma unroll
-      for (int j = 0; j < KV; ++j) {
-        gsc[j] = p.gn_scale[(long)b * p.Cin + ci + j];
-        gsh[j] = p.gn_shift[(long)b * p.Cin + ci + j];
+      for (int j = 0; j < KV / 4; ++j) {
+        const float4 a = ps[j], cc = ph[j];
+        gsc[4 * j] = a.x; gsc[4 * j + 1] = a.y; gsc[4 * j + 2] = a.z; gsc[4 * j + 3] = a.w;
+        gsh[4 * j] = cc.x; gsh[4 * j + 1] = cc.y; gsh[4 * j + 2] = cc.z; gsh[4 * j + 3] = cc.w;
       }
     }
   };
   auto store_chunk = [&]() {
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
-      if (alds[k] >= 0) {
+      if (a_in(k)) {
         uint4 v = pa[k];
-        if (has_gn && apix[k] >= 0 && ch_ok) v = GnVec<T>::run(v, gsc, gsh, p.gn_act);
-        *reinterpret_cast<uint4*>(sA + alds[k]) = v;
+        if (has_gn && aval[k] && ch_ok) v = GnVec<T>::run(v, gsc, gsh, p.gn_act);
+        *reinterpret_cast<uint4*>(sA + lds0 + k * RPS * ROWB) = v;
       }
     }
 #pragma unroll
     for (int k = 0; k < NB; ++k)
-      if (blds[k] >= 0) *reinterpret_cast<uint4*>(sB + blds[k]) = pb[k];
+      if (b_in(k)) *reinterpret_cast<uint4*>(sB + lds0 + k * RPS * ROWB) = pb[k];
   };
 
+  CT_DECL
   load_chunk(0);
-  for (int ci0 = 0; ci0 < p.Cin; ci0 += KC) {
+  CT_MARK(0)
+  for (int c = 0; c < nch; ++c) {
     __syncthreads();  // previous chunk's fragment reads are done
     store_chunk();
     __syncthreads();
-    if (ci0 + KC < p.Cin) load_chunk(ci0 + KC);  // in flight during the MFMA loop below
+    CT_MARK(1)
+    if (c + 1 < nch) load_chunk(c + 1);  // in flight during the MFMA loop below
+    CT_MARK(2)
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int toff = (TAPS == 9) ? ((tap / 3) * HW_ + (tap % 3)) * ROWB : 0;
@@ -264,77 +359,115 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
           for (int j = 0; j < WN; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
       }
     }
+    CT_MARK(3)
   }
 
-  // ---- epilogue, part 1: accumulators -> LDS (fp32, [pixel][cout]).
+  // ---- epilogue: accumulators -> LDS (fp32, [pixel][cout]) -> bias / temb / residual / scale -> 16-byte
+  // stores, in EP passes over the wave's M blocks (a smaller staging buffer lets more blocks share a CU).
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h.
-  __syncthreads();
-  float* so = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int i = 0; i < WM; ++i)
-#pragma unroll
-    for (int j = 0; j < WN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int pp = (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int cc = (wn * WN + j) * 32 + l32;
-        *reinterpret_cast<float*>(smem + pp * OROW + cc * 4) = acc[i][j][r];
-      }
-  __syncthreads();
-  // ---- part 2: one thread = one pixel x 8 couts: bias / temb / residual / scale, 16-byte stores
-  T* yb = reinterpret_cast<T*>(p.y) + (long)b * p.y_bs;
-  const T* rb = p.res ? reinterpret_cast<const T*>(p.res) + (long)b * p.res_bs : nullptr;
+  const __amdgpu_buffer_rsrc_t ry =
+      make_rsrc(reinterpret_cast<T*>(p.y) + (long)b * p.y_bs, (unsigned)M * p.ldy * ESZ);
+  const __amdgpu_buffer_rsrc_t rr = make_rsrc(
+      p.res ? reinterpret_cast<const T*>(p.res) + (long)b * p.res_bs : reinterpret_cast<const T*>(p.y),
+      p.res ? (unsigned)M * p.ldr * ESZ : 0u);  // no residual: zero records -> every load returns 0
   const int cout8 = (p.Cout + 7) & ~7;
   const float dvs = p.div_b ? p.div_b[b] : 1.0f;
   constexpr int NCG = BN / 8;
   static_assert(256 % NCG == 0, "a thread keeps one cout group across the epilogue loop");
+  constexpr int WME = WM / EP;  // M blocks of a wave per pass
+  constexpr int RV = ESZ * 8 / 16;  // 16-byte vectors per 8 channels
   const int cg = tid % NCG;
   const int co = n0 + cg * 8;
-  float bv[8];  // per-thread column bias (conv bias + per-batch temb bias), loaded once
+  // per-thread column bias (conv bias + per-batch temb bias): 16 independent loads issued back to back
+  float bv[8];
+  {
+    float b1[8], b2[8];
+    const float* pb1 = (p.bias_mode == 0 && p.bias) ? p.bias : nullptr;
+    const float* pb2 = (p.bias_mode == 0 && p.bias_b) ? p.bias_b + (long)b * p.bias_b_ld : nullptr;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float t = 0.f;
-    const int c = co + j;
-    if (p.bias_mode == 0 && c < p.Cout) {
-      if (p.bias) t += p.bias[c];
-      if (p.bias_b) t += p.bias_b[(long)b * p.bias_b_ld + c];
+    for (int j = 0; j < 8; ++j) {
+      const int cc = (co + j < p.Cout) ? co + j : p.Cout - 1;
+      b1[j] = pb1 ? pb1[cc] : 0.f;
+      b2[j] = pb2 ? pb2[cc] : 0.f;
     }
-    bv[j] = t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = b1[j] + b2[j];
   }
   float ssum[8], ssq[8];  // GroupNorm statistics of what this thread writes (consumed by the next GN)
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
-  if (co < cout8) {
-    for (int pp = tid / NCG; pp < BM; pp += 256 / NCG) {
-      long m;
+#pragma unroll
+  for (int e = 0; e < EP; ++e) {
+    __syncthreads();  // fragment reads (e = 0) / the previous pass's reads are done
+#pragma unroll
+    for (int i = 0; i < WME; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lp = (wm * WME + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int cc = (wn * WN + j) * 32 + l32;
+          *reinterpret_cast<float*>(smem + lp * OROW + cc * 4) = acc[e * WME + i][j][r];
+        }
+    // rows of this thread: pixel index (or -1) -> byte offsets of its 8-channel vector in y / res
+    constexpr int NROW = (BM / EP) / (256 / NCG);
+    static_assert((BM / EP) % (256 / NCG) == 0, "whole rows per thread");
+    int mrow[NROW];
+    unsigned voy[NROW], vor[NROW];
+    uint4 rraw[NROW][RV];
+#pragma unroll
+    for (int it = 0; it < NROW; ++it) {
+      const int lp = tid / NCG + it * (256 / NCG);
+      const int pp = ((lp / (32 * WME)) * WM + e * WME + (lp / 32) % WME) * 32 + (lp & 31);
+      int m = -1;
       if (TAPS == 9) {
         const int gy = y0 + pp / TW, gx = x0 + pp % TW;
-        if (gy >= p.H || gx >= p.W) continue;
-        m = (long)gy * p.W + gx;
+        if (gy < p.H && gx < p.W) m = gy * p.W + gx;
       } else {
-        m = m0 + pp;
-        if (m >= M) continue;
+        if (m0 + pp < M) m = m0 + pp;
       }
+      if (co >= cout8) m = -1;
+      mrow[it] = m;
+      voy[it] = m >= 0 ? (unsigned)(m * p.ldy + co) * ESZ : DS_OOB;
+      vor[it] = m >= 0 ? (unsigned)(m * p.ldr + co) * ESZ : DS_OOB;
+#pragma unroll
+      for (int q = 0; q < RV; ++q) rraw[it][q] = buf_load16(rr, vor[it], 16u * q);
+    }
+    __syncthreads();
+    CT_MARK(4)
+    uint4 oraw[NROW][RV];
+#pragma unroll
+    for (int it = 0; it < NROW; ++it) {
+      const int m = mrow[it];
+      const int lp = tid / NCG + it * (256 / NCG);
       float v[8];
-      const float4 a0 = *reinterpret_cast<const float4*>(smem + pp * OROW + cg * 32);
-      const float4 a1 = *reinterpret_cast<const float4*>(smem + pp * OROW + cg * 32 + 16);
+      const float4 a0 = *reinterpret_cast<const float4*>(smem + lp * OROW + cg * 32);
+      const float4 a1 = *reinterpret_cast<const float4*>(smem + lp * OROW + cg * 32 + 16);
       v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
       float rv[8];
-      if (rb) load8<T>(rb + m * p.ldr + co, rv);
-      const float rowb = (p.bias_mode == 1 && p.bias) ? p.bias[m] : 0.f;
+      unpack8<T>(rraw[it], rv);
+      const float rowb = (p.bias_mode == 1 && p.bias) ? p.bias[m < 0 ? 0 : m] : 0.f;
+      const float keep = m < 0 ? 0.f : 1.f;  // rows outside the image do not count in the statistics
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float t = v[j];
         if (p.div_b) t = t / dvs;
         t = (co + j < p.Cout) ? t + bv[j] + rowb : 0.f;
-        if (rb) t += rv[j];
+        t += rv[j];
         v[j] = t * p.out_scale;
-        ssum[j] += v[j];
-        ssq[j] = fmaf(v[j], v[j], ssq[j]);
+        ssum[j] = fmaf(keep, v[j], ssum[j]);
+        ssq[j] = fmaf(keep * v[j], v[j], ssq[j]);
       }
-      store8<T>(yb + m * p.ldy + co, v);
+      pack8<T>(v, oraw[it]);
     }
+    CT_MARK(5)
+#pragma unroll
+    for (int it = 0; it < NROW; ++it)
+#pragma unroll
+      for (int q = 0; q < RV; ++q) buf_store16(ry, voy[it], 16u * q, oraw[it][q]);
+    CT_MARK(6)
   }
+  CT_FLUSH
   if (p.stats) {  // block-reduce the per-thread partials: 256/NCG threads share a cout group
     __syncthreads();
     float* sr = reinterpret_cast<float*>(smem);  // [256/NCG][BN][2]
@@ -347,23 +480,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
     __syncthreads();
     if (tid < BN && n0 + tid < p.Cout) {
       double a = 0.0, q = 0.0;
-      for (int rr = 0; rr < 256 / NCG; ++rr) {
-        a += (double)sr[(rr * BN + tid) * 2 + 0];
-        q += (double)sr[(rr * BN + tid) * 2 + 1];
+      for (int rr2 = 0; rr2 < 256 / NCG; ++rr2) {
+        a += (double)sr[(rr2 * BN + tid) * 2 + 0];
+        q += (double)sr[(rr2 * BN + tid) * 2 + 1];
       }
       double* o = p.stats + (((long)b * gridDim.x + blockIdx.x) * p.Cout + n0 + tid) * 2;
       o[0] = a;
       o[1] = q;
     }
   }
-  (void)so;
 }
 
-template <typename T, int TAPS, int TH, int TW, int BN, int WM, int WN, int KC>
+template <typename T, int TAPS, int TH, int TW, int BN, int WM, int WN, int KC, int EP = 1, int OCC = 2>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
-  using G = ConvGeom<T, TAPS, TH, TW, BN, KC>;
+  using G = ConvGeom<T, TAPS, TH, TW, BN, KC, EP>;
   constexpr int LDS = G::LDS;
-  auto kern = conv_mfma_kernel<T, TAPS, TH, TW, BN, WM, WN, KC>;
+  auto kern = conv_mfma_kernel<T, TAPS, TH, TW, BN, WM, WN, KC, EP, OCC>;
   static bool attr_done = false;
   if (!attr_done) {
     DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -398,7 +530,13 @@ static int launch_typed(const ConvArgs& a, hipStream_t st) {
   constexpr int KC9 = (sizeof(T) == 4) ? 16 : 32;
   constexpr int KC1 = (sizeof(T) == 4) ? 32 : 64;
   switch (ds_conv_config_id(a)) {
-    case 0: return launch_cfg<T, 9, 8, 32, 64, 2, 2, KC9>(a, st);
+    case 0: {
+      static int alt = -1;
+      if (alt < 0) { const char* v = getenv("DIFFSEP_CONV_ALT"); alt = v ? atoi(v) : 0; }
+      if (alt == 1) return launch_cfg<T, 9, 8, 32, 64, 2, 2, KC9 / 2, 2, 3>(a, st);  // 44 KB LDS, 3 blocks / CU
+      if (alt == 2) return launch_cfg<T, 9, 8, 32, 64, 2, 2, KC9, 2, 2>(a, st);      // 2-pass epilogue only
+      return launch_cfg<T, 9, 8, 32, 64, 2, 2, KC9>(a, st);
+    }
     case 1: return launch_cfg<T, 9, 8, 32, 32, 2, 1, KC9>(a, st);
     case 2: return launch_cfg<T, 9, 8, 8, 64, 1, 1, KC9>(a, st);
     case 3: return launch_cfg<T, 1, 8, 32, 64, 2, 2, KC1>(a, st);
@@ -435,8 +573,14 @@ int ds_launch_conv(const ConvArgs& a, hipStream_t st) {
   DS_CHECK(a.x && a.w && a.y, "conv: null pointer");
   DS_CHECK(a.ldy >= ((a.Cout + 7) & ~7), "conv: output pixel stride must cover Cout rounded up to 8");
   DS_CHECK(!a.x2 || (a.C1 % 8 == 0 && a.C1 > 0 && a.C1 < a.Cin && a.ldx2 % 8 == 0), "conv: bad concat split");
-  DS_CHECK((long)a.H * a.W * (a.ldx > a.ldy ? a.ldx : a.ldy) < 2147483647L, "conv: image too large for 32-bit offsets");
-  DS_CHECK((long)a.Cout * a.taps * a.Cin < 2147483647L, "conv: weight tensor too large");
+  {  // 32-bit buffer offsets with bit 31 reserved as the out-of-range marker: < 2 GiB per batch entry
+    const long esz = a.dtype == DS_F32 ? 4 : 2, M = (long)a.H * a.W;
+    long mld = a.ldx > a.ldy ? a.ldx : a.ldy;
+    if (a.x2 && a.ldx2 > mld) mld = a.ldx2;
+    if (a.res && a.ldr > mld) mld = a.ldr;
+    DS_CHECK(M * mld * esz < 2147483647L, "conv: image too large for 32-bit buffer offsets");
+    DS_CHECK((long)a.Cout * a.taps * a.Cin * esz < 2147483647L, "conv: weight tensor too large");
+  }
   if (a.dtype == DS_F32) return launch_typed<float>(a, st);
   if (a.dtype == DS_BF16) return launch_typed<bf16_t>(a, st);
   DS_CHECK(false, "conv: unknown dtype");
