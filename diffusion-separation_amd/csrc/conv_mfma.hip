@@ -390,9 +390,13 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
       b1[j] = pb1 ? pb1[cc] : 0.f;
       b2[j] = pb2 ? pb2[cc] : 0.f;
     }
+    // channels past Cout (padding up to a multiple of 8) have zero weights and a zero residual: a zero bias
+    // makes them come out as exact zeros without any per-element select
 #pragma unroll
-    for (int j = 0; j < 8; ++j) bv[j] = b1[j] + b2[j];
+    for (int j = 0; j < 8; ++j) bv[j] = (co + j < p.Cout) ? b1[j] + b2[j] : 0.f;
   }
+  // tiles that overhang the image must keep their outside rows out of the statistics
+  const bool overhang = (TAPS == 9) ? (y0 + TH > p.H || x0 + TW > p.W) : (m0 + BM > M);
   float ssum[8], ssq[8];  // GroupNorm statistics of what this thread writes (consumed by the next GN)
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
@@ -446,17 +450,30 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
       v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
       float rv[8];
       unpack8<T>(rraw[it], rv);
-      const float rowb = (p.bias_mode == 1 && p.bias) ? p.bias[m < 0 ? 0 : m] : 0.f;
-      const float keep = m < 0 ? 0.f : 1.f;  // rows outside the image do not count in the statistics
+      if (p.div_b) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float t = v[j];
-        if (p.div_b) t = t / dvs;
-        t = (co + j < p.Cout) ? t + bv[j] + rowb : 0.f;
-        t += rv[j];
-        v[j] = t * p.out_scale;
-        ssum[j] = fmaf(keep, v[j], ssum[j]);
-        ssq[j] = fmaf(keep * v[j], v[j], ssq[j]);
+        for (int j = 0; j < 8; ++j) v[j] = v[j] / dvs;
+      }
+      if (p.bias_mode == 1 && p.bias) {  // row bias (the V^T GEMM of the attention block)
+        const float rowb = p.bias[m < 0 ? 0 : m];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (co + j < p.Cout) ? v[j] + rowb : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (v[j] + bv[j] + rv[j]) * p.out_scale;
+      if (!overhang) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          ssum[j] += v[j];
+          ssq[j] = fmaf(v[j], v[j], ssq[j]);
+        }
+      } else {
+        const float keep = m < 0 ? 0.f : 1.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          ssum[j] = fmaf(keep, v[j], ssum[j]);
+          ssq[j] = fmaf(keep * v[j], v[j], ssq[j]);
+        }
       }
       pack8<T>(v, oraw[it]);
     }
