@@ -64,18 +64,20 @@ template <> struct Mma<bf16_t> {
 // GN-apply (+SiLU) on one 16-byte vector of KV channels
 template <typename T> struct GnVec;
 template <> struct GnVec<float> {
-  __device__ static inline uint4 run(const uint4& u, const float* sc, const float* sh, int act) {
+  template <bool ACT>
+  __device__ static inline uint4 run(const uint4& u, const float* sc, const float* sh) {
     float f[4] = {__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float v = f[j] * sc[j] + sh[j];
-      f[j] = act ? silu_t<float>(v) : v;
+      f[j] = ACT ? silu_t<float>(v) : v;
     }
     return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
   }
 };
 template <> struct GnVec<bf16_t> {
-  __device__ static inline uint4 run(const uint4& u, const float* sc, const float* sh, int act) {
+  template <bool ACT>
+  __device__ static inline uint4 run(const uint4& u, const float* sc, const float* sh) {
     float f[8];
     f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
     f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
@@ -84,7 +86,7 @@ template <> struct GnVec<bf16_t> {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = f[j] * sc[j] + sh[j];
-      f[j] = act ? silu_t<bf16_t>(v) : v;
+      f[j] = ACT ? silu_t<bf16_t>(v) : v;
     }
     uint4 o;
     o.x = pack_bf16x2(f[0], f[1]);
@@ -319,14 +321,20 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     }
   };
   auto store_chunk = [&]() {
+    if (has_gn) {  // act(GN(x)) on the fly; zero padding (pixels outside the image, channel tails) stays zero
+      if (p.gn_act) {
 #pragma unroll
-    for (int k = 0; k < NA; ++k) {
-      if (a_in(k)) {
-        uint4 v = pa[k];
-        if (has_gn && aval[k] && ch_ok) v = GnVec<T>::run(v, gsc, gsh, p.gn_act);
-        *reinterpret_cast<uint4*>(sA + lds0 + k * RPS * ROWB) = v;
+        for (int k = 0; k < NA; ++k)
+          if (aval[k] && ch_ok) pa[k] = GnVec<T>::template run<true>(pa[k], gsc, gsh);
+      } else {
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+          if (aval[k] && ch_ok) pa[k] = GnVec<T>::template run<false>(pa[k], gsc, gsh);
       }
     }
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+      if (a_in(k)) *reinterpret_cast<uint4*>(sA + lds0 + k * RPS * ROWB) = pa[k];
 #pragma unroll
     for (int k = 0; k < NB; ++k)
       if (b_in(k)) *reinterpret_cast<uint4*>(sB + lds0 + k * RPS * ROWB) = pb[k];
@@ -419,18 +427,31 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     int mrow[NROW];
     unsigned voy[NROW], vor[NROW];
     uint4 rraw[NROW][RV];
+    // EP == 1: local row lp IS the tile pixel, so successive rows of a thread advance linearly
+    // ((256/NCG)/TW image rows, or 256/NCG flat pixels): one add per row instead of div/mod/mul
+    constexpr int RSTEP = 256 / NCG;
+    const int pp0 = tid / NCG;
+    const int gy0 = y0 + pp0 / TW, gx0 = x0 + pp0 % TW;
+    const int mlin0 = (TAPS == 9) ? gy0 * p.W + gx0 : m0 + pp0;
+    const int mstep = (TAPS == 9) ? (RSTEP / TW) * p.W : RSTEP;
+    const bool col_ok = co < cout8 && (TAPS != 9 || gx0 < p.W);
 #pragma unroll
     for (int it = 0; it < NROW; ++it) {
-      const int lp = tid / NCG + it * (256 / NCG);
-      const int pp = ((lp / (32 * WME)) * WM + e * WME + (lp / 32) % WME) * 32 + (lp & 31);
       int m = -1;
-      if (TAPS == 9) {
-        const int gy = y0 + pp / TW, gx = x0 + pp % TW;
-        if (gy < p.H && gx < p.W) m = gy * p.W + gx;
+      if (EP == 1 && (TAPS != 9 || RSTEP % TW == 0)) {
+        const bool ok = col_ok && ((TAPS == 9) ? (gy0 + it * (RSTEP / TW) < p.H) : (mlin0 + it * mstep < M));
+        m = ok ? mlin0 + it * mstep : -1;
       } else {
-        if (m0 + pp < M) m = m0 + pp;
+        const int lp = tid / NCG + it * (256 / NCG);
+        const int pp = ((lp / (32 * WME)) * WM + e * WME + (lp / 32) % WME) * 32 + (lp & 31);
+        if (TAPS == 9) {
+          const int gy = y0 + pp / TW, gx = x0 + pp % TW;
+          if (gy < p.H && gx < p.W) m = gy * p.W + gx;
+        } else {
+          if (m0 + pp < M) m = m0 + pp;
+        }
+        if (co >= cout8) m = -1;
       }
-      if (co >= cout8) m = -1;
       mrow[it] = m;
       voy[it] = m >= 0 ? (unsigned)(m * p.ldy + co) * ESZ : DS_OOB;
       vor[it] = m >= 0 ? (unsigned)(m * p.ldr + co) * ESZ : DS_OOB;
