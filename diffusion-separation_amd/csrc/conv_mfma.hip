@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
   // are computed once (pixels: one per source because the pixel strides differ).
   constexpr int RPS = 256 / NVEC;  // rows covered by one pass of the block
   constexpr bool B_TAPSTEP = (RPS % BN == 0);
-  static_assert(B_TAPSTEP || (TAPS == 1 && BN % RPS == 0), "weight rows must be linear in the pass index");
+  static_assert(B_TAPSTEP || BN % RPS == 0, "a pass of the block covers whole taps or a whole fraction of one");
   const int vch = (tid % NVEC) * KV;  // channel offset of this thread's vectors inside a chunk
   const int row0 = tid / NVEC;
   const int lds0 = row0 * ROWB + (tid % NVEC) * 16;  // + k * RPS * ROWB
@@ -244,14 +244,20 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     voa1[k] = pixi >= 0 ? (unsigned)(pixi * p.ldx + vch) * ESZ : DS_OOB;
     voa2[k] = pixi >= 0 ? (unsigned)(pixi * p.ldx2 + vch) * ESZ : DS_OOB;
   }
-  const int bco0 = n0 + (B_TAPSTEP ? row0 % BN : row0);                  // cout of pass 0
-  const int boff0 = (bco0 * TAPS + (B_TAPSTEP ? row0 / BN : 0)) * p.Cin;   // element offset of its weight row
-  const int bstep = B_TAPSTEP ? (RPS / BN) * p.Cin : RPS * TAPS * p.Cin;   // per pass
-  unsigned vob[NB];
+  unsigned vob[NB];  // byte offsets of the thread's weight vectors (row = cout, tap): DS_OOB past Cout
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
-    const bool ok = b_in(k) && (B_TAPSTEP ? bco0 : bco0 + k * RPS) < p.Cout;
-    vob[k] = ok ? (unsigned)(boff0 + k * bstep + vch) * ESZ : DS_OOB;
+    int col, tap;
+    if (B_TAPSTEP) {  // a pass covers whole taps
+      col = row0 % BN;
+      tap = row0 / BN + k * (RPS / BN);
+    } else {          // BN / RPS passes per tap
+      constexpr int Q = BN / RPS;
+      col = row0 + (k % Q) * RPS;
+      tap = k / Q;
+    }
+    const bool ok = b_in(k) && n0 + col < p.Cout && tap < TAPS;
+    vob[k] = ok ? (unsigned)(((n0 + col) * TAPS + tap) * p.Cin + vch) * ESZ : DS_OOB;
   }
 
   f32x16 acc[WM][WN];
@@ -576,7 +582,12 @@ static int launch_typed(const ConvArgs& a, hipStream_t st) {
       return launch_cfg<T, 9, 8, 32, 64, 2, 2, KC9>(a, st);
     }
     case 1: return launch_cfg<T, 9, 8, 32, 32, 2, 1, KC9>(a, st);
-    case 2: return launch_cfg<T, 9, 8, 8, 64, 1, 1, KC9>(a, st);
+    case 2: {  // small images: latency bound on the K pipeline -> twice the chunk depth (half the barriers)
+      static int alt2 = -1;
+      if (alt2 < 0) { const char* v = getenv("DIFFSEP_CONV_ALT2"); alt2 = v ? atoi(v) : 0; }
+      if (alt2 == 1) return launch_cfg<T, 9, 8, 8, 64, 1, 1, KC9 * 2>(a, st);
+      return launch_cfg<T, 9, 8, 8, 64, 1, 1, KC9>(a, st);
+    }
     case 3: return launch_cfg<T, 1, 8, 32, 64, 2, 2, KC1>(a, st);
     case 4: return launch_cfg<T, 1, 8, 32, 32, 2, 1, KC1>(a, st);
     default: return launch_cfg<T, 1, 8, 8, 64, 1, 1, KC1>(a, st);
