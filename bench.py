@@ -149,7 +149,7 @@ def main():
             eng.profile_begin()
             step(10_000)
             prof = eng.profile_end()
-            fl, ms, n = prof["conv3x3_8x32xN64"]
+            fl, ms, n, by = prof["conv3x3_8x32xN64"]
             tot_ms = sum(v[1] for v in prof.values())
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             peak = PEAK_TFLOPS[args.dtype]
@@ -158,12 +158,14 @@ def main():
             if os.path.exists(pmc):
                 try:
                     traffic = json.load(open(pmc)).get(f"hbm_bytes_per_launch_{args.dtype}_B{B}")
+                    traffic = round(traffic) if traffic else None
                 except Exception:
                     traffic = None
             roof = {"bound": "mfma", "kernel": "conv_mfma_kernel<%s,9,8,32,64,2,2>" % args.dtype,
                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "traffic": traffic, "launches": n, "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
-                    "flops_per_launch": fl / max(n, 1),
+                    "flops_per_launch": fl / max(n, 1), "algorithmic_bytes_per_launch": by / max(n, 1),
+                    "hbm_floor_us": round(by / max(n, 1) / 5.0e12 * 1e6, 2),
                     "all_mfma_kernels_ms": round(tot_ms, 2),
                     "all_mfma_kernels_tflops": round(sum(v[0] for v in prof.values()) / (tot_ms * 1e-3) / 1e12, 2)}
 

@@ -328,7 +328,7 @@ struct diffsep_engine {
   int use_side = 0;  // measured on MI355X: parallel graph branches cost ~5 % here (DIFFSEP_SIDE=1|2|3 enables them)
   // optional per-launch timing of the MFMA kernels (HIP events on the launch stream)
   bool prof = false;
-  struct ProfRec { hipEvent_t a, b; double flops; int cls; };
+  struct ProfRec { hipEvent_t a, b; double flops, bytes; int cls; };
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
 };
@@ -359,6 +359,11 @@ static int conv_launch_prof(diffsep_engine* e, const ConvArgs& a, hipStream_t st
   diffsep_engine::ProfRec r;
   r.a = prof_event(e); r.b = prof_event(e);
   r.flops = 2.0 * a.taps * (double)a.Cin * a.Cout * (double)a.H * a.W * a.B;
+  {  // algorithmic HBM bytes: input + output (+ residual) once each, weights once
+    const double esz = a.dtype == DS_F32 ? 4.0 : 2.0;
+    r.bytes = esz * ((double)a.B * a.H * a.W * ((double)a.Cin + a.Cout + (a.res ? a.Cout : 0)) +
+                     (double)a.taps * a.Cin * a.Cout);
+  }
   r.cls = ds_conv_config_id(a);
   hipEventRecord(r.a, st);
   const int rc = ds_launch_conv(a, st);
@@ -843,14 +848,16 @@ extern "C" int32_t diffsep_engine_profile_begin(diffsep_engine* e) {
   e->prof_recs.clear();
   return 0;
 }
-extern "C" int32_t diffsep_engine_profile_end(diffsep_engine* e, double* flops, double* ms, int64_t* launches) {
+extern "C" int32_t diffsep_engine_profile_end(diffsep_engine* e, double* flops, double* ms, int64_t* launches,
+                                               double* bytes) {
   DS_CHECK(e && flops && ms && launches, "profile_end: null argument");
   DS_HIP(hipDeviceSynchronize());
-  for (int i = 0; i < DS_NCLS; ++i) { flops[i] = 0; ms[i] = 0; launches[i] = 0; }
+  for (int i = 0; i < DS_NCLS; ++i) { flops[i] = 0; ms[i] = 0; launches[i] = 0; if (bytes) bytes[i] = 0; }
   for (auto& r : e->prof_recs) {
     float t = 0.f;
     hipEventElapsedTime(&t, r.a, r.b);
     flops[r.cls] += r.flops;
+    if (bytes) bytes[r.cls] += r.bytes;
     ms[r.cls] += t;
     launches[r.cls] += 1;
     e->ev_pool.push_back(r.a);

@@ -54,7 +54,8 @@ _SIGS = {
                                C.POINTER(_I), _P]),
     "diffsep_engine_set_graph": (_I, [_P, _I]),
     "diffsep_engine_profile_begin": (_I, [_P]),
-    "diffsep_engine_profile_end": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L)]),
+    "diffsep_engine_profile_end": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L),
+                                        C.POINTER(C.c_double)]),
     "diffsep_upfirdn2d": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "diffsep_groupnorm_act": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _L, _P]),
     "diffsep_conv2d": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),

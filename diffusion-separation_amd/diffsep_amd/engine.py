@@ -96,10 +96,11 @@ class Engine:
         check(lib().diffsep_engine_profile_begin(self._h))
 
     def profile_end(self):
-        """{class: (algorithmic flops, milliseconds, launches)} of the MFMA kernels since profile_begin."""
-        fl, ms, n = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_int64 * 6)()
-        check(lib().diffsep_engine_profile_end(self._h, fl, ms, n))
-        return {k: (fl[i], ms[i], int(n[i])) for i, k in enumerate(self.CONV_CLASSES)}
+        """{class: (algorithmic flops, milliseconds, launches, algorithmic bytes)} of the MFMA kernels since
+        profile_begin."""
+        fl, ms, n, by = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_int64 * 6)(), (C.c_double * 6)()
+        check(lib().diffsep_engine_profile_end(self._h, fl, ms, n, by))
+        return {k: (fl[i], ms[i], int(n[i]), by[i]) for i, k in enumerate(self.CONV_CLASSES)}
 
     def padded_frames(self, T):
         return int(lib().diffsep_padded_frames(C.byref(self.cfg), T))
