@@ -177,11 +177,15 @@ int ds_launch_istft(const void* x, float* out, int B, int S, long T, int n_fft, 
 int ds_build_stft_table(int n_fft, float** dev_tab);
 
 struct SdeP { int kind; int ndim; float d_lambda, sigma_min, sigma_max; };
-int ds_launch_sde_prior(const SdeP& s, const float* y, const float* z, float* x, int B, int S, long T, hipStream_t st);
+// smix: per-sample sigma_mix [B][T] of PriorMixSDE (kind 1), null for MixSDE (kind 0)
+int ds_launch_sigma_mix(const float* mix, float* out, int B, long T, int avg_len, hipStream_t st);
+int ds_launch_sde_prior(const SdeP& s, const float* y, const float* z, float* x, int B, int S, long T,
+                        const float* smix, hipStream_t st);
 int ds_launch_sde_corrector(const SdeP& s, float snr, const float* x, const float* t, const float* score,
-                            const float* z, float* xo, float* xm, int B, int S, long T, hipStream_t st);
+                            const float* z, float* xo, float* xm, int B, int S, long T, const float* smix,
+                            hipStream_t st);
 int ds_launch_sde_predictor(const SdeP& s, int N, const float* x, const float* t, const float* score, const float* z,
-                            float* xo, float* xm, int B, int S, long T, hipStream_t st);
+                            float* xo, float* xm, int B, int S, long T, const float* smix, hipStream_t st);
 int ds_launch_normalize(const float* mix, float* out, float* mean, float* std, int B, long T, hipStream_t st);
 int ds_launch_scale_output(const float* mix, float* sep, int B, int S, long T, hipStream_t st);
 int ds_launch_randn(float* out, long n, uint64_t seed, uint64_t stream_id, hipStream_t st);

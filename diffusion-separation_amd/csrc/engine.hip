@@ -308,7 +308,7 @@ struct diffsep_engine {
   long planT = -1;
   // sampler state (inside the arena, below fwd_base)
   float *st_x = nullptr, *st_xm = nullptr, *st_score = nullptr, *st_t = nullptr, *st_noise = nullptr,
-        *st_ts = nullptr, *st_mix = nullptr;
+        *st_ts = nullptr, *st_mix = nullptr, *st_smix = nullptr;
   // graph of one NFE: (st_x, st_t, st_mix) -> st_score
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
@@ -716,7 +716,8 @@ static int ensure_plan(diffsep_engine* e, int B, long T, hipStream_t st) {
   e->top = 0;
   e->dry = true;
   e_alloc(e, nst * 4); e_alloc(e, nst * 4); e_alloc(e, nst * 4); e_alloc(e, nst * 4);
-  e_alloc(e, (size_t)B * 4); e_alloc(e, (size_t)B * T * 4); e_alloc(e, 4096 * (size_t)B * 4);
+  e_alloc(e, (size_t)B * 4); e_alloc(e, (size_t)B * T * 4); e_alloc(e, (size_t)B * T * 4);
+  e_alloc(e, 4096 * (size_t)B * 4);
   e->fwd_base = (e->top + 255) & ~(size_t)255;
   const int rc = score_forward_impl(e, nullptr, nullptr, nullptr, nullptr, B, T, st);
   e->dry = false;
@@ -738,6 +739,7 @@ static int ensure_plan(diffsep_engine* e, int B, long T, hipStream_t st) {
   e->st_noise = (float*)e_alloc(e, nst * 4);
   e->st_t = (float*)e_alloc(e, (size_t)B * 4);
   e->st_mix = (float*)e_alloc(e, (size_t)B * T * 4);
+  e->st_smix = (float*)e_alloc(e, (size_t)B * T * 4);
   e->st_ts = (float*)e_alloc(e, 4096 * (size_t)B * 4);
   e->planB = B;
   e->planT = T;
@@ -947,7 +949,8 @@ extern "C" int32_t diffsep_pc_sample(diffsep_engine* e, const diffsep_sde_config
                                      const float* mix_norm, float* out, int32_t B, int64_t T, const float* noise,
                                      uint64_t seed, const float* timesteps_host, int32_t* nfe_out, void* stream) {
   DS_CHECK(e && sde && smp && mix_norm && out, "pc_sample: null argument");
-  DS_CHECK(sde->kind == DIFFSEP_SDE_MIX, "pc_sample: only MixSDE runs on the device path in this build");
+  DS_CHECK(sde->kind == DIFFSEP_SDE_MIX || sde->kind == DIFFSEP_SDE_PRIORMIX, "pc_sample: unknown SDE kind");
+  DS_CHECK(sde->kind == DIFFSEP_SDE_MIX || sde->avg_len >= 1, "pc_sample: PriorMixSDE needs avg_len >= 1");
   DS_CHECK(sde->ndim == e->cfg.num_sources, "pc_sample: sde.ndim != num_sources");
   DS_CHECK(smp->N >= 1 && smp->N <= 4096, "pc_sample: N must be in [1,4096]");
   DS_CHECK(smp->predictor == DIFFSEP_PRED_REVERSE_DIFFUSION || smp->predictor == DIFFSEP_PRED_NONE,
@@ -983,7 +986,12 @@ extern "C" int32_t diffsep_pc_sample(diffsep_engine* e, const diffsep_sde_config
   };
   const float* z = nullptr;
   if (next_noise(&z)) return 1;
-  if (ds_launch_sde_prior(sp, e->st_mix, z, e->st_x, B, S, T, st)) return 1;
+  const float* smix = nullptr;
+  if (sde->kind == DIFFSEP_SDE_PRIORMIX) {  // per-sample noise scale from the mixture envelope (sdes.py:477-489)
+    if (ds_launch_sigma_mix(e->st_mix, e->st_smix, B, T, sde->avg_len, st)) return 1;
+    smix = e->st_smix;
+  }
+  if (ds_launch_sde_prior(sp, e->st_mix, z, e->st_x, B, S, T, smix, st)) return 1;
   DS_HIP(hipMemcpyAsync(e->st_xm, e->st_x, nst * 4, hipMemcpyDeviceToDevice, st));
   int nfe = 0;
   for (int i = 0; i < N; ++i) {
@@ -992,14 +1000,16 @@ extern "C" int32_t diffsep_pc_sample(diffsep_engine* e, const diffsep_sde_config
       if (run_nfe(e, B, T, st)) return 1;
       ++nfe;
       if (next_noise(&z)) return 1;
-      if (ds_launch_sde_corrector(sp, smp->snr, e->st_x, e->st_t, e->st_score, z, e->st_x, e->st_xm, B, S, T, st))
+      if (ds_launch_sde_corrector(sp, smp->snr, e->st_x, e->st_t, e->st_score, z, e->st_x, e->st_xm, B, S, T, smix,
+                                  st))
         return 1;
     }
     if (smp->predictor == DIFFSEP_PRED_REVERSE_DIFFUSION) {
       if (run_nfe(e, B, T, st)) return 1;
       ++nfe;
       if (next_noise(&z)) return 1;
-      if (ds_launch_sde_predictor(sp, N, e->st_x, e->st_t, e->st_score, z, e->st_x, e->st_xm, B, S, T, st)) return 1;
+      if (ds_launch_sde_predictor(sp, N, e->st_x, e->st_t, e->st_score, z, e->st_x, e->st_xm, B, S, T, smix, st))
+        return 1;
     } else {
       DS_HIP(hipMemcpyAsync(e->st_xm, e->st_x, nst * 4, hipMemcpyDeviceToDevice, st));
     }
@@ -1129,22 +1139,29 @@ extern "C" int32_t diffsep_istft_unpack(const void* x, float* out, int32_t B, in
 
 static SdeP to_sdep(const diffsep_sde_config* s) { return SdeP{s->kind, s->ndim, s->d_lambda, s->sigma_min, s->sigma_max}; }
 
+extern "C" int32_t diffsep_sde_sigma_mix(const float* mix, float* sigma_mix, int32_t B, int64_t T, int32_t avg_len,
+                                         void* stream) {
+  DS_CHECK(mix && sigma_mix, "sde_sigma_mix: null pointer");
+  return ds_launch_sigma_mix(mix, sigma_mix, B, T, avg_len, (hipStream_t)stream);
+}
 extern "C" int32_t diffsep_sde_prior(const diffsep_sde_config* sde, const float* y, const float* z, float* x, int32_t B,
-                                     int32_t S, int64_t T, void* stream) {
+                                     int32_t S, int64_t T, const float* sigma_mix, void* stream) {
   DS_CHECK(sde && y && z && x, "sde_prior: null pointer");
-  return ds_launch_sde_prior(to_sdep(sde), y, z, x, B, S, T, (hipStream_t)stream);
+  return ds_launch_sde_prior(to_sdep(sde), y, z, x, B, S, T, sigma_mix, (hipStream_t)stream);
 }
 extern "C" int32_t diffsep_sde_corrector_update(const diffsep_sde_config* sde, float snr, const float* x, const float* t,
                                                 const float* score, const float* z, float* x_out, float* x_mean_out,
-                                                int32_t B, int32_t S, int64_t T, void* stream) {
+                                                int32_t B, int32_t S, int64_t T, const float* sigma_mix, void* stream) {
   DS_CHECK(sde && x && t && score && x_out, "sde_corrector_update: null pointer");
-  return ds_launch_sde_corrector(to_sdep(sde), snr, x, t, score, z, x_out, x_mean_out, B, S, T, (hipStream_t)stream);
+  return ds_launch_sde_corrector(to_sdep(sde), snr, x, t, score, z, x_out, x_mean_out, B, S, T, sigma_mix,
+                                 (hipStream_t)stream);
 }
 extern "C" int32_t diffsep_sde_predictor_update(const diffsep_sde_config* sde, int32_t N, const float* x, const float* t,
                                                 const float* score, const float* z, float* x_out, float* x_mean_out,
-                                                int32_t B, int32_t S, int64_t T, void* stream) {
+                                                int32_t B, int32_t S, int64_t T, const float* sigma_mix, void* stream) {
   DS_CHECK(sde && x && t && score && x_out, "sde_predictor_update: null pointer");
-  return ds_launch_sde_predictor(to_sdep(sde), N, x, t, score, z, x_out, x_mean_out, B, S, T, (hipStream_t)stream);
+  return ds_launch_sde_predictor(to_sdep(sde), N, x, t, score, z, x_out, x_mean_out, B, S, T, sigma_mix,
+                                 (hipStream_t)stream);
 }
 extern "C" int32_t diffsep_normalize_batch(const float* mix, float* mix_norm, float* mean, float* std, int32_t B,
                                            int64_t T, void* stream) {

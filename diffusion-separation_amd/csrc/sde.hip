@@ -21,17 +21,44 @@ __device__ inline void mix_eig(const SdeP& s, float t, float& ev1, float& ev2) {
   ev2 = mult * (srp - ex) / denom;
 }
 
+// PriorMixSDE._std_sigma_mix  sdes.py:477-489: 0.5 * sqrt(clamp(avg_pool1d(mix^2, k, stride 1, pad k/2), 1e-4)),
+// zero padding counted in the average; for even k the extra trailing output is dropped.
+__global__ __launch_bounds__(256) void sde_sigma_mix_kernel(const float* __restrict__ mix, float* __restrict__ out,
+                                                            long T, int k) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= T) return;
+  const float* m = mix + (long)b * T;
+  const long lo = t - k / 2;
+  float acc = 0.f;
+  for (int j = 0; j < k; ++j) {
+    const long i = lo + j;
+    if (i >= 0 && i < T) acc = fmaf(m[i], m[i], acc);
+  }
+  float v = acc / (float)k;
+  if (v < 1e-4f) v = 1e-4f;
+  out[(long)b * T + t] = 0.5f * sqrtf(v);
+}
+int ds_launch_sigma_mix(const float* mix, float* out, int B, long T, int avg_len, hipStream_t st) {
+  DS_CHECK(avg_len >= 1, "sigma_mix: avg_len must be positive");
+  hipLaunchKernelGGL(sde_sigma_mix_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, mix, out, T, avg_len);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+
 // x_T = c*y + L(T=1) @ z          MixSDE.prior_sampling  sdes.py:334-346 (c = 0.5 hard-coded for S = 2: quirk Q2)
+// PriorMixSDE (smix != null): L is scaled per sample by sigma_mix, mean is 0.5*mix for any S (sdes.py:564-587)
 __global__ __launch_bounds__(256) void sde_prior_kernel(SdeP s, const float* __restrict__ y,
                                                         const float* __restrict__ z, float* __restrict__ x, int S,
-                                                        long T) {
+                                                        long T, const float* __restrict__ smix) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   if (t >= T) return;
   float ev1, ev2;
   mix_eig(s, 1.0f, ev1, ev2);
-  const float a = sqrtf(ev1), p = sqrtf(ev2);
-  const float c = (S == 2) ? 0.5f : 1.0f / (float)S;
+  const float sm = smix ? smix[(long)b * T + t] : 1.0f;
+  const float a = sqrtf(ev1) * sm, p = sqrtf(ev2) * sm;
+  const float c = (S == 2 || smix) ? 0.5f : 1.0f / (float)S;
   const float m = c * y[(long)b * T + t];
   float zz[DS_MAX_SRC], mz = 0.f;
   for (int i = 0; i < S; ++i) { zz[i] = z[((long)b * S + i) * T + t]; mz += zz[i]; }
@@ -45,13 +72,15 @@ __global__ __launch_bounds__(256) void sde_corrector_kernel(SdeP s, float snr, c
                                                             const float* __restrict__ tt,
                                                             const float* __restrict__ score,
                                                             const float* __restrict__ z, float* __restrict__ xo,
-                                                            float* __restrict__ xm, int S, long T) {
+                                                            float* __restrict__ xm, int S, long T,
+                                                            const float* __restrict__ smix) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   if (t >= T) return;
   float ev1, ev2;
   mix_eig(s, tt[b], ev1, ev2);
-  const float a = sqrtf(ev1), p = sqrtf(ev2);
+  const float sm = smix ? smix[(long)b * T + t] : 1.0f;  // PriorMixSDE._std: L * sigma_mix (sdes.py:515-532)
+  const float a = sqrtf(ev1) * sm, p = sqrtf(ev2) * sm;
   const float step = 2.0f * snr * snr;
   float g[DS_MAX_SRC], n[DS_MAX_SRC], mg = 0.f, mn = 0.f;
   for (int i = 0; i < S; ++i) {
@@ -80,14 +109,16 @@ __global__ __launch_bounds__(256) void sde_predictor_kernel(SdeP s, int N, const
                                                             const float* __restrict__ tt,
                                                             const float* __restrict__ score,
                                                             const float* __restrict__ z, float* __restrict__ xo,
-                                                            float* __restrict__ xm, int S, long T) {
+                                                            float* __restrict__ xm, int S, long T,
+                                                            const float* __restrict__ smix) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   if (t >= T) return;
   const float r = s.sigma_max / s.sigma_min;
   const float dt = 1.0f / (float)N;
   const float sigma = s.sigma_min * powf(r, tt[b]);
-  const float diffusion = sigma * sqrtf(2.0f * logf(r));
+  // PriorMixSDE.sde: diffusion = sigma(t) sqrt(2 ln r) * sigma_mix per sample (sdes.py:451-470)
+  const float diffusion = sigma * sqrtf(2.0f * logf(r)) * (smix ? smix[(long)b * T + t] : 1.0f);
   const float G = diffusion * sqrtf(dt);
   float xv[DS_MAX_SRC], mx = 0.f;
   for (int i = 0; i < S; ++i) { xv[i] = x[((long)b * S + i) * T + t]; mx += xv[i]; }
@@ -103,27 +134,30 @@ __global__ __launch_bounds__(256) void sde_predictor_kernel(SdeP s, int N, const
   }
 }
 
-int ds_launch_sde_prior(const SdeP& s, const float* y, const float* z, float* x, int B, int S, long T, hipStream_t st) {
-  DS_CHECK(s.kind == 0, "sde: only MixSDE is implemented on the device path");
+int ds_launch_sde_prior(const SdeP& s, const float* y, const float* z, float* x, int B, int S, long T,
+                        const float* smix, hipStream_t st) {
+  DS_CHECK((s.kind == 1) == (smix != nullptr), "sde: PriorMixSDE needs sigma_mix, MixSDE must not get one");
   DS_CHECK(S >= 1 && S <= DS_MAX_SRC, "sde: too many sources");
-  hipLaunchKernelGGL(sde_prior_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, s, y, z, x, S, T);
+  hipLaunchKernelGGL(sde_prior_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, s, y, z, x, S, T, smix);
   DS_LAUNCH_CHECK();
   return 0;
 }
 int ds_launch_sde_corrector(const SdeP& s, float snr, const float* x, const float* t, const float* score,
-                            const float* z, float* xo, float* xm, int B, int S, long T, hipStream_t st) {
-  DS_CHECK(s.kind == 0, "sde: only MixSDE is implemented on the device path");
+                            const float* z, float* xo, float* xm, int B, int S, long T, const float* smix,
+                            hipStream_t st) {
+  DS_CHECK((s.kind == 1) == (smix != nullptr), "sde: PriorMixSDE needs sigma_mix, MixSDE must not get one");
   DS_CHECK(S >= 1 && S <= DS_MAX_SRC, "sde: too many sources");
   hipLaunchKernelGGL(sde_corrector_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, s, snr, x, t, score, z, xo, xm, S,
-                     T);
+                     T, smix);
   DS_LAUNCH_CHECK();
   return 0;
 }
 int ds_launch_sde_predictor(const SdeP& s, int N, const float* x, const float* t, const float* score, const float* z,
-                            float* xo, float* xm, int B, int S, long T, hipStream_t st) {
-  DS_CHECK(s.kind == 0, "sde: only MixSDE is implemented on the device path");
+                            float* xo, float* xm, int B, int S, long T, const float* smix, hipStream_t st) {
+  DS_CHECK((s.kind == 1) == (smix != nullptr), "sde: PriorMixSDE needs sigma_mix, MixSDE must not get one");
   DS_CHECK(S >= 1 && S <= DS_MAX_SRC && N >= 1, "sde: bad arguments");
-  hipLaunchKernelGGL(sde_predictor_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, s, N, x, t, score, z, xo, xm, S, T);
+  hipLaunchKernelGGL(sde_predictor_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, s, N, x, t, score, z, xo, xm, S, T,
+                     smix);
   DS_LAUNCH_CHECK();
   return 0;
 }

@@ -21,7 +21,7 @@ class ModelConfig(C.Structure):
 
 class SdeConfig(C.Structure):
     _fields_ = [("kind", C.c_int32), ("ndim", C.c_int32), ("d_lambda", C.c_float), ("sigma_min", C.c_float),
-                ("sigma_max", C.c_float)]
+                ("sigma_max", C.c_float), ("avg_len", C.c_int32)]
 
 
 class SamplerConfig(C.Structure):
@@ -65,9 +65,10 @@ _SIGS = {
     "diffsep_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),
     "diffsep_stft_pack": (_I, [_P, _P, _P, _I, _I, _L, _I, _I, _F, _F, _I, _I, _I, _I, _P, _L, _P]),
     "diffsep_istft_unpack": (_I, [_P, _P, _I, _I, _L, _I, _I, _F, _F, _I, _I, _I, _P, _L, _P]),
-    "diffsep_sde_prior": (_I, [C.POINTER(SdeConfig), _P, _P, _P, _I, _I, _L, _P]),
-    "diffsep_sde_corrector_update": (_I, [C.POINTER(SdeConfig), _F, _P, _P, _P, _P, _P, _P, _I, _I, _L, _P]),
-    "diffsep_sde_predictor_update": (_I, [C.POINTER(SdeConfig), _I, _P, _P, _P, _P, _P, _P, _I, _I, _L, _P]),
+    "diffsep_sde_sigma_mix": (_I, [_P, _P, _I, _L, _I, _P]),
+    "diffsep_sde_prior": (_I, [C.POINTER(SdeConfig), _P, _P, _P, _I, _I, _L, _P, _P]),
+    "diffsep_sde_corrector_update": (_I, [C.POINTER(SdeConfig), _F, _P, _P, _P, _P, _P, _P, _I, _I, _L, _P, _P]),
+    "diffsep_sde_predictor_update": (_I, [C.POINTER(SdeConfig), _I, _P, _P, _P, _P, _P, _P, _I, _I, _L, _P, _P]),
     "diffsep_normalize_batch": (_I, [_P, _P, _P, _P, _I, _L, _P]),
     "diffsep_scale_output": (_I, [_P, _P, _I, _I, _L, _P]),
     "diffsep_randn": (_I, [_P, _L, _U64, _U64, _P]),

@@ -138,7 +138,7 @@ class Engine:
         B, one, T = mix_norm.shape
         assert one == 1
         sc = _lib.SdeConfig(sde.get("kind", _lib.SDE_MIX), sde["ndim"], sde["d_lambda"], sde["sigma_min"],
-                            sde["sigma_max"])
+                            sde["sigma_max"], sde.get("avg_len", 0))
         pred = {"reverse_diffusion": _lib.PRED_REVERSE_DIFFUSION, "none": _lib.PRED_NONE}[predictor]
         corr = {"ald2": _lib.CORR_ALD2, "none": _lib.CORR_NONE}[corrector]
         sm = _lib.SamplerConfig(N, corrector_steps, snr, eps, int(bool(denoise)), pred, corr)

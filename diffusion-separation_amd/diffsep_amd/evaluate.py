@@ -23,7 +23,7 @@ import torch.distributed as dist
 
 from . import synth, wavio
 from .dist_utils import gather_objects, shard_range
-from .pl_model import DiffSepModel, cfg_get, default_config
+from .pl_model import DiffSepModel, cfg_get, default_config, enhancement_config
 
 
 def si_sdr_pit(est, ref):
@@ -42,6 +42,21 @@ def si_sdr_pit(est, ref):
 
 
 def load_dataset(args, fs):
+    if args.dataset_dir and args.enhance:
+        # VoiceBank-DEMAND layout (datasets/vctk_demand.py:51-61): noisy/ and clean/ with matching file names;
+        # the target is [clean, noisy - clean]
+        root = Path(args.dataset_dir)
+        names = sorted(p.name for p in (root / "noisy").glob("*.wav"))
+        if args.limit:
+            names = names[: args.limit]
+
+        def get_e(i):
+            noisy, _ = wavio.load(root / "noisy" / names[i])
+            clean, _ = wavio.load(root / "clean" / names[i])
+            n = min(noisy.shape[-1], clean.shape[-1])
+            noisy, clean = noisy[:1, :n], clean[:1, :n]
+            return noisy, torch.cat([clean, noisy - clean], 0)
+        return len(names), get_e
     if args.dataset_dir:
         root = Path(args.dataset_dir)
         names = sorted(p.name for p in (root / "mix").glob("*.wav"))
@@ -77,6 +92,9 @@ def main(argv=None):
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("-o", "--output-dir", type=Path, default=Path("results"))
     ap.add_argument("--save-wav", action="store_true")
+    ap.add_argument("--enhance", action="store_true",
+                    help="speech enhancement (evaluate.py:173-176,268-271): PriorMixSDE model, metrics on the first "
+                         "source (clean speech) only")
     args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,7 +107,9 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if args.synthetic_weights or args.ckpt is None:
-        model = DiffSepModel(default_config(nf=args.synthetic_weights or 64, n_speakers=args.n_speakers), dtype=args.dtype)
+        cfg = (enhancement_config(nf=args.synthetic_weights or 128) if args.enhance
+               else default_config(nf=args.synthetic_weights or 64, n_speakers=args.n_speakers))
+        model = DiffSepModel(cfg, dtype=args.dtype)
     else:
         model = DiffSepModel.load_from_checkpoint(args.ckpt, dtype=args.dtype)
     fs = cfg_get(model.config, "model.fs", 8000)
@@ -111,7 +131,10 @@ def main(argv=None):
         est, nfe, *_ = sampler()
         torch.cuda.synchronize()
         runtime = time.perf_counter() - t0
-        sdr, per = si_sdr_pit(est[0], tgt_n[0])
+        if args.enhance:  # n_src = 1: only the clean-speech estimate is scored (evaluate.py:270)
+            sdr, per = si_sdr_pit(est[0, :1], tgt_n[0, :1])
+        else:
+            sdr, per = si_sdr_pit(est[0], tgt_n[0])
         records.append({"batch_idx": i, "si_sdr": sdr, "si_sdr_per_source": per, "nfe": int(nfe), "runtime": runtime,
                         "len_s": mix.shape[-1] / fs})
         if args.save_wav:

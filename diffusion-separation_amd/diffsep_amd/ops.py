@@ -128,32 +128,41 @@ def istft_unpack(x, S, T, n_fft=510, hop=128, exponent=0.5, factor=0.33):
 
 
 def _sde(s):
-    return SdeConfig(s.get("kind", SDE_MIX), s["ndim"], s["d_lambda"], s["sigma_min"], s["sigma_max"])
+    return SdeConfig(s.get("kind", SDE_MIX), s["ndim"], s["d_lambda"], s["sigma_min"], s["sigma_max"],
+                     s.get("avg_len", 0))
 
 
-def sde_prior(sde, y, z):
+def sde_sigma_mix(mix, avg_len=510):
+    """PriorMixSDE per-sample noise scale: mix [B,1,T] -> [B,T]."""
+    B, _, T = mix.shape
+    out = torch.empty((B, T), dtype=torch.float32, device=mix.device)
+    check(lib().diffsep_sde_sigma_mix(_ptr(mix), _ptr(out), B, T, avg_len, _stream_ptr()))
+    return out
+
+
+def sde_prior(sde, y, z, sigma_mix=None):
     B, S, T = z.shape
     x = torch.empty_like(z)
     sc = _sde(sde)
-    check(lib().diffsep_sde_prior(C.byref(sc), _ptr(y), _ptr(z), _ptr(x), B, S, T, _stream_ptr()))
+    check(lib().diffsep_sde_prior(C.byref(sc), _ptr(y), _ptr(z), _ptr(x), B, S, T, _ptr(sigma_mix), _stream_ptr()))
     return x
 
 
-def sde_corrector_update(sde, snr, x, t, score, z):
+def sde_corrector_update(sde, snr, x, t, score, z, sigma_mix=None):
     B, S, T = x.shape
     xo, xm = torch.empty_like(x), torch.empty_like(x)
     sc = _sde(sde)
     check(lib().diffsep_sde_corrector_update(C.byref(sc), snr, _ptr(x), _ptr(t), _ptr(score), _ptr(z), _ptr(xo),
-                                             _ptr(xm), B, S, T, _stream_ptr()))
+                                             _ptr(xm), B, S, T, _ptr(sigma_mix), _stream_ptr()))
     return xo, xm
 
 
-def sde_predictor_update(sde, N, x, t, score, z):
+def sde_predictor_update(sde, N, x, t, score, z, sigma_mix=None):
     B, S, T = x.shape
     xo, xm = torch.empty_like(x), torch.empty_like(x)
     sc = _sde(sde)
     check(lib().diffsep_sde_predictor_update(C.byref(sc), N, _ptr(x), _ptr(t), _ptr(score), _ptr(z), _ptr(xo),
-                                             _ptr(xm), B, S, T, _stream_ptr()))
+                                             _ptr(xm), B, S, T, _ptr(sigma_mix), _stream_ptr()))
     return xo, xm
 
 

@@ -9,7 +9,7 @@ import torch
 from . import ops, sdes
 from .engine import param_table
 from .score_models import ScoreModelNCSNpp
-from .sdes import MixSDE
+from .sdes import MixSDE, PriorMixSDE
 
 
 def cfg_get(cfg, path, default=None):
@@ -44,6 +44,14 @@ def denormalize_batch(x, mean, std):
     return x * std + mean
 
 
+def enhancement_config(nf=128):
+    """config/model/nr.yaml restated (values only): 16 kHz, nf 128, spec_factor 0.15, PriorMixSDE."""
+    cfg = default_config(nf=nf, n_speakers=2, fs=16000, spec_factor=0.15)
+    cfg["model"]["sde"] = {"_target_": "sdes.sdes.PriorMixSDE", "ndim": 2, "d_lambda": 2.0, "sigma_min": 0.05,
+                           "sigma_max": 0.5, "N": 30}
+    return cfg
+
+
 def default_config(nf=64, n_speakers=2, fs=8000, spec_factor=0.33):
     """config/model/default.yaml restated as a plain dict (values only)."""
     return {"model": {
@@ -65,10 +73,13 @@ class DiffSepModel:
         sm["backbone_args"] = {k: v for k, v in dict(sm["backbone_args"]).items()}
         self.score_model = ScoreModelNCSNpp(dtype=dtype, device=device, init_seed=init_seed, **sm)
         sd = dict(cfg_get(config, "model.sde"))
-        target = sd.pop("_target_", "sdes.sdes.MixSDE")
-        if not str(target).endswith("MixSDE") or str(target).endswith("PriorMixSDE"):
-            raise NotImplementedError(f"SDE '{target}' is not on the accelerated path yet (MixSDE only)")
-        self.sde = MixSDE(**sd)
+        target = str(sd.pop("_target_", "sdes.sdes.MixSDE"))
+        if target.endswith("PriorMixSDE"):
+            self.sde = PriorMixSDE(**sd)  # speech enhancement (config/model/nr.yaml:30-37)
+        elif target.endswith("MixSDE"):
+            self.sde = MixSDE(**sd)
+        else:
+            raise NotImplementedError(f"SDE '{target}' is not on the accelerated path (MixSDE / PriorMixSDE)")
         self.t_eps = cfg_get(config, "model.t_eps", 0.03)
         self.t_max = self.sde.T
         self.normalize_batch = normalize_batch

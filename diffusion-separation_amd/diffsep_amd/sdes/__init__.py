@@ -12,9 +12,9 @@ import torch
 
 from .correctors import Corrector, CorrectorRegistry
 from .predictors import Predictor, PredictorRegistry, ReverseDiffusionPredictor
-from .sdes import MixSDE, SDERegistry
+from .sdes import MixSDE, PriorMixSDE, SDERegistry
 
-__all__ = ["PredictorRegistry", "CorrectorRegistry", "SDERegistry", "Predictor", "Corrector", "MixSDE",
+__all__ = ["PredictorRegistry", "CorrectorRegistry", "SDERegistry", "Predictor", "Corrector", "MixSDE", "PriorMixSDE",
            "get_pc_sampler", "get_pc_scheduled_sampler"]
 
 

@@ -30,11 +30,12 @@ class AnnealedLangevinDynamics2(Corrector):
 
     def update_fn(self, x, t, *args, **kwargs):
         x_mean = x
+        smix = self.sde.sigma_mix(args[0]) if args else None
         for _ in range(self.n_steps):
             score = self.score_fn(x, t, *args)
             z = torch.randn_like(x)
             x, x_mean = ops.sde_corrector_update(self.sde.engine_config(), self.snr, x.contiguous(), t.contiguous(),
-                                                 score, z)
+                                                 score, z, smix)
         return x, x_mean
 
 

@@ -29,7 +29,9 @@ class ReverseDiffusionPredictor(Predictor):
     def update_fn(self, x, t, *args, **kwargs):
         score = self.score_fn(x, t, *args)
         z = torch.randn_like(x)
-        return ops.sde_predictor_update(self.sde.engine_config(), self.sde.N, x.contiguous(), t.contiguous(), score, z)
+        smix = self.sde.sigma_mix(args[0]) if args else None
+        return ops.sde_predictor_update(self.sde.engine_config(), self.sde.N, x.contiguous(), t.contiguous(), score, z,
+                                        smix)
 
 
 @PredictorRegistry.register("none")

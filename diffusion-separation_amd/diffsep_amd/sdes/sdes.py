@@ -54,8 +54,36 @@ class MixSDE(SDE):
         ev2 = mult * (srp - torch.exp(-2.0 * self.d_lambda * t)) / (1.0 + self.d_lambda / self.logsig)
         return ev1, ev2
 
+    def sigma_mix(self, y):
+        """Per-sample noise scale (None for MixSDE: the perturbation kernel does not depend on the mixture)."""
+        return None
+
     def prior_sampling(self, shape, y):
         """x_T = 0.5 y + L(T) z   (sdes/sdes.py:334-346); z from torch's generator like the reference."""
         B, _, T = y.shape
         z = torch.randn((B, self.ndim, T), dtype=y.dtype, device=y.device)
-        return ops.sde_prior(self.engine_config(), y.contiguous(), z)
+        return ops.sde_prior(self.engine_config(), y.contiguous(), z, self.sigma_mix(y))
+
+
+@SDERegistry.register("priormix")
+class PriorMixSDE(MixSDE):
+    """MixSDE whose noise level follows the local energy of the mixture (speech enhancement, config/model/nr.yaml):
+    sigma_mix = 0.5 sqrt(clamp(avg_pool1d(mix^2, avg_len), 1e-4)) scales L(t) and g(t) per sample
+    (reference sdes/sdes.py:352-590)."""
+
+    def __init__(self, ndim, d_lambda, sigma_min, sigma_max, N=1000, avg_len=510):
+        super().__init__(ndim, d_lambda, sigma_min, sigma_max, N=N)
+        self.avg_len = avg_len
+
+    def copy(self):
+        return PriorMixSDE(self.ndim, self.d_lambda, self.sigma_min, self.sigma_max, N=self.N, avg_len=self.avg_len)
+
+    def engine_config(self):
+        c = super().engine_config()
+        c.update(kind=_lib.SDE_PRIORMIX, avg_len=self.avg_len)
+        return c
+
+    def sigma_mix(self, y):
+        if y.shape[1] != 1:
+            raise ValueError("PriorMixSDE expects a single-channel mixture [B,1,T]")
+        return ops.sde_sigma_mix(y.contiguous(), self.avg_len)

@@ -68,6 +68,7 @@ typedef struct {
   int32_t kind; /* DIFFSEP_SDE_* */
   int32_t ndim; /* number of sources */
   float d_lambda, sigma_min, sigma_max;
+  int32_t avg_len; /* PriorMixSDE only: length of the mix^2 moving average (510, sdes.py:383) */
 } diffsep_sde_config;
 
 /* sdes/__init__.py:132-145 (get_pc_sampler kwargs) + pl_model.py:687-701. */
@@ -208,19 +209,25 @@ int32_t diffsep_istft_unpack(const void* x, float* out, int32_t B, int32_t S, in
                              int32_t hop, float exponent, float factor, int32_t W, int32_t Cpad, int32_t dtype,
                              void* workspace, int64_t workspace_bytes, void* stream);
 
-/* MixSDE.prior_sampling (sdes/sdes.py:334-346): x_T = 0.5*y (bcast) + L(T) @ z. */
+/* PriorMixSDE._std_sigma_mix (sdes/sdes.py:477-489): sigma_mix[b,t] = 0.5*sqrt(clamp(avg_pool1d(mix^2, avg_len,
+ * stride 1, pad avg_len/2), 1e-4)); mix [B,1,T] -> sigma_mix [B,T].  The three updates below take it as their
+ * `sigma_mix` argument for kind = DIFFSEP_SDE_PRIORMIX (time-varying std, sdes.py:451-470,515-532) and NULL
+ * for MixSDE. */
+int32_t diffsep_sde_sigma_mix(const float* mix, float* sigma_mix, int32_t B, int64_t T, int32_t avg_len, void* stream);
+/* MixSDE.prior_sampling (sdes/sdes.py:334-346) / PriorMixSDE.prior_sampling (:564-587):
+ * x_T = 0.5*y (bcast) + L(T) @ z. */
 int32_t diffsep_sde_prior(const diffsep_sde_config* sde, const float* y, const float* z, float* x, int32_t B,
-                          int32_t S, int64_t T, void* stream);
+                          int32_t S, int64_t T, const float* sigma_mix, void* stream);
 /* AnnealedLangevinDynamics2.update_fn body for one step given the score
  * (sdes/correctors.py:115-126). t [B] device. */
 int32_t diffsep_sde_corrector_update(const diffsep_sde_config* sde, float snr, const float* x, const float* t,
                                      const float* score, const float* z, float* x_out, float* x_mean_out,
-                                     int32_t B, int32_t S, int64_t T, void* stream);
+                                     int32_t B, int32_t S, int64_t T, const float* sigma_mix, void* stream);
 /* ReverseDiffusionPredictor.update_fn given the score (sdes/predictors.py:60-66 ->
  * sdes/sdes.py:163-171,93-107,275-284); dt = 1/N. */
 int32_t diffsep_sde_predictor_update(const diffsep_sde_config* sde, int32_t N, const float* x, const float* t,
                                      const float* score, const float* z, float* x_out, float* x_mean_out,
-                                     int32_t B, int32_t S, int64_t T, void* stream);
+                                     int32_t B, int32_t S, int64_t T, const float* sigma_mix, void* stream);
 
 /* normalize_batch (pl_model.py:81-88): per-utterance mean / unbiased std (clamped 1e-5) over (1,T).
  * mix [B,1,T] -> mix_norm; mean,std [B] (nullable). */

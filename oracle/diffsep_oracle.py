@@ -305,40 +305,60 @@ def mix_std(cfg, t, S):
     return ev1[:, None, None].sqrt() * A + ev2[:, None, None].sqrt() * P
 
 
-def prior_sampling(cfg, y, z):
-    """MixSDE.prior_sampling  sdes/sdes.py:334-346 (mean 0.5*y broadcast to 2 sources: quirk Q2)."""
+def sigma_mix(mix, avg_len=510):
+    """PriorMixSDE._std_sigma_mix  sdes/sdes.py:477-489: [B,1,T] -> [B,1,T]."""
+    sm = F.avg_pool1d(mix ** 2, kernel_size=avg_len, stride=1, padding=avg_len // 2)
+    sm = sm.clamp(min=1e-4).sqrt()
+    if avg_len % 2 == 0:
+        sm = sm[..., :-1]
+    return 0.5 * sm
+
+
+def _apply_std(L, v, smix):
+    """MixSDE.mult_std (L @ v)  sdes.py:326-328, or PriorMixSDE.mult_std with L * sigma_mix per sample
+    (einsum 'bcdt,bdt->bct')  sdes.py:515-537."""
+    out = L @ v
+    return out if smix is None else out * smix
+
+
+def prior_sampling(cfg, y, z, smix=None):
+    """MixSDE.prior_sampling  sdes/sdes.py:334-346 (mean 0.5*y broadcast to 2 sources: quirk Q2);
+    PriorMixSDE.prior_sampling :564-587 when smix (= sigma_mix(y)) is given: mean 0.5*mix for any S."""
     S = z.shape[1]
     t = torch.ones((y.shape[0],), dtype=y.dtype)
-    c = 0.5 if S == 2 else 1.0 / S
-    return torch.broadcast_to(c * y, z.shape) + mix_std(cfg, t, S) @ z
+    c = 0.5 if (S == 2 or smix is not None) else 1.0 / S
+    return torch.broadcast_to(c * y, z.shape) + _apply_std(mix_std(cfg, t, S), z, smix)
 
 
-def corrector_ald2(cfg, x, t, score, z, snr):
+def corrector_ald2(cfg, x, t, score, z, snr, smix=None):
     """AnnealedLangevinDynamics2.update_fn body  sdes/correctors.py:115-126."""
     L = mix_std(cfg, t, x.shape[1])
-    g = L @ (L @ score)
+    g = _apply_std(L, _apply_std(L, score, smix), smix)
     x_mean = x + 2 * snr ** 2 * g
-    return x_mean + (2 * snr * L) @ z, x_mean
+    return x_mean + _apply_std(2 * snr * L, z, smix), x_mean
 
 
-def predictor_reverse_diffusion(cfg, x, t, score, z, N):
+def predictor_reverse_diffusion(cfg, x, t, score, z, N, smix=None):
     """ReverseDiffusionPredictor.update_fn  sdes/predictors.py:60-66 with RSDE.discretize
-    sdes/sdes.py:163-171, SDE.discretize :93-107 (dt = 1/N always: quirk Q1), MixSDE.sde :275-284."""
+    sdes/sdes.py:163-171, SDE.discretize :93-107 (dt = 1/N always: quirk Q1), MixSDE.sde :275-284
+    (PriorMixSDE.sde :451-470: the diffusion is additionally scaled per sample by sigma_mix)."""
     S = x.shape[1]
     _, P = mix_mats(S, x.dtype)
     r = cfg["sigma_max"] / cfg["sigma_min"]
     drift = -cfg["d_lambda"] * P @ x
-    diffusion = cfg["sigma_min"] * r ** t * np.sqrt(2 * math.log(r))
+    diffusion = (cfg["sigma_min"] * r ** t * np.sqrt(2 * math.log(r)))[:, None, None]
+    if smix is not None:
+        diffusion = diffusion * smix
     dt = 1 / N
     f = drift * dt
     G = diffusion * torch.sqrt(torch.tensor(dt, dtype=x.dtype))
-    rev_f = f - G[:, None, None] ** 2 * score
+    rev_f = f - G ** 2 * score
     x_mean = x - rev_f
-    return x_mean + G[:, None, None] * z, x_mean
+    return x_mean + G * z, x_mean
 
 
 def pc_sampler(p, cfg, y, noise, N=None, corrector_steps=None, snr=None, eps=None, denoise=True, score_fn=None,
-               timesteps=None):
+               timesteps=None, priormix_avg_len=None):
     """sdes.get_pc_sampler(...)()  sdes/__init__.py:166-188 with predictor 'reverse_diffusion' and
     corrector 'ald2'.  `noise` is the list of N(0,1) draws in the reference's RNG order (Q7):
     prior, then per step: corrector draw(s), predictor draw."""
@@ -350,15 +370,16 @@ def pc_sampler(p, cfg, y, noise, N=None, corrector_steps=None, snr=None, eps=Non
         def score_fn(x, t, m):
             return score_forward(p, cfg, x, t, m)
     it = iter(noise)
+    smix = None if priormix_avg_len is None else sigma_mix(y, priormix_avg_len)  # PriorMixSDE (enhancement)
     with torch.no_grad():
-        xt = prior_sampling(cfg, y, next(it))
+        xt = prior_sampling(cfg, y, next(it), smix)
         xm = xt
         ts = torch.linspace(1.0, eps, N, dtype=torch.float32) if timesteps is None else timesteps
         for i in range(N):
             vec_t = torch.ones(y.shape[0], dtype=y.dtype) * ts[i].to(y.dtype)
             for _ in range(cs):
-                xt, xm = corrector_ald2(cfg, xt, vec_t, score_fn(xt, vec_t, y), next(it), snr)
-            xt, xm = predictor_reverse_diffusion(cfg, xt, vec_t, score_fn(xt, vec_t, y), next(it), N)
+                xt, xm = corrector_ald2(cfg, xt, vec_t, score_fn(xt, vec_t, y), next(it), snr, smix)
+            xt, xm = predictor_reverse_diffusion(cfg, xt, vec_t, score_fn(xt, vec_t, y), next(it), N, smix)
     return (xm if denoise else xt), N * (cs + 1)
 
 

@@ -349,6 +349,30 @@ def main():
         out["g10_separate"] = ref_separate.separate(mixb[0], model, kw, "cpu").numpy()
     out["g10_scale_output"] = ref_separate.scale_output(mixb, sep).numpy()
 
+    # ---- G11 PriorMixSDE (speech enhancement, config/model/nr.yaml): sigma_mix, prior, isolated updates, full sampler
+    cfgp = model_config(nf, S)
+    cfgp["model"]["sde"] = AD(_target_="sdes.sdes.PriorMixSDE", ndim=S, d_lambda=2.0, sigma_min=0.05, sigma_max=0.5, N=30)
+    modelp = ref_pl.DiffSepModel(cfgp)
+    load_synth_weights(modelp.score_model.backbone, 7)
+    modelp.eval()
+    psde = modelp.sde.copy(); psde.N = N
+    out["g11_sigma_mix"] = psde._std_sigma_mix(mix_norm).numpy()
+    with InjectedNoise([draws[0]]):
+        out["g11_prior"] = psde.prior_sampling(mix_norm.shape, mix_norm).numpy()
+    predp = ref_sdes.PredictorRegistry.get_by_name("reverse_diffusion")(psde, modelp)
+    corrp = ref_sdes.CorrectorRegistry.get_by_name("ald2")(psde, modelp, snr=0.5, n_steps=1)
+    with InjectedNoise([draws[1]]):
+        xc, xcm = corrp.update_fn(x0, tv, mix_norm)
+    with InjectedNoise([draws[2]]):
+        xp, xpm = predp.update_fn(x0, tv, mix_norm)
+    out["g11_corr_x"], out["g11_corr_mean"] = xc.numpy(), xcm.numpy()
+    out["g11_pred_x"], out["g11_pred_mean"] = xp.numpy(), xpm.numpy()
+    with InjectedNoise(draws) as inj:
+        sampler = modelp.get_pc_sampler("reverse_diffusion", "ald2", mix_norm, N=N, denoise=True, intermediate=False,
+                                        corrector_steps=cs, snr=0.5, schedule=None)
+        out["g11_sep"] = sampler()[0].numpy()
+        assert inj.i == len(draws)
+
     np.savez_compressed(os.path.join(HERE, "golden_ref.npz"), **{k: np.asarray(v) for k, v in out.items()})
     with open(os.path.join(HERE, "golden_meta.json"), "w") as f:
         json.dump(meta, f)

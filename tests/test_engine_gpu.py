@@ -197,3 +197,16 @@ def test_full_size_sampler_nf64_N30_parity_with_oracle():
     s = si_sdr(out16, ref)
     print(f"[bf16 vs fp32 reference] rel rms {rel_rms(out16, ref):.3e}  SI-SDR(out16, ref) {s.flatten().tolist()}")
     assert torch.isfinite(out16).all()
+
+
+def test_priormix_sampler_matches_reference_golden(golden):
+    # the enhancement path: DiffSepModel.get_pc_sampler with PriorMixSDE, whole sampler in one engine call
+    g, _ = golden
+    eng, _ = engine(16, 2, _lib.F32)
+    mix, draws, N, cs = _g9_inputs()
+    mix_norm, _, _ = ops.normalize_batch(mix.to(DEV))
+    psde = dict(kind=_lib.SDE_PRIORMIX, ndim=2, d_lambda=2.0, sigma_min=0.05, sigma_max=0.5, avg_len=510)
+    sep, nfe = eng.pc_sample(mix_norm, psde, N=N, corrector_steps=cs, snr=0.5, eps=0.03, denoise=True,
+                             noise=draws.to(DEV))
+    assert nfe == 6
+    assert rel_rms(sep, g["g11_sep"]) < 1e-4 and diff_rms(sep, g["g11_sep"]) < 1e-3

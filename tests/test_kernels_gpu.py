@@ -256,3 +256,30 @@ def test_randn_is_standard_normal_and_reproducible():
     assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1.0) < 5e-3
     assert abs(float((a ** 4).mean()) - 3.0) < 0.05
     assert abs(float((a * c).mean())) < 5e-3
+
+
+def test_priormix_sde_kernels_match_reference_golden(golden):
+    # PriorMixSDE (speech enhancement): time-varying std from the mixture envelope (sdes/sdes.py:352-590)
+    g, _ = golden
+    B, S, T, N = 2, 2, 4000, 3
+    PSDE = dict(kind=1, ndim=2, d_lambda=2.0, sigma_min=0.05, sigma_max=0.5, avg_len=510)
+    mix_norm = torch.from_numpy(g["g10_mix_norm"]).to(DEV)
+    smix = ops.sde_sigma_mix(mix_norm, 510)
+    assert rel_rms(smix.cpu(), g["g11_sigma_mix"][:, 0]) < 1e-6
+    draws = [rnd(f"g9.z{i}", (B, S, T)) for i in range(3)]
+    assert rel_rms(ops.sde_prior(PSDE, mix_norm, draws[0].to(DEV), smix).cpu(), g["g11_prior"]) < 1e-6
+    cfg = O.default_config(16, 2)
+    p = O.to_torch(synth.synth_state_dict(O.param_table(cfg), 7))
+    x0 = rnd("g9.x0", (B, S, T), 0.5)
+    tv = torch.tensor([0.8, 0.2])
+    sc = O.score_forward(p, cfg, x0, tv, torch.from_numpy(g["g10_mix_norm"]))
+    xc, xcm = ops.sde_corrector_update(PSDE, 0.5, x0.to(DEV), tv.to(DEV), sc.to(DEV), draws[1].to(DEV), smix)
+    xp, xpm = ops.sde_predictor_update(PSDE, N, x0.to(DEV), tv.to(DEV), sc.to(DEV), draws[2].to(DEV), smix)
+    for a, k in ((xc, "g11_corr_x"), (xcm, "g11_corr_mean"), (xp, "g11_pred_x"), (xpm, "g11_pred_mean")):
+        assert rel_rms(a.cpu(), g[k]) < 2e-5, k
+    # even window lengths drop the extra trailing sample; a window longer than the signal still works
+    for k_len in (8, 509, 9000):
+        ref = O.sigma_mix(torch.from_numpy(g["g10_mix_norm"]), k_len)[:, 0]
+        assert rel_rms(ops.sde_sigma_mix(mix_norm, k_len).cpu(), ref) < 1e-5, k_len
+    with pytest.raises(Exception):
+        ops.sde_prior(PSDE, mix_norm, draws[0].to(DEV), None)  # PriorMixSDE without sigma_mix is an error

@@ -152,3 +152,27 @@ def test_pc_sampler_and_separate(golden):
     out, _ = O.separate(p, cfg, mix[:1], d1, N=2, corrector_steps=1, snr=0.5, eps=0.03, denoise=True)
     assert rel_rms(out.numpy(), g["g10_separate"]) < 1e-4
     assert rel_rms(O.scale_output(mix, torch.from_numpy(g["g9_sep"])).numpy(), g["g10_scale_output"]) < 1e-6
+
+
+def test_priormix_sde_enhancement_path(golden):
+    """PriorMixSDE (config/model/nr.yaml, evaluate.py --enhance): sigma_mix, prior, isolated updates, full sampler."""
+    g, _ = golden
+    cfg = O.default_config(16, 2)
+    p = weights(cfg, 7)
+    B, S, T, N, cs = 2, 2, 4000, 3, 1
+    mix = torch.from_numpy(synth.synth_batch(B, T=T)[0])
+    mix_norm, _, _ = O.normalize_batch(mix)
+    smix = O.sigma_mix(mix_norm, 510)
+    assert smix.shape == (B, 1, T) and rel_rms(smix.numpy(), g["g11_sigma_mix"]) < 1e-6
+    draws = [torch.from_numpy(synth.synth_noise(f"g9.z{i}", (B, S, T))) for i in range(1 + N * (cs + 1))]
+    assert rel_rms(O.prior_sampling(cfg, mix_norm, draws[0], smix).numpy(), g["g11_prior"]) < 1e-6
+    x0 = torch.from_numpy(synth.synth_noise("g9.x0", (B, S, T))) * 0.5
+    tv = torch.tensor([0.8, 0.2])
+    sc = O.score_forward(p, cfg, x0, tv, mix_norm)
+    xc, xcm = O.corrector_ald2(cfg, x0, tv, sc, draws[1], 0.5, smix)
+    xp, xpm = O.predictor_reverse_diffusion(cfg, x0, tv, sc, draws[2], N, smix)
+    for a, k in ((xc, "g11_corr_x"), (xcm, "g11_corr_mean"), (xp, "g11_pred_x"), (xpm, "g11_pred_mean")):
+        assert rel_rms(a.numpy(), g[k]) < 2e-5, k
+    sep, nfe = O.pc_sampler(p, cfg, mix_norm, draws, N=N, corrector_steps=cs, snr=0.5, eps=0.03, denoise=True,
+                            priormix_avg_len=510)
+    assert nfe == 6 and rel_rms(sep.numpy(), g["g11_sep"]) < 1e-4
