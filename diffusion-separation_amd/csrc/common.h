@@ -183,9 +183,12 @@ int ds_launch_sde_prior(const SdeP& s, const float* y, const float* z, float* x,
                         const float* smix, hipStream_t st);
 int ds_launch_sde_corrector(const SdeP& s, float snr, const float* x, const float* t, const float* score,
                             const float* z, float* xo, float* xm, int B, int S, long T, const float* smix,
-                            hipStream_t st);
+                            int variant, hipStream_t st);  // variant 0 = ald2, 1 = ald
 int ds_launch_sde_predictor(const SdeP& s, int N, const float* x, const float* t, const float* score, const float* z,
-                            float* xo, float* xm, int B, int S, long T, const float* smix, hipStream_t st);
+                            float* xo, float* xm, int B, int S, long T, const float* smix, int pflow, hipStream_t st);
+// Langevin corrector step; ws >= 16*B + 16 bytes
+int ds_launch_langevin(float snr, const float* x, const float* score, const float* z, float* xo, float* xm, int B,
+                       long n_per_batch, void* ws, hipStream_t st);
 int ds_launch_normalize(const float* mix, float* out, float* mean, float* std, int B, long T, hipStream_t st);
 int ds_launch_scale_output(const float* mix, float* sep, int B, int S, long T, hipStream_t st);
 int ds_launch_randn(float* out, long n, uint64_t seed, uint64_t stream_id, hipStream_t st);

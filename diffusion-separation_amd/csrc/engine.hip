@@ -308,7 +308,7 @@ struct diffsep_engine {
   long planT = -1;
   // sampler state (inside the arena, below fwd_base)
   float *st_x = nullptr, *st_xm = nullptr, *st_score = nullptr, *st_t = nullptr, *st_noise = nullptr,
-        *st_ts = nullptr, *st_mix = nullptr, *st_smix = nullptr;
+        *st_ts = nullptr, *st_mix = nullptr, *st_smix = nullptr, *st_lang = nullptr;
   // graph of one NFE: (st_x, st_t, st_mix) -> st_score
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
@@ -717,7 +717,7 @@ static int ensure_plan(diffsep_engine* e, int B, long T, hipStream_t st) {
   e->dry = true;
   e_alloc(e, nst * 4); e_alloc(e, nst * 4); e_alloc(e, nst * 4); e_alloc(e, nst * 4);
   e_alloc(e, (size_t)B * 4); e_alloc(e, (size_t)B * T * 4); e_alloc(e, (size_t)B * T * 4);
-  e_alloc(e, 4096 * (size_t)B * 4);
+  e_alloc(e, 4096 * (size_t)B * 4); e_alloc(e, 16 * (size_t)B + 64);
   e->fwd_base = (e->top + 255) & ~(size_t)255;
   const int rc = score_forward_impl(e, nullptr, nullptr, nullptr, nullptr, B, T, st);
   e->dry = false;
@@ -741,6 +741,7 @@ static int ensure_plan(diffsep_engine* e, int B, long T, hipStream_t st) {
   e->st_mix = (float*)e_alloc(e, (size_t)B * T * 4);
   e->st_smix = (float*)e_alloc(e, (size_t)B * T * 4);
   e->st_ts = (float*)e_alloc(e, 4096 * (size_t)B * 4);
+  e->st_lang = (float*)e_alloc(e, 16 * (size_t)B + 64);
   e->planB = B;
   e->planT = T;
   e->warmed = false;
@@ -953,14 +954,18 @@ extern "C" int32_t diffsep_pc_sample(diffsep_engine* e, const diffsep_sde_config
   DS_CHECK(sde->kind == DIFFSEP_SDE_MIX || sde->avg_len >= 1, "pc_sample: PriorMixSDE needs avg_len >= 1");
   DS_CHECK(sde->ndim == e->cfg.num_sources, "pc_sample: sde.ndim != num_sources");
   DS_CHECK(smp->N >= 1 && smp->N <= 4096, "pc_sample: N must be in [1,4096]");
-  DS_CHECK(smp->predictor == DIFFSEP_PRED_REVERSE_DIFFUSION || smp->predictor == DIFFSEP_PRED_NONE,
-           "pc_sample: predictor must be reverse_diffusion or none");
-  DS_CHECK(smp->corrector == DIFFSEP_CORR_ALD2 || smp->corrector == DIFFSEP_CORR_NONE,
-           "pc_sample: corrector must be ald2 or none");
+  DS_CHECK(smp->predictor == DIFFSEP_PRED_REVERSE_DIFFUSION || smp->predictor == DIFFSEP_PRED_EULER_MARUYAMA ||
+               smp->predictor == DIFFSEP_PRED_NONE,
+           "pc_sample: predictor must be reverse_diffusion, euler_maruyama or none");
+  DS_CHECK(smp->corrector == DIFFSEP_CORR_ALD2 || smp->corrector == DIFFSEP_CORR_NONE ||
+               smp->corrector == DIFFSEP_CORR_ALD || smp->corrector == DIFFSEP_CORR_LANGEVIN,
+           "pc_sample: corrector must be ald2, ald, langevin or none");
+  DS_CHECK(smp->corrector != DIFFSEP_CORR_ALD || sde->kind == DIFFSEP_SDE_MIX,
+           "pc_sample: the 'ald' corrector supports MixSDE only (sdes/correctors.py:64-67)");
   StreamScope sc_(e, stream);
   hipStream_t st = sc_.st;
   const int S = e->cfg.num_sources, N = smp->N;
-  const int csteps = smp->corrector == DIFFSEP_CORR_ALD2 ? smp->corrector_steps : 0;
+  const int csteps = smp->corrector == DIFFSEP_CORR_NONE ? 0 : smp->corrector_steps;
   if (ensure_plan(e, B, T, st)) return 1;
   const size_t nst = (size_t)B * S * T;
   SdeP sp{sde->kind, sde->ndim, sde->d_lambda, sde->sigma_min, sde->sigma_max};
@@ -1000,15 +1005,21 @@ extern "C" int32_t diffsep_pc_sample(diffsep_engine* e, const diffsep_sde_config
       if (run_nfe(e, B, T, st)) return 1;
       ++nfe;
       if (next_noise(&z)) return 1;
-      if (ds_launch_sde_corrector(sp, smp->snr, e->st_x, e->st_t, e->st_score, z, e->st_x, e->st_xm, B, S, T, smix,
-                                  st))
+      if (smp->corrector == DIFFSEP_CORR_LANGEVIN) {
+        if (ds_launch_langevin(smp->snr, e->st_x, e->st_score, z, e->st_x, e->st_xm, B, (long)S * T, e->st_lang, st))
+          return 1;
+      } else if (ds_launch_sde_corrector(sp, smp->snr, e->st_x, e->st_t, e->st_score, z, e->st_x, e->st_xm, B, S, T,
+                                         smix, smp->corrector == DIFFSEP_CORR_ALD ? 1 : 0, st)) {
         return 1;
+      }
     }
-    if (smp->predictor == DIFFSEP_PRED_REVERSE_DIFFUSION) {
+    if (smp->predictor != DIFFSEP_PRED_NONE) {
+      // euler_maruyama (sdes/predictors.py:39-52) takes x + f*dt with the reverse drift f = drift - g^2 score and
+      // noise g sqrt(dt): algebraically the reverse_diffusion step (dt = 1/N, G = g sqrt(dt)) — one kernel for both
       if (run_nfe(e, B, T, st)) return 1;
       ++nfe;
       if (next_noise(&z)) return 1;
-      if (ds_launch_sde_predictor(sp, N, e->st_x, e->st_t, e->st_score, z, e->st_x, e->st_xm, B, S, T, smix, st))
+      if (ds_launch_sde_predictor(sp, N, e->st_x, e->st_t, e->st_score, z, e->st_x, e->st_xm, B, S, T, smix, 0, st))
         return 1;
     } else {
       DS_HIP(hipMemcpyAsync(e->st_xm, e->st_x, nst * 4, hipMemcpyDeviceToDevice, st));
@@ -1151,17 +1162,26 @@ extern "C" int32_t diffsep_sde_prior(const diffsep_sde_config* sde, const float*
 }
 extern "C" int32_t diffsep_sde_corrector_update(const diffsep_sde_config* sde, float snr, const float* x, const float* t,
                                                 const float* score, const float* z, float* x_out, float* x_mean_out,
-                                                int32_t B, int32_t S, int64_t T, const float* sigma_mix, void* stream) {
+                                                int32_t B, int32_t S, int64_t T, const float* sigma_mix, int32_t variant,
+                                                void* stream) {
   DS_CHECK(sde && x && t && score && x_out, "sde_corrector_update: null pointer");
-  return ds_launch_sde_corrector(to_sdep(sde), snr, x, t, score, z, x_out, x_mean_out, B, S, T, sigma_mix,
+  return ds_launch_sde_corrector(to_sdep(sde), snr, x, t, score, z, x_out, x_mean_out, B, S, T, sigma_mix, variant,
                                  (hipStream_t)stream);
 }
 extern "C" int32_t diffsep_sde_predictor_update(const diffsep_sde_config* sde, int32_t N, const float* x, const float* t,
                                                 const float* score, const float* z, float* x_out, float* x_mean_out,
-                                                int32_t B, int32_t S, int64_t T, const float* sigma_mix, void* stream) {
+                                                int32_t B, int32_t S, int64_t T, const float* sigma_mix,
+                                                int32_t probability_flow, void* stream) {
   DS_CHECK(sde && x && t && score && x_out, "sde_predictor_update: null pointer");
   return ds_launch_sde_predictor(to_sdep(sde), N, x, t, score, z, x_out, x_mean_out, B, S, T, sigma_mix,
-                                 (hipStream_t)stream);
+                                 probability_flow, (hipStream_t)stream);
+}
+extern "C" int32_t diffsep_sde_langevin_update(float snr, const float* x, const float* score, const float* z,
+                                               float* x_out, float* x_mean_out, int32_t B, int64_t n_per_batch,
+                                               void* workspace, int64_t workspace_bytes, void* stream) {
+  DS_CHECK(x && score && z && x_out && workspace, "sde_langevin_update: null pointer");
+  DS_CHECK(workspace_bytes >= 16 * (int64_t)B + 16, "sde_langevin_update: workspace too small");
+  return ds_launch_langevin(snr, x, score, z, x_out, x_mean_out, B, n_per_batch, workspace, (hipStream_t)stream);
 }
 extern "C" int32_t diffsep_normalize_batch(const float* mix, float* mix_norm, float* mean, float* std, int32_t B,
                                            int64_t T, void* stream) {

@@ -73,12 +73,15 @@ __global__ __launch_bounds__(256) void sde_corrector_kernel(SdeP s, float snr, c
                                                             const float* __restrict__ score,
                                                             const float* __restrict__ z, float* __restrict__ xo,
                                                             float* __restrict__ xm, int S, long T,
-                                                            const float* __restrict__ smix) {
+                                                            const float* __restrict__ smix, int variant) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   if (t >= T) return;
   float ev1, ev2;
   mix_eig(s, tt[b], ev1, ev2);
+  // variant 1 = 'ald' (sdes/correctors.py:58-91): a scalar std = sqrt(sum_j (L L)[0, j]) = sqrt(ev1) for every source,
+  // i.e. the same update with L replaced by sqrt(ev1) I
+  if (variant == 1) ev2 = ev1;
   const float sm = smix ? smix[(long)b * T + t] : 1.0f;  // PriorMixSDE._std: L * sigma_mix (sdes.py:515-532)
   const float a = sqrtf(ev1) * sm, p = sqrtf(ev2) * sm;
   const float step = 2.0f * snr * snr;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void sde_predictor_kernel(SdeP s, int N, const
                                                             const float* __restrict__ score,
                                                             const float* __restrict__ z, float* __restrict__ xo,
                                                             float* __restrict__ xm, int S, long T,
-                                                            const float* __restrict__ smix) {
+                                                            const float* __restrict__ smix, int pflow) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   if (t >= T) return;
@@ -127,10 +130,11 @@ __global__ __launch_bounds__(256) void sde_predictor_kernel(SdeP s, int N, const
     const long o = ((long)b * S + i) * T + t;
     const float drift = -s.d_lambda * (xv[i] - mx);
     const float f = drift * dt;
-    const float rev_f = f - G * G * score[o];
+    // probability-flow ODE (sdes.py:165-171): half the score term, no noise
+    const float rev_f = f - G * G * score[o] * (pflow ? 0.5f : 1.0f);
     const float mean = xv[i] - rev_f;
     if (xm) xm[o] = mean;
-    xo[o] = mean + G * (z ? z[o] : 0.f);
+    xo[o] = mean + ((z && !pflow) ? G * z[o] : 0.f);
   }
 }
 
@@ -144,20 +148,83 @@ int ds_launch_sde_prior(const SdeP& s, const float* y, const float* z, float* x,
 }
 int ds_launch_sde_corrector(const SdeP& s, float snr, const float* x, const float* t, const float* score,
                             const float* z, float* xo, float* xm, int B, int S, long T, const float* smix,
-                            hipStream_t st) {
+                            int variant, hipStream_t st) {
   DS_CHECK((s.kind == 1) == (smix != nullptr), "sde: PriorMixSDE needs sigma_mix, MixSDE must not get one");
   DS_CHECK(S >= 1 && S <= DS_MAX_SRC, "sde: too many sources");
+  DS_CHECK(variant == 0 || (variant == 1 && s.kind == 0), "sde: corrector variant must be ald2 (0) or ald on MixSDE (1)");
   hipLaunchKernelGGL(sde_corrector_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, s, snr, x, t, score, z, xo, xm, S,
-                     T, smix);
+                     T, smix, variant);
   DS_LAUNCH_CHECK();
   return 0;
 }
 int ds_launch_sde_predictor(const SdeP& s, int N, const float* x, const float* t, const float* score, const float* z,
-                            float* xo, float* xm, int B, int S, long T, const float* smix, hipStream_t st) {
+                            float* xo, float* xm, int B, int S, long T, const float* smix, int pflow,
+                            hipStream_t st) {
   DS_CHECK((s.kind == 1) == (smix != nullptr), "sde: PriorMixSDE needs sigma_mix, MixSDE must not get one");
   DS_CHECK(S >= 1 && S <= DS_MAX_SRC && N >= 1, "sde: bad arguments");
   hipLaunchKernelGGL(sde_predictor_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, s, N, x, t, score, z, xo, xm, S, T,
-                     smix);
+                     smix, pflow);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ Langevin corrector (sdes/correctors.py:35-55)
+// step = 2 (snr * mean_b ||z_b|| / mean_b ||g_b||)^2 is ONE scalar for the whole batch (the reference couples the
+// batch entries here); x_mean = x + step g ; x = x_mean + sqrt(2 step) z.
+__global__ __launch_bounds__(1024) void batch_norm2_kernel(const float* __restrict__ g, const float* __restrict__ z,
+                                                           double* __restrict__ out, long n) {
+  __shared__ double sh[16];
+  const int b = blockIdx.x;
+  double a = 0.0, c = 0.0;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const double u = (double)g[(long)b * n + i], v = (double)z[(long)b * n + i];
+    a += u * u;
+    c += v * v;
+  }
+  a = wave_sum_d(a);
+  c = wave_sum_d(c);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sh[w] = a;
+  __syncthreads();
+  double ta = 0.0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) ta += sh[i];
+  __syncthreads();
+  if (lane == 0) sh[w] = c;
+  __syncthreads();
+  double tc = 0.0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tc += sh[i];
+  if (threadIdx.x == 0) { out[2 * b] = sqrt(ta); out[2 * b + 1] = sqrt(tc); }
+}
+__global__ void langevin_step_kernel(const double* __restrict__ norms, int B, float snr, float* __restrict__ step) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double gn = 0.0, zn = 0.0;
+    for (int b = 0; b < B; ++b) { gn += norms[2 * b]; zn += norms[2 * b + 1]; }
+    gn /= B; zn /= B;
+    const float r = snr * (float)zn / (float)gn;
+    step[0] = r * r * 2.0f;
+  }
+}
+__global__ __launch_bounds__(256) void langevin_update_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                              const float* __restrict__ z,
+                                                              const float* __restrict__ step, float* __restrict__ xo,
+                                                              float* __restrict__ xm, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float st = step[0];
+  const float mean = x[i] + st * g[i];
+  if (xm) xm[i] = mean;
+  xo[i] = mean + z[i] * sqrtf(st * 2.0f);
+}
+int ds_launch_langevin(float snr, const float* x, const float* score, const float* z, float* xo, float* xm, int B,
+                       long n_per_batch, void* ws, hipStream_t st) {
+  double* norms = reinterpret_cast<double*>(ws);
+  float* step = reinterpret_cast<float*>(norms + 2 * (size_t)B);
+  hipLaunchKernelGGL(batch_norm2_kernel, dim3(B), dim3(1024), 0, st, score, z, norms, n_per_batch);
+  DS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(langevin_step_kernel, dim3(1), dim3(64), 0, st, norms, B, snr, step);
+  DS_LAUNCH_CHECK();
+  const long n = (long)B * n_per_batch;
+  hipLaunchKernelGGL(langevin_update_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, x, score, z, step, xo, xm, n);
   DS_LAUNCH_CHECK();
   return 0;
 }

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("DIFFSEP_LIB", os.path.join(os.path.dirname(_HERE), "l
 F32, BF16 = 0, 1
 SDE_MIX, SDE_PRIORMIX = 0, 1
 PRED_REVERSE_DIFFUSION, PRED_EULER_MARUYAMA, PRED_NONE = 0, 1, 2
-CORR_ALD2, CORR_NONE = 0, 1
+CORR_ALD2, CORR_NONE, CORR_ALD, CORR_LANGEVIN = 0, 1, 2, 3
 
 
 class ModelConfig(C.Structure):
@@ -67,8 +67,9 @@ _SIGS = {
     "diffsep_istft_unpack": (_I, [_P, _P, _I, _I, _L, _I, _I, _F, _F, _I, _I, _I, _P, _L, _P]),
     "diffsep_sde_sigma_mix": (_I, [_P, _P, _I, _L, _I, _P]),
     "diffsep_sde_prior": (_I, [C.POINTER(SdeConfig), _P, _P, _P, _I, _I, _L, _P, _P]),
-    "diffsep_sde_corrector_update": (_I, [C.POINTER(SdeConfig), _F, _P, _P, _P, _P, _P, _P, _I, _I, _L, _P, _P]),
-    "diffsep_sde_predictor_update": (_I, [C.POINTER(SdeConfig), _I, _P, _P, _P, _P, _P, _P, _I, _I, _L, _P, _P]),
+    "diffsep_sde_corrector_update": (_I, [C.POINTER(SdeConfig), _F, _P, _P, _P, _P, _P, _P, _I, _I, _L, _P, _I, _P]),
+    "diffsep_sde_predictor_update": (_I, [C.POINTER(SdeConfig), _I, _P, _P, _P, _P, _P, _P, _I, _I, _L, _P, _I, _P]),
+    "diffsep_sde_langevin_update": (_I, [_F, _P, _P, _P, _P, _P, _I, _L, _P, _L, _P]),
     "diffsep_normalize_batch": (_I, [_P, _P, _P, _P, _I, _L, _P]),
     "diffsep_scale_output": (_I, [_P, _P, _I, _I, _L, _P]),
     "diffsep_randn": (_I, [_P, _L, _U64, _U64, _P]),

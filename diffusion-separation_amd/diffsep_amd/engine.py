@@ -139,14 +139,16 @@ class Engine:
         assert one == 1
         sc = _lib.SdeConfig(sde.get("kind", _lib.SDE_MIX), sde["ndim"], sde["d_lambda"], sde["sigma_min"],
                             sde["sigma_max"], sde.get("avg_len", 0))
-        pred = {"reverse_diffusion": _lib.PRED_REVERSE_DIFFUSION, "none": _lib.PRED_NONE}[predictor]
-        corr = {"ald2": _lib.CORR_ALD2, "none": _lib.CORR_NONE}[corrector]
+        pred = {"reverse_diffusion": _lib.PRED_REVERSE_DIFFUSION, "euler_maruyama": _lib.PRED_EULER_MARUYAMA,
+                "none": _lib.PRED_NONE}[predictor]
+        corr = {"ald2": _lib.CORR_ALD2, "none": _lib.CORR_NONE, "ald": _lib.CORR_ALD,
+                "langevin": _lib.CORR_LANGEVIN}[corrector]
         sm = _lib.SamplerConfig(N, corrector_steps, snr, eps, int(bool(denoise)), pred, corr)
         out = torch.empty((B, self.S, T), dtype=torch.float32, device=mix_norm.device)
         if noise is not None:
             noise = self._f32(noise)
-            ncs = corrector_steps if corrector == "ald2" else 0
-            npred = 1 if predictor == "reverse_diffusion" else 0
+            ncs = corrector_steps if corrector != "none" else 0
+            npred = 1 if predictor != "none" else 0
             assert noise.shape == (1 + N * (ncs + npred), B, self.S, T), "noise must be [draws,B,S,T]"
         ts = None
         if timesteps is not None:

@@ -148,21 +148,33 @@ def sde_prior(sde, y, z, sigma_mix=None):
     return x
 
 
-def sde_corrector_update(sde, snr, x, t, score, z, sigma_mix=None):
+def sde_corrector_update(sde, snr, x, t, score, z, sigma_mix=None, variant=0):
+    """variant 0: ald2, 1: ald."""
     B, S, T = x.shape
     xo, xm = torch.empty_like(x), torch.empty_like(x)
     sc = _sde(sde)
     check(lib().diffsep_sde_corrector_update(C.byref(sc), snr, _ptr(x), _ptr(t), _ptr(score), _ptr(z), _ptr(xo),
-                                             _ptr(xm), B, S, T, _ptr(sigma_mix), _stream_ptr()))
+                                             _ptr(xm), B, S, T, _ptr(sigma_mix), variant, _stream_ptr()))
     return xo, xm
 
 
-def sde_predictor_update(sde, N, x, t, score, z, sigma_mix=None):
+def sde_predictor_update(sde, N, x, t, score, z, sigma_mix=None, probability_flow=False):
     B, S, T = x.shape
     xo, xm = torch.empty_like(x), torch.empty_like(x)
     sc = _sde(sde)
     check(lib().diffsep_sde_predictor_update(C.byref(sc), N, _ptr(x), _ptr(t), _ptr(score), _ptr(z), _ptr(xo),
-                                             _ptr(xm), B, S, T, _ptr(sigma_mix), _stream_ptr()))
+                                             _ptr(xm), B, S, T, _ptr(sigma_mix), int(bool(probability_flow)),
+                                             _stream_ptr()))
+    return xo, xm
+
+
+def sde_langevin_update(snr, x, score, z):
+    B = x.shape[0]
+    n = x.numel() // B
+    xo, xm = torch.empty_like(x), torch.empty_like(x)
+    ws = torch.empty(16 * B + 64, dtype=torch.uint8, device=x.device)
+    check(lib().diffsep_sde_langevin_update(snr, _ptr(x), _ptr(score), _ptr(z), _ptr(xo), _ptr(xm), B, n, _ptr(ws),
+                                            ws.numel(), _stream_ptr()))
     return xo, xm
 
 

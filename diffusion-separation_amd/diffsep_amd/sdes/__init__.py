@@ -42,9 +42,10 @@ def _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, d
     predictor = PredictorRegistry.get_by_name(predictor_name)(sde, score_fn, probability_flow=probability_flow)
     corrector = CorrectorRegistry.get_by_name(corrector_name)(sde, score_fn, snr=snr, n_steps=corrector_steps)
     eng = _engine_of(score_fn)
-    fused = (eng is not None and not intermediate and true_mean is None and not probability_flow
-             and predictor_name in ("reverse_diffusion", "none") and corrector_name in ("ald2", "none")
-             and isinstance(sde, MixSDE))
+    fused = (eng is not None and not intermediate and true_mean is None
+             and predictor_name in ("reverse_diffusion", "euler_maruyama", "none")
+             and corrector_name in ("ald2", "ald", "langevin", "none") and isinstance(sde, MixSDE)
+             and not (corrector_name == "ald" and type(sde) is not MixSDE))
 
     def pc_sampler():
         with torch.no_grad():

@@ -39,6 +39,39 @@ class AnnealedLangevinDynamics2(Corrector):
         return x, x_mean
 
 
+@CorrectorRegistry.register("ald")
+class AnnealedLangevinDynamics(Corrector):
+    """The scalar-std annealed Langevin corrector (sdes/correctors.py:58-91): std = sqrt(sum_j (L L)[0, j]) = sqrt(ev1);
+    step = 2 (snr std)^2; x_mean = x + step g; x = x_mean + sqrt(2 step) z.  MixSDE only, like the reference."""
+
+    def __init__(self, sde, score_fn, snr, n_steps):
+        super().__init__(sde, score_fn, snr, n_steps)
+        if type(sde) is not MixSDE:
+            raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+
+    def update_fn(self, x, t, *args, **kwargs):
+        x_mean = x
+        for _ in range(self.n_steps):
+            score = self.score_fn(x, t, *args)
+            z = torch.randn_like(x)
+            x, x_mean = ops.sde_corrector_update(self.sde.engine_config(), self.snr, x.contiguous(), t.contiguous(),
+                                                 score, z, None, variant=1)
+        return x, x_mean
+
+
+@CorrectorRegistry.register("langevin")
+class LangevinCorrector(Corrector):
+    """step = 2 (snr <||z_b||> / <||g_b||>)^2 from batch-mean norms (sdes/correctors.py:35-55)."""
+
+    def update_fn(self, x, t, *args, **kwargs):
+        x_mean = x
+        for _ in range(self.n_steps):
+            score = self.score_fn(x, t, *args)
+            z = torch.randn_like(x)
+            x, x_mean = ops.sde_langevin_update(self.snr, x.contiguous(), score, z)
+        return x, x_mean
+
+
 @CorrectorRegistry.register("none")
 class NoneCorrector(Corrector):
     def __init__(self, *args, **kwargs):

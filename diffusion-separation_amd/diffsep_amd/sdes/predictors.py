@@ -12,9 +12,10 @@ PredictorRegistry = Registry("Predictor")
 
 class Predictor(abc.ABC):
     def __init__(self, sde, score_fn, probability_flow=False):
+        # The reference stores probability_flow but builds its reverse SDE without it
+        # (sdes/predictors.py:15-18: `self.rsde = sde.reverse(score_fn)`), so the flag never changes a PC-sampler
+        # update there; it is accepted and ignored here for the same behaviour.
         self.sde, self.score_fn, self.probability_flow = sde, score_fn, probability_flow
-        if probability_flow:
-            raise NotImplementedError("probability_flow sampling is outside the accelerated path")
 
     @abc.abstractmethod
     def update_fn(self, x, t, *args, **kwargs):
@@ -32,6 +33,12 @@ class ReverseDiffusionPredictor(Predictor):
         smix = self.sde.sigma_mix(args[0]) if args else None
         return ops.sde_predictor_update(self.sde.engine_config(), self.sde.N, x.contiguous(), t.contiguous(), score, z,
                                         smix)
+
+
+@PredictorRegistry.register("euler_maruyama")
+class EulerMaruyamaPredictor(ReverseDiffusionPredictor):
+    """x_mean = x + f dt with the reverse drift f = drift - g^2 score, dt = -1/N, noise g sqrt(1/N) z
+    (sdes/predictors.py:39-52): algebraically the reverse-diffusion step, so it shares its kernel."""
 
 
 @PredictorRegistry.register("none")

@@ -41,8 +41,10 @@ extern "C" {
 #define DIFFSEP_PRED_EULER_MARUYAMA 1    /* sdes/predictors.py:39-52 */
 #define DIFFSEP_PRED_NONE 2              /* sdes/predictors.py:69-77 */
 
-#define DIFFSEP_CORR_ALD2 0 /* sdes/correctors.py:94-128  */
-#define DIFFSEP_CORR_NONE 1 /* sdes/correctors.py:131-141 */
+#define DIFFSEP_CORR_ALD2 0     /* sdes/correctors.py:94-128  */
+#define DIFFSEP_CORR_NONE 1     /* sdes/correctors.py:131-141 */
+#define DIFFSEP_CORR_ALD 2      /* sdes/correctors.py:58-91 (MixSDE only) */
+#define DIFFSEP_CORR_LANGEVIN 3 /* sdes/correctors.py:35-55 (one step size for the whole batch) */
 
 typedef struct diffsep_engine diffsep_engine; /* opaque */
 
@@ -222,12 +224,21 @@ int32_t diffsep_sde_prior(const diffsep_sde_config* sde, const float* y, const f
  * (sdes/correctors.py:115-126). t [B] device. */
 int32_t diffsep_sde_corrector_update(const diffsep_sde_config* sde, float snr, const float* x, const float* t,
                                      const float* score, const float* z, float* x_out, float* x_mean_out,
-                                     int32_t B, int32_t S, int64_t T, const float* sigma_mix, void* stream);
+                                     int32_t B, int32_t S, int64_t T, const float* sigma_mix, int32_t variant,
+                                     void* stream); /* variant: 0 = ald2, 1 = ald (sdes/correctors.py:58-91) */
 /* ReverseDiffusionPredictor.update_fn given the score (sdes/predictors.py:60-66 ->
- * sdes/sdes.py:163-171,93-107,275-284); dt = 1/N. */
+ * sdes/sdes.py:163-171,93-107,275-284); dt = 1/N.  EulerMaruyamaPredictor (predictors.py:39-52) is the same
+ * update.  probability_flow != 0: RSDE.discretize with half the score term and no noise (sdes.py:165-171). */
 int32_t diffsep_sde_predictor_update(const diffsep_sde_config* sde, int32_t N, const float* x, const float* t,
                                      const float* score, const float* z, float* x_out, float* x_mean_out,
-                                     int32_t B, int32_t S, int64_t T, const float* sigma_mix, void* stream);
+                                     int32_t B, int32_t S, int64_t T, const float* sigma_mix,
+                                     int32_t probability_flow, void* stream);
+/* LangevinCorrector.update_fn body for one step (sdes/correctors.py:43-53): step = 2 (snr <||z_b||> / <||g_b||>)^2
+ * from batch-mean norms, x_mean = x + step g, x = x_mean + sqrt(2 step) z.  x etc. are [B, n_per_batch];
+ * ws >= 16*B + 16 bytes. */
+int32_t diffsep_sde_langevin_update(float snr, const float* x, const float* score, const float* z, float* x_out,
+                                    float* x_mean_out, int32_t B, int64_t n_per_batch, void* workspace,
+                                    int64_t workspace_bytes, void* stream);
 
 /* normalize_batch (pl_model.py:81-88): per-utterance mean / unbiased std (clamped 1e-5) over (1,T).
  * mix [B,1,T] -> mix_norm; mean,std [B] (nullable). */

@@ -338,6 +338,35 @@ def corrector_ald2(cfg, x, t, score, z, snr, smix=None):
     return x_mean + _apply_std(2 * snr * L, z, smix), x_mean
 
 
+def corrector_ald(cfg, x, t, score, z, snr):
+    """AnnealedLangevinDynamics.update_fn body  sdes/correctors.py:73-89: scalar std from the first row of L L."""
+    L = mix_std(cfg, t, x.shape[1])
+    std = (L @ L)[:, 0, :].sum(dim=-1, keepdim=True).sqrt()[..., None]
+    step = (snr * std) ** 2 * 2
+    x_mean = x + step * score
+    return x_mean + z * torch.sqrt(step * 2), x_mean
+
+
+def corrector_langevin(x, score, z, snr):
+    """LangevinCorrector.update_fn body  sdes/correctors.py:43-53: ONE step size from batch-mean norms."""
+    gn = torch.norm(score.reshape(score.shape[0], -1), dim=-1).mean()
+    zn = torch.norm(z.reshape(z.shape[0], -1), dim=-1).mean()
+    step = (snr * zn / gn) ** 2 * 2
+    x_mean = x + step * score
+    return x_mean + z * torch.sqrt(step * 2), x_mean
+
+
+def scheduled_timesteps(N, eps, schedule, T=1.0):
+    """get_pc_scheduled_sampler's N+1 time points  sdes/__init__.py:91-111 (the step stays 1/N: quirk Q1)."""
+    if schedule == "linear":
+        return torch.linspace(T, eps, N + 1)
+    if schedule == "log":
+        return torch.logspace(math.log(T) / math.log(10), math.log(eps) / math.log(10), N + 1, base=10)
+    if schedule == "revlog":
+        return torch.logspace(math.log(eps) / math.log(10), math.log(T) / math.log(10), N + 1, base=10).flip(dims=(0,))
+    raise NotImplementedError(schedule)
+
+
 def predictor_reverse_diffusion(cfg, x, t, score, z, N, smix=None):
     """ReverseDiffusionPredictor.update_fn  sdes/predictors.py:60-66 with RSDE.discretize
     sdes/sdes.py:163-171, SDE.discretize :93-107 (dt = 1/N always: quirk Q1), MixSDE.sde :275-284
@@ -358,7 +387,7 @@ def predictor_reverse_diffusion(cfg, x, t, score, z, N, smix=None):
 
 
 def pc_sampler(p, cfg, y, noise, N=None, corrector_steps=None, snr=None, eps=None, denoise=True, score_fn=None,
-               timesteps=None, priormix_avg_len=None):
+               timesteps=None, priormix_avg_len=None, corrector="ald2"):
     """sdes.get_pc_sampler(...)()  sdes/__init__.py:166-188 with predictor 'reverse_diffusion' and
     corrector 'ald2'.  `noise` is the list of N(0,1) draws in the reference's RNG order (Q7):
     prior, then per step: corrector draw(s), predictor draw."""
@@ -378,7 +407,13 @@ def pc_sampler(p, cfg, y, noise, N=None, corrector_steps=None, snr=None, eps=Non
         for i in range(N):
             vec_t = torch.ones(y.shape[0], dtype=y.dtype) * ts[i].to(y.dtype)
             for _ in range(cs):
-                xt, xm = corrector_ald2(cfg, xt, vec_t, score_fn(xt, vec_t, y), next(it), snr, smix)
+                sc = score_fn(xt, vec_t, y)
+                if corrector == "ald2":
+                    xt, xm = corrector_ald2(cfg, xt, vec_t, sc, next(it), snr, smix)
+                elif corrector == "ald":
+                    xt, xm = corrector_ald(cfg, xt, vec_t, sc, next(it), snr)
+                else:
+                    xt, xm = corrector_langevin(xt, sc, next(it), snr)
             xt, xm = predictor_reverse_diffusion(cfg, xt, vec_t, score_fn(xt, vec_t, y), next(it), N, smix)
     return (xm if denoise else xt), N * (cs + 1)
 

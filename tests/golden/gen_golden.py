@@ -373,6 +373,33 @@ def main():
         out["g11_sep"] = sampler()[0].numpy()
         assert inj.i == len(draws)
 
+    # ---- G12 remaining sampler surface: euler_maruyama predictor, ald / langevin correctors,
+    # scheduled sampler, probability-flow discretisation of the reverse SDE
+    em = ref_sdes.PredictorRegistry.get_by_name("euler_maruyama")(sdec, model)
+    with InjectedNoise([draws[2]]):
+        xe, xem = em.update_fn(x0, tv, mix_norm)
+    out["g12_em_x"], out["g12_em_mean"] = xe.numpy(), xem.numpy()
+    ald = ref_sdes.CorrectorRegistry.get_by_name("ald")(sdec, model, snr=0.5, n_steps=1)
+    with InjectedNoise([draws[1]]):
+        xa, xam = ald.update_fn(x0, tv, mix_norm)
+    out["g12_ald_x"], out["g12_ald_mean"] = xa.numpy(), xam.numpy()
+    lan = ref_sdes.CorrectorRegistry.get_by_name("langevin")(sdec, model, snr=0.5, n_steps=1)
+    with InjectedNoise([draws[1]]):
+        xl, xlm = lan.update_fn(x0, tv, mix_norm)
+    out["g12_langevin_x"], out["g12_langevin_mean"] = xl.numpy(), xlm.numpy()
+    rs_pf = sdec.reverse(model, probability_flow=True)
+    fpf, gpf = rs_pf.discretize(x0, tv, mix_norm)
+    out["g12_pflow_mean"] = (x0 - fpf).numpy()
+    meta["g12_pflow_G_is_zero"] = bool((gpf == 0).all())
+    with InjectedNoise(draws) as inj:
+        sampler = model.get_pc_sampler("euler_maruyama", "ald", mix_norm, N=N, denoise=True, intermediate=False,
+                                       corrector_steps=cs, snr=0.5, schedule="log")
+        out["g12_sep_em_ald_log"] = sampler()[0].numpy()
+    with InjectedNoise(draws) as inj:
+        sampler = model.get_pc_sampler("reverse_diffusion", "langevin", mix_norm, N=N, denoise=True, intermediate=False,
+                                       corrector_steps=cs, snr=0.5, schedule=None)
+        out["g12_sep_rd_langevin"] = sampler()[0].numpy()
+
     np.savez_compressed(os.path.join(HERE, "golden_ref.npz"), **{k: np.asarray(v) for k, v in out.items()})
     with open(os.path.join(HERE, "golden_meta.json"), "w") as f:
         json.dump(meta, f)

@@ -210,3 +210,18 @@ def test_priormix_sampler_matches_reference_golden(golden):
                              noise=draws.to(DEV))
     assert nfe == 6
     assert rel_rms(sep, g["g11_sep"]) < 1e-4 and diff_rms(sep, g["g11_sep"]) < 1e-3
+
+
+def test_other_samplers_match_reference_golden(golden):
+    # euler_maruyama + ald on the 'log' schedule, reverse_diffusion + langevin: whole samplers in one engine call
+    g, _ = golden
+    eng, _ = engine(16, 2, _lib.F32)
+    mix, draws, N, cs = _g9_inputs()
+    mix_norm, _, _ = ops.normalize_batch(mix.to(DEV))
+    ts = O.scheduled_timesteps(N, 0.03, "log").numpy()
+    a, nfe = eng.pc_sample(mix_norm, SDE, N=N, corrector_steps=cs, snr=0.5, eps=0.03, predictor="euler_maruyama",
+                           corrector="ald", noise=draws.to(DEV), timesteps=ts)
+    assert nfe == 6 and rel_rms(a, g["g12_sep_em_ald_log"]) < 1e-4
+    b, _ = eng.pc_sample(mix_norm, SDE, N=N, corrector_steps=cs, snr=0.5, eps=0.03, corrector="langevin",
+                         noise=draws.to(DEV))
+    assert rel_rms(b, g["g12_sep_rd_langevin"]) < 1e-4

@@ -16,8 +16,9 @@ from diffsep_amd.sdes import CorrectorRegistry, PredictorRegistry, SDERegistry, 
 
 
 def test_registries_expose_reference_names():
-    assert {"reverse_diffusion", "none"} <= set(PredictorRegistry.get_all_names())
-    assert {"ald2", "none"} <= set(CorrectorRegistry.get_all_names())
+    assert {"reverse_diffusion", "euler_maruyama", "none"} == set(PredictorRegistry.get_all_names())
+    assert {"ald2", "ald", "langevin", "none"} == set(CorrectorRegistry.get_all_names())  # = the reference's set
+    assert set(SDERegistry.get_all_names()) >= {"mix", "priormix"}
     assert SDERegistry.get_by_name("mix") is MixSDE
     with pytest.raises(ValueError):
         PredictorRegistry.get_by_name("nope")

@@ -283,3 +283,24 @@ def test_priormix_sde_kernels_match_reference_golden(golden):
         assert rel_rms(ops.sde_sigma_mix(mix_norm, k_len).cpu(), ref) < 1e-5, k_len
     with pytest.raises(Exception):
         ops.sde_prior(PSDE, mix_norm, draws[0].to(DEV), None)  # PriorMixSDE without sigma_mix is an error
+
+
+def test_remaining_correctors_and_predictors_match_reference_golden(golden):
+    g, _ = golden
+    B, S, T, N = 2, 2, 4000, 3
+    mix_norm = torch.from_numpy(g["g10_mix_norm"])
+    cfg = O.default_config(16, 2)
+    p = O.to_torch(synth.synth_state_dict(O.param_table(cfg), 7))
+    x0 = rnd("g9.x0", (B, S, T), 0.5)
+    tv = torch.tensor([0.8, 0.2])
+    sc = O.score_forward(p, cfg, x0, tv, mix_norm)
+    draws = [rnd(f"g9.z{i}", (B, S, T)) for i in range(3)]
+    xa, xam = ops.sde_corrector_update(SDE, 0.5, x0.to(DEV), tv.to(DEV), sc.to(DEV), draws[1].to(DEV), variant=1)
+    assert rel_rms(xa.cpu(), g["g12_ald_x"]) < 2e-5 and rel_rms(xam.cpu(), g["g12_ald_mean"]) < 2e-5
+    xl, xlm = ops.sde_langevin_update(0.5, x0.to(DEV), sc.to(DEV), draws[1].to(DEV))
+    assert rel_rms(xl.cpu(), g["g12_langevin_x"]) < 2e-5 and rel_rms(xlm.cpu(), g["g12_langevin_mean"]) < 2e-5
+    xe, xem = ops.sde_predictor_update(SDE, N, x0.to(DEV), tv.to(DEV), sc.to(DEV), draws[2].to(DEV))
+    assert rel_rms(xe.cpu(), g["g12_em_x"]) < 2e-5 and rel_rms(xem.cpu(), g["g12_em_mean"]) < 2e-5
+    xp, xpm = ops.sde_predictor_update(SDE, N, x0.to(DEV), tv.to(DEV), sc.to(DEV), draws[2].to(DEV),
+                                       probability_flow=True)
+    assert rel_rms(xpm.cpu(), g["g12_pflow_mean"]) < 2e-5 and torch.equal(xp, xpm)  # no noise on the ODE

@@ -176,3 +176,28 @@ def test_priormix_sde_enhancement_path(golden):
     sep, nfe = O.pc_sampler(p, cfg, mix_norm, draws, N=N, corrector_steps=cs, snr=0.5, eps=0.03, denoise=True,
                             priormix_avg_len=510)
     assert nfe == 6 and rel_rms(sep.numpy(), g["g11_sep"]) < 1e-4
+
+
+def test_remaining_sampler_surface(golden):
+    """euler_maruyama == reverse_diffusion, 'ald' and 'langevin' correctors, scheduled sampler."""
+    g, meta = golden
+    cfg = O.default_config(16, 2)
+    p = weights(cfg, 7)
+    B, S, T, N, cs = 2, 2, 4000, 3, 1
+    mix_norm = torch.from_numpy(g["g10_mix_norm"])
+    draws = [torch.from_numpy(synth.synth_noise(f"g9.z{i}", (B, S, T))) for i in range(7)]
+    x0 = torch.from_numpy(synth.synth_noise("g9.x0", (B, S, T))) * 0.5
+    tv = torch.tensor([0.8, 0.2])
+    sc = O.score_forward(p, cfg, x0, tv, mix_norm)
+    xe, xem = O.predictor_reverse_diffusion(cfg, x0, tv, sc, draws[2], N)  # the same update as euler_maruyama
+    assert rel_rms(xe.numpy(), g["g12_em_x"]) < 2e-5 and rel_rms(xem.numpy(), g["g12_em_mean"]) < 2e-5
+    xa, xam = O.corrector_ald(cfg, x0, tv, sc, draws[1], 0.5)
+    assert rel_rms(xa.numpy(), g["g12_ald_x"]) < 2e-5 and rel_rms(xam.numpy(), g["g12_ald_mean"]) < 2e-5
+    xl, xlm = O.corrector_langevin(x0, sc, draws[1], 0.5)
+    assert rel_rms(xl.numpy(), g["g12_langevin_x"]) < 2e-5 and rel_rms(xlm.numpy(), g["g12_langevin_mean"]) < 2e-5
+    assert meta["g12_pflow_G_is_zero"]
+    a, _ = O.pc_sampler(p, cfg, mix_norm, draws, N=N, corrector_steps=cs, snr=0.5, eps=0.03, corrector="ald",
+                        timesteps=O.scheduled_timesteps(N, 0.03, "log"))
+    assert rel_rms(a.numpy(), g["g12_sep_em_ald_log"]) < 1e-4
+    b, _ = O.pc_sampler(p, cfg, mix_norm, draws, N=N, corrector_steps=cs, snr=0.5, eps=0.03, corrector="langevin")
+    assert rel_rms(b.numpy(), g["g12_sep_rd_langevin"]) < 1e-4
