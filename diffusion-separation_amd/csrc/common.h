@@ -192,6 +192,7 @@ int ds_launch_langevin(float snr, const float* x, const float* score, const floa
 int ds_launch_normalize(const float* mix, float* out, float* mean, float* std, int B, long T, hipStream_t st);
 int ds_launch_scale_output(const float* mix, float* sep, int B, int S, long T, hipStream_t st);
 int ds_launch_randn(float* out, long n, uint64_t seed, uint64_t stream_id, hipStream_t st);
+int ds_launch_gram(const float* ref, const float* est, double* out, int B, int S, long T, hipStream_t st);
 int ds_launch_convert(const void* src, void* dst, long n, int sd, int dd, hipStream_t st);
 int ds_launch_fill(float* p, float v, long n, hipStream_t st);
 

@@ -1192,6 +1192,11 @@ extern "C" int32_t diffsep_scale_output(const float* mix, float* sep, int32_t B,
   DS_CHECK(mix && sep, "scale_output: null pointer");
   return ds_launch_scale_output(mix, sep, B, S, T, (hipStream_t)stream);
 }
+extern "C" int32_t diffsep_gram(const float* ref, const float* est, double* out, int32_t B, int32_t S, int64_t T,
+                                void* stream) {
+  DS_CHECK(ref && est && out, "gram: null pointer");
+  return ds_launch_gram(ref, est, out, B, S, T, (hipStream_t)stream);
+}
 extern "C" int32_t diffsep_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream) {
   DS_CHECK(out, "randn: null pointer");
   return ds_launch_randn(out, n, seed, stream_id, (hipStream_t)stream);

@@ -297,6 +297,54 @@ int ds_launch_scale_output(const float* mix, float* sep, int B, int S, long T, h
   return 0;
 }
 
+// ------------------------------------------------------------------ Gram matrices for the BSS metrics
+// out[b] = { ref ref^T, ref est^T, est est^T } (each [S][S], fp64): everything SI-SDR / SI-SIR / SI-SAR and the
+// best permutation need (evaluate.py:103-132 -> fast_bss_eval.si_bss_eval_sources); one pass over the waveforms.
+__global__ __launch_bounds__(1024) void gram_kernel(const float* __restrict__ ref, const float* __restrict__ est,
+                                                    double* __restrict__ out, int S, long T) {
+  __shared__ double sh[16];
+  const int b = blockIdx.x;
+  double acc[3 * DS_MAX_SRC * DS_MAX_SRC];
+#pragma unroll
+  for (int k = 0; k < 3 * DS_MAX_SRC * DS_MAX_SRC; ++k) acc[k] = 0.0;
+  for (long i = threadIdx.x; i < T; i += blockDim.x) {
+    double r[DS_MAX_SRC], e[DS_MAX_SRC];
+#pragma unroll
+    for (int a = 0; a < DS_MAX_SRC; ++a) {
+      r[a] = a < S ? (double)ref[((long)b * S + a) * T + i] : 0.0;
+      e[a] = a < S ? (double)est[((long)b * S + a) * T + i] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < DS_MAX_SRC; ++a)
+#pragma unroll
+      for (int c = 0; c < DS_MAX_SRC; ++c) {
+        acc[(0 * DS_MAX_SRC + a) * DS_MAX_SRC + c] += r[a] * r[c];
+        acc[(1 * DS_MAX_SRC + a) * DS_MAX_SRC + c] += r[a] * e[c];
+        acc[(2 * DS_MAX_SRC + a) * DS_MAX_SRC + c] += e[a] * e[c];
+      }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int m = 0; m < 3; ++m)
+    for (int a = 0; a < S; ++a)
+      for (int c = 0; c < S; ++c) {
+        double v = wave_sum_d(acc[(m * DS_MAX_SRC + a) * DS_MAX_SRC + c]);
+        __syncthreads();
+        if (lane == 0) sh[w] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          double t = 0.0;
+          for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+          out[(((long)b * 3 + m) * S + a) * S + c] = t;
+        }
+      }
+}
+int ds_launch_gram(const float* ref, const float* est, double* out, int B, int S, long T, hipStream_t st) {
+  DS_CHECK(S >= 1 && S <= DS_MAX_SRC, "gram: too many sources");
+  hipLaunchKernelGGL(gram_kernel, dim3(B), dim3(1024), 0, st, ref, est, out, S, T);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+
 // ------------------------------------------------------------------ Philox4x32-10 + Box–Muller
 __device__ inline void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
   const uint64_t p0 = (uint64_t)0xD2511F53u * c0;

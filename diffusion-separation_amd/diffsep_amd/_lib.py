@@ -72,6 +72,7 @@ _SIGS = {
     "diffsep_sde_langevin_update": (_I, [_F, _P, _P, _P, _P, _P, _I, _L, _P, _L, _P]),
     "diffsep_normalize_batch": (_I, [_P, _P, _P, _P, _I, _L, _P]),
     "diffsep_scale_output": (_I, [_P, _P, _I, _I, _L, _P]),
+    "diffsep_gram": (_I, [_P, _P, _P, _I, _I, _L, _P]),
     "diffsep_randn": (_I, [_P, _L, _U64, _U64, _P]),
     "diffsep_convert": (_I, [_P, _P, _L, _I, _I, _P]),
 }

@@ -21,24 +21,18 @@ from pathlib import Path
 import torch
 import torch.distributed as dist
 
-from . import synth, wavio
+from . import metrics, synth, wavio
 from .dist_utils import gather_objects, shard_range
 from .pl_model import DiffSepModel, cfg_get, default_config, enhancement_config
 
 
-def si_sdr_pit(est, ref):
-    """est, ref [S,T] -> (best mean SI-SDR dB, per-source list) over source permutations (zero_mean=False)."""
-    S = ref.shape[0]
-    best, best_vals = None, None
-    for perm in itertools.permutations(range(S)):
-        e = est[list(perm)]
-        a = (e * ref).sum(-1, keepdim=True) / (ref * ref).sum(-1, keepdim=True).clamp(min=1e-20)
-        num = ((a * ref) ** 2).sum(-1)
-        den = ((e - a * ref) ** 2).sum(-1).clamp(min=1e-20)
-        v = 10 * torch.log10(num / den)
-        if best is None or float(v.mean()) > best:
-            best, best_vals = float(v.mean()), [float(x) for x in v]
-    return best, best_vals
+def compute_metrics(est, ref):
+    """est, ref [S,T] -> dict with the reference's record fields (evaluate.py:103-132): si_sdr / si_sir / si_sar
+    (mean over sources at the best permutation), per-source SI-SDR and the permutation.  The waveform reductions run
+    in the HIP Gram kernel."""
+    sdr, sir, sar, perm = metrics.si_bss_eval_sources(ref[None], est[None])
+    return {"si_sdr": float(sdr.mean()), "si_sir": float(sir.mean()), "si_sar": float(sar.mean()),
+            "si_sdr_per_source": [float(v) for v in sdr[0]], "perm": [int(v) for v in perm[0]]}
 
 
 def load_dataset(args, fs):
@@ -132,10 +126,10 @@ def main(argv=None):
         torch.cuda.synchronize()
         runtime = time.perf_counter() - t0
         if args.enhance:  # n_src = 1: only the clean-speech estimate is scored (evaluate.py:270)
-            sdr, per = si_sdr_pit(est[0, :1], tgt_n[0, :1])
+            met = compute_metrics(est[0, :1], tgt_n[0, :1])
         else:
-            sdr, per = si_sdr_pit(est[0], tgt_n[0])
-        records.append({"batch_idx": i, "si_sdr": sdr, "si_sdr_per_source": per, "nfe": int(nfe), "runtime": runtime,
+            met = compute_metrics(est[0], tgt_n[0])
+        records.append({"batch_idx": i, **met, "pesq": None, "stoi": None, "nfe": int(nfe), "runtime": runtime,
                         "len_s": mix.shape[-1] / fs})
         if args.save_wav:
             d = args.output_dir / "wav"

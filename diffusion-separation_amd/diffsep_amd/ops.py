@@ -198,3 +198,11 @@ def randn(n, seed, stream_id, device="cuda"):
     out = torch.empty(n, dtype=torch.float32, device=device)
     check(lib().diffsep_randn(_ptr(out), n, seed, stream_id, _stream_ptr()))
     return out
+
+
+def gram(ref, est):
+    """[B,S,T] x2 -> float64 [B,3,S,S] = (ref ref^T, ref est^T, est est^T)."""
+    B, S, T = ref.shape
+    out = torch.empty((B, 3, S, S), dtype=torch.float64, device=ref.device)
+    check(lib().diffsep_gram(_ptr(ref.contiguous()), _ptr(est.contiguous()), _ptr(out), B, S, T, _stream_ptr()))
+    return out

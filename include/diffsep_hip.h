@@ -247,6 +247,11 @@ int32_t diffsep_normalize_batch(const float* mix, float* mix_norm, float* mean, 
 /* scale_output (separate.py:73-78): alpha = <mix,sep>/sum(sep^2+1e-10); sep*alpha, in place. */
 int32_t diffsep_scale_output(const float* mix, float* sep, int32_t B, int32_t S, int64_t T, void* stream);
 
+/* Gram matrices of references and estimates for the separation metrics (evaluate.py:103-132:
+ * fast_bss_eval.si_bss_eval_sources(ref, est, zero_mean=False, compute_permutation=True)): out [B][3][S][S] float64 =
+ * { ref ref^T, ref est^T, est est^T }.  SI-SDR / SI-SIR / SI-SAR and the best permutation follow from these alone. */
+int32_t diffsep_gram(const float* ref, const float* est, double* out, int32_t B, int32_t S, int64_t T, void* stream);
+
 /* on-device standard normal draws (Philox4x32-10 + Box-Muller); used when noise == NULL. */
 int32_t diffsep_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
 

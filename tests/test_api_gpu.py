@@ -135,3 +135,4 @@ def test_evaluate_cli_writes_reference_style_results(tmp_path):
              "--enhance", "-o", str(tmp_path / "enh")])
     rec = json.load(open(tmp_path / "enh" / "results.json"))
     assert len(rec) == 2 and all(len(r["si_sdr_per_source"]) == 1 for r in rec)
+    assert all({"batch_idx", "si_sdr", "si_sir", "si_sar", "pesq", "stoi", "nfe", "runtime", "len_s"} <= set(r) for r in rec)
