@@ -7,12 +7,12 @@
 Utterances are sharded over ranks in contiguous ranges (evaluate_mp.py:495-503); each rank separates its
 share, records {batch_idx, si_sdr, nfe, runtime, len_s} per utterance (evaluate.py:394-405; runtime is
 measured WITH a device sync, unlike evaluate.py:374-376) and rank 0 gathers everything (RCCL) and writes
-results.json + results_summary.json.  Dataset: --dataset-dir ROOT with WSJ0-mix style sub-folders
-mix/, s1/, s2/ (datasets/wsj0_mix.py:64-92) or --synthetic N speech-like mixtures.  SI-SDR (scale-invariant
+<split>.json + <split>_summary.json (evaluate.py:436-443).  Dataset: --dataset-dir ROOT in the WSJ0-mix layout
+(datasets/wsj0_mix.py:64-92; with --enhance the VoiceBank-DEMAND layout, datasets/vctk_demand.py:33-36), a flat
+ROOT/{mix,s1,s2} folder, or --synthetic N speech-like mixtures.  SI-SDR (scale-invariant
 SDR with the best source permutation) is computed in the normalised domain like evaluate.py:360,382.
 """
 import argparse
-import itertools
 import json
 import os
 import time
@@ -21,7 +21,7 @@ from pathlib import Path
 import torch
 import torch.distributed as dist
 
-from . import metrics, synth, wavio
+from . import datasets, metrics, synth, wavio
 from .dist_utils import gather_objects, shard_range
 from .pl_model import DiffSepModel, cfg_get, default_config, enhancement_config
 
@@ -37,31 +37,22 @@ def compute_metrics(est, ref):
 
 def load_dataset(args, fs):
     if args.dataset_dir and args.enhance:
-        # VoiceBank-DEMAND layout (datasets/vctk_demand.py:51-61): noisy/ and clean/ with matching file names;
-        # the target is [clean, noisy - clean]
-        root = Path(args.dataset_dir)
-        names = sorted(p.name for p in (root / "noisy").glob("*.wav"))
-        if args.limit:
-            names = names[: args.limit]
-
-        def get_e(i):
-            noisy, _ = wavio.load(root / "noisy" / names[i])
-            clean, _ = wavio.load(root / "clean" / names[i])
-            n = min(noisy.shape[-1], clean.shape[-1])
-            noisy, clean = noisy[:1, :n], clean[:1, :n]
-            return noisy, torch.cat([clean, noisy - clean], 0)
-        return len(names), get_e
+        ds = datasets.NoisyDataset(args.dataset_dir, fs=fs, split=args.split)
+        n = len(ds) if args.limit is None else min(len(ds), args.limit)
+        return n, lambda i: tuple(t[..., : min(ds[i][0].shape[-1], ds[i][1].shape[-1])] for t in ds[i])
     if args.dataset_dir:
         root = Path(args.dataset_dir)
-        names = sorted(p.name for p in (root / "mix").glob("*.wav"))
-        if args.limit:
-            names = names[: args.limit]
+        if (root / "mix").is_dir():  # flat folder: mix/, s1/, s2/ ...
+            names = sorted(p.name for p in (root / "mix").glob("*.wav"))[: args.limit]
 
-        def get(i):
-            mix, _ = wavio.load(root / "mix" / names[i])
-            tgt = torch.cat([wavio.load(root / f"s{k + 1}" / names[i])[0][:1] for k in range(args.n_speakers)], 0)
-            return mix[:1], tgt
-        return len(names), get
+            def get_flat(i):
+                mix, _ = wavio.load(root / "mix" / names[i])
+                tgt = torch.cat([wavio.load(root / f"s{k + 1}" / names[i])[0][:1] for k in range(args.n_speakers)], 0)
+                return mix[:1], tgt
+            return len(names), get_flat
+        ds = datasets.WSJ0_mix(root, n_spkr=args.n_speakers, fs=fs, cut=args.cut, split=args.split,
+                               max_n_samples=args.limit)
+        return len(ds), lambda i: ds[i]
     n = args.synthetic
 
     def get(i):
@@ -79,6 +70,8 @@ def main(argv=None):
     ap.add_argument("--samples", type=int, default=32000)
     ap.add_argument("--n-speakers", type=int, default=2)
     ap.add_argument("-l", "--limit", type=int, default=None)
+    ap.add_argument("-s", "--split", default="test", choices=["train", "val", "test", "libri2mix_test"])
+    ap.add_argument("--cut", default="max", choices=["min", "max"])
     ap.add_argument("-N", type=int, default=None)
     ap.add_argument("--snr", type=float, default=None)
     ap.add_argument("--corrector-steps", type=int, default=None)
@@ -140,14 +133,13 @@ def main(argv=None):
     if rank == 0:
         flat = sorted([r for part in allrec for r in part], key=lambda r: r["batch_idx"])
         args.output_dir.mkdir(parents=True, exist_ok=True)
-        with open(args.output_dir / "results.json", "w") as f:
-            json.dump(flat, f, indent=1)
+        with open(args.output_dir / f"{args.split}.json", "w") as f:
+            json.dump(flat, f, indent=2)
+        summary = datasets.summarize([{k: v for k, v in r.items() if k not in ("batch_idx", "perm")} for r in flat])
         tot_rt = sum(r["runtime"] for r in flat)
-        summary = {"n": len(flat), "si_sdr": sum(r["si_sdr"] for r in flat) / max(len(flat), 1),
-                   "runtime": tot_rt / max(len(flat), 1), "nfe": flat[0]["nfe"] if flat else 0,
-                   "rtf": tot_rt / max(sum(r["len_s"] for r in flat), 1e-9), "world_size": world}
-        with open(args.output_dir / "results_summary.json", "w") as f:
-            json.dump(summary, f, indent=1)
+        summary.update({"rtf": tot_rt / max(sum(r["len_s"] for r in flat), 1e-9), "world_size": world})
+        with open(args.output_dir / f"{args.split}_summary.json", "w") as f:
+            json.dump(summary, f, indent=2)
         print(json.dumps(summary))
     if world > 1:
         dist.barrier()

@@ -125,14 +125,34 @@ def test_evaluate_cli_writes_reference_style_results(tmp_path):
     from diffsep_amd import evaluate as ev
     ev.main(["--synthetic", "3", "--samples", "4000", "--synthetic-weights", "16", "-N", "2", "--dtype", "f32", "-o",
              str(tmp_path / "sep")])
-    rec = json.load(open(tmp_path / "sep" / "results.json"))
+    rec = json.load(open(tmp_path / "sep" / "test.json"))
     assert [r["batch_idx"] for r in rec] == [0, 1, 2]
     assert all(r["nfe"] == 4 and r["runtime"] > 0 and abs(r["len_s"] - 0.5) < 1e-9 and np.isfinite(r["si_sdr"]) for r in rec)
-    summ = json.load(open(tmp_path / "sep" / "results_summary.json"))
-    assert summ["n"] == 3 and summ["world_size"] == 1
+    summ = json.load(open(tmp_path / "sep" / "test_summary.json"))
+    assert summ["number"] == 3 and summ["world_size"] == 1 and summ["nfe"] == 4
+    assert abs(summ["si_sdr"] - np.mean([r["si_sdr"] for r in rec])) < 1e-9
     # --enhance: PriorMixSDE model (nr.yaml), metrics on the first source only
     ev.main(["--synthetic", "2", "--samples", "4000", "--synthetic-weights", "16", "-N", "2", "--dtype", "f32",
              "--enhance", "-o", str(tmp_path / "enh")])
-    rec = json.load(open(tmp_path / "enh" / "results.json"))
+    rec = json.load(open(tmp_path / "enh" / "test.json"))
     assert len(rec) == 2 and all(len(r["si_sdr_per_source"]) == 1 for r in rec)
     assert all({"batch_idx", "si_sdr", "si_sir", "si_sar", "pesq", "stoi", "nfe", "runtime", "len_s"} <= set(r) for r in rec)
+
+
+def test_evaluate_cli_on_wsj0_mix_tree(tmp_path):
+    # WSJ0-mix on-disk layout -> evaluate: file order, (mix, tgt) shapes, variable lengths
+    import json
+    from diffsep_amd import evaluate as ev, wavio
+    base = tmp_path / "wsj" / "2speakers" / "wav8k" / "min" / "tt"
+    for d in ("mix", "s1", "s2"):
+        (base / d).mkdir(parents=True)
+    for i, T in enumerate((4000, 3000)):
+        mix, tgt = synth.synth_mixture(i, T=T, fs=8000, n_src=2)
+        wavio.save(base / "mix" / f"u{i}.wav", torch.from_numpy(mix) * 0.5, 8000)
+        for k in range(2):
+            wavio.save(base / f"s{k + 1}" / f"u{i}.wav", torch.from_numpy(tgt[k:k + 1]) * 0.5, 8000)
+    ev.main(["--dataset-dir", str(tmp_path / "wsj"), "--cut", "min", "--split", "test", "--synthetic-weights", "16",
+             "-N", "2", "--dtype", "f32", "-o", str(tmp_path / "out")])
+    rec = json.load(open(tmp_path / "out" / "test.json"))
+    assert [abs(r["len_s"] - t) < 1e-9 for r, t in zip(rec, (0.5, 0.375))] == [True, True]
+    assert json.load(open(tmp_path / "out" / "test_summary.json"))["number"] == 2

@@ -118,3 +118,52 @@ def test_gather_across_two_ranks_gloo():
         assert p.exitcode == 0
     assert got == [((2, 100 + 10 * i), float(i)) for i in range(5)]
     assert [r["batch_idx"] for part in objs for r in part] == list(range(5))
+
+
+def test_wsj0_mix_and_noisy_dataset_layouts(tmp_path):
+    # datasets/wsj0_mix.py:64-92 and datasets/vctk_demand.py:33-61 on-disk contracts
+    from diffsep_amd import datasets, wavio
+    base = tmp_path / "3speakers" / "wav16k" / "max" / "cv"
+    for d in ("mix", "s1", "s2", "s3"):
+        (base / d).mkdir(parents=True)
+    g = torch.Generator().manual_seed(0)
+    lens = {"b.wav": 900, "a.wav": 1200}
+    for name, T in lens.items():
+        src = (torch.rand(3, T, generator=g) - 0.5) * 0.4
+        for k in range(3):
+            wavio.save(base / f"s{k + 1}" / name, src[k:k + 1], 16000)
+        wavio.save(base / "mix" / name, src.sum(0, keepdim=True), 16000)
+    ds = datasets.WSJ0_mix(tmp_path, n_spkr=3, fs=16000, cut="max", split="val")
+    assert ds.file_list == ["a.wav", "b.wav"] and len(ds) == 2
+    mix, tgt = ds[0]
+    assert mix.shape == (1, 1200) and tgt.shape == (3, 1200)
+    assert (mix - tgt.sum(0, keepdim=True)).abs().max() < 3e-4  # 16-bit quantisation
+    assert len(datasets.WSJ0_mix(tmp_path, n_spkr=3, fs=16000, split="val", max_n_samples=1)) == 1
+    cut = datasets.WSJ0_mix(tmp_path, n_spkr=3, fs=16000, split="val", max_len_s=0.05)[0]
+    assert cut[0].shape == (1, 800) and cut[1].shape == (3, 800)
+    for bad in (dict(fs=44100), dict(n_spkr=4), dict(cut="mid"), dict(split="dev")):
+        with pytest.raises(ValueError):
+            datasets.WSJ0_mix(tmp_path, **{**dict(n_spkr=3, fs=16000, split="val"), **bad})
+    mb, tb = datasets.max_collator([ds[0], ds[1]])
+    assert mb.shape == (2, 1, 1200) and tb.shape == (2, 3, 1200)
+    assert mb[1, 0, :150].abs().max() == 0 and mb[1, 0, 150] == ds[1][0][0, 0]  # centre padding
+    for split in ("train", "test"):
+        for d in ("noisy", "clean"):
+            (tmp_path / "vb" / split / d).mkdir(parents=True)
+        clean = (torch.rand(1, 700, generator=g) - 0.5) * 0.4
+        noisy = clean + (torch.rand(1, 700, generator=g) - 0.5) * 0.1
+        wavio.save(tmp_path / "vb" / split / "clean" / "p1.wav", clean, 16000)
+        wavio.save(tmp_path / "vb" / split / "noisy" / "p1.wav", noisy, 16000)
+    noisy_t, tgt_t = datasets.NoisyDataset(tmp_path / "vb", split="test")[0]
+    assert noisy_t.shape == (1, 700) and tgt_t.shape == (2, 700)
+    assert torch.equal(tgt_t[0:1] + tgt_t[1:2], noisy_t) or (tgt_t.sum(0, keepdim=True) - noisy_t).abs().max() < 1e-6
+    noisy_tr, tgt_tr = datasets.NoisyDataset(tmp_path / "vb", audio_len=0.05, split="train")[0]
+    assert noisy_tr.shape == (1, 800) and tgt_tr.shape == (2, 800)   # shorter than audio_len: tiled x2 then cut
+    with pytest.raises(ValueError):
+        datasets.NoisyDataset(tmp_path / "vb", split="val")
+
+
+def test_summarize_matches_reference_schema():
+    from diffsep_amd.datasets import summarize
+    s = summarize([{"si_sdr": 1.0, "pesq": None, "nfe": 60, "x": [1.0, 3.0]}, {"si_sdr": 3.0, "pesq": None, "nfe": 60, "x": [3.0, 5.0]}])
+    assert s == {"si_sdr": 2.0, "nfe": 60.0, "x": 3.0, "number": 2}
