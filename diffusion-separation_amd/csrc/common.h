@@ -147,6 +147,9 @@ struct ConvArgs {
 int ds_launch_conv(const ConvArgs& a, hipStream_t st);
 int ds_conv_config_id(const ConvArgs& a);
 int ds_conv_tiles(const ConvArgs& a);
+bool ds_conv_ws_eligible(const ConvArgs& a);   // conv3x3_ws.hip: weight-stationary 64 -> 64 bf16 kernel
+int ds_conv_ws_tiles(const ConvArgs& a);
+int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st);
 
 // GroupNorm: stats -> per-(b,c) scale/shift -> apply(+SiLU)(+FIR resample)
 // ws layout: doubles [B][nblk][C][2] then floats scale[B][C], shift[B][C]

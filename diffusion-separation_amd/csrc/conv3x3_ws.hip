@@ -1,0 +1,403 @@
+// conv3x3_ws.hip — weight-stationary 3x3 convolution for the 64 -> 64 channel layers of NCSN++ (bf16, gfx950).
+//
+// These layers (ddpm_conv3x3 in ResnetBlockBigGANpp at the 256^2 and 128^2 levels, reference layers.py:141-156,
+// layerspp.py:291-323) are HBM-bound: 77 GFLOP against 400 MB of activations per launch at B = 16.  The generic
+// implicit-GEMM kernel (conv_mfma.hip) re-stages the whole 73 KB weight tensor for every 256-pixel tile, which is
+// 63 % of its L2 -> CU traffic and of its LDS writes.  Here a block is persistent:
+//
+//   * one block of 8 waves per CU; the [9][64][64] weights are copied into LDS ONCE per block (83 KB, rows padded
+//     to 144 B) and stay there for all of the block's tiles (a contiguous raster range of one image);
+//   * the 10 x 34 pixel halo tile is staged 32 channels at a time through a 2-slot LDS ring (27 KB each); the chunk
+//     after the one being multiplied is in flight in registers, gets its GroupNorm affine + SiLU applied there
+//     (VALU interleaved with the MFMAs of the same wave) and is written to the free slot: ONE barrier per chunk,
+//     and the first chunk of the NEXT tile is already loading while this tile's epilogue runs;
+//   * MFMA operands are swapped (A = weights, B = pixels), so a lane ends up holding 4 consecutive output
+//     channels of ONE pixel per accumulator quad = one 16-byte LDS write.  The epilogue turns the wave's 32 x 64
+//     result into pixel rows through a private 2.3 KB LDS scratch, 8 pixels at a time (no block barrier: LDS
+//     operations of one wave execute in order); a lane then owns 8 consecutive couts of a pixel: bias / residual
+//     / scale / statistics / bf16 packing and full 128-byte-line stores;
+//   * GroupNorm statistics of the output are accumulated in 16 registers per lane over all tiles of the block
+//     and reduced once at the end (partials [B][G][64][2], G = blocks per image).
+//
+// K order (chunk, tap, 16-channel block) is the same as in conv_mfma.hip.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ inline __amdgpu_buffer_rsrc_t rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ inline uint4 ld16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+constexpr int C = 64;                 // input and output channels
+constexpr int TH = 8, TW = 32;        // output tile
+constexpr int HW_ = TW + 2, HH_ = TH + 2, HP = HW_ * HH_;  // halo tile: 340 pixels
+constexpr int KC = 32;                // channels per chunk
+constexpr int AROW = KC * 2 + 16;     // 80 B: halo pixel row in LDS (bank-conflict padding)
+constexpr int WROW = C * 2 + 16;      // 144 B: weight row (tap, cout) in LDS
+constexpr int LDS_W = 9 * C * WROW;   // 82,944
+constexpr int LDS_A = HP * AROW;      // 27,200 per ring slot
+constexpr int LDS_TAB = 3 * C * 4;    // GN scale, GN shift, (bias + temb bias) * out_scale
+constexpr int NA = (HP * (KC / 8) + 511) / 512;  // 16-byte vectors per thread per chunk: 3
+constexpr int EROW = 288;             // epilogue scratch: 8 pixel rows of 64 fp32 (+32 B: conflict-free quad writes)
+constexpr int LDS_E = 8 * EROW;       // per wave
+constexpr int RED_ROW = 20;           // final statistics reduce: 16 floats per thread (+4 pad)
+constexpr int LDS_MAIN = LDS_W + 2 * LDS_A + LDS_TAB;
+constexpr int LDS_TOTAL = LDS_MAIN + 8 * LDS_E;
+static_assert(512 * RED_ROW * 4 <= LDS_TOTAL, "the statistics reduce reuses the block's LDS");
+
+struct WsK {
+  const bf16_t* x; long x_bs; int ldx;
+  const bf16_t* w;
+  const float* gn_scale; const float* gn_shift;
+  const float* bias; const float* bias_b; int bias_b_ld;
+  const bf16_t* res; long res_bs; int ldr;
+  float out_scale;
+  bf16_t* y; long y_bs; int ldy;
+  double* stats;
+  int H, W, G, tiles_x, tiles_per_img;
+};
+
+// GN affine (+ SiLU) on 8 bf16 channels
+template <bool ACT>
+__device__ inline uint4 gn8(const uint4& u, const float* sc, const float* sh) {
+  float f[8];
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = f[j] * sc[j] + sh[j];
+    f[j] = ACT ? silu_t<bf16_t>(v) : v;
+  }
+  uint4 o;
+  o.x = pack_bf16x2(f[0], f[1]);
+  o.y = pack_bf16x2(f[2], f[3]);
+  o.z = pack_bf16x2(f[4], f[5]);
+  o.w = pack_bf16x2(f[6], f[7]);
+  return o;
+}
+
+template <int MODE>  // 1: GN affine (identity tables when the input is raw), 2: GN affine + SiLU
+__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsK p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sW = smem;
+  char* sA = smem + LDS_W;
+  float* sTab = reinterpret_cast<float*>(smem + LDS_W + 2 * LDS_A);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l32 = lane & 31, h = lane >> 5;
+  const int b = blockIdx.x / p.G, part = blockIdx.x % p.G;
+  const int t0 = (int)((long)part * p.tiles_per_img / p.G);
+  const int nt = (int)((long)(part + 1) * p.tiles_per_img / p.G) - t0;
+  const int Q = 2 * nt;  // chunks this block walks through
+
+  // ---- one-time: weights [cout][tap][cin] -> LDS [tap][cout] rows, per-image tables
+  {
+    const __amdgpu_buffer_rsrc_t rw = rsrc(p.w, 9u * C * C * 2u);
+    uint4 wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = ld16(rw, (unsigned)(tid + 512 * k) * 16u, 0);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int v = tid + 512 * k, row = v >> 3, piece = v & 7;
+      const int co = row / 9, tap = row - co * 9;
+      *reinterpret_cast<uint4*>(sW + (tap * C + co) * WROW + piece * 16) = wv[k];
+    }
+    if (tid < C) {
+      sTab[tid] = p.gn_scale ? p.gn_scale[(long)b * C + tid] : 1.f;
+      sTab[C + tid] = p.gn_shift ? p.gn_shift[(long)b * C + tid] : 0.f;
+      sTab[2 * C + tid] =
+          ((p.bias ? p.bias[tid] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + tid] : 0.f)) * p.out_scale;
+    }
+  }
+
+  // ---- staging descriptors: vector v = tid + 512 k -> halo pixel v / 4, 16-byte slot v % 4 (= tid % 4)
+  const int slot = tid & 3;
+  int rel[NA], ldo[NA];
+  unsigned flg[NA];
+  bool in[NA];
+#pragma unroll
+  for (int k = 0; k < NA; ++k) {
+    const int v = tid + 512 * k;
+    in[k] = v < HP * 4;
+    const int pix = v >> 2, hy = pix / HW_, hx = pix - hy * HW_;
+    rel[k] = (((hy - 1) * p.W + (hx - 1)) * p.ldx + slot * 8) * 2;
+    flg[k] = (hy == 0 ? 1u : 0u) | (hy == HH_ - 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == HW_ - 1 ? 8u : 0u);
+    ldo[k] = pix * AROW + slot * 16;
+  }
+  const __amdgpu_buffer_rsrc_t rx = rsrc(p.x + (long)b * p.x_bs, (unsigned)(p.H * p.W) * p.ldx * 2u);
+  const __amdgpu_buffer_rsrc_t ry = rsrc(p.y + (long)b * p.y_bs, (unsigned)(p.H * p.W) * p.ldy * 2u);
+  const __amdgpu_buffer_rsrc_t rr =
+      rsrc(p.res ? p.res + (long)b * p.res_bs : p.y, p.res ? (unsigned)(p.H * p.W) * p.ldr * 2u : 0u);
+
+  uint4 pa[NA];
+  bool pval[NA];
+  auto issue = [&](int q) {  // global loads of chunk q (tile q / 2, channels 32 (q & 1) ...) into registers
+    const int t = t0 + (q >> 1);
+    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const unsigned edge = (y0 == 0 ? 1u : 0u) | (y0 + TH == p.H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) |
+                          (x0 + TW == p.W ? 8u : 0u);
+    const int tbase = (y0 * p.W + x0) * p.ldx * 2;
+#ifdef ABL_NOLOAD
+    return;
+#endif
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      pval[k] = in[k] && !(flg[k] & edge);
+      pa[k] = ld16(rx, pval[k] ? (unsigned)(rel[k] + tbase) : OOB, (unsigned)(q & 1) * (KC * 2));
+    }
+  };
+  auto act = [&](int k, int c) {  // zero padding stays zero: the activation applies to inside pixels only
+#ifdef ABL_NOACT
+    return;
+#endif
+    if constexpr (MODE != 0) {
+      float sc[8], sh[8];
+      const float4* ts = reinterpret_cast<const float4*>(sTab + c * KC + slot * 8);
+      const float4* th = reinterpret_cast<const float4*>(sTab + C + c * KC + slot * 8);
+      const float4 s0 = ts[0], s1 = ts[1], h0 = th[0], h1 = th[1];
+      sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+      sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+      uint4 r = gn8<MODE == 2>(pa[k], sc, sh);
+      asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));  // keep it branch free inside the MFMA loop
+      pa[k].x = pval[k] ? r.x : pa[k].x;
+      pa[k].y = pval[k] ? r.y : pa[k].y;
+      pa[k].z = pval[k] ? r.z : pa[k].z;
+      pa[k].w = pval[k] ? r.w : pa[k].w;
+    }
+  };
+  auto write = [&](int slot_) {
+    char* dst = sA + slot_ * LDS_A;
+#ifdef ABL_NOLDSW
+    return;
+#endif
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+      if (in[k]) *reinterpret_cast<uint4*>(dst + ldo[k]) = pa[k];
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float ssum[8], ssq[8];  // statistics of the 8 couts this lane writes (row-oriented epilogue role)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+
+  // fragment addresses: the wave owns output row `wave` of the tile; lane = pixel l32 (B operand) / cout l32 (A)
+  const int aoff = (wave * HW_ + l32) * AROW + h * 16;
+  const int woff = l32 * WROW + h * 16;
+
+  auto mma = [&](int c, int slot_, auto NEXT_) {  // 36 MFMAs on ring slot `slot_`; activates the chunk in flight
+    constexpr bool NEXT = decltype(NEXT_)::value;
+    const char* a = sA + slot_ * LDS_A + aoff;
+    const char* w = sW + woff + c * (KC * 2);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#ifdef ABL_NOMFMA
+        continue;
+#endif
+        const uint4 pf = *reinterpret_cast<const uint4*>(a + ((tap / 3) * HW_ + (tap % 3)) * AROW + kb * 32);
+        const uint4 w0 = *reinterpret_cast<const uint4*>(w + tap * C * WROW + kb * 32);
+        const uint4 w1 = *reinterpret_cast<const uint4*>(w + (tap * C + 32) * WROW + kb * 32);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0),
+                                                        __builtin_bit_cast(bf16x8, pf), acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1),
+                                                        __builtin_bit_cast(bf16x8, pf), acc[1], 0, 0, 0);
+        if constexpr (NEXT) {
+          const int s = tap * 2 + kb;
+          if (s == 6) act(0, c ^ 1);
+          if (s == 10) act(1, c ^ 1);
+          if (s == 14) act(2, c ^ 1);
+        }
+      }
+    }
+  };
+
+  // epilogue roles: lane = (pixel epx of an 8-pixel group, 8-cout group ecg)
+  char* sE = smem + LDS_MAIN + wave * LDS_E;
+  const int epx = lane >> 3, ecg = lane & 7;
+  const bool has_res = p.res != nullptr, has_stats = p.stats != nullptr;
+  const float osc = p.out_scale;
+  uint4 rres[4];
+  auto issue_res = [&](int t) {
+    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+    const unsigned o = (unsigned)((((ty * TH + wave) * p.W + tx * TW + epx) * p.ldr + ecg * 8) * 2);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) rres[s4] = ld16(rr, o + (unsigned)(s4 * 8 * p.ldr * 2), 0);
+  };
+  // lane layout of the 32x32 result: column = pixel l32, rows (couts) = (r & 3) + 8 (r >> 2) + 4 h
+  auto epilogue = [&](int t, const float* bz) {
+    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+    const unsigned o = (unsigned)((((ty * TH + wave) * p.W + tx * TW + epx) * p.ldy + ecg * 8) * 2);
+#ifdef ABL_NOEPI
+    if (acc[0][0] + acc[1][3] == 12345.678f) reinterpret_cast<float*>(p.y)[tid] = acc[0][1];
+    return;
+#endif
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      if ((l32 >> 3) == s4) {  // the 8 pixels of this pass hand over their 8 quads (all 64 couts)
+        char* dst = sE + (l32 & 7) * EROW + h * 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(dst + (j * 32 + g * 8) * 4) =
+                make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      const float4 a0 = *reinterpret_cast<const float4*>(sE + epx * EROW + ecg * 32);
+      const float4 a1 = *reinterpret_cast<const float4*>(sE + epx * EROW + ecg * 32 + 16);
+      __builtin_amdgcn_wave_barrier();
+      float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], osc, bz[j]);
+      if (has_res) {
+        const uint4 u = rres[s4];
+        v[0] = fmaf(__uint_as_float(u.x << 16), osc, v[0]); v[1] = fmaf(__uint_as_float(u.x & 0xffff0000u), osc, v[1]);
+        v[2] = fmaf(__uint_as_float(u.y << 16), osc, v[2]); v[3] = fmaf(__uint_as_float(u.y & 0xffff0000u), osc, v[3]);
+        v[4] = fmaf(__uint_as_float(u.z << 16), osc, v[4]); v[5] = fmaf(__uint_as_float(u.z & 0xffff0000u), osc, v[5]);
+        v[6] = fmaf(__uint_as_float(u.w << 16), osc, v[6]); v[7] = fmaf(__uint_as_float(u.w & 0xffff0000u), osc, v[7]);
+      }
+      if (has_stats) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          ssum[j] += v[j];
+          ssq[j] = fmaf(v[j], v[j], ssq[j]);
+        }
+      }
+      u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+      __builtin_amdgcn_raw_buffer_store_b128(ov, ry, o + (unsigned)(s4 * 8 * p.ldy * 2), 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  };
+
+  // ---- pipeline
+  issue(0);
+  __syncthreads();  // tables visible
+  float bz[8];      // (bias + temb bias) * out_scale of this lane's 8 couts
+  {
+    const float4 b0 = *reinterpret_cast<const float4*>(sTab + 2 * C + ecg * 8);
+    const float4 b1 = *reinterpret_cast<const float4*>(sTab + 2 * C + ecg * 8 + 4);
+    bz[0] = b0.x; bz[1] = b0.y; bz[2] = b0.z; bz[3] = b0.w; bz[4] = b1.x; bz[5] = b1.y; bz[6] = b1.z; bz[7] = b1.w;
+  }
+#pragma unroll
+  for (int k = 0; k < NA; ++k) act(k, 0);
+  write(0);
+  issue(1);
+  for (int q = 0; q < Q; q += 2) {
+    const int t = t0 + (q >> 1);
+    // chunk 0 of the tile: the tile's second chunk is in flight
+    __syncthreads();
+    mma(0, 0, std::true_type{});
+    write(1);
+    const bool more = q + 2 < Q;
+    if (more) issue(q + 2);  // first chunk of the next tile: lands during the MFMAs + epilogue below
+    if (has_res) issue_res(t);
+    // chunk 1
+    __syncthreads();
+    if (more) {
+      mma(1, 1, std::true_type{});
+      write(0);
+      issue(q + 3);
+    } else {
+      mma(1, 1, std::false_type{});
+    }
+    epilogue(t, bz);
+  }
+
+  // ---- statistics: 64 threads (8 per wave) share a cout group; reduce them in fp64
+  if (has_stats) {
+    __syncthreads();  // LDS is free now
+    float* red = reinterpret_cast<float*>(smem);
+    *reinterpret_cast<float4*>(red + tid * RED_ROW) = make_float4(ssum[0], ssum[1], ssum[2], ssum[3]);
+    *reinterpret_cast<float4*>(red + tid * RED_ROW + 4) = make_float4(ssum[4], ssum[5], ssum[6], ssum[7]);
+    *reinterpret_cast<float4*>(red + tid * RED_ROW + 8) = make_float4(ssq[0], ssq[1], ssq[2], ssq[3]);
+    *reinterpret_cast<float4*>(red + tid * RED_ROW + 12) = make_float4(ssq[4], ssq[5], ssq[6], ssq[7]);
+    __syncthreads();
+    if (tid < 128) {
+      const int co = tid >> 1, st = tid & 1;
+      const float* src = red + (co >> 3) * RED_ROW + st * 8 + (co & 7);
+      double a = 0.0;
+#pragma unroll 8
+      for (int i = 0; i < 64; ++i) a += (double)src[i * 8 * RED_ROW];
+      p.stats[(((long)b * p.G + part) * C + co) * 2 + st] = a;
+    }
+  }
+}
+
+int ws_blocks_per_image(const ConvArgs& a) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  const int tiles = (a.H / TH) * (a.W / TW);
+  int g = cus / a.B;
+  if (g < 1) g = 1;
+  if (g > tiles) g = tiles;
+  return g;
+}
+
+}  // namespace
+
+// The layers this kernel takes over from conv_mfma.hip (DIFFSEP_CONV_WS=0 switches it off for A/B runs).
+bool ds_conv_ws_eligible(const ConvArgs& a) {
+  static int on = -1;
+  if (on < 0) { const char* v = getenv("DIFFSEP_CONV_WS"); on = v ? atoi(v) : 1; }
+  return on && a.dtype == DS_BF16 && a.taps == 9 && a.Cin == C && a.Cout == C && !a.x2 && a.w_bs == 0 &&
+         a.bias_mode == 0 && !a.div_b && a.H % TH == 0 && a.W % TW == 0 && a.ldx >= C && a.ldy >= C &&
+         (!a.res || a.ldr >= C);
+}
+int ds_conv_ws_tiles(const ConvArgs& a) { return ws_blocks_per_image(a); }
+
+int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st) {
+  WsK k;
+  k.x = reinterpret_cast<const bf16_t*>(a.x); k.x_bs = a.x_bs; k.ldx = a.ldx;
+  k.w = reinterpret_cast<const bf16_t*>(a.w);
+  k.gn_scale = a.gn_scale; k.gn_shift = a.gn_shift;
+  k.bias = a.bias; k.bias_b = a.bias_b; k.bias_b_ld = a.bias_b_ld;
+  k.res = reinterpret_cast<const bf16_t*>(a.res); k.res_bs = a.res_bs; k.ldr = a.ldr;
+  k.out_scale = a.out_scale;
+  k.y = reinterpret_cast<bf16_t*>(a.y); k.y_bs = a.y_bs; k.ldy = a.ldy;
+  k.stats = a.stats_out;
+  k.H = a.H; k.W = a.W; k.G = ws_blocks_per_image(a);
+  k.tiles_x = a.W / TW; k.tiles_per_img = (a.H / TH) * (a.W / TW);
+  const int mode = (a.gn_scale && a.gn_act) ? 2 : 1;  // raw input = affine with scale 1, shift 0 (exact in bf16)
+  static bool attr_done = false;
+  if (!attr_done) {
+    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+    attr_done = true;
+  }
+  const dim3 grid(a.B * k.G), block(512);
+  if (mode == 1) hipLaunchKernelGGL(conv3x3_ws_kernel<1>, grid, block, LDS_TOTAL, st, k);
+  else hipLaunchKernelGGL(conv3x3_ws_kernel<2>, grid, block, LDS_TOTAL, st, k);
+  DS_LAUNCH_CHECK();
+  return 0;
+}

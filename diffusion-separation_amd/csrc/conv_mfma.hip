@@ -27,21 +27,25 @@
 // channel-contiguous stores with coalesced residual reads.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 #ifdef CONV_TIMING  // profiling build only (tools/conv_timing.sh): per-phase cycle totals of wave 0 of every block
-__device__ unsigned long long g_conv_dbg[8];
-#define CT_DECL unsigned long long ct_prev = clock64(), ct_acc[7] = {0, 0, 0, 0, 0, 0, 0};
-#define CT_MARK(i) { unsigned long long ct_now = clock64(); ct_acc[i] += ct_now - ct_prev; ct_prev = ct_now; }
-#define CT_FLUSH if (threadIdx.x == 0) { for (int q = 0; q < 7; ++q) atomicAdd(&g_conv_dbg[q], ct_acc[q]); atomicAdd(&g_conv_dbg[7], 1ull); }
+__device__ unsigned long long g_conv_dbg[16];
+#define CT_DECL unsigned long long ct_prev = __builtin_readcyclecounter(), ct_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define CT_MARK(i) { unsigned long long ct_now = __builtin_readcyclecounter(); ct_acc[i] += ct_now - ct_prev; ct_prev = ct_now; }
+#define CT_WAIT __builtin_amdgcn_s_waitcnt(0);
+#define CT_FLUSH if (threadIdx.x == 0) { for (int q = 0; q < 12; ++q) atomicAdd(&g_conv_dbg[q], ct_acc[q]); atomicAdd(&g_conv_dbg[15], 1ull); }
 extern "C" int diffsep_debug_read(unsigned long long* out, int reset) {
-  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_dbg), sizeof(unsigned long long) * 8);
-  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_conv_dbg), z, sizeof(z)); }
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_dbg), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_dbg), z, sizeof(z)); }
   return 0;
 }
 #else
 #define CT_DECL
 #define CT_MARK(i)
+#define CT_WAIT
 #define CT_FLUSH
 #endif
 
@@ -56,6 +60,10 @@ template <> struct Mma<float> {
 };
 template <> struct Mma<bf16_t> {
   __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
+#ifdef ABL_NOMFMA
+    c[0] += __uint_as_float(a.x ^ b.x);
+    return;
+#endif
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
                                                 0);
   }
@@ -184,6 +192,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
   static_assert(KC % (2 * KV) == 0, "KC must hold whole k-blocks");
   static_assert(256 % NVEC == 0, "a thread keeps one channel offset across its vectors");
 
+  CT_DECL
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
   char* sB = smem + HP * ROWB;
@@ -294,6 +303,9 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     const int wb = second ? C1 + cb : cb;                // channel offset inside the weights / GN tables
     ch_ok = vch < width;
     const unsigned so = (unsigned)cb * ESZ, sw = (unsigned)wb * ESZ;
+#ifdef ABL_NOLOAD
+    return;
+#endif
     if (width >= KC) {  // uniform fast path: every lane's offsets are the precomputed ones
       if (!second) {
 #pragma unroll
@@ -326,18 +338,13 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
       }
     }
   };
-  auto store_chunk = [&]() {
-    if (has_gn) {  // act(GN(x)) on the fly; zero padding (pixels outside the image, channel tails) stays zero
-      if (p.gn_act) {
-#pragma unroll
-        for (int k = 0; k < NA; ++k)
-          if (aval[k] && ch_ok) pa[k] = GnVec<T>::template run<true>(pa[k], gsc, gsh);
-      } else {
-#pragma unroll
-        for (int k = 0; k < NA; ++k)
-          if (aval[k] && ch_ok) pa[k] = GnVec<T>::template run<false>(pa[k], gsc, gsh);
-      }
-    }
+  // The chunk in flight is activated IN REGISTERS (GN affine + SiLU) while the matrix pipe works on the chunk
+  // that is resident in LDS: the activation's VALU is spread over the MFMA loop of the same wave, so between
+  // the two barriers of a chunk only the LDS writes remain.
+  auto write_chunk = [&]() {
+#ifdef ABL_NOLDSW
+    return;
+#endif
 #pragma unroll
     for (int k = 0; k < NA; ++k)
       if (a_in(k)) *reinterpret_cast<uint4*>(sA + lds0 + k * RPS * ROWB) = pa[k];
@@ -345,36 +352,81 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     for (int k = 0; k < NB; ++k)
       if (b_in(k)) *reinterpret_cast<uint4*>(sB + lds0 + k * RPS * ROWB) = pb[k];
   };
-
-  CT_DECL
-  load_chunk(0);
-  CT_MARK(0)
-  for (int c = 0; c < nch; ++c) {
-    __syncthreads();  // previous chunk's fragment reads are done
-    store_chunk();
-    __syncthreads();
+  constexpr int SLOTS = TAPS * NKB;                 // k-blocks of one chunk
+  constexpr int S0 = SLOTS / 3;                     // the loads of the next chunk get this long to land
+  auto run_chunks = [&](auto MODE_) {               // 0: raw input, 1: GN affine, 2: GN affine + SiLU
+    constexpr int MODE = decltype(MODE_)::value;
+    auto act = [&](int k) {  // branch free: zero padding (outside pixels, channel tails) keeps its loaded zeros
+#ifdef ABL_NOACT
+      return;
+#endif
+      if constexpr (MODE != 0) {
+        uint4 r = GnVec<T>::template run<MODE == 2>(pa[k], gsc, gsh);
+        // keep the arithmetic unconditional (a branch here would cut the MFMA loop into pieces)
+        asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
+        const bool ok = aval[k] && ch_ok;
+        pa[k].x = ok ? r.x : pa[k].x;
+        pa[k].y = ok ? r.y : pa[k].y;
+        pa[k].z = ok ? r.z : pa[k].z;
+        pa[k].w = ok ? r.w : pa[k].w;
+      }
+    };
+    auto mma_chunk = [&](auto NEXT_) {
+      constexpr bool NEXT = decltype(NEXT_)::value && MODE != 0;
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int toff = (TAPS == 9) ? ((tap / 3) * HW_ + (tap % 3)) * ROWB : 0;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          uint4 af[WM], bfr[WN];
+#pragma unroll
+          for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const uint4*>(sA + aoff[i] + toff + kb * 32);
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            bfr[j] = *reinterpret_cast<const uint4*>(sB + boff[j] + tap * BN * ROWB + kb * 32);
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
+          if constexpr (NEXT) {
+            const int s = tap * NKB + kb;
+            if (s >= S0) {
+              const int k0 = (s - S0) * NA / (SLOTS - S0), k1 = (s + 1 - S0) * NA / (SLOTS - S0);
+#pragma unroll
+              for (int k = 0; k < NA; ++k)
+                if (k >= k0 && k < k1) act(k);
+            }
+          }
+        }
+      }
+    };
+    CT_MARK(0)
+    load_chunk(0);
     CT_MARK(1)
-    if (c + 1 < nch) load_chunk(c + 1);  // in flight during the MFMA loop below
+    CT_WAIT
     CT_MARK(2)
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int toff = (TAPS == 9) ? ((tap / 3) * HW_ + (tap % 3)) * ROWB : 0;
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) {
-        uint4 af[WM], bfr[WN];
-#pragma unroll
-        for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const uint4*>(sA + aoff[i] + toff + kb * 32);
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-          bfr[j] = *reinterpret_cast<const uint4*>(sB + boff[j] + tap * BN * ROWB + kb * 32);
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-          for (int j = 0; j < WN; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
-      }
-    }
+    for (int k = 0; k < NA; ++k) act(k);
     CT_MARK(3)
-  }
+    for (int c = 0; c < nch; ++c) {
+      __syncthreads();  // previous chunk's fragment reads are done
+      write_chunk();
+      __syncthreads();
+      CT_MARK(4)
+      if (c + 1 < nch) {
+        load_chunk(c + 1);  // in flight during the first third of the MFMA loop below
+        CT_MARK(5)
+        mma_chunk(std::true_type{});
+      } else {
+        CT_MARK(5)
+        mma_chunk(std::false_type{});
+      }
+      CT_MARK(6)
+    }
+  };
+  if (!has_gn) run_chunks(std::integral_constant<int, 0>{});
+  else if (p.gn_act) run_chunks(std::integral_constant<int, 2>{});
+  else run_chunks(std::integral_constant<int, 1>{});
 
   // ---- epilogue: accumulators -> LDS (fp32, [pixel][cout]) -> bias / temb / residual / scale -> 16-byte
   // stores, in EP passes over the wave's M blocks (a smaller staging buffer lets more blocks share a CU).
@@ -384,6 +436,19 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
   const __amdgpu_buffer_rsrc_t rr = make_rsrc(
       p.res ? reinterpret_cast<const T*>(p.res) + (long)b * p.res_bs : reinterpret_cast<const T*>(p.y),
       p.res ? (unsigned)M * p.ldr * ESZ : 0u);  // no residual: zero records -> every load returns 0
+#ifdef ABL_NOEPI
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 12345.678f) reinterpret_cast<float*>(p.y)[tid] = t;
+    return;
+  }
+#endif
   const int cout8 = (p.Cout + 7) & ~7;
   const float dvs = p.div_b ? p.div_b[b] : 1.0f;
   constexpr int NCG = BN / 8;
@@ -465,7 +530,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
       for (int q = 0; q < RV; ++q) rraw[it][q] = buf_load16(rr, vor[it], 16u * q);
     }
     __syncthreads();
-    CT_MARK(4)
+    CT_MARK(7)
     uint4 oraw[NROW][RV];
 #pragma unroll
     for (int it = 0; it < NROW; ++it) {
@@ -504,14 +569,13 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
       }
       pack8<T>(v, oraw[it]);
     }
-    CT_MARK(5)
+    CT_MARK(8)
 #pragma unroll
     for (int it = 0; it < NROW; ++it)
 #pragma unroll
       for (int q = 0; q < RV; ++q) buf_store16(ry, voy[it], 16u * q, oraw[it][q]);
-    CT_MARK(6)
+    CT_MARK(9)
   }
-  CT_FLUSH
   if (p.stats) {  // block-reduce the per-thread partials: 256/NCG threads share a cout group
     __syncthreads();
     float* sr = reinterpret_cast<float*>(smem);  // [256/NCG][BN][2]
@@ -533,6 +597,8 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
       o[1] = q;
     }
   }
+  CT_MARK(10)
+  CT_FLUSH
 }
 
 template <typename T, int TAPS, int TH, int TW, int BN, int WM, int WN, int KC, int EP = 1, int OCC = 2>
@@ -597,6 +663,7 @@ static int launch_typed(const ConvArgs& a, hipStream_t st) {
 // grid.x of the launch = number of output tiles per image (the stride of the statistics partials)
 int ds_conv_tiles(const ConvArgs& a) {
   const int id = ds_conv_config_id(a);
+  if (id == 6) return ds_conv_ws_tiles(a);
   if (id <= 1) return cdiv(a.W, 32) * cdiv(a.H, 8);
   if (id == 2) return cdiv(a.W, 8) * cdiv(a.H, 8);
   const long M = (long)a.H * a.W;
@@ -604,8 +671,9 @@ int ds_conv_tiles(const ConvArgs& a) {
 }
 
 // Which instantiation ds_launch_conv picks (profiling label): 0/1/2 = 3x3 {8x32xBN64, 8x32xBN32, 8x8xBN64},
-// 3/4/5 = the same tiles for 1x1 / GEMM.
+// 3/4/5 = the same tiles for 1x1 / GEMM, 6 = the weight-stationary 64 -> 64 kernel (conv3x3_ws.hip).
 int ds_conv_config_id(const ConvArgs& a) {
+  if (ds_conv_ws_eligible(a)) return 6;
   if (a.taps == 9) {
     if (a.W >= 32 && a.H >= 8) return a.Cout <= 32 ? 1 : 0;
     return 2;
@@ -630,6 +698,7 @@ int ds_launch_conv(const ConvArgs& a, hipStream_t st) {
     DS_CHECK(M * mld * esz < 2147483647L, "conv: image too large for 32-bit buffer offsets");
     DS_CHECK((long)a.Cout * a.taps * a.Cin * esz < 2147483647L, "conv: weight tensor too large");
   }
+  if (ds_conv_ws_eligible(a)) return ds_launch_conv_ws(a, st);
   if (a.dtype == DS_F32) return launch_typed<float>(a, st);
   if (a.dtype == DS_BF16) return launch_typed<bf16_t>(a, st);
   DS_CHECK(false, "conv: unknown dtype");

@@ -82,17 +82,24 @@ def groupnorm_stats(x, gamma, beta, groups, eps=1e-6, x2=None):
 
 
 def conv2d_fused(x, wpacked, bias, cout, ksize, x2=None, gn=None, gn_act=1, bias_b=None, res=None, out_scale=1.0,
-                 cout_pad=None):
+                 cout_pad=None, out=None, stats=False):
+    """stats=True additionally returns the per-tile float64 partials [B,tiles,cout,2] of the output."""
     B, H, W, C1 = x.shape
     Cin = C1 + (x2.shape[-1] if x2 is not None else 0)
     cp = cout if cout_pad is None else cout_pad
-    y = torch.zeros((B, H, W, cp), dtype=x.dtype, device=x.device)
+    y = torch.zeros((B, H, W, cp), dtype=x.dtype, device=x.device) if out is None else out
     sc, sh = gn if gn is not None else (None, None)
+    st = None
+    if stats is True:
+        st = torch.zeros((B, lib().diffsep_conv2d_tiles(B, H, W, Cin, cout, ksize, _dt(x)), cout, 2), dtype=torch.float64,
+                         device=x.device)
+    elif stats is not False:
+        st = stats
     check(lib().diffsep_conv2d_fused(_ptr(x), _ptr(x2), C1, _ptr(sc), _ptr(sh), gn_act, _ptr(wpacked), _ptr(bias),
                                      _ptr(bias_b), _ptr(res), _ptr(y), B, H, W, Cin, cout, ksize, C1,
                                      x2.shape[-1] if x2 is not None else 0, res.shape[-1] if res is not None else 0, cp,
-                                     out_scale, _dt(x), _stream_ptr()))
-    return y
+                                     out_scale, _dt(x), _ptr(st), _stream_ptr()))
+    return (y, st) if stats is not False else y
 
 
 def attention(q, k, vt):

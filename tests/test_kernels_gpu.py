@@ -334,3 +334,52 @@ def test_gram_and_separation_metrics():
     n = n * (0.1 * x.norm() / n.norm())
     sdr1, _, _, _ = metrics.si_bss_eval_sources(x.to(DEV), (x + n).to(DEV))
     assert abs(sdr1[0, 0] - 20.0) < 1e-3
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ksize,H,W", [(3, 16, 64), (3, 12, 40), (1, 16, 32), (3, 8, 8)])
+def test_conv_epilogue_statistics(dt, ksize, H, W):
+    # the per-tile partials the conv epilogue emits for the next GroupNorm sum to the statistics of its own output
+    B, ci, co = 2, 16, 64
+    x = rnd("cs.x", (B, H, W, ci)).to(DEV).to(dt)
+    w = (rnd("cs.w", (co, ksize * ksize, ci)) / (ksize * ksize * ci) ** 0.5).to(DEV).to(dt)
+    b = rnd("cs.b", (co,)).to(DEV)
+    res = rnd("cs.r", (B, H, W, co)).to(DEV).to(dt)
+    y, st = ops.conv2d_fused(x, w, b, co, ksize, res=res, out_scale=0.7071, stats=True)
+    s = st.sum(1)  # [B, co, 2]
+    yd = y.double()
+    tol = 1e-6 if dt == torch.float32 else 2e-3  # the partials are taken before the bf16 rounding of the output
+    assert torch.allclose(s[..., 0], yd.sum((1, 2)), rtol=tol, atol=tol * H * W)
+    assert torch.allclose(s[..., 1], (yd * yd).sum((1, 2)), rtol=tol, atol=tol * H * W)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 16, 64), (5, 8, 32), (128, 16, 64), (256, 24, 32)])
+@pytest.mark.parametrize("act", [1, 0, None])
+def test_weight_stationary_conv3x3_64_to_64(B, H, W, act):
+    # the persistent 64 -> 64 bf16 kernel (conv3x3_ws.hip): one or several tiles per block, image borders,
+    # GN affine (+SiLU) on the input, conv bias + per-batch temb bias, residual, 1/sqrt(2), statistics partials
+    dt = torch.bfloat16
+    x = (rnd(f"ws.x{B}{H}", (B, H, W, 64), 1.2) + 0.1).to(DEV).to(dt)
+    w = rnd("ws.w", (64, 64, 3, 3), 1.0 / 24.0)
+    bias, bb = rnd("ws.b", (64,), 0.1).to(DEV), rnd(f"ws.bb{B}", (B, 64), 0.1).to(DEV)
+    res = rnd(f"ws.r{B}{H}", (B, H, W, 64)).to(DEV).to(dt)
+    sc = (1.0 + rnd(f"ws.sc{B}", (B, 64), 0.2)).to(DEV)
+    sh = rnd(f"ws.sh{B}", (B, 64), 0.2).to(DEV)
+    xf = x.float()
+    if act is not None:
+        xf = xf * sc[:, None, None, :] + sh[:, None, None, :]
+        if act:
+            xf = F.silu(xf)
+        xf = xf.to(dt).float()  # the kernel rounds the activated input to bf16 before the MFMA
+    wq = w.to(dt).float().to(DEV)
+    ref = F.conv2d(xf.permute(0, 3, 1, 2), wq, bias, padding=1).permute(0, 2, 3, 1)
+    ref = (ref + bb[:, None, None, :] + res.float()) * 0.70710678
+    y, st = ops.conv2d_fused(x, ops.pack_conv_weight(w, dt).to(DEV), bias, 64, 3, gn=None if act is None else (sc, sh),
+                             gn_act=act or 0, bias_b=bb, res=res, out_scale=0.70710678, stats=True)
+    assert rel_rms(y.float(), ref) < 4e-3
+    s = st.sum(1)
+    assert torch.allclose(s[..., 0], ref.double().sum((1, 2)), rtol=2e-3, atol=2e-3 * H * W)
+    assert torch.allclose(s[..., 1], (ref.double() ** 2).sum((1, 2)), rtol=2e-3, atol=2e-3 * H * W)
+    y2 = ops.conv2d_fused(x, ops.pack_conv_weight(w, dt).to(DEV), None, 64, 3)  # no bias / residual / statistics
+    ref2 = F.conv2d(x.float().permute(0, 3, 1, 2), wq, None, padding=1).permute(0, 2, 3, 1)
+    assert rel_rms(y2.float(), ref2) < 4e-3

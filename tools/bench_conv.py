@@ -19,6 +19,9 @@ SHAPES = [  # (ksize, Cin, Cout, H, W, count per forward)
 ]
 
 
+FUSED = os.environ.get("BENCH_CONV_PLAIN", "0") != "1"
+
+
 def main():
     dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float32
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -32,13 +35,21 @@ def main():
         w = (torch.randn(co, k * k, ci, device="cuda") / (k * k * ci) ** 0.5).to(dt)
         b = torch.randn(co, device="cuda")
         cp = (co + 7) // 8 * 8
+        y = torch.zeros(B, H, W, cp, device="cuda", dtype=dt)
+        if FUSED and ci >= 64:  # GroupNorm + SiLU on the input, residual add: the shape of the engine's launches
+            sc, sh = torch.rand(B, ci, device="cuda") + 0.5, torch.randn(B, ci, device="cuda") * 0.1
+            res = torch.randn(B, H, W, cp, device="cuda").to(dt)
+            _, st = ops.conv2d_fused(x, w, b, co, k, cout_pad=cp, out=y, stats=True)
+            run = lambda: ops.conv2d_fused(x, w, b, co, k, gn=(sc, sh), gn_act=1, res=res, out_scale=0.7071, cout_pad=cp, out=y, stats=st)
+        else:
+            run = lambda: ops.conv2d_fused(x, w, b, co, k, cout_pad=cp, out=y)
         for _ in range(3):
-            ops.conv2d(x, w, b, co, k, cout_pad=cp)
+            run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(reps):
-            ops.conv2d(x, w, b, co, k, cout_pad=cp)
+            run()
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps

@@ -12,24 +12,27 @@ import ctypes, sys, os, torch
 sys.path.insert(0, "diffusion-separation_amd")
 from diffsep_amd import ops, _lib
 l = ctypes.CDLL(os.environ["DIFFSEP_LIB"])
-names = ["issue first loads", "wait+LDS store+2 barriers", "issue next loads", "MFMA loop", "acc dump+barriers+residual loads", "epilogue LDS read+math", "epilogue global stores"]
+names = ["setup (offsets, descriptors)", "issue first loads", "wait first loads", "activation of chunk 0", "barrier+LDS store+barrier", "issue next loads", "MFMA loop (+activation of next)", "acc dump+barriers+residual loads", "epilogue LDS read+math", "epilogue global stores", "statistics reduce", "-"]
 for (k, ci, co, H, W) in [(3, 64, 64, 256, 256), (3, 128, 64, 256, 256), (3, 128, 128, 64, 64), (1, 128, 64, 256, 256)]:
     B = 16
     x = torch.randn(B, H, W, ci, device="cuda").to(torch.bfloat16)
     w = (torch.randn(co, k * k, ci, device="cuda") / (k * k * ci) ** 0.5).to(torch.bfloat16)
     b = torch.randn(co, device="cuda")
-    for _ in range(2): ops.conv2d(x, w, b, co, k)
+    sc = torch.rand(B, ci, device="cuda") + 0.5; sh = torch.randn(B, ci, device="cuda") * 0.1
+    res = torch.randn(B, H, W, co, device="cuda").to(torch.bfloat16)
+    run = lambda: ops.conv2d_fused(x, w, b, co, k, gn=(sc, sh), gn_act=1, res=res, out_scale=0.7071)
+    for _ in range(2): run()
     torch.cuda.synchronize()
-    out = (ctypes.c_ulonglong * 8)()
+    out = (ctypes.c_ulonglong * 16)()
     l.diffsep_debug_read(out, 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(5): ops.conv2d(x, w, b, co, k)
+    for _ in range(5): run()
     e1.record(); torch.cuda.synchronize()
     l.diffsep_debug_read(out, 1)
-    nb = out[7]
-    tot = sum(out[i] for i in range(7))
-    print(f"k{k} {ci}->{co} {H}x{W}: {e0.elapsed_time(e1)/5*1e3:.1f} us/launch, {nb//5} blocks, {tot/nb:.0f} cycles/block (clock64 = 100 MHz ticks?)")
-    for i in range(7):
+    nb = out[15]
+    tot = sum(out[i] for i in range(12))
+    print(f"k{k} {ci}->{co} {H}x{W}: {e0.elapsed_time(e1)/5*1e3:.1f} us/launch, {nb//5} blocks, {tot/nb:.0f} cycles/block ")
+    for i in range(11):
         print(f"    {names[i]:28s} {out[i]/nb:9.0f}  {100*out[i]/tot:5.1f} %")
 PY
