@@ -130,6 +130,7 @@ struct ConvArgs {
   const void* x2; long x2_bs; int ldx2;  // optional second A source: channels [C1, Cin) come from x2 (concat in place)
   int C1;                                // channels taken from x when x2 != null
   const void* w; long w_bs;              // Bt operand: [Cout][taps][Cin]; w_bs batch stride (0 = shared)
+  int w_chunked;                         // != 0: weights are chunk-major [Cin/kc][taps][Cout][kc] with kc = this value
   const float* gn_scale;                 // optional fused GroupNorm-apply on A: f(x) = act(x*scale[b,c] + shift[b,c])
   const float* gn_shift; int gn_act;     //   scale/shift are [B][Cin] fp32; gn_act: 0 none, 1 SiLU
   const float* bias;                     // [Cout] (mode 0) or [M] (mode 1) or null
@@ -147,6 +148,7 @@ struct ConvArgs {
 int ds_launch_conv(const ConvArgs& a, hipStream_t st);
 int ds_conv_config_id(const ConvArgs& a);
 int ds_conv_tiles(const ConvArgs& a);
+int ds_conv_chunk(int taps, int dtype);
 bool ds_conv_ws_eligible(const ConvArgs& a);   // conv3x3_ws.hip: weight-stationary 64 -> 64 bf16 kernel
 int ds_conv_ws_tiles(const ConvArgs& a);
 int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st);

@@ -7,15 +7,18 @@
 //
 //   * one block of 8 waves per CU; the [9][64][64] weights are copied into LDS ONCE per block (83 KB, rows padded
 //     to 144 B) and stay there for all of the block's tiles (a contiguous raster range of one image);
-//   * the 10 x 34 pixel halo tile is staged 32 channels at a time through a 2-slot LDS ring (27 KB each); the chunk
-//     after the one being multiplied is in flight in registers, gets its GroupNorm affine + SiLU applied there
-//     (VALU interleaved with the MFMAs of the same wave) and is written to the free slot: ONE barrier per chunk,
-//     and the first chunk of the NEXT tile is already loading while this tile's epilogue runs;
-//   * MFMA operands are swapped (A = weights, B = pixels), so a lane ends up holding 4 consecutive output
-//     channels of ONE pixel per accumulator quad = one 16-byte LDS write.  The epilogue turns the wave's 32 x 64
-//     result into pixel rows through a private 2.3 KB LDS scratch, 8 pixels at a time (no block barrier: LDS
-//     operations of one wave execute in order); a lane then owns 8 consecutive couts of a pixel: bias / residual
-//     / scale / statistics / bf16 packing and full 128-byte-line stores;
+//   * the 8 waves form two groups of 4 that work on alternating tiles in PING-PONG: while one group multiplies
+//     (MFMA + LDS fragment reads only), the other group does everything else for its own tile — GroupNorm affine +
+//     SiLU on the chunk it has in flight in registers, the LDS write of that chunk into the group's staging slot,
+//     the global loads of the following chunk, and the epilogue.  The groups swap roles at every block barrier
+//     (group 1 is started one phase late), so the matrix pipe / LDS read port and the VALU / memory path are
+//     busy at the same time without any intra-wave instruction interleaving;
+//   * a wave owns 2 pixel rows x 64 couts of its group's 8 x 32 tile (2 x 2 MFMA tiles: one LDS fragment read per
+//     MFMA).  MFMA operands are swapped (A = weights, B = pixels), so a lane ends up holding 4 consecutive output
+//     channels of ONE pixel per accumulator quad = one 16-byte LDS write.  The epilogue turns the wave's result
+//     into pixel rows through a private 2.3 KB LDS scratch, 8 pixels at a time (no block barrier: LDS operations
+//     of one wave execute in order); a lane then owns 8 consecutive couts of a pixel: bias / residual / scale /
+//     statistics / bf16 packing and full 128-byte-line stores;
 //   * GroupNorm statistics of the output are accumulated in 16 registers per lane over all tiles of the block
 //     and reduced once at the end (partials [B][G][64][2], G = blocks per image).
 //
@@ -25,6 +28,22 @@
 #include <type_traits>
 
 #include "common.h"
+
+#ifdef WS_TIMING  // profiling build only: per-phase cycle totals of wave 0 (group 0) and wave 4 (group 1)
+__device__ unsigned long long g_ws_dbg[32];
+#define WT_DECL unsigned wt_prev = (unsigned)__builtin_readcyclecounter(), wt_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define WT_MARK(i) { unsigned wt_now = (unsigned)__builtin_readcyclecounter(); wt_acc[i] += wt_now - wt_prev; wt_prev = wt_now; }
+#define WT_FLUSH if ((threadIdx.x & 255) == 0) { for (int q = 0; q < 12; ++q) atomicAdd(&g_ws_dbg[(threadIdx.x >> 8) * 16 + q], (unsigned long long)wt_acc[q]); atomicAdd(&g_ws_dbg[(threadIdx.x >> 8) * 16 + 15], 1ull); }
+extern "C" int diffsep_ws_debug_read(unsigned long long* out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ws_dbg), sizeof(unsigned long long) * 32);
+  if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ws_dbg), z, sizeof(z)); }
+  return 0;
+}
+#else
+#define WT_DECL
+#define WT_MARK(i)
+#define WT_FLUSH
+#endif
 
 namespace {
 
@@ -39,6 +58,10 @@ __device__ inline uint4 ld16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned s
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// Block barrier that only orders LDS traffic.  __syncthreads() is a workgroup-scope fence: it drains vmcnt, i.e. it
+// would wait for the global prefetch loads issued just before it and serialize them with the barrier.
+__device__ inline void sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int C = 64;                 // input and output channels
 constexpr int TH = 8, TW = 32;        // output tile
 constexpr int HW_ = TW + 2, HH_ = TH + 2, HP = HW_ * HH_;  // halo tile: 340 pixels
@@ -48,12 +71,14 @@ constexpr int WROW = C * 2 + 16;      // 144 B: weight row (tap, cout) in LDS
 constexpr int LDS_W = 9 * C * WROW;   // 82,944
 constexpr int LDS_A = HP * AROW;      // 27,200 per ring slot
 constexpr int LDS_TAB = 3 * C * 4;    // GN scale, GN shift, (bias + temb bias) * out_scale
-constexpr int NA = (HP * (KC / 8) + 511) / 512;  // 16-byte vectors per thread per chunk: 3
+constexpr int NA = (HP * (KC / 8) + 255) / 256;  // 16-byte vectors per thread (of a 4-wave group) per chunk: 6
 constexpr int EROW = 288;             // epilogue scratch: 8 pixel rows of 64 fp32 (+32 B: conflict-free quad writes)
 constexpr int LDS_E = 8 * EROW;       // per wave
 constexpr int RED_ROW = 20;           // final statistics reduce: 16 floats per thread (+4 pad)
+constexpr int LDS_DESC = NA * 256 * 4; // staging descriptors (global byte offset | border flags) per group thread
 constexpr int LDS_MAIN = LDS_W + 2 * LDS_A + LDS_TAB;
-constexpr int LDS_TOTAL = LDS_MAIN + 8 * LDS_E;
+constexpr int LDS_TOTAL = LDS_MAIN + 8 * LDS_E + LDS_DESC;
+static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget of one CU");
 static_assert(512 * RED_ROW * 4 <= LDS_TOTAL, "the statistics reduce reuses the block's LDS");
 
 struct WsK {
@@ -102,7 +127,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsK p) {
   const int b = blockIdx.x / p.G, part = blockIdx.x % p.G;
   const int t0 = (int)((long)part * p.tiles_per_img / p.G);
   const int nt = (int)((long)(part + 1) * p.tiles_per_img / p.G) - t0;
-  const int Q = 2 * nt;  // chunks this block walks through
+  // the two wave groups take alternating tiles of the block's range
+#ifdef WS_GROUP_INTERLEAVED
+  const int group = wave & 1, gw = wave >> 1, gtid = (gw << 6) | lane;
+#else
+  const int group = wave >> 2, gw = wave & 3, gtid = tid & 255;
+#endif
+  const int ntg = (nt - group + 1) >> 1;   // tiles of this group
+  const int Qg = 2 * ntg;                  // chunks this group walks through
+  const int steps = 2 * ((nt + 1) >> 1);   // phase pairs both groups execute (barrier counts must match)
 
   // ---- one-time: weights [cout][tap][cin] -> LDS [tap][cout] rows, per-image tables
   {
@@ -124,88 +157,97 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsK p) {
     }
   }
 
-  // ---- staging descriptors: vector v = tid + 512 k -> halo pixel v / 4, 16-byte slot v % 4 (= tid % 4)
+  // ---- staging descriptors: vector v = gtid + 256 k -> halo pixel v / 4, 16-byte slot v % 4 (= tid % 4).
+  // Kept in LDS (one 4-byte word per vector: byte offset relative to the tile origin, multiple of 16, with the
+  // border flags in the low 4 bits) so that they do not occupy 18 registers for the whole kernel.
   const int slot = tid & 3;
-  int rel[NA], ldo[NA];
-  unsigned flg[NA];
-  bool in[NA];
+  int* sDesc = reinterpret_cast<int*>(smem + LDS_MAIN + 8 * LDS_E);
+  if (group == 0) {
 #pragma unroll
-  for (int k = 0; k < NA; ++k) {
-    const int v = tid + 512 * k;
-    in[k] = v < HP * 4;
-    const int pix = v >> 2, hy = pix / HW_, hx = pix - hy * HW_;
-    rel[k] = (((hy - 1) * p.W + (hx - 1)) * p.ldx + slot * 8) * 2;
-    flg[k] = (hy == 0 ? 1u : 0u) | (hy == HH_ - 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == HW_ - 1 ? 8u : 0u);
-    ldo[k] = pix * AROW + slot * 16;
+    for (int k = 0; k < NA; ++k) {
+      const int v = gtid + 256 * k;
+      const int pix = v >> 2, hy = pix / HW_, hx = pix - hy * HW_;
+      const int rel = (((hy - 1) * p.W + (hx - 1)) * p.ldx + slot * 8) * 2;
+      const int flg = (hy == 0 ? 1 : 0) | (hy == HH_ - 1 ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx == HW_ - 1 ? 8 : 0);
+      sDesc[k * 256 + gtid] = rel | flg;
+    }
   }
+  const int ldo0 = (gtid >> 2) * AROW + slot * 16;  // LDS offset of vector 0; vector k is 64 pixels further
+  const bool in_last = gtid + 256 * (NA - 1) < HP * 4;
   const __amdgpu_buffer_rsrc_t rx = rsrc(p.x + (long)b * p.x_bs, (unsigned)(p.H * p.W) * p.ldx * 2u);
   const __amdgpu_buffer_rsrc_t ry = rsrc(p.y + (long)b * p.y_bs, (unsigned)(p.H * p.W) * p.ldy * 2u);
   const __amdgpu_buffer_rsrc_t rr =
       rsrc(p.res ? p.res + (long)b * p.res_bs : p.y, p.res ? (unsigned)(p.H * p.W) * p.ldr * 2u : 0u);
+  char* sAg = sA + group * LDS_A;  // the group's staging slot
 
+  auto tile_of = [&](int q) { return t0 + group + 2 * (q >> 1); };  // chunk q of the group -> tile index
   uint4 pa[NA];
   bool pval[NA];
-  auto issue = [&](int q) {  // global loads of chunk q (tile q / 2, channels 32 (q & 1) ...) into registers
-    const int t = t0 + (q >> 1);
+  auto issue = [&](int q) {  // global loads of the group's chunk q into registers
+    const int t = tile_of(q);
     const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
     const int y0 = ty * TH, x0 = tx * TW;
     const unsigned edge = (y0 == 0 ? 1u : 0u) | (y0 + TH == p.H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) |
                           (x0 + TW == p.W ? 8u : 0u);
     const int tbase = (y0 * p.W + x0) * p.ldx * 2;
-#ifdef ABL_NOLOAD
-    return;
-#endif
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
-      pval[k] = in[k] && !(flg[k] & edge);
-      pa[k] = ld16(rx, pval[k] ? (unsigned)(rel[k] + tbase) : OOB, (unsigned)(q & 1) * (KC * 2));
+      const int d = sDesc[k * 256 + gtid];
+      pval[k] = (k < NA - 1 || in_last) && !((unsigned)d & edge);
+#ifdef ABL_NOLOAD
+      pa[k] = make_uint4(tbase, tbase, tbase, tbase);
+#else
+      pa[k] = ld16(rx, pval[k] ? (unsigned)((d & ~15) + tbase) : OOB, (unsigned)(q & 1) * (KC * 2));
+#endif
     }
   };
-  auto act = [&](int k, int c) {  // zero padding stays zero: the activation applies to inside pixels only
+  float gsc[8], gsh[8];  // GN scale / shift of this thread's 8 channels of the chunk in flight
+  auto act_tab = [&](int c) {
+    const float4* ts = reinterpret_cast<const float4*>(sTab + c * KC + slot * 8);
+    const float4* th = reinterpret_cast<const float4*>(sTab + C + c * KC + slot * 8);
+    const float4 s0 = ts[0], s1 = ts[1], h0 = th[0], h1 = th[1];
+    gsc[0] = s0.x; gsc[1] = s0.y; gsc[2] = s0.z; gsc[3] = s0.w; gsc[4] = s1.x; gsc[5] = s1.y; gsc[6] = s1.z; gsc[7] = s1.w;
+    gsh[0] = h0.x; gsh[1] = h0.y; gsh[2] = h0.z; gsh[3] = h0.w; gsh[4] = h1.x; gsh[5] = h1.y; gsh[6] = h1.z; gsh[7] = h1.w;
+  };
+  auto act_one = [&](int k) {  // zero padding stays zero: the activation applies to inside pixels only
 #ifdef ABL_NOACT
     return;
 #endif
-    if constexpr (MODE != 0) {
-      float sc[8], sh[8];
-      const float4* ts = reinterpret_cast<const float4*>(sTab + c * KC + slot * 8);
-      const float4* th = reinterpret_cast<const float4*>(sTab + C + c * KC + slot * 8);
-      const float4 s0 = ts[0], s1 = ts[1], h0 = th[0], h1 = th[1];
-      sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
-      sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
-      uint4 r = gn8<MODE == 2>(pa[k], sc, sh);
-      asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));  // keep it branch free inside the MFMA loop
-      pa[k].x = pval[k] ? r.x : pa[k].x;
-      pa[k].y = pval[k] ? r.y : pa[k].y;
-      pa[k].z = pval[k] ? r.z : pa[k].z;
-      pa[k].w = pval[k] ? r.w : pa[k].w;
-    }
+    uint4 r = gn8<MODE == 2>(pa[k], gsc, gsh);
+    asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));  // unconditional: no branch inside the MFMA loop
+    pa[k].x = pval[k] ? r.x : pa[k].x;
+    pa[k].y = pval[k] ? r.y : pa[k].y;
+    pa[k].z = pval[k] ? r.z : pa[k].z;
+    pa[k].w = pval[k] ? r.w : pa[k].w;
   };
-  auto write = [&](int slot_) {
-    char* dst = sA + slot_ * LDS_A;
+  auto write = [&]() {
 #ifdef ABL_NOLDSW
     return;
 #endif
 #pragma unroll
     for (int k = 0; k < NA; ++k)
-      if (in[k]) *reinterpret_cast<uint4*>(dst + ldo[k]) = pa[k];
+      if (k < NA - 1 || in_last) *reinterpret_cast<uint4*>(sAg + ldo0 + k * 64 * AROW) = pa[k];
   };
 
-  f32x16 acc[2];
+  f32x16 acc[2][2];  // [pixel row of the wave][cout half]
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float ssum[8], ssq[8];  // statistics of the 8 couts this lane writes (row-oriented epilogue role)
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
 
-  // fragment addresses: the wave owns output row `wave` of the tile; lane = pixel l32 (B operand) / cout l32 (A)
-  const int aoff = (wave * HW_ + l32) * AROW + h * 16;
+  // fragment addresses: the wave owns output rows 2 gw, 2 gw + 1 of its group's tile; lane = pixel l32 (B
+  // operand) / cout l32 (A operand)
+  const int aoff = ((2 * gw) * HW_ + l32) * AROW + h * 16;
   const int woff = l32 * WROW + h * 16;
-
-  auto mma = [&](int c, int slot_, auto NEXT_) {  // 36 MFMAs on ring slot `slot_`; activates the chunk in flight
+  auto mma = [&](int c, auto NEXT_) {  // 72 MFMAs on the group's slot; activates the chunk in flight meanwhile
     constexpr bool NEXT = decltype(NEXT_)::value;
-    const char* a = sA + slot_ * LDS_A + aoff;
+    if constexpr (NEXT) act_tab(c ^ 1);
+    const char* a = sAg + aoff;
     const char* w = sW + woff + c * (KC * 2);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -214,18 +256,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsK p) {
 #ifdef ABL_NOMFMA
         continue;
 #endif
-        const uint4 pf = *reinterpret_cast<const uint4*>(a + ((tap / 3) * HW_ + (tap % 3)) * AROW + kb * 32);
-        const uint4 w0 = *reinterpret_cast<const uint4*>(w + tap * C * WROW + kb * 32);
-        const uint4 w1 = *reinterpret_cast<const uint4*>(w + (tap * C + 32) * WROW + kb * 32);
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0),
-                                                        __builtin_bit_cast(bf16x8, pf), acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1),
-                                                        __builtin_bit_cast(bf16x8, pf), acc[1], 0, 0, 0);
+        const int po = ((tap / 3) * HW_ + (tap % 3)) * AROW + kb * 32;
+        const bf16x8 p0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a + po));
+        const bf16x8 p1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a + po + HW_ * AROW));
+        const bf16x8 w0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(w + tap * C * WROW + kb * 32));
+        const bf16x8 w1 =
+            __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(w + (tap * C + 32) * WROW + kb * 32));
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, p0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p0, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, p1, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p1, acc[1][1], 0, 0, 0);
         if constexpr (NEXT) {
           const int s = tap * 2 + kb;
-          if (s == 6) act(0, c ^ 1);
-          if (s == 10) act(1, c ^ 1);
-          if (s == 14) act(2, c ^ 1);
+          if (s >= 4 && s < 4 + 2 * NA && (s & 1) == 0) act_one((s - 4) >> 1);
         }
       }
     }
@@ -236,99 +279,127 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsK p) {
   const int epx = lane >> 3, ecg = lane & 7;
   const bool has_res = p.res != nullptr, has_stats = p.stats != nullptr;
   const float osc = p.out_scale;
-  uint4 rres[4];
+  // All residual loads of a tile are issued before its first store: vmcnt retires in order and counts stores on
+  // gfx950, so a load issued between two stores could only be waited for together with the older store's
+  // round trip to L2.
+  uint4 rres[8];
   auto issue_res = [&](int t) {
     const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
-    const unsigned o = (unsigned)((((ty * TH + wave) * p.W + tx * TW + epx) * p.ldr + ecg * 8) * 2);
+    const unsigned o = (unsigned)((((ty * TH + 2 * gw) * p.W + tx * TW + epx) * p.ldr + ecg * 8) * 2);
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) rres[s4] = ld16(rr, o + (unsigned)(s4 * 8 * p.ldr * 2), 0);
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+        rres[i * 4 + s4] = ld16(rr, o + (unsigned)((i * p.W + s4 * 8) * p.ldr * 2), 0);
   };
   // lane layout of the 32x32 result: column = pixel l32, rows (couts) = (r & 3) + 8 (r >> 2) + 4 h
-  auto epilogue = [&](int t, const float* bz) {
+  auto epilogue = [&](int t) {
     const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
-    const unsigned o = (unsigned)((((ty * TH + wave) * p.W + tx * TW + epx) * p.ldy + ecg * 8) * 2);
+    const unsigned o = (unsigned)((((ty * TH + 2 * gw) * p.W + tx * TW + epx) * p.ldy + ecg * 8) * 2);
+    float bz[8];  // (bias + temb bias) * out_scale of this lane's 8 couts
+    {
+      const float4 b0 = *reinterpret_cast<const float4*>(sTab + 2 * C + ecg * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(sTab + 2 * C + ecg * 8 + 4);
+      bz[0] = b0.x; bz[1] = b0.y; bz[2] = b0.z; bz[3] = b0.w; bz[4] = b1.x; bz[5] = b1.y; bz[6] = b1.z; bz[7] = b1.w;
+    }
 #ifdef ABL_NOEPI
-    if (acc[0][0] + acc[1][3] == 12345.678f) reinterpret_cast<float*>(p.y)[tid] = acc[0][1];
+    if (acc[0][0][0] + acc[1][1][3] == 12345.678f) reinterpret_cast<float*>(p.y)[tid] = acc[0][1][1];
     return;
 #endif
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      if ((l32 >> 3) == s4) {  // the 8 pixels of this pass hand over their 8 quads (all 64 couts)
-        char* dst = sE + (l32 & 7) * EROW + h * 16;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+      for (int s4 = 0; s4 < 4; ++s4) {
+        if ((l32 >> 3) == s4) {  // the 8 pixels of this pass hand over their 8 quads (all 64 couts)
+          char* dst = sE + (l32 & 7) * EROW + h * 16;
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(dst + (j * 32 + g * 8) * 4) =
-                make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
-      }
-      __builtin_amdgcn_wave_barrier();
-      const float4 a0 = *reinterpret_cast<const float4*>(sE + epx * EROW + ecg * 32);
-      const float4 a1 = *reinterpret_cast<const float4*>(sE + epx * EROW + ecg * 32 + 16);
-      __builtin_amdgcn_wave_barrier();
-      float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], osc, bz[j]);
-      if (has_res) {
-        const uint4 u = rres[s4];
-        v[0] = fmaf(__uint_as_float(u.x << 16), osc, v[0]); v[1] = fmaf(__uint_as_float(u.x & 0xffff0000u), osc, v[1]);
-        v[2] = fmaf(__uint_as_float(u.y << 16), osc, v[2]); v[3] = fmaf(__uint_as_float(u.y & 0xffff0000u), osc, v[3]);
-        v[4] = fmaf(__uint_as_float(u.z << 16), osc, v[4]); v[5] = fmaf(__uint_as_float(u.z & 0xffff0000u), osc, v[5]);
-        v[6] = fmaf(__uint_as_float(u.w << 16), osc, v[6]); v[7] = fmaf(__uint_as_float(u.w & 0xffff0000u), osc, v[7]);
-      }
-      if (has_stats) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          ssum[j] += v[j];
-          ssq[j] = fmaf(v[j], v[j], ssq[j]);
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<float4*>(dst + (j * 32 + g * 8) * 4) = make_float4(
+                  acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
         }
+        __builtin_amdgcn_wave_barrier();
+        const float4 a0 = *reinterpret_cast<const float4*>(sE + epx * EROW + ecg * 32);
+        const float4 a1 = *reinterpret_cast<const float4*>(sE + epx * EROW + ecg * 32 + 16);
+        __builtin_amdgcn_wave_barrier();
+        float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], osc, bz[j]);
+        if (has_res) {
+          const uint4 u = rres[i * 4 + s4];
+          v[0] = fmaf(__uint_as_float(u.x << 16), osc, v[0]); v[1] = fmaf(__uint_as_float(u.x & 0xffff0000u), osc, v[1]);
+          v[2] = fmaf(__uint_as_float(u.y << 16), osc, v[2]); v[3] = fmaf(__uint_as_float(u.y & 0xffff0000u), osc, v[3]);
+          v[4] = fmaf(__uint_as_float(u.z << 16), osc, v[4]); v[5] = fmaf(__uint_as_float(u.z & 0xffff0000u), osc, v[5]);
+          v[6] = fmaf(__uint_as_float(u.w << 16), osc, v[6]); v[7] = fmaf(__uint_as_float(u.w & 0xffff0000u), osc, v[7]);
+        }
+        if (has_stats) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            ssum[j] += v[j];
+            ssq[j] = fmaf(v[j], v[j], ssq[j]);
+          }
+        }
+        u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                      pack_bf16x2(v[6], v[7])};
+        __builtin_amdgcn_raw_buffer_store_b128(ov, ry, o + (unsigned)((i * p.W + s4 * 8) * p.ldy * 2), 0, 0);
       }
-      u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-      __builtin_amdgcn_raw_buffer_store_b128(ov, ry, o + (unsigned)(s4 * 8 * p.ldy * 2), 0, 0);
-    }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   };
 
-  // ---- pipeline
-  issue(0);
-  __syncthreads();  // tables visible
-  float bz[8];      // (bias + temb bias) * out_scale of this lane's 8 couts
-  {
-    const float4 b0 = *reinterpret_cast<const float4*>(sTab + 2 * C + ecg * 8);
-    const float4 b1 = *reinterpret_cast<const float4*>(sTab + 2 * C + ecg * 8 + 4);
-    bz[0] = b0.x; bz[1] = b0.y; bz[2] = b0.z; bz[3] = b0.w; bz[4] = b1.x; bz[5] = b1.y; bz[6] = b1.z; bz[7] = b1.w;
-  }
+  // ---- pipeline.  Phase P1 = multiply the chunk in the group's slot; phase P2 = activate + stage the next chunk,
+  // fetch the one after, finish the tile.  Group 1 starts one barrier late, so P1 of one group runs beside P2 of
+  // the other.
+  WT_DECL
+  sync_lds();  // weights, tables and descriptors visible
+  if (Qg > 0) {
+    issue(0);
+    act_tab(0);
 #pragma unroll
-  for (int k = 0; k < NA; ++k) act(k, 0);
-  write(0);
-  issue(1);
-  for (int q = 0; q < Q; q += 2) {
-    const int t = t0 + (q >> 1);
-    // chunk 0 of the tile: the tile's second chunk is in flight
-    __syncthreads();
-    mma(0, 0, std::true_type{});
-    write(1);
-    const bool more = q + 2 < Q;
-    if (more) issue(q + 2);  // first chunk of the next tile: lands during the MFMAs + epilogue below
-    if (has_res) issue_res(t);
-    // chunk 1
-    __syncthreads();
-    if (more) {
-      mma(1, 1, std::true_type{});
-      write(0);
-      issue(q + 3);
-    } else {
-      mma(1, 1, std::false_type{});
-    }
-    epilogue(t, bz);
+    for (int k = 0; k < NA; ++k) act_one(k);
+    write();
+    issue(1);
   }
+  sync_lds();
+  if (group == 1) sync_lds();
+  WT_MARK(4)
+  for (int s = 0; s < steps; ++s) {
+    for (int c = 0; c < 2; ++c) {
+      const int q = 2 * s + c;
+      const bool live = q < Qg;
+      if (live) {
+        if (q + 1 < Qg) mma(c, std::true_type{});
+        else mma(c, std::false_type{});
+      }
+      WT_MARK(0)
+      sync_lds();
+      WT_MARK(1)
+      if (live) {
+        if (c == 1 && has_res) issue_res(tile_of(q));
+        WT_MARK(6)
+        if (q + 1 < Qg) {
+          WT_MARK(7)
+          write();
+          WT_MARK(8)
+          if (q + 2 < Qg) issue(q + 2);
+          WT_MARK(9)
+        }
+        if (c == 1) epilogue(tile_of(q));
+      }
+      WT_MARK(2)
+      sync_lds();
+      WT_MARK(3)
+    }
+  }
+  if (group == 0) sync_lds();
 
   // ---- statistics: 64 threads (8 per wave) share a cout group; reduce them in fp64
-  if (has_stats) {
-    __syncthreads();  // LDS is free now
+  if (has_stats) {  // (the loop above ends on a block barrier: LDS is free now)
     float* red = reinterpret_cast<float*>(smem);
     *reinterpret_cast<float4*>(red + tid * RED_ROW) = make_float4(ssum[0], ssum[1], ssum[2], ssum[3]);
     *reinterpret_cast<float4*>(red + tid * RED_ROW + 4) = make_float4(ssum[4], ssum[5], ssum[6], ssum[7]);
@@ -344,6 +415,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsK p) {
       p.stats[(((long)b * p.G + part) * C + co) * 2 + st] = a;
     }
   }
+  WT_MARK(5)
+  WT_FLUSH
 }
 
 int ws_blocks_per_image(const ConvArgs& a) {
@@ -364,11 +437,13 @@ int ws_blocks_per_image(const ConvArgs& a) {
 
 }  // namespace
 
-// The layers this kernel takes over from conv_mfma.hip (DIFFSEP_CONV_WS=0 switches it off for A/B runs).
+// The layers this kernel can take over from conv_mfma.hip when DIFFSEP_CONV_WS=1.  It is parity-tested but not
+// faster than the generic kernel yet (both ~160 us for 64->64 @256^2, B=16), so it is off by default.
 bool ds_conv_ws_eligible(const ConvArgs& a) {
-  static int on = -1;
-  if (on < 0) { const char* v = getenv("DIFFSEP_CONV_WS"); on = v ? atoi(v) : 1; }
+  const char* v = getenv("DIFFSEP_CONV_WS");  // experimental: opt-in (see profiles/experiments/README.md)
+  const int on = v ? atoi(v) : 0;
   return on && a.dtype == DS_BF16 && a.taps == 9 && a.Cin == C && a.Cout == C && !a.x2 && a.w_bs == 0 &&
+         !a.w_chunked &&
          a.bias_mode == 0 && !a.div_b && a.H % TH == 0 && a.W % TW == 0 && a.ldx >= C && a.ldy >= C &&
          (!a.res || a.ldr >= C);
 }

@@ -131,7 +131,7 @@ template <> __device__ inline void pack8<bf16_t>(const float* f, uint4* u) {
 struct ConvK {  // kernel-side copy of ConvArgs (typed by the template)
   const void* x; long x_bs; int ldx; int C1;
   const void* x2; long x2_bs; int ldx2;
-  const void* w; long w_bs;
+  const void* w; long w_bs; int w_chunked;
   const float* gn_scale; const float* gn_shift; int gn_act;
   const float* bias; const float* bias_b; int bias_b_ld; int bias_mode;
   const float* div_b;
@@ -266,7 +266,11 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
       tap = k / Q;
     }
     const bool ok = b_in(k) && n0 + col < p.Cout && tap < TAPS;
-    vob[k] = ok ? (unsigned)(((n0 + col) * TAPS + tap) * p.Cin + vch) * ESZ : DS_OOB;
+    // weights: [Cout][tap][Cin] or, chunk-major, [Cin / KC][tap][Cout][KC] (a stage's rows are then contiguous:
+    // full 128-byte lines per request instead of 64-byte pieces)
+    vob[k] = !ok ? DS_OOB
+                 : p.w_chunked ? (unsigned)((tap * p.Cout + n0 + col) * KC + vch) * ESZ
+                               : (unsigned)(((n0 + col) * TAPS + tap) * p.Cin + vch) * ESZ;
   }
 
   f32x16 acc[WM][WN];
@@ -302,7 +306,8 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     const int width = (second ? C2 : C1) - cb;           // channels left in the source (>= 1)
     const int wb = second ? C1 + cb : cb;                // channel offset inside the weights / GN tables
     ch_ok = vch < width;
-    const unsigned so = (unsigned)cb * ESZ, sw = (unsigned)wb * ESZ;
+    const unsigned so = (unsigned)cb * ESZ;
+    const unsigned sw = p.w_chunked ? (unsigned)(wb / KC) * (unsigned)(TAPS * p.Cout * KC * ESZ) : (unsigned)wb * ESZ;
 #ifdef ABL_NOLOAD
     return;
 #endif
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
           for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < WN; ++j) Mma<T>::run(af[i], bfr[j], acc[i][j]);
+            for (int j = 0; j < WN; ++j) Mma<T>::run(bfr[j], af[i], acc[i][j]);  // D[cout][pixel]
           if constexpr (NEXT) {
             const int s = tap * NKB + kb;
             if (s >= S0) {
@@ -430,7 +435,6 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
 
   // ---- epilogue: accumulators -> LDS (fp32, [pixel][cout]) -> bias / temb / residual / scale -> 16-byte
   // stores, in EP passes over the wave's M blocks (a smaller staging buffer lets more blocks share a CU).
-  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 h.
   const __amdgpu_buffer_rsrc_t ry =
       make_rsrc(reinterpret_cast<T*>(p.y) + (long)b * p.y_bs, (unsigned)M * p.ldy * ESZ);
   const __amdgpu_buffer_rsrc_t rr = make_rsrc(
@@ -473,24 +477,33 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     // makes them come out as exact zeros without any per-element select
 #pragma unroll
     for (int j = 0; j < 8; ++j) bv[j] = (co + j < p.Cout) ? b1[j] + b2[j] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(bv[j]));  // computed once, not rematerialised per row
   }
   // tiles that overhang the image must keep their outside rows out of the statistics
   const bool overhang = (TAPS == 9) ? (y0 + TH > p.H || x0 + TW > p.W) : (m0 + BM > M);
+  // the common case (column bias, no division, whole tile inside the image, whole cout groups) runs without any
+  // per-element selects; everything else takes the general path
+  const bool lean = p.bias_mode == 0 && !p.div_b && !overhang && n0 + BN <= cout8;
   float ssum[8], ssq[8];  // GroupNorm statistics of what this thread writes (consumed by the next GN)
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
 #pragma unroll
   for (int e = 0; e < EP; ++e) {
     __syncthreads();  // fragment reads (e = 0) / the previous pass's reads are done
+    // C/D layout of the 32x32 MFMA with the weights as the A operand: lane = pixel l32 of the M block, register
+    // quad g = couts 8 g + 4 h .. + 3 of the N block: one 16-byte LDS write per quad
 #pragma unroll
     for (int i = 0; i < WME; ++i)
 #pragma unroll
       for (int j = 0; j < WN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int lp = (wm * WME + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int cc = (wn * WN + j) * 32 + l32;
-          *reinterpret_cast<float*>(smem + lp * OROW + cc * 4) = acc[e * WME + i][j][r];
+        for (int g = 0; g < 4; ++g) {
+          const int lp = (wm * WME + i) * 32 + l32;
+          const int cc = (wn * WN + j) * 32 + 8 * g + 4 * h;
+          *reinterpret_cast<float4*>(smem + lp * OROW + cc * 4) =
+              make_float4(acc[e * WME + i][j][4 * g], acc[e * WME + i][j][4 * g + 1], acc[e * WME + i][j][4 * g + 2],
+                          acc[e * WME + i][j][4 * g + 3]);
         }
     // rows of this thread: pixel index (or -1) -> byte offsets of its 8-channel vector in y / res
     constexpr int NROW = (BM / EP) / (256 / NCG);
@@ -532,42 +545,65 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     __syncthreads();
     CT_MARK(7)
     uint4 oraw[NROW][RV];
+    if (lean) {
+      const float osc = p.out_scale;
+      float bs[8];
 #pragma unroll
-    for (int it = 0; it < NROW; ++it) {
-      const int m = mrow[it];
-      const int lp = tid / NCG + it * (256 / NCG);
-      float v[8];
-      const float4 a0 = *reinterpret_cast<const float4*>(smem + lp * OROW + cg * 32);
-      const float4 a1 = *reinterpret_cast<const float4*>(smem + lp * OROW + cg * 32 + 16);
-      v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-      float rv[8];
-      unpack8<T>(rraw[it], rv);
-      if (p.div_b) {
+      for (int j = 0; j < 8; ++j) bs[j] = bv[j] * osc;
+      const bool has_res = p.res != nullptr, has_stats = p.stats != nullptr;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = v[j] / dvs;
-      }
-      if (p.bias_mode == 1 && p.bias) {  // row bias (the V^T GEMM of the attention block)
-        const float rowb = p.bias[m < 0 ? 0 : m];
+      for (int it = 0; it < NROW; ++it) {
+        const int lp = tid / NCG + it * (256 / NCG);
+        const float4 a0 = *reinterpret_cast<const float4*>(smem + lp * OROW + cg * 32);
+        const float4 a1 = *reinterpret_cast<const float4*>(smem + lp * OROW + cg * 32 + 16);
+        float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (co + j < p.Cout) ? v[j] + rowb : 0.f;
-      }
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], osc, bs[j]);
+        if (has_res) {
+          float rv[8];
+          unpack8<T>(rraw[it], rv);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (v[j] + bv[j] + rv[j]) * p.out_scale;
-      if (!overhang) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          ssum[j] += v[j];
-          ssq[j] = fmaf(v[j], v[j], ssq[j]);
+          for (int j = 0; j < 8; ++j) v[j] = fmaf(rv[j], osc, v[j]);
         }
-      } else {
+        if (has_stats) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            ssum[j] += v[j];
+            ssq[j] = fmaf(v[j], v[j], ssq[j]);
+          }
+        }
+        pack8<T>(v, oraw[it]);
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < NROW; ++it) {
+        const int m = mrow[it];
+        const int lp = tid / NCG + it * (256 / NCG);
+        float v[8];
+        const float4 a0 = *reinterpret_cast<const float4*>(smem + lp * OROW + cg * 32);
+        const float4 a1 = *reinterpret_cast<const float4*>(smem + lp * OROW + cg * 32 + 16);
+        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+        float rv[8];
+        unpack8<T>(rraw[it], rv);
+        if (p.div_b) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = v[j] / dvs;
+        }
+        if (p.bias_mode == 1 && p.bias) {  // row bias (the V^T GEMM of the attention block)
+          const float rowb = p.bias[m < 0 ? 0 : m];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (co + j < p.Cout) ? v[j] + rowb : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (v[j] + bv[j] + rv[j]) * p.out_scale;
         const float keep = m < 0 ? 0.f : 1.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           ssum[j] = fmaf(keep, v[j], ssum[j]);
           ssq[j] = fmaf(keep * v[j], v[j], ssq[j]);
         }
+        pack8<T>(v, oraw[it]);
       }
-      pack8<T>(v, oraw[it]);
     }
     CT_MARK(8)
 #pragma unroll
@@ -615,6 +651,9 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   k.x = a.x; k.x_bs = a.x_bs; k.ldx = a.ldx; k.C1 = a.x2 ? a.C1 : a.Cin;
   k.x2 = a.x2; k.x2_bs = a.x2_bs; k.ldx2 = a.ldx2;
   k.w = a.w; k.w_bs = a.w_bs;
+  DS_CHECK(a.w_chunked == 0 || (a.w_chunked == KC && a.Cin % KC == 0 && (!a.x2 || a.C1 % KC == 0)),
+           "conv: chunk-major weights need kc == the kernel's chunk width and whole chunks per source");
+  k.w_chunked = a.w_chunked ? 1 : 0;
   k.gn_scale = a.gn_scale; k.gn_shift = a.gn_shift; k.gn_act = a.gn_act;
   k.bias = a.bias; k.bias_b = a.bias_b; k.bias_b_ld = a.bias_b_ld; k.bias_mode = a.bias_mode; k.div_b = a.div_b;
   k.res = a.res; k.res_bs = a.res_bs; k.ldr = a.ldr; k.out_scale = a.out_scale;
@@ -658,6 +697,12 @@ static int launch_typed(const ConvArgs& a, hipStream_t st) {
     case 4: return launch_cfg<T, 1, 8, 32, 32, 2, 1, KC1>(a, st);
     default: return launch_cfg<T, 1, 8, 8, 64, 1, 1, KC1>(a, st);
   }
+}
+
+// chunk width (channels per K stage) of the kernel that would run this problem: the kc of chunk-major weights
+int ds_conv_chunk(int taps, int dtype) {
+  if (dtype == DS_F32) return taps == 9 ? 16 : 32;
+  return taps == 9 ? 32 : 64;
 }
 
 // grid.x of the launch = number of output tiles per image (the stride of the statistics partials)

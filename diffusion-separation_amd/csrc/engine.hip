@@ -1085,11 +1085,12 @@ extern "C" int32_t diffsep_conv2d_fused(const void* x, const void* x2, int32_t C
                                         const float* bias_b, const void* res, void* y, int32_t B, int32_t H, int32_t W,
                                         int32_t Cin, int32_t Cout, int32_t ksize, int32_t ldx, int32_t ldx2,
                                         int32_t ldr, int32_t ldy, float out_scale, int32_t dtype, double* stats,
-                                        void* stream) {
+                                        int32_t w_chunk, void* stream) {
   DS_CHECK(ksize == 1 || ksize == 3, "conv2d: ksize must be 1 or 3");
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.stats_out = stats;
+  a.w_chunked = w_chunk;
   a.x = x; a.x_bs = (long)H * W * ldx; a.ldx = ldx;
   a.x2 = x2; a.x2_bs = (long)H * W * ldx2; a.ldx2 = ldx2; a.C1 = C1;
   a.gn_scale = gn_scale; a.gn_shift = gn_shift; a.gn_act = gn_act;
@@ -1101,6 +1102,8 @@ extern "C" int32_t diffsep_conv2d_fused(const void* x, const void* x2, int32_t C
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.taps = ksize == 3 ? 9 : 1; a.dtype = dtype;
   return ds_launch_conv(a, (hipStream_t)stream);
 }
+
+extern "C" int32_t diffsep_conv2d_chunk(int32_t ksize, int32_t dtype) { return ds_conv_chunk(ksize == 3 ? 9 : 1, dtype); }
 
 extern "C" int32_t diffsep_conv2d_tiles(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                                         int32_t dtype) {

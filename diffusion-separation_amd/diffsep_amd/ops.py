@@ -29,14 +29,22 @@ def to_nchw(y, c=None):
     return (y if c is None else y[:, :c]).contiguous()
 
 
-def pack_conv_weight(w, dtype):
-    """OIHW float32 -> [O][taps][Ipad] in `dtype` (Ipad = roundup(I, 8))."""
+def pack_conv_weight(w, dtype, chunk=0):
+    """OIHW float32 -> [O][taps][Ipad] in `dtype` (Ipad = roundup(I, 8)); chunk = kc > 0: chunk-major
+    [Ipad/kc][taps][O][kc] (kc = conv2d_chunk(ksize, dtype); needs Ipad % kc == 0)."""
     O, I, kh, kw = w.shape
     wp = w.permute(0, 2, 3, 1).reshape(O, kh * kw, I)
     ipad = (I + 7) // 8 * 8
     if ipad != I:
         wp = torch.nn.functional.pad(wp, (0, ipad - I))
+    if chunk:
+        assert ipad % chunk == 0
+        wp = wp.reshape(O, kh * kw, ipad // chunk, chunk).permute(2, 1, 0, 3)
     return wp.contiguous().to(dtype)
+
+
+def conv2d_chunk(ksize, dtype):
+    return lib().diffsep_conv2d_chunk(ksize, F32 if dtype == torch.float32 else BF16)
 
 
 def upfirdn2d(x, up):
@@ -82,7 +90,7 @@ def groupnorm_stats(x, gamma, beta, groups, eps=1e-6, x2=None):
 
 
 def conv2d_fused(x, wpacked, bias, cout, ksize, x2=None, gn=None, gn_act=1, bias_b=None, res=None, out_scale=1.0,
-                 cout_pad=None, out=None, stats=False):
+                 cout_pad=None, out=None, stats=False, w_chunk=0):
     """stats=True additionally returns the per-tile float64 partials [B,tiles,cout,2] of the output."""
     B, H, W, C1 = x.shape
     Cin = C1 + (x2.shape[-1] if x2 is not None else 0)
@@ -98,7 +106,7 @@ def conv2d_fused(x, wpacked, bias, cout, ksize, x2=None, gn=None, gn_act=1, bias
     check(lib().diffsep_conv2d_fused(_ptr(x), _ptr(x2), C1, _ptr(sc), _ptr(sh), gn_act, _ptr(wpacked), _ptr(bias),
                                      _ptr(bias_b), _ptr(res), _ptr(y), B, H, W, Cin, cout, ksize, C1,
                                      x2.shape[-1] if x2 is not None else 0, res.shape[-1] if res is not None else 0, cp,
-                                     out_scale, _dt(x), _ptr(st), _stream_ptr()))
+                                     out_scale, _dt(x), _ptr(st), w_chunk, _stream_ptr()))
     return (y, st) if stats is not False else y
 
 

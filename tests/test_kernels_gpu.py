@@ -355,7 +355,8 @@ def test_conv_epilogue_statistics(dt, ksize, H, W):
 
 @pytest.mark.parametrize("B,H,W", [(2, 16, 64), (5, 8, 32), (128, 16, 64), (256, 24, 32)])
 @pytest.mark.parametrize("act", [1, 0, None])
-def test_weight_stationary_conv3x3_64_to_64(B, H, W, act):
+def test_weight_stationary_conv3x3_64_to_64(B, H, W, act, monkeypatch):
+    monkeypatch.setenv("DIFFSEP_CONV_WS", "1")  # experimental kernel, opt-in
     # the persistent 64 -> 64 bf16 kernel (conv3x3_ws.hip): one or several tiles per block, image borders,
     # GN affine (+SiLU) on the input, conv bias + per-batch temb bias, residual, 1/sqrt(2), statistics partials
     dt = torch.bfloat16
@@ -383,3 +384,19 @@ def test_weight_stationary_conv3x3_64_to_64(B, H, W, act):
     y2 = ops.conv2d_fused(x, ops.pack_conv_weight(w, dt).to(DEV), None, 64, 3)  # no bias / residual / statistics
     ref2 = F.conv2d(x.float().permute(0, 3, 1, 2), wq, None, padding=1).permute(0, 2, 3, 1)
     assert rel_rms(y2.float(), ref2) < 4e-3
+
+
+@pytest.mark.parametrize("dtype,tol", DT)
+@pytest.mark.parametrize("C1,C2,Cout,H,W,k", [(64, 0, 64, 16, 64, 3), (64, 64, 64, 16, 32, 3), (128, 64, 32, 8, 32, 3),
+                                             (128, 0, 64, 16, 32, 1), (64, 64, 128, 4, 4, 3)])
+def test_conv_chunk_major_weights_are_equivalent(dtype, tol, C1, C2, Cout, H, W, k):
+    # chunk-major weights [Cin/kc][taps][Cout][kc] (the engine's layout) give bit-identical results to [Cout][taps][Cin]
+    B = 2
+    a = rnd(f"ck.a{C1}{H}", (B, H, W, C1)).to(DEV, dtype)
+    bt = rnd(f"ck.b{C2}{H}", (B, H, W, C2)).to(DEV, dtype) if C2 else None
+    w = rnd(f"ck.w{C1}{C2}{Cout}{k}", (Cout, C1 + C2, k, k), 1.0 / math.sqrt(k * k * (C1 + C2)))
+    bias = rnd(f"ck.bias{Cout}", (Cout,), 0.1).to(DEV)
+    kc = ops.conv2d_chunk(k, dtype)
+    y0 = ops.conv2d_fused(a, ops.pack_conv_weight(w, dtype).to(DEV), bias, Cout, k, x2=bt)
+    y1 = ops.conv2d_fused(a, ops.pack_conv_weight(w, dtype, chunk=kc).to(DEV), bias, Cout, k, x2=bt, w_chunk=kc)
+    assert torch.equal(y0, y1)

@@ -12,5 +12,5 @@ done
 wait
 for v in "" NOMFMA NOACT NOLOAD NOLDSW NOEPI; do
   if [ -z "$v" ]; then unset DIFFSEP_LIB; else export DIFFSEP_LIB=$PWD/diffusion-separation_amd/abl/lib_$v.so; fi
-  echo "== variant ${v:-BASE}"; python tools/bench_conv.py bf16 20 ${1:-0,1,2,5,14} 2>&1 | grep -E "^k"
+  echo "== variant ${v:-BASE}"; timeout 60 python tools/bench_conv.py bf16 20 ${1:-0,1,2,5,14} 2>&1 | grep -E "^k"
 done

@@ -20,6 +20,7 @@ SHAPES = [  # (ksize, Cin, Cout, H, W, count per forward)
 
 
 FUSED = os.environ.get("BENCH_CONV_PLAIN", "0") != "1"
+CHUNKED = os.environ.get("BENCH_CONV_CHUNKED", "0") == "1"
 
 
 def main():
@@ -33,16 +34,19 @@ def main():
             continue
         x = torch.randn(B, H, W, ci, device="cuda").to(dt)
         w = (torch.randn(co, k * k, ci, device="cuda") / (k * k * ci) ** 0.5).to(dt)
+        kc = ops.conv2d_chunk(k, dt) if (CHUNKED and ci % ops.conv2d_chunk(k, dt) == 0) else 0
+        if kc:
+            w = w.reshape(co, k * k, ci // kc, kc).permute(2, 1, 0, 3).contiguous()
         b = torch.randn(co, device="cuda")
         cp = (co + 7) // 8 * 8
         y = torch.zeros(B, H, W, cp, device="cuda", dtype=dt)
         if FUSED and ci >= 64:  # GroupNorm + SiLU on the input, residual add: the shape of the engine's launches
             sc, sh = torch.rand(B, ci, device="cuda") + 0.5, torch.randn(B, ci, device="cuda") * 0.1
             res = torch.randn(B, H, W, cp, device="cuda").to(dt)
-            _, st = ops.conv2d_fused(x, w, b, co, k, cout_pad=cp, out=y, stats=True)
-            run = lambda: ops.conv2d_fused(x, w, b, co, k, gn=(sc, sh), gn_act=1, res=res, out_scale=0.7071, cout_pad=cp, out=y, stats=st)
+            _, st = ops.conv2d_fused(x, w, b, co, k, cout_pad=cp, out=y, stats=True, w_chunk=kc)
+            run = lambda: ops.conv2d_fused(x, w, b, co, k, gn=(sc, sh), gn_act=1, res=res, out_scale=0.7071, cout_pad=cp, out=y, stats=st, w_chunk=kc)
         else:
-            run = lambda: ops.conv2d_fused(x, w, b, co, k, cout_pad=cp, out=y)
+            run = lambda: ops.conv2d_fused(x, w, b, co, k, cout_pad=cp, out=y, w_chunk=kc)
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -8,7 +8,7 @@ for f in sorted(glob.glob(os.path.join(d, "p*", "*counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"].split("(")[0][:90]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
-    if "conv_mfma" not in k and len(sys.argv) < 3:
+    if "conv" not in k and len(sys.argv) < 3:
         continue
     print("==", k)
     for c, v in sorted(cs.items()):
