@@ -37,6 +37,10 @@ import torch  # noqa: E402
 
 GFLOP_PER_NFE = {64: 133.83, 128: 532.89}  # SURVEY.md §8d, per utterance at W=256 (probe-counted 2*MAC)
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # MI355X_MICROARCH.md: dense MFMA peaks
+HBM_PEAK_BPS = 8.0e12                          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+KERNEL_NAMES = {"conv3x3_8x32xN64": "conv_mfma_kernel<%(dt)s,9,8,32,64,2,2>",
+                "conv3x3_ws_64to64": "conv3x3_ws1_kernel<%(dt)s> (weight-stationary 64->64)",
+                "gemm1x1_256xN64": "conv_mfma_kernel<%(dt)s,1,8,32,64,2,2>"}
 
 
 def cpu_baseline(nf, T, budget_s=12.0, max_nfe=12):
@@ -149,7 +153,8 @@ def main():
             eng.profile_begin()
             step(10_000)
             prof = eng.profile_end()
-            fl, ms, n, by = prof["conv3x3_8x32xN64"]
+            dom = max(prof, key=lambda k: prof[k][1])  # the kernel instantiation with the most GPU time
+            fl, ms, n, by = prof[dom]
             tot_ms = sum(v[1] for v in prof.values())
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             peak = PEAK_TFLOPS[args.dtype]
@@ -161,13 +166,26 @@ def main():
                     traffic = round(traffic) if traffic else None
                 except Exception:
                     traffic = None
-            roof = {"bound": "mfma", "kernel": "conv_mfma_kernel<%s,9,8,32,64,2,2>" % args.dtype,
-                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "launches": n, "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
+            # the bound is whichever floor of an average launch is higher: HBM at 8 TB/s or dense MFMA at `peak`
+            hbm_floor_us = by / max(n, 1) / HBM_PEAK_BPS * 1e6
+            mfma_floor_us = fl / max(n, 1) / (peak * 1e12) * 1e6
+            kname = KERNEL_NAMES.get(dom, dom) % {"dt": args.dtype}
+            if dom != "conv3x3_8x32xN64":
+                traffic = None  # the committed PMC traffic figure belongs to the generic 3x3 kernel
+            if hbm_floor_us > mfma_floor_us:
+                gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                roof = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": HBM_PEAK_BPS / 1e9,
+                        "unit": "GB/s", "frac": round(gbs / (HBM_PEAK_BPS / 1e9), 4)}
+            else:
+                roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4)}
+            roof.update({"traffic": traffic, "launches": n, "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
                     "flops_per_launch": fl / max(n, 1), "algorithmic_bytes_per_launch": by / max(n, 1),
-                    "hbm_floor_us": round(by / max(n, 1) / 5.0e12 * 1e6, 2),
+                    "hbm_floor_us": round(hbm_floor_us, 2), "mfma_floor_us": round(mfma_floor_us, 2),
+                    "achieved_tflops": round(ach, 2),
+                    "per_kernel_ms": {k: round(v[1], 2) for k, v in prof.items() if v[2]},
                     "all_mfma_kernels_ms": round(tot_ms, 2),
-                    "all_mfma_kernels_tflops": round(sum(v[0] for v in prof.values()) / (tot_ms * 1e-3) / 1e12, 2)}
+                    "all_mfma_kernels_tflops": round(sum(v[0] for v in prof.values()) / (tot_ms * 1e-3) / 1e12, 2)})
 
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")

@@ -75,7 +75,7 @@ constexpr int NA = (HP * (KC / 8) + 255) / 256;  // 16-byte vectors per thread (
 constexpr int EROW = 288;             // epilogue scratch: 8 pixel rows of 64 fp32 (+32 B: conflict-free quad writes)
 constexpr int LDS_E = 8 * EROW;       // per wave
 constexpr int RED_ROW = 20;           // final statistics reduce: 16 floats per thread (+4 pad)
-constexpr int LDS_DESC = NA * 256 * 4; // staging descriptors (global byte offset | border flags) per group thread
+constexpr int LDS_DESC = NA * 256 * 4;  // (variant B: NA1 * 512 * 4, the same) // staging descriptors (global byte offset | border flags) per group thread
 constexpr int LDS_MAIN = LDS_W + 2 * LDS_A + LDS_TAB;
 constexpr int LDS_TOTAL = LDS_MAIN + 8 * LDS_E + LDS_DESC;
 static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget of one CU");
@@ -83,7 +83,7 @@ static_assert(512 * RED_ROW * 4 <= LDS_TOTAL, "the statistics reduce reuses the 
 
 struct WsK {
   const bf16_t* x; long x_bs; int ldx;
-  const bf16_t* w;
+  const bf16_t* w; int w_chunked;
   const float* gn_scale; const float* gn_shift;
   const float* bias; const float* bias_b; int bias_b_ld;
   const bf16_t* res; long res_bs; int ldr;
@@ -145,9 +145,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsK p) {
     for (int k = 0; k < 9; ++k) wv[k] = ld16(rw, (unsigned)(tid + 512 * k) * 16u, 0);
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-      const int v = tid + 512 * k, row = v >> 3, piece = v & 7;
-      const int co = row / 9, tap = row - co * 9;
-      *reinterpret_cast<uint4*>(sW + (tap * C + co) * WROW + piece * 16) = wv[k];
+      const int v = tid + 512 * k;
+      int dst;
+      if (p.w_chunked) {  // [chunk][tap][cout][32 ch]
+        const int row = v >> 2, piece = v & 3;
+        const int co = row & (C - 1), tap = (row >> 6) % 9, chunk = row / (9 * C);
+        dst = (tap * C + co) * WROW + chunk * (KC * 2) + piece * 16;
+      } else {            // [cout][tap][64 ch]
+        const int row = v >> 3, piece = v & 7;
+        const int co = row / 9, tap = row - co * 9;
+        dst = (tap * C + co) * WROW + piece * 16;
+      }
+      *reinterpret_cast<uint4*>(sW + dst) = wv[k];
     }
     if (tid < C) {
       sTab[tid] = p.gn_scale ? p.gn_scale[(long)b * C + tid] : 1.f;
@@ -419,6 +428,246 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsK p) {
   WT_FLUSH
 }
 
+// ---- variant B (DIFFSEP_CONV_WS=2): all 8 waves in the same phase.  A wave owns ONE pixel row x 64 couts
+// (36 MFMAs per chunk); the halo chunks go through a 2-slot ring with ONE barrier per chunk; the chunk in flight
+// is activated in registers between the MFMAs of the same wave; the next tile's first chunk is loading while
+// this tile's epilogue runs.
+constexpr int NA1 = (HP * (KC / 8) + 511) / 512;  // 16-byte vectors per thread per chunk: 3
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sW = smem;
+  char* sA = smem + LDS_W;
+  float* sTab = reinterpret_cast<float*>(smem + LDS_W + 2 * LDS_A);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l32 = lane & 31, h = lane >> 5;
+  const int b = blockIdx.x / p.G, part = blockIdx.x % p.G;
+  const int t0 = (int)((long)part * p.tiles_per_img / p.G);
+  const int nt = (int)((long)(part + 1) * p.tiles_per_img / p.G) - t0;
+  const int Q = 2 * nt;
+  {
+    const __amdgpu_buffer_rsrc_t rw = rsrc(p.w, 9u * C * C * 2u);
+    uint4 wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = ld16(rw, (unsigned)(tid + 512 * k) * 16u, 0);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int v = tid + 512 * k;
+      int dst;
+      if (p.w_chunked) {  // [chunk][tap][cout][32 ch]
+        const int row = v >> 2, piece = v & 3;
+        const int co = row & (C - 1), tap = (row >> 6) % 9, chunk = row / (9 * C);
+        dst = (tap * C + co) * WROW + chunk * (KC * 2) + piece * 16;
+      } else {            // [cout][tap][64 ch]
+        const int row = v >> 3, piece = v & 7;
+        const int co = row / 9, tap = row - co * 9;
+        dst = (tap * C + co) * WROW + piece * 16;
+      }
+      *reinterpret_cast<uint4*>(sW + dst) = wv[k];
+    }
+    if (tid < C) {
+      sTab[tid] = p.gn_scale ? p.gn_scale[(long)b * C + tid] : 1.f;
+      sTab[C + tid] = p.gn_shift ? p.gn_shift[(long)b * C + tid] : 0.f;
+      sTab[2 * C + tid] =
+          ((p.bias ? p.bias[tid] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + tid] : 0.f)) * p.out_scale;
+    }
+  }
+  const int slot = tid & 3;
+  int* sDesc = reinterpret_cast<int*>(smem + LDS_MAIN + 8 * LDS_E);
+#pragma unroll
+  for (int k = 0; k < NA1; ++k) {
+    const int v = tid + 512 * k;
+    const int pix = v >> 2, hy = pix / HW_, hx = pix - hy * HW_;
+    const int rel = (((hy - 1) * p.W + (hx - 1)) * p.ldx + slot * 8) * 2;
+    const int flg = (hy == 0 ? 1 : 0) | (hy == HH_ - 1 ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx == HW_ - 1 ? 8 : 0);
+    sDesc[k * 512 + tid] = rel | flg;
+  }
+  const int ldo0 = (tid >> 2) * AROW + slot * 16;  // vector k is 128 pixels further
+  const bool in_last = tid + 512 * (NA1 - 1) < HP * 4;
+  const __amdgpu_buffer_rsrc_t rx = rsrc(p.x + (long)b * p.x_bs, (unsigned)(p.H * p.W) * p.ldx * 2u);
+  const __amdgpu_buffer_rsrc_t ry = rsrc(p.y + (long)b * p.y_bs, (unsigned)(p.H * p.W) * p.ldy * 2u);
+  const __amdgpu_buffer_rsrc_t rr =
+      rsrc(p.res ? p.res + (long)b * p.res_bs : p.y, p.res ? (unsigned)(p.H * p.W) * p.ldr * 2u : 0u);
+
+  uint4 pa[NA1];
+  bool pval[NA1];
+  auto issue = [&](int q) {
+    const int t = t0 + (q >> 1);
+    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const unsigned edge = (y0 == 0 ? 1u : 0u) | (y0 + TH == p.H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) |
+                          (x0 + TW == p.W ? 8u : 0u);
+    const int tbase = (y0 * p.W + x0) * p.ldx * 2;
+#pragma unroll
+    for (int k = 0; k < NA1; ++k) {
+      const int d = sDesc[k * 512 + tid];
+      pval[k] = (k < NA1 - 1 || in_last) && !((unsigned)d & edge);
+      pa[k] = ld16(rx, pval[k] ? (unsigned)((d & ~15) + tbase) : OOB, (unsigned)(q & 1) * (KC * 2));
+    }
+  };
+  float gsc[8], gsh[8];
+  auto act_tab = [&](int c) {
+    const float4* ts = reinterpret_cast<const float4*>(sTab + c * KC + slot * 8);
+    const float4* th = reinterpret_cast<const float4*>(sTab + C + c * KC + slot * 8);
+    const float4 s0 = ts[0], s1 = ts[1], h0 = th[0], h1 = th[1];
+    gsc[0] = s0.x; gsc[1] = s0.y; gsc[2] = s0.z; gsc[3] = s0.w; gsc[4] = s1.x; gsc[5] = s1.y; gsc[6] = s1.z; gsc[7] = s1.w;
+    gsh[0] = h0.x; gsh[1] = h0.y; gsh[2] = h0.z; gsh[3] = h0.w; gsh[4] = h1.x; gsh[5] = h1.y; gsh[6] = h1.z; gsh[7] = h1.w;
+  };
+  auto act_one = [&](int k) {
+    uint4 r = gn8<MODE == 2>(pa[k], gsc, gsh);
+    asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
+    pa[k].x = pval[k] ? r.x : pa[k].x;
+    pa[k].y = pval[k] ? r.y : pa[k].y;
+    pa[k].z = pval[k] ? r.z : pa[k].z;
+    pa[k].w = pval[k] ? r.w : pa[k].w;
+  };
+  auto write = [&](int sl) {
+    char* dst = sA + sl * LDS_A;
+#pragma unroll
+    for (int k = 0; k < NA1; ++k)
+      if (k < NA1 - 1 || in_last) *reinterpret_cast<uint4*>(dst + ldo0 + k * 128 * AROW) = pa[k];
+  };
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+  const int aoff = (wave * HW_ + l32) * AROW + h * 16;
+  const int woff = l32 * WROW + h * 16;
+  auto mma = [&](int c, int sl, auto NEXT_) {
+    constexpr bool NEXT = decltype(NEXT_)::value;
+    if constexpr (NEXT) act_tab(c ^ 1);
+    const char* a = sA + sl * LDS_A + aoff;
+    const char* w = sW + woff + c * (KC * 2);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const bf16x8 pf = __builtin_bit_cast(
+            bf16x8, *reinterpret_cast<const uint4*>(a + ((tap / 3) * HW_ + (tap % 3)) * AROW + kb * 32));
+        const bf16x8 w0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(w + tap * C * WROW + kb * 32));
+        const bf16x8 w1 =
+            __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(w + (tap * C + 32) * WROW + kb * 32));
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, pf, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, pf, acc[1], 0, 0, 0);
+        if constexpr (NEXT) {
+          const int s = tap * 2 + kb;
+          if (s == 6) act_one(0);
+          if (s == 10) act_one(1);
+          if (s == 14) act_one(2);
+        }
+      }
+    }
+  };
+  char* sE = smem + LDS_MAIN + wave * LDS_E;
+  const int epx = lane >> 3, ecg = lane & 7;
+  const bool has_res = p.res != nullptr, has_stats = p.stats != nullptr;
+  const float osc = p.out_scale;
+  uint4 rres[4];
+  auto issue_res = [&](int t) {
+    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+    const unsigned o = (unsigned)((((ty * TH + wave) * p.W + tx * TW + epx) * p.ldr + ecg * 8) * 2);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) rres[s4] = ld16(rr, o + (unsigned)(s4 * 8 * p.ldr * 2), 0);
+  };
+  auto epilogue = [&](int t) {
+    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+    const unsigned o = (unsigned)((((ty * TH + wave) * p.W + tx * TW + epx) * p.ldy + ecg * 8) * 2);
+    float bz[8];
+    {
+      const float4 b0 = *reinterpret_cast<const float4*>(sTab + 2 * C + ecg * 8);
+      const float4 b1 = *reinterpret_cast<const float4*>(sTab + 2 * C + ecg * 8 + 4);
+      bz[0] = b0.x; bz[1] = b0.y; bz[2] = b0.z; bz[3] = b0.w; bz[4] = b1.x; bz[5] = b1.y; bz[6] = b1.z; bz[7] = b1.w;
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      if ((l32 >> 3) == s4) {
+        char* dst = sE + (l32 & 7) * EROW + h * 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(dst + (j * 32 + g * 8) * 4) =
+                make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      const float4 a0 = *reinterpret_cast<const float4*>(sE + epx * EROW + ecg * 32);
+      const float4 a1 = *reinterpret_cast<const float4*>(sE + epx * EROW + ecg * 32 + 16);
+      __builtin_amdgcn_wave_barrier();
+      float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], osc, bz[j]);
+      if (has_res) {
+        const uint4 u = rres[s4];
+        v[0] = fmaf(__uint_as_float(u.x << 16), osc, v[0]); v[1] = fmaf(__uint_as_float(u.x & 0xffff0000u), osc, v[1]);
+        v[2] = fmaf(__uint_as_float(u.y << 16), osc, v[2]); v[3] = fmaf(__uint_as_float(u.y & 0xffff0000u), osc, v[3]);
+        v[4] = fmaf(__uint_as_float(u.z << 16), osc, v[4]); v[5] = fmaf(__uint_as_float(u.z & 0xffff0000u), osc, v[5]);
+        v[6] = fmaf(__uint_as_float(u.w << 16), osc, v[6]); v[7] = fmaf(__uint_as_float(u.w & 0xffff0000u), osc, v[7]);
+      }
+      if (has_stats) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          ssum[j] += v[j];
+          ssq[j] = fmaf(v[j], v[j], ssq[j]);
+        }
+      }
+      u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+      __builtin_amdgcn_raw_buffer_store_b128(ov, ry, o + (unsigned)(s4 * 8 * p.ldy * 2), 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  };
+
+  sync_lds();  // weights, tables, descriptors visible
+  issue(0);
+  act_tab(0);
+#pragma unroll
+  for (int k = 0; k < NA1; ++k) act_one(k);
+  write(0);
+  issue(1);
+  for (int q = 0; q < Q; q += 2) {
+    const int t = t0 + (q >> 1);
+    sync_lds();                      // slot 0 written by everybody; slot 1 no longer read
+    mma(0, 0, std::true_type{});     // activates the tile's second chunk (in flight) meanwhile
+    write(1);
+    const bool more = q + 2 < Q;
+    if (has_res) issue_res(t);       // before the prefetch: needed first
+    if (more) issue(q + 2);          // first chunk of the next tile: lands during the MFMAs + epilogue below
+    sync_lds();
+    if (more) {
+      mma(1, 1, std::true_type{});
+      write(0);
+      issue(q + 3);
+    } else {
+      mma(1, 1, std::false_type{});
+    }
+    epilogue(t);
+  }
+  if (has_stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    *reinterpret_cast<float4*>(red + tid * RED_ROW) = make_float4(ssum[0], ssum[1], ssum[2], ssum[3]);
+    *reinterpret_cast<float4*>(red + tid * RED_ROW + 4) = make_float4(ssum[4], ssum[5], ssum[6], ssum[7]);
+    *reinterpret_cast<float4*>(red + tid * RED_ROW + 8) = make_float4(ssq[0], ssq[1], ssq[2], ssq[3]);
+    *reinterpret_cast<float4*>(red + tid * RED_ROW + 12) = make_float4(ssq[4], ssq[5], ssq[6], ssq[7]);
+    __syncthreads();
+    if (tid < 128) {
+      const int co = tid >> 1, st = tid & 1;
+      const float* src = red + (co >> 3) * RED_ROW + st * 8 + (co & 7);
+      double a = 0.0;
+#pragma unroll 8
+      for (int i = 0; i < 64; ++i) a += (double)src[i * 8 * RED_ROW];
+      p.stats[(((long)b * p.G + part) * C + co) * 2 + st] = a;
+    }
+  }
+}
+
 int ws_blocks_per_image(const ConvArgs& a) {
   static int cus = 0;
   if (!cus) {
@@ -437,13 +686,12 @@ int ws_blocks_per_image(const ConvArgs& a) {
 
 }  // namespace
 
-// The layers this kernel can take over from conv_mfma.hip when DIFFSEP_CONV_WS=1.  It is parity-tested but not
-// faster than the generic kernel yet (both ~160 us for 64->64 @256^2, B=16), so it is off by default.
+// The layers these kernels take over from conv_mfma.hip (DIFFSEP_CONV_WS=0 switches them off for A/B runs).
 bool ds_conv_ws_eligible(const ConvArgs& a) {
-  const char* v = getenv("DIFFSEP_CONV_WS");  // experimental: opt-in (see profiles/experiments/README.md)
-  const int on = v ? atoi(v) : 0;
+  const char* v = getenv("DIFFSEP_CONV_WS");  // 0: off, 1: ping-pong variant, 2 (default): one-phase variant
+  const int on = v ? atoi(v) : 2;
   return on && a.dtype == DS_BF16 && a.taps == 9 && a.Cin == C && a.Cout == C && !a.x2 && a.w_bs == 0 &&
-         !a.w_chunked &&
+         (a.w_chunked == 0 || a.w_chunked == KC) &&
          a.bias_mode == 0 && !a.div_b && a.H % TH == 0 && a.W % TW == 0 && a.ldx >= C && a.ldy >= C &&
          (!a.res || a.ldr >= C);
 }
@@ -452,7 +700,7 @@ int ds_conv_ws_tiles(const ConvArgs& a) { return ws_blocks_per_image(a); }
 int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st) {
   WsK k;
   k.x = reinterpret_cast<const bf16_t*>(a.x); k.x_bs = a.x_bs; k.ldx = a.ldx;
-  k.w = reinterpret_cast<const bf16_t*>(a.w);
+  k.w = reinterpret_cast<const bf16_t*>(a.w); k.w_chunked = a.w_chunked;
   k.gn_scale = a.gn_scale; k.gn_shift = a.gn_shift;
   k.bias = a.bias; k.bias_b = a.bias_b; k.bias_b_ld = a.bias_b_ld;
   k.res = reinterpret_cast<const bf16_t*>(a.res); k.res_bs = a.res_bs; k.ldr = a.ldr;
@@ -471,6 +719,21 @@ int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st) {
     attr_done = true;
   }
   const dim3 grid(a.B * k.G), block(512);
+  const char* v = getenv("DIFFSEP_CONV_WS");
+  if (!v || atoi(v) == 2) {
+    static bool attr1 = false;
+    if (!attr1) {
+      DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws1_kernel<1>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+      DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws1_kernel<2>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+      attr1 = true;
+    }
+    if (mode == 1) hipLaunchKernelGGL(conv3x3_ws1_kernel<1>, grid, block, LDS_TOTAL, st, k);
+    else hipLaunchKernelGGL(conv3x3_ws1_kernel<2>, grid, block, LDS_TOTAL, st, k);
+    DS_LAUNCH_CHECK();
+    return 0;
+  }
   if (mode == 1) hipLaunchKernelGGL(conv3x3_ws_kernel<1>, grid, block, LDS_TOTAL, st, k);
   else hipLaunchKernelGGL(conv3x3_ws_kernel<2>, grid, block, LDS_TOTAL, st, k);
   DS_LAUNCH_CHECK();

@@ -259,10 +259,11 @@ extern "C" int32_t diffsep_padded_frames(const diffsep_model_config* cfg, int64_
 }
 
 // ------------------------------------------------------------------ weight repack kernel
-// dst[o][tap][i] (i < Ipad, zero padded) = src[o*so + i*si + tap*st]
+// dst[o][tap][i] (i < Ipad, zero padded) = src[o*so + i*si + tap*st]; kc > 0: chunk-major dst[i / kc][tap][o][i % kc]
+// (one K stage of the conv kernel contiguous in memory -> whole 128-byte lines per request)
 template <typename T>
 __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ src, T* __restrict__ dst, int O, int I,
-                                                     int Ipad, int taps, long so, long si, long st) {
+                                                     int Ipad, int taps, long so, long si, long st, int kc) {
   const long total = (long)O * taps * Ipad;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int i = (int)(idx % Ipad);
@@ -270,9 +271,12 @@ __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ s
     const int tap = (int)(r % taps);
     const int o = (int)(r / taps);
     const float v = (i < I) ? src[o * so + i * si + tap * st] : 0.f;
-    Elt<T>::st(dst + idx, v);
+    const long d = kc ? ((((long)(i / kc) * taps + tap) * O + o) * kc + i % kc) : idx;
+    Elt<T>::st(dst + d, v);
   }
 }
+// Which weights the engine keeps chunk-major: every conv whose input channels (and concat split) are multiples of 64
+static int weight_chunk(int taps, int cin, int dtype) { return (cin % 64 == 0) ? ds_conv_chunk(taps, dtype) : 0; }
 
 // ------------------------------------------------------------------ engine
 struct Tn {  // NHWC view; optionally the in-place channel concat of two tensors (C1 channels from p, rest from p2)
@@ -332,7 +336,7 @@ struct diffsep_engine {
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
 };
-#define DS_NCLS 6
+#define DS_NCLS 7
 static hipEvent_t fj_event(diffsep_engine* e) {
   if (e->fj_i == e->fj_events.size()) {
     hipEvent_t v = nullptr;
@@ -413,20 +417,20 @@ static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.B = B; a.H = x.H; a.W = x.W; a.Cin = x.C; a.Cout = Cout; a.taps = taps; a.dtype = e->cfg.dtype;
-  if (want_stats) {  // the consumer's GroupNorm reads these partials instead of re-reading the tensor
-    y.nt = ds_conv_tiles(a);
-    y.st = (double*)e_alloc(e, (size_t)B * y.nt * Cout * 2 * sizeof(double));
-    a.stats_out = y.st;
-  }
-  if (e->dry) return 0;
   a.x = x.p; a.x_bs = (long)x.H * x.W * x.ld; a.ldx = x.ld;
   a.x2 = x.p2; a.x2_bs = (long)x.H * x.W * x.ld2; a.ldx2 = x.ld2; a.C1 = x.C1;
   a.gn_scale = gn ? gn->scale : nullptr; a.gn_shift = gn ? gn->shift : nullptr; a.gn_act = gn_act;
-  a.w = w; a.w_bs = 0;
+  a.w = w; a.w_bs = 0; a.w_chunked = weight_chunk(taps, x.C, e->cfg.dtype);
   a.bias = bias; a.bias_b = bias_b; a.bias_b_ld = bias_b_ld; a.bias_mode = 0; a.div_b = div_b;
   a.res = res ? res->p : nullptr; a.res_bs = res ? (long)res->H * res->W * res->ld : 0; a.ldr = res ? res->ld : 0;
   a.out_scale = scale;
   a.y = y.p; a.y_bs = (long)y.H * y.W * y.ld; a.ldy = y.ld;
+  if (want_stats) {  // the consumer's GroupNorm reads these partials instead of re-reading the tensor
+    y.nt = ds_conv_tiles(a);  // (depends on which kernel takes the launch: every field above matters)
+    y.st = (double*)e_alloc(e, (size_t)B * y.nt * Cout * 2 * sizeof(double));
+    a.stats_out = y.st;
+  }
+  if (e->dry) return 0;
   return conv_launch_prof(e, a, st);
 }
 
@@ -778,17 +782,19 @@ extern "C" int32_t diffsep_engine_create(const diffsep_model_config* cfg, const 
   DS_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
   DS_HIP(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
 
-  auto repack = [&](const PRef& src, long pk, int O, int I, int taps, long so, long si, long stp) -> int {
+  auto repack = [&](const PRef& src, long pk, int O, int I, int taps, long so, long si, long stp,
+                    bool allow_chunk = true) -> int {
     const int Ipad = rup8(I);
+    const int kc = allow_chunk ? weight_chunk(taps, I, cfg->dtype) : 0;
     const long total = (long)O * taps * Ipad;
     long nb = (total + 255) / 256;
     if (nb > 4096) nb = 4096;
     if (cfg->dtype == DS_F32)
       hipLaunchKernelGGL(repack_kernel<float>, dim3(nb), dim3(256), 0, 0, e->d_blob + src.off,
-                         (float*)(e->d_pack) + pk, O, I, Ipad, taps, so, si, stp);
+                         (float*)(e->d_pack) + pk, O, I, Ipad, taps, so, si, stp, kc);
     else
       hipLaunchKernelGGL(repack_kernel<bf16_t>, dim3(nb), dim3(256), 0, 0, e->d_blob + src.off,
-                         (bf16_t*)(e->d_pack) + pk, O, I, Ipad, taps, so, si, stp);
+                         (bf16_t*)(e->d_pack) + pk, O, I, Ipad, taps, so, si, stp, kc);
     DS_LAUNCH_CHECK();
     return 0;
   };
@@ -809,7 +815,8 @@ extern "C" int32_t diffsep_engine_create(const diffsep_model_config* cfg, const 
                          hipMemcpyDeviceToDevice));
         break;
       case MK_ATTN:  // NIN.W is [in][out] (layers.py:678-689): packed as [out][in]
-        for (int i = 0; i < 4; ++i) rc |= repack(m.nin_w[i], m.pk_nin[i], m.in_ch, m.in_ch, 1, 1, m.in_ch, 0);
+        // (the V projection is the A operand of its GEMM: it stays row-major)
+        for (int i = 0; i < 4; ++i) rc |= repack(m.nin_w[i], m.pk_nin[i], m.in_ch, m.in_ch, 1, 1, m.in_ch, 0, i != 2);
         break;
       default: break;
     }
@@ -843,8 +850,8 @@ extern "C" int32_t diffsep_engine_set_graph(diffsep_engine* e, int32_t enable) {
 
 // Per-launch timing of the MFMA contraction kernels inside the real launch sequence: between
 // profile_begin and profile_end every conv/GEMM launch is bracketed by HIP events on its stream
-// (graph replay is bypassed meanwhile).  Arrays have 6 entries: 3x3 {8x32xBN64, 8x32xBN32, 8x8xBN64},
-// then the same three tiles for 1x1/GEMM.  flops = algorithmic 2*taps*Cin*Cout*H*W*B (unpadded).
+// (graph replay is bypassed meanwhile).  Arrays have 7 entries: 3x3 {8x32xBN64, 8x32xBN32, 8x8xBN64},
+// then the same three tiles for 1x1/GEMM, then the weight-stationary 64 -> 64 3x3 kernel.  flops = algorithmic 2*taps*Cin*Cout*H*W*B (unpadded).
 extern "C" int32_t diffsep_engine_profile_begin(diffsep_engine* e) {
   DS_CHECK(e, "null engine");
   e->prof = true;
