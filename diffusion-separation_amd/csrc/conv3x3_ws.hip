@@ -490,21 +490,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
   const __amdgpu_buffer_rsrc_t rr =
       rsrc(p.res ? p.res + (long)b * p.res_bs : p.y, p.res ? (unsigned)(p.H * p.W) * p.ldr * 2u : 0u);
 
-  uint4 pa[NA1];
-  bool pval[NA1];
-  auto issue = [&](int q) {
+  // two register sets: while set (q+1)&1 (the chunk after the one in LDS) is activated and written, set q&1
+  // already receives chunk q+2: every global load has a full chunk phase to land before its first use
+  uint4 pa[2][NA1];
+  bool pval[2][NA1];
+  // global loads are issued ONE per k-step inside the MFMA loop: the texture addresser takes ~25 cycles per
+  // 16-byte wave load, and a burst of them right after the barrier would hold back every wave's first MFMA
+  unsigned ld_edge = 0, ld_soff = 0;
+  int ld_tbase = 0;
+  auto prep = [&](int q) {  // geometry of chunk q (tile q / 2, channels 32 (q & 1) ...)
     const int t = t0 + (q >> 1);
     const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
     const int y0 = ty * TH, x0 = tx * TW;
-    const unsigned edge = (y0 == 0 ? 1u : 0u) | (y0 + TH == p.H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) |
-                          (x0 + TW == p.W ? 8u : 0u);
-    const int tbase = (y0 * p.W + x0) * p.ldx * 2;
+    ld_edge = (y0 == 0 ? 1u : 0u) | (y0 + TH == p.H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + TW == p.W ? 8u : 0u);
+    ld_tbase = (y0 * p.W + x0) * p.ldx * 2;
+    ld_soff = (unsigned)(q & 1) * (KC * 2);
+  };
+  auto issue_one = [&](int set, int k) {
+    const int d = sDesc[k * 512 + tid];
+    pval[set][k] = (k < NA1 - 1 || in_last) && !((unsigned)d & ld_edge);
+    pa[set][k] = ld16(rx, pval[set][k] ? (unsigned)((d & ~15) + ld_tbase) : OOB, ld_soff);
+  };
+  auto issue = [&](int q, int set) {
+    prep(q);
 #pragma unroll
-    for (int k = 0; k < NA1; ++k) {
-      const int d = sDesc[k * 512 + tid];
-      pval[k] = (k < NA1 - 1 || in_last) && !((unsigned)d & edge);
-      pa[k] = ld16(rx, pval[k] ? (unsigned)((d & ~15) + tbase) : OOB, (unsigned)(q & 1) * (KC * 2));
-    }
+    for (int k = 0; k < NA1; ++k) issue_one(set, k);
   };
   float gsc[8], gsh[8];
   auto act_tab = [&](int c) {
@@ -514,19 +524,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
     gsc[0] = s0.x; gsc[1] = s0.y; gsc[2] = s0.z; gsc[3] = s0.w; gsc[4] = s1.x; gsc[5] = s1.y; gsc[6] = s1.z; gsc[7] = s1.w;
     gsh[0] = h0.x; gsh[1] = h0.y; gsh[2] = h0.z; gsh[3] = h0.w; gsh[4] = h1.x; gsh[5] = h1.y; gsh[6] = h1.z; gsh[7] = h1.w;
   };
-  auto act_one = [&](int k) {
-    uint4 r = gn8<MODE == 2>(pa[k], gsc, gsh);
+  auto act_one = [&](int set, int k) {
+    uint4 r = gn8<MODE == 2>(pa[set][k], gsc, gsh);
     asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
-    pa[k].x = pval[k] ? r.x : pa[k].x;
-    pa[k].y = pval[k] ? r.y : pa[k].y;
-    pa[k].z = pval[k] ? r.z : pa[k].z;
-    pa[k].w = pval[k] ? r.w : pa[k].w;
+    pa[set][k].x = pval[set][k] ? r.x : pa[set][k].x;
+    pa[set][k].y = pval[set][k] ? r.y : pa[set][k].y;
+    pa[set][k].z = pval[set][k] ? r.z : pa[set][k].z;
+    pa[set][k].w = pval[set][k] ? r.w : pa[set][k].w;
   };
-  auto write = [&](int sl) {
-    char* dst = sA + sl * LDS_A;
+  auto write = [&](int set) {  // chunk parity = register set = ring slot
+    char* dst = sA + set * LDS_A;
 #pragma unroll
     for (int k = 0; k < NA1; ++k)
-      if (k < NA1 - 1 || in_last) *reinterpret_cast<uint4*>(dst + ldo0 + k * 128 * AROW) = pa[k];
+      if (k < NA1 - 1 || in_last) *reinterpret_cast<uint4*>(dst + ldo0 + k * 128 * AROW) = pa[set][k];
   };
   f32x16 acc[2];
 #pragma unroll
@@ -538,7 +548,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
   for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
   const int aoff = (wave * HW_ + l32) * AROW + h * 16;
   const int woff = l32 * WROW + h * 16;
-  auto mma = [&](int c, int sl, auto NEXT_) {
+  char* sE = smem + LDS_MAIN + wave * LDS_E;
+  const int epx = lane >> 3, ecg = lane & 7;
+  const bool has_res = p.res != nullptr, has_stats = p.stats != nullptr;
+  const float osc = p.out_scale;
+  unsigned res_o = 0;
+  uint4 rres[4];
+  auto mma = [&](int c, int sl, auto NEXT_, bool loads, bool resl) {
     constexpr bool NEXT = decltype(NEXT_)::value;
     if constexpr (NEXT) act_tab(c ^ 1);
     const char* a = sA + sl * LDS_A + aoff;
@@ -554,25 +570,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
             __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(w + (tap * C + 32) * WROW + kb * 32));
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, pf, acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, pf, acc[1], 0, 0, 0);
+        const int s = tap * 2 + kb;
+        if (s < NA1 && loads) issue_one(c, s);                    // chunk q + 2 -> the set chunk q came from
+        if (s >= NA1 && s < NA1 + 4 && resl)                      // the tile's residual rows
+          rres[s - NA1] = ld16(rr, res_o + (unsigned)((s - NA1) * 8 * p.ldr * 2), 0);
         if constexpr (NEXT) {
-          const int s = tap * 2 + kb;
-          if (s == 6) act_one(0);
-          if (s == 10) act_one(1);
-          if (s == 14) act_one(2);
+          if (s == 8) act_one(c ^ 1, 0);
+          if (s == 11) act_one(c ^ 1, 1);
+          if (s == 14) act_one(c ^ 1, 2);
         }
       }
     }
   };
-  char* sE = smem + LDS_MAIN + wave * LDS_E;
-  const int epx = lane >> 3, ecg = lane & 7;
-  const bool has_res = p.res != nullptr, has_stats = p.stats != nullptr;
-  const float osc = p.out_scale;
-  uint4 rres[4];
-  auto issue_res = [&](int t) {
+  auto prep_res = [&](int t) {
     const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
-    const unsigned o = (unsigned)((((ty * TH + wave) * p.W + tx * TW + epx) * p.ldr + ecg * 8) * 2);
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) rres[s4] = ld16(rr, o + (unsigned)(s4 * 8 * p.ldr * 2), 0);
+    res_o = (unsigned)((((ty * TH + wave) * p.W + tx * TW + epx) * p.ldr + ecg * 8) * 2);
   };
   auto epilogue = [&](int t) {
     const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
@@ -624,30 +636,44 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   };
 
+  WT_DECL
   sync_lds();  // weights, tables, descriptors visible
-  issue(0);
+  issue(0, 0);
+  if (Q > 1) issue(1, 1);
   act_tab(0);
 #pragma unroll
-  for (int k = 0; k < NA1; ++k) act_one(k);
+  for (int k = 0; k < NA1; ++k) act_one(0, k);
   write(0);
-  issue(1);
+  WT_MARK(4)
   for (int q = 0; q < Q; q += 2) {
     const int t = t0 + (q >> 1);
-    sync_lds();                      // slot 0 written by everybody; slot 1 no longer read
-    mma(0, 0, std::true_type{});     // activates the tile's second chunk (in flight) meanwhile
-    write(1);
     const bool more = q + 2 < Q;
-    if (has_res) issue_res(t);       // before the prefetch: needed first
-    if (more) issue(q + 2);          // first chunk of the next tile: lands during the MFMAs + epilogue below
+    // ---- chunk 0 (slot 0); set 1 = the tile's second chunk (issued a phase ago), set 0 <- next tile's first
     sync_lds();
+    WT_MARK(0)
+    if (more) prep(q + 2);
+    if (has_res) prep_res(t);        // (the residual is consumed by the epilogue at the end of the next phase)
+    WT_MARK(1)
+    mma(0, 0, std::true_type{}, more, has_res);   // activates set 1, fetches set 0 + the residual meanwhile
+    WT_MARK(2)
+    write(1);
+    WT_MARK(3)
+    // ---- chunk 1 (slot 1); set 0 = next tile's first chunk, set 1 <- next tile's second
+    sync_lds();
+    WT_MARK(0)
     if (more) {
-      mma(1, 1, std::true_type{});
+      prep(q + 3);
+      WT_MARK(1)
+      mma(1, 1, std::true_type{}, true, false);   // activates set 0, fetches set 1 meanwhile
+      WT_MARK(2)
       write(0);
-      issue(q + 3);
+      WT_MARK(3)
     } else {
-      mma(1, 1, std::false_type{});
+      mma(1, 1, std::false_type{}, false, false);
+      WT_MARK(2)
     }
     epilogue(t);
+    WT_MARK(6)
   }
   if (has_stats) {
     __syncthreads();
@@ -666,6 +692,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
       p.stats[(((long)b * p.G + part) * C + co) * 2 + st] = a;
     }
   }
+  WT_MARK(5)
+  WT_FLUSH
 }
 
 int ws_blocks_per_image(const ConvArgs& a) {

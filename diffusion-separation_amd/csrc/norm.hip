@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
 }
 
 // GroupNorm scale/shift from the per-tile channel partials the conv epilogue wrote (no extra pass over the
-// activation).  grid (B); threads split (channel, tile-slice); two partial sources = in-place concat.
-__global__ __launch_bounds__(256) void gn_finalize_parts_kernel(const double* __restrict__ p1, int nt1, int C1,
+// activation).  grid (B) x 1024 threads split (channel, tile-slice); two partial sources = in-place concat.
+__global__ __launch_bounds__(1024) void gn_finalize_parts_kernel(const double* __restrict__ p1, int nt1, int C1,
                                                                 const double* __restrict__ p2, int nt2, int C2,
                                                                 int groups, double count, float eps,
                                                                 const float* __restrict__ gamma,
@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256) void gn_finalize_parts_kernel(const double* __
   __shared__ float gm[256], gr[256];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int C = C1 + C2;
-  const int Cw = C < 256 ? C : 256;
-  const int nsl = 256 / Cw;
+  const int Cw = C < 1024 ? C : 1024;
+  const int nsl = 1024 / Cw;  // tile slices summed in parallel (the loop below is a chain of L2 round trips)
   const int cl = tid % Cw, sl = tid / Cw;
   if (sl < nsl) {
     for (int c = cl; c < C; c += Cw) {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void gn_finalize_parts_kernel(const double* __
       const double* src = second ? p2 : p1;
       const int nt = second ? nt2 : nt1, Cs = second ? C2 : C1, cc = second ? c - C1 : c;
       double a = 0.0, q = 0.0;
-#pragma unroll 4
+#pragma unroll 8
       for (int t = sl; t < nt; t += nsl) {
         const double* o = src + (((long)b * nt + t) * Cs + cc) * 2;
         a += o[0];
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void gn_finalize_parts_kernel(const double* __
     }
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
+  for (int c = tid; c < C; c += 1024) {
     double a = 0.0, q = 0.0;
     for (int s = 0; s < nsl; ++s) { a += cs[s * C + c]; q += cq[s * C + c]; }
     cs[c] = a;  // slot (0, c) is read by this thread only: no hazard with the other threads' reads
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void gn_finalize_parts_kernel(const double* __
   }
   __syncthreads();
   const int cpg = C / groups;
-  for (int g = tid; g < groups; g += 256) {
+  for (int g = tid; g < groups; g += 1024) {
     double a = 0.0, q = 0.0;
     for (int j = 0; j < cpg; ++j) { a += cs[g * cpg + j]; q += cq[g * cpg + j]; }
     const double mean = a / count;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void gn_finalize_parts_kernel(const double* __
     gr[g] = (float)(1.0 / sqrt(var + (double)eps));
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
+  for (int c = tid; c < C; c += 1024) {
     const int g = c / cpg;
     const float sc = gr[g] * (gamma ? gamma[c] : 1.f);
     scale[(long)b * C + c] = sc;
@@ -165,7 +165,7 @@ int ds_launch_gn_finalize_parts(const double* p1, int nt1, int C1, const double*
   const int C = C1 + C2;
   DS_CHECK(C <= 1024 && C % groups == 0 && groups <= 256, "groupnorm(parts): unsupported channel / group count");
   const double count = (double)npix * (double)(C / groups);
-  hipLaunchKernelGGL(gn_finalize_parts_kernel, dim3(B), dim3(256), 0, st, p1, nt1, C1, p2, nt2, C2, groups, count, eps,
+  hipLaunchKernelGGL(gn_finalize_parts_kernel, dim3(B), dim3(1024), 0, st, p1, nt1, C1, p2, nt2, C2, groups, count, eps,
                      gamma, beta, scale, shift);
   DS_LAUNCH_CHECK();
   return 0;

@@ -11,7 +11,7 @@ import ctypes, sys, os, torch
 sys.path.insert(0, "diffusion-separation_amd")
 from diffsep_amd import ops
 l = ctypes.CDLL(os.environ["DIFFSEP_LIB"])
-names = ["P1 multiply", "barrier after P1", "P2: epilogue", "barrier after P2", "prologue", "tail (stats)", "P2: issue residual loads", "P2: wait + activation", "P2: LDS write", "P2: issue next loads", "-", "-"]
+names = ["barrier wait", "issue loads", "MFMA + activation", "LDS write", "prologue", "tail (stats)", "epilogue", "-", "-", "-", "-", "-"]
 for (H, W) in [(256, 256)]:
     B, ci, co, k = 16, 64, 64, 3
     x = torch.randn(B, H, W, ci, device="cuda").to(torch.bfloat16)
@@ -35,6 +35,6 @@ for (H, W) in [(256, 256)]:
     for g in range(2):
         nb = out[g * 16 + 15]; tot = sum(out[g * 16 + i] for i in range(12))
         print(f"  group {g}: {tot/nb:.0f} ticks/block")
-        for i in range(10):
+        for i in range(7):
             print(f"    {names[i]:26s} {out[g*16+i]/nb:9.0f}  {100*out[g*16+i]/tot:5.1f} %")
 PY
