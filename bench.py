@@ -162,7 +162,9 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "pmc_conv3x3.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get(f"hbm_bytes_per_launch_{args.dtype}_B{B}")
+                    tkey = {"conv3x3_8x32xN64": f"hbm_bytes_per_launch_{args.dtype}_B{B}",
+                            "conv3x3_ws_64to64": f"hbm_bytes_per_launch_ws_{args.dtype}_B{B}"}.get(dom)
+                    traffic = json.load(open(pmc)).get(tkey) if tkey else None
                     traffic = round(traffic) if traffic else None
                 except Exception:
                     traffic = None
@@ -170,8 +172,6 @@ def main():
             hbm_floor_us = by / max(n, 1) / HBM_PEAK_BPS * 1e6
             mfma_floor_us = fl / max(n, 1) / (peak * 1e12) * 1e6
             kname = KERNEL_NAMES.get(dom, dom) % {"dt": args.dtype}
-            if dom != "conv3x3_8x32xN64":
-                traffic = None  # the committed PMC traffic figure belongs to the generic 3x3 kernel
             if hbm_floor_us > mfma_floor_us:
                 gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
                 roof = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": HBM_PEAK_BPS / 1e9,
