@@ -131,6 +131,10 @@ struct ConvArgs {
   int C1;                                // channels taken from x when x2 != null
   const void* w; long w_bs;              // Bt operand: [Cout][taps][Cin]; w_bs batch stride (0 = shared)
   int w_chunked;                         // != 0: weights are chunk-major [Cin/kc][taps][Cout][kc] with kc = this value
+  // optional fused 1x1 skip convolution on the raw block input (3x3 launches only): y += sw * cat([sx, sx2])
+  const void* sx; long sx_bs; int ldsx;  //   [B][M][ldsx], sCin channels (sC1 from sx when sx2 != null)
+  const void* sx2; long sx2_bs; int ldsx2; int sC1; int sCin;
+  const void* sw; int sw_chunked;        //   [Cout][sCin] or chunk-major [sCin/kc][Cout][kc] (kc = the 3x3 kernel's)
   const float* gn_scale;                 // optional fused GroupNorm-apply on A: f(x) = act(x*scale[b,c] + shift[b,c])
   const float* gn_shift; int gn_act;     //   scale/shift are [B][Cin] fp32; gn_act: 0 none, 1 SiLU
   const float* bias;                     // [Cout] (mode 0) or [M] (mode 1) or null
@@ -149,6 +153,7 @@ int ds_launch_conv(const ConvArgs& a, hipStream_t st);
 int ds_conv_config_id(const ConvArgs& a);
 int ds_conv_tiles(const ConvArgs& a);
 int ds_conv_chunk(int taps, int dtype);
+bool ds_conv_skip_supported(int H, int W, int Cout, int dtype);
 bool ds_conv_ws_eligible(const ConvArgs& a);   // conv3x3_ws.hip: weight-stationary 64 -> 64 bf16 kernel
 int ds_conv_ws_tiles(const ConvArgs& a);
 int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st);

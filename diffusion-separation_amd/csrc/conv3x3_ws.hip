@@ -719,7 +719,7 @@ bool ds_conv_ws_eligible(const ConvArgs& a) {
   const char* v = getenv("DIFFSEP_CONV_WS");  // 0: off, 1: ping-pong variant, 2 (default): one-phase variant
   const int on = v ? atoi(v) : 2;
   return on && a.dtype == DS_BF16 && a.taps == 9 && a.Cin == C && a.Cout == C && !a.x2 && a.w_bs == 0 &&
-         (a.w_chunked == 0 || a.w_chunked == KC) &&
+         (a.w_chunked == 0 || a.w_chunked == KC) && !a.sx &&
          a.bias_mode == 0 && !a.div_b && a.H % TH == 0 && a.W % TW == 0 && a.ldx >= C && a.ldy >= C &&
          (!a.res || a.ldr >= C);
 }

@@ -26,6 +26,7 @@
 // under the matrix work.  Epilogue: accumulators go through LDS (fp32) and leave as 16-byte,
 // channel-contiguous stores with coalesced residual reads.
 #include <stdlib.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -132,6 +133,9 @@ struct ConvK {  // kernel-side copy of ConvArgs (typed by the template)
   const void* x; long x_bs; int ldx; int C1;
   const void* x2; long x2_bs; int ldx2;
   const void* w; long w_bs; int w_chunked;
+  // fused 1x1 skip convolution (ResnetBlockBigGANpp Conv_2): extra K chunks with one tap, raw input
+  const void* sx; long sx_bs; int ldsx; const void* sx2; long sx2_bs; int ldsx2; int sC1; int sCin;
+  const void* sw; int sw_chunked;
   const float* gn_scale; const float* gn_shift; int gn_act;
   const float* bias; const float* bias_b; int bias_b_ld; int bias_mode;
   const float* div_b;
@@ -158,6 +162,8 @@ struct ConvGeom {
   static constexpr int LDS_STAGE = HP * ROWB + TAPS * BN * ROWB;
   static constexpr int LDS_OUT = (BM / EP) * OROW;  // the epilogue streams the tile out in EP passes
   static constexpr int LDS = LDS_STAGE > LDS_OUT ? LDS_STAGE : LDS_OUT;
+  // fused 1x1 skip convolution: needs one weight staging pass per tap (256 / NVEC rows per pass == BN)
+  static constexpr bool SKIP_OK = TAPS == 9 && (256 / NVEC) == BN;
 };
 
 // ---- buffer addressing (SRSRC): a wave-uniform descriptor + a 32-bit per-lane byte offset + a uniform
@@ -232,10 +238,13 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
   const int vch = (tid % NVEC) * KV;  // channel offset of this thread's vectors inside a chunk
   const int row0 = tid / NVEC;
   const int lds0 = row0 * ROWB + (tid % NVEC) * 16;  // + k * RPS * ROWB
-  auto a_in = [&](int k) { return row0 + k * RPS < HP; };
-  auto b_in = [&](int k) { return row0 + k * RPS < TAPS * BN; };
-  unsigned voa1[NA], voa2[NA];  // byte offsets of the thread's halo vectors in source 1 / 2 (DS_OOB: zero)
+  auto a_in = [&](int k) __attribute__((always_inline)) { return row0 + k * RPS < HP; };
+  auto b_in = [&](int k) __attribute__((always_inline)) { return row0 + k * RPS < TAPS * BN; };
+  // pixel index of the thread's halo vectors (-1: outside the image).  The byte offset in a source is
+  // (pixi * ld + vch) * ESZ; for pixi = -1 that is negative = far beyond num_records as unsigned: reads zero.
+  int pixi_[NA];
   bool aval[NA];
+  bool ain[NA];  // the vector belongs to the tile proper (not its halo): all the fused 1x1 skip conv needs
 #pragma unroll
   for (int k = 0; k < NA; ++k) {
     int pixi = -1;
@@ -250,9 +259,14 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
       }
     }
     aval[k] = pixi >= 0;
-    voa1[k] = pixi >= 0 ? (unsigned)(pixi * p.ldx + vch) * ESZ : DS_OOB;
-    voa2[k] = pixi >= 0 ? (unsigned)(pixi * p.ldx2 + vch) * ESZ : DS_OOB;
+    pixi_[k] = pixi;
+    {
+      const int pix = row0 + k * RPS;
+      const int hy = pix / HW_, hx = pix - hy * HW_;
+      ain[k] = TAPS != 9 || (hy >= R && hy < R + TH && hx >= R && hx < R + TW);
+    }
   }
+  auto voa = [&](int k, int ld) __attribute__((always_inline)) { return (unsigned)((pixi_[k] * ld + vch) * ESZ); };
   unsigned vob[NB];  // byte offsets of the thread's weight vectors (row = cout, tap): DS_OOB past Cout
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
@@ -300,7 +314,36 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
   // channels of x, chunks [nch1, nch) channels of x2 (weights follow the concatenated channel index).
   const int nch1 = (C1 + KC - 1) / KC;
   const int nch = nch1 + (C2 + KC - 1) / KC;
-  auto load_chunk = [&](int c) {
+  // fused skip convolution: chunks [nch, ncht) carry the raw block input through ONE tap (the centre)
+  const int sC1 = p.sC1, sC2 = p.sCin - p.sC1;
+  const int nchs1 = p.sx ? (sC1 + KC - 1) / KC : 0;
+  const int ncht = nch + nchs1 + (p.sx ? (sC2 + KC - 1) / KC : 0);
+  // (supported by the instantiations whose weight staging makes one pass per tap; the launcher checks)
+  constexpr bool SKIP_OK = TAPS == 9 && B_TAPSTEP && RPS == BN;
+  constexpr int KSKIP = SKIP_OK ? 4 : 0;  // staging pass that holds the centre tap
+  auto load_chunk = [&](int c) __attribute__((always_inline)) {
+    if (SKIP_OK && c >= nch) {  // skip chunk: raw input, centre-tap weights only
+      const int cs = c - nch;
+      const bool second = cs >= nchs1;
+      const int cb = (second ? cs - nchs1 : cs) * KC;
+      const int width = (second ? sC2 : sC1) - cb;
+      const int wb = second ? sC1 + cb : cb;
+      ch_ok = vch < width;
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(
+          second ? reinterpret_cast<const T*>(p.sx2) + (long)b * p.sx2_bs : reinterpret_cast<const T*>(p.sx) + (long)b * p.sx_bs,
+          (unsigned)M * (second ? p.ldsx2 : p.ldsx) * ESZ);
+      const __amdgpu_buffer_rsrc_t rsw = make_rsrc(p.sw, (unsigned)p.Cout * p.sCin * ESZ);
+      const int lds_ = second ? p.ldsx2 : p.ldsx;
+      const unsigned so = (unsigned)cb * ESZ;
+#pragma unroll
+      for (int k = 0; k < NA; ++k) pa[k] = buf_load16(rs, (ch_ok && ain[k]) ? voa(k, lds_) : DS_OOB, so);
+      const int col = row0 % BN;
+      const bool okw = ch_ok && n0 + col < p.Cout;
+      const unsigned vo = p.sw_chunked ? (unsigned)(((wb / KC) * p.Cout + n0 + col) * KC + vch) * ESZ
+                                       : (unsigned)((n0 + col) * p.sCin + wb + vch) * ESZ;
+      pb[KSKIP] = buf_load16(rsw, okw ? vo : DS_OOB, 0);
+      return;
+    }
     const bool second = c >= nch1;
     const int cb = (second ? c - nch1 : c) * KC;        // channel offset inside the source
     const int width = (second ? C2 : C1) - cb;           // channels left in the source (>= 1)
@@ -311,23 +354,24 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
 #ifdef ABL_NOLOAD
     return;
 #endif
-    if (width >= KC) {  // uniform fast path: every lane's offsets are the precomputed ones
+    const int ld_ = second ? p.ldx2 : p.ldx;
+    if (width >= KC) {  // uniform fast path
       if (!second) {
 #pragma unroll
-        for (int k = 0; k < NA; ++k) pa[k] = buf_load16(rx1, voa1[k], so);
+        for (int k = 0; k < NA; ++k) pa[k] = buf_load16(rx1, voa(k, ld_), so);
       } else {
 #pragma unroll
-        for (int k = 0; k < NA; ++k) pa[k] = buf_load16(rx2, voa2[k], so);
+        for (int k = 0; k < NA; ++k) pa[k] = buf_load16(rx2, voa(k, ld_), so);
       }
 #pragma unroll
       for (int k = 0; k < NB; ++k) pb[k] = buf_load16(rw, vob[k], sw);
     } else {  // channel tail of a source: lanes past the end read zeros
       if (!second) {
 #pragma unroll
-        for (int k = 0; k < NA; ++k) pa[k] = buf_load16(rx1, ch_ok ? voa1[k] : DS_OOB, so);
+        for (int k = 0; k < NA; ++k) pa[k] = buf_load16(rx1, ch_ok ? voa(k, ld_) : DS_OOB, so);
       } else {
 #pragma unroll
-        for (int k = 0; k < NA; ++k) pa[k] = buf_load16(rx2, ch_ok ? voa2[k] : DS_OOB, so);
+        for (int k = 0; k < NA; ++k) pa[k] = buf_load16(rx2, ch_ok ? voa(k, ld_) : DS_OOB, so);
       }
 #pragma unroll
       for (int k = 0; k < NB; ++k) pb[k] = buf_load16(rw, ch_ok ? vob[k] : DS_OOB, sw);
@@ -346,22 +390,26 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
   // The chunk in flight is activated IN REGISTERS (GN affine + SiLU) while the matrix pipe works on the chunk
   // that is resident in LDS: the activation's VALU is spread over the MFMA loop of the same wave, so between
   // the two barriers of a chunk only the LDS writes remain.
-  auto write_chunk = [&]() {
+  auto write_chunk = [&](bool skip) __attribute__((always_inline)) {
 #ifdef ABL_NOLDSW
     return;
 #endif
 #pragma unroll
     for (int k = 0; k < NA; ++k)
       if (a_in(k)) *reinterpret_cast<uint4*>(sA + lds0 + k * RPS * ROWB) = pa[k];
+    if (skip) {  // only the centre tap's weight rows exist (and only they are read)
+      *reinterpret_cast<uint4*>(sB + lds0 + KSKIP * RPS * ROWB) = pb[KSKIP];
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < NB; ++k)
       if (b_in(k)) *reinterpret_cast<uint4*>(sB + lds0 + k * RPS * ROWB) = pb[k];
   };
   constexpr int SLOTS = TAPS * NKB;                 // k-blocks of one chunk
   constexpr int S0 = SLOTS / 3;                     // the loads of the next chunk get this long to land
-  auto run_chunks = [&](auto MODE_) {               // 0: raw input, 1: GN affine, 2: GN affine + SiLU
+  auto run_chunks = [&](auto MODE_) __attribute__((always_inline)) {               // 0: raw input, 1: GN affine, 2: GN affine + SiLU
     constexpr int MODE = decltype(MODE_)::value;
-    auto act = [&](int k) {  // branch free: zero padding (outside pixels, channel tails) keeps its loaded zeros
+    auto act = [&](int k) __attribute__((always_inline)) {  // branch free: zero padding (outside pixels, channel tails) keeps its loaded zeros
 #ifdef ABL_NOACT
       return;
 #endif
@@ -376,10 +424,11 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
         pa[k].w = ok ? r.w : pa[k].w;
       }
     };
-    auto mma_chunk = [&](auto NEXT_) {
+    auto mma_chunk = [&](auto NEXT_, auto SKIP_) __attribute__((always_inline)) {
       constexpr bool NEXT = decltype(NEXT_)::value && MODE != 0;
+      constexpr bool SKIP = decltype(SKIP_)::value;  // fused skip convolution: the centre tap only
 #pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) {
+      for (int tap = (SKIP ? 4 : 0); tap < (SKIP ? 5 : TAPS); ++tap) {
         const int toff = (TAPS == 9) ? ((tap / 3) * HW_ + (tap % 3)) * ROWB : 0;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
@@ -415,18 +464,28 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     CT_MARK(3)
     for (int c = 0; c < nch; ++c) {
       __syncthreads();  // previous chunk's fragment reads are done
-      write_chunk();
+      write_chunk(false);
       __syncthreads();
       CT_MARK(4)
       if (c + 1 < nch) {
         load_chunk(c + 1);  // in flight during the first third of the MFMA loop below
         CT_MARK(5)
-        mma_chunk(std::true_type{});
+        mma_chunk(std::true_type{}, std::false_type{});
       } else {
+        if (c + 1 < ncht) load_chunk(c + 1);  // first skip chunk (raw: nothing to activate)
         CT_MARK(5)
-        mma_chunk(std::false_type{});
+        mma_chunk(std::false_type{}, std::false_type{});
       }
       CT_MARK(6)
+    }
+    if constexpr (SKIP_OK) {
+      for (int c = nch; c < ncht; ++c) {  // fused 1x1 skip convolution: extra K through the centre tap
+        __syncthreads();
+        write_chunk(true);
+        __syncthreads();
+        if (c + 1 < ncht) load_chunk(c + 1);
+        mma_chunk(std::false_type{}, std::true_type{});
+      }
     }
   };
   if (!has_gn) run_chunks(std::integral_constant<int, 0>{});
@@ -654,6 +713,11 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   DS_CHECK(a.w_chunked == 0 || (a.w_chunked == KC && a.Cin % KC == 0 && (!a.x2 || a.C1 % KC == 0)),
            "conv: chunk-major weights need kc == the kernel's chunk width and whole chunks per source");
   k.w_chunked = a.w_chunked ? 1 : 0;
+  DS_CHECK(!a.sx || (G::SKIP_OK && a.sw && a.sCin % 8 == 0 && a.ldsx % 8 == 0 &&
+                     (a.sw_chunked == 0 || (a.sw_chunked == KC && a.sCin % KC == 0 && (!a.sx2 || a.sC1 % KC == 0)))),
+           "conv: bad fused skip convolution arguments");
+  k.sx = a.sx; k.sx_bs = a.sx_bs; k.ldsx = a.ldsx; k.sx2 = a.sx2; k.sx2_bs = a.sx2_bs; k.ldsx2 = a.ldsx2;
+  k.sC1 = a.sx2 ? a.sC1 : a.sCin; k.sCin = a.sCin; k.sw = a.sw; k.sw_chunked = a.sw_chunked ? 1 : 0;
   k.gn_scale = a.gn_scale; k.gn_shift = a.gn_shift; k.gn_act = a.gn_act;
   k.bias = a.bias; k.bias_b = a.bias_b; k.bias_b_ld = a.bias_b_ld; k.bias_mode = a.bias_mode; k.div_b = a.div_b;
   k.res = a.res; k.res_bs = a.res_bs; k.ldr = a.ldr; k.out_scale = a.out_scale;
@@ -697,6 +761,15 @@ static int launch_typed(const ConvArgs& a, hipStream_t st) {
     case 4: return launch_cfg<T, 1, 8, 32, 32, 2, 1, KC1>(a, st);
     default: return launch_cfg<T, 1, 8, 8, 64, 1, 1, KC1>(a, st);
   }
+}
+
+// whether the instantiation that would run a 3x3 launch of this shape can take the fused 1x1 skip convolution
+bool ds_conv_skip_supported(int H, int W, int Cout, int dtype) {
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.H = H; a.W = W; a.Cout = Cout; a.taps = 9; a.dtype = dtype; a.sx = &a;
+  const int id = ds_conv_config_id(a);
+  return id == 0 || id == 2;
 }
 
 // chunk width (channels per K stage) of the kernel that would run this problem: the kc of chunk-major weights

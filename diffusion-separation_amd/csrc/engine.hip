@@ -277,6 +277,8 @@ __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ s
 }
 // Which weights the engine keeps chunk-major: every conv whose input channels (and concat split) are multiples of 64
 static int weight_chunk(int taps, int cin, int dtype) { return (cin % 64 == 0) ? ds_conv_chunk(taps, dtype) : 0; }
+// Conv_2 of a block is folded into its second 3x3 convolution when that one runs on a 64-cout tile
+static bool fuse_skip(const Module& m) { return m.has_conv2 && m.out_ch > 32; }
 
 // ------------------------------------------------------------------ engine
 struct Tn {  // NHWC view; optionally the in-place channel concat of two tensors (C1 channels from p, rest from p2)
@@ -362,11 +364,12 @@ static int conv_launch_prof(diffsep_engine* e, const ConvArgs& a, hipStream_t st
   if (!e->prof) return ds_launch_conv(a, st);
   diffsep_engine::ProfRec r;
   r.a = prof_event(e); r.b = prof_event(e);
-  r.flops = 2.0 * a.taps * (double)a.Cin * a.Cout * (double)a.H * a.W * a.B;
-  {  // algorithmic HBM bytes: input + output (+ residual) once each, weights once
+  r.flops = 2.0 * ((double)a.taps * a.Cin + (a.sx ? a.sCin : 0)) * a.Cout * (double)a.H * a.W * a.B;
+  {  // algorithmic HBM bytes: input (+ fused skip input) + output (+ residual) once each, weights once
     const double esz = a.dtype == DS_F32 ? 4.0 : 2.0;
-    r.bytes = esz * ((double)a.B * a.H * a.W * ((double)a.Cin + a.Cout + (a.res ? a.Cout : 0)) +
-                     (double)a.taps * a.Cin * a.Cout);
+    r.bytes = esz * ((double)a.B * a.H * a.W *
+                         ((double)a.Cin + a.Cout + (a.res ? a.Cout : 0) + (a.sx ? a.sCin : 0)) +
+                     ((double)a.taps * a.Cin + (a.sx ? a.sCin : 0)) * a.Cout);
   }
   r.cls = ds_conv_config_id(a);
   hipEventRecord(r.a, st);
@@ -411,9 +414,11 @@ static const void* PK(diffsep_engine* e, long off) { return e->d_pack + off * e-
 
 // ---- launch helpers (skip when dry)
 struct GnAff { float* scale; float* shift; };
+struct SkipConv { const Tn* x; const void* w; int chunk; };  // fused 1x1 skip convolution on the raw block input
 static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias, const float* bias_b, int bias_b_ld,
                 const Tn* res, float scale, Tn& y, int Cout, int taps, int B, const float* div_b,
-                hipStream_t st, const GnAff* gn = nullptr, int gn_act = 0, bool want_stats = false) {
+                hipStream_t st, const GnAff* gn = nullptr, int gn_act = 0, bool want_stats = false,
+                const SkipConv* skip = nullptr) {
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.B = B; a.H = x.H; a.W = x.W; a.Cin = x.C; a.Cout = Cout; a.taps = taps; a.dtype = e->cfg.dtype;
@@ -425,6 +430,12 @@ static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias
   a.res = res ? res->p : nullptr; a.res_bs = res ? (long)res->H * res->W * res->ld : 0; a.ldr = res ? res->ld : 0;
   a.out_scale = scale;
   a.y = y.p; a.y_bs = (long)y.H * y.W * y.ld; a.ldy = y.ld;
+  if (skip) {
+    const Tn& sx = *skip->x;
+    a.sx = sx.p; a.sx_bs = (long)sx.H * sx.W * sx.ld; a.ldsx = sx.ld;
+    a.sx2 = sx.p2; a.sx2_bs = (long)sx.H * sx.W * sx.ld2; a.ldsx2 = sx.ld2; a.sC1 = sx.C1; a.sCin = sx.C;
+    a.sw = skip->w; a.sw_chunked = skip->chunk;
+  }
   if (want_stats) {  // the consumer's GroupNorm reads these partials instead of re-reading the tensor
     y.nt = ds_conv_tiles(a);  // (depends on which kernel takes the launch: every field above matters)
     y.st = (double*)e_alloc(e, (size_t)B * y.nt * Cout * 2 * sizeof(double));
@@ -477,18 +488,9 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
     xr = e_tensor(e, B, Ho, Wo, m.in_ch);
     if (gn_apply(e, x, &a0, &h0m, &xr, B, 1, mode, st)) return 1;
   }
-  // the 1x1 skip convolution only needs the (resampled) block input: run it beside conv0 -> GN1
-  Tn skip = xr;
-  const bool side = m.has_conv2 && !e->dry && (e->use_side & 1);
-  if (m.has_conv2) {
-    skip = e_tensor(e, B, Ho, Wo, m.out_ch);
-    hipStream_t s2 = side ? e->sideA : st;
-    if (side && stream_dep(e, st, s2)) return 1;
-    if (conv(e, xr, PK(e, m.pk2), P(e, m.conv2_b), nullptr, 0, nullptr, 1.f, skip, m.out_ch, 1, B, nullptr, s2))
-      return 1;
-  } else {
-    DS_CHECK(xr.p2 == nullptr, "internal: identity skip on a concat view");
-  }
+  // Conv_2 (1x1 on the raw, possibly resampled block input; layerspp.py:317-318) is folded into the second 3x3
+  // convolution as extra K through its centre tap: no separate launch, no skip tensor in HBM
+  if (!m.has_conv2) DS_CHECK(xr.p2 == nullptr, "internal: identity skip on a concat view");
   if (mode) {
     if (conv(e, h0m, PK(e, m.pk0), P(e, m.conv0_b), temb_proj + m.temb_off, e->arch.dense_total, nullptr, 1.f, h1,
              m.out_ch, 9, B, nullptr, st, nullptr, 0, true))
@@ -499,8 +501,19 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
       return 1;
   }
   if (gn_stats(e, h1, P(e, m.gn1_w), P(e, m.gn1_b), B, a1, st)) return 1;
-  if (side && stream_dep(e, e->sideA, st)) return 1;
   out = e_tensor(e, B, Ho, Wo, m.out_ch);
+  if (m.has_conv2 && fuse_skip(m)) {
+    DS_CHECK(ds_conv_skip_supported(Ho, Wo, m.out_ch, e->cfg.dtype), "internal: fused skip conv on an unsupported tile");
+    const SkipConv sk = {&xr, PK(e, m.pk2), weight_chunk(9, m.in_ch, e->cfg.dtype)};
+    // conv bias + Conv_2 bias: the second goes in as a "per-batch" bias with stride 0
+    return conv(e, h1, PK(e, m.pk1), P(e, m.conv1_b), P(e, m.conv2_b), 0, nullptr, kInvSqrt2, out, m.out_ch, 9, B,
+                nullptr, st, &a1, 1, true, &sk);
+  }
+  Tn skip = xr;
+  if (m.has_conv2) {  // narrow blocks (<= 32 couts use the 32-cout tile, which has no skip path): separate 1x1 launch
+    skip = e_tensor(e, B, Ho, Wo, m.out_ch);
+    if (conv(e, xr, PK(e, m.pk2), P(e, m.conv2_b), nullptr, 0, nullptr, 1.f, skip, m.out_ch, 1, B, nullptr, st)) return 1;
+  }
   return conv(e, h1, PK(e, m.pk1), P(e, m.conv1_b), nullptr, 0, &skip, kInvSqrt2, out, m.out_ch, 9, B, nullptr, st,
               &a1, 1, true);
 }
@@ -783,9 +796,10 @@ extern "C" int32_t diffsep_engine_create(const diffsep_model_config* cfg, const 
   DS_HIP(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
 
   auto repack = [&](const PRef& src, long pk, int O, int I, int taps, long so, long si, long stp,
-                    bool allow_chunk = true) -> int {
+                    bool allow_chunk = true, int kc_taps = 0) -> int {
     const int Ipad = rup8(I);
-    const int kc = allow_chunk ? weight_chunk(taps, I, cfg->dtype) : 0;
+    // kc_taps: the kernel that will READ these weights (the fused skip conv is read by the 3x3 kernel)
+    const int kc = allow_chunk ? weight_chunk(kc_taps ? kc_taps : taps, I, cfg->dtype) : 0;
     const long total = (long)O * taps * Ipad;
     long nb = (total + 255) / 256;
     if (nb > 4096) nb = 4096;
@@ -807,7 +821,7 @@ extern "C" int32_t diffsep_engine_create(const diffsep_model_config* cfg, const 
       case MK_RES:
         rc |= repack(m.conv0_w, m.pk0, m.out_ch, m.in_ch, 9, (long)m.in_ch * 9, 9, 1);
         rc |= repack(m.conv1_w, m.pk1, m.out_ch, m.out_ch, 9, (long)m.out_ch * 9, 9, 1);
-        if (m.has_conv2) rc |= repack(m.conv2_w, m.pk2, m.out_ch, m.in_ch, 1, m.in_ch, 1, 0);
+        if (m.has_conv2) rc |= repack(m.conv2_w, m.pk2, m.out_ch, m.in_ch, 1, m.in_ch, 1, 0, true, fuse_skip(m) ? 9 : 0);
         // Dense_0 rows -> concatenated projection [dense_total][4 nf]
         DS_HIP(hipMemcpy(e->d_dense_w + (size_t)m.temb_off * 4 * cfg->nf, e->d_blob + m.dense_w.off,
                          (size_t)m.dense_w.numel * 4, hipMemcpyDeviceToDevice));
