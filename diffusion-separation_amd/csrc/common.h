@@ -13,6 +13,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 #define DS_F32 0
 #define DS_BF16 1
 #define DS_MAX_SRC 4
+// fixed-point scales of the GroupNorm channel-sum accumulators (int64): sums 2^-24, sums of squares 2^-16
+#define DS_STAT_SUM_SCALE 16777216.0
+#define DS_STAT_SQ_SCALE 65536.0
 
 // ---------------------------------------------------------------- error plumbing (host)
 void ds_set_error(const std::string& s);
@@ -144,18 +147,21 @@ struct ConvArgs {
   const void* res; long res_bs; int ldr; // residual added before out_scale, or null
   float out_scale;
   void* y; long y_bs; int ldy;
-  double* stats_out;                     // optional [B][ds_conv_tiles][Cout][2] per-tile (sum, sumsq) of the output
+  // optional [B][Cout][2] accumulators (sum, sum of squares of the output, fixed point DS_STAT_*_SCALE, int64):
+  // every block ADDS its tile's totals with integer atomics (bit-reproducible); the caller zeroes them first
+  long long* stats_acc;
+  // GroupNorm of the INPUT straight from such accumulators (of x and x2) instead of gn_scale / gn_shift:
+  const long long* gn_acc1; const long long* gn_acc2; const float* gn_gamma; const float* gn_beta;
+  int gn_groups; float gn_inv_count; float gn_eps;  // inv_count = 1 / (H * W * Cin / groups)
   int B, H, W;                           // taps==9: image H x W; taps==1: M = H*W rows
   int Cin, Cout, taps;
   int dtype;
 };
 int ds_launch_conv(const ConvArgs& a, hipStream_t st);
 int ds_conv_config_id(const ConvArgs& a);
-int ds_conv_tiles(const ConvArgs& a);
 int ds_conv_chunk(int taps, int dtype);
 bool ds_conv_skip_supported(int H, int W, int Cout, int dtype);
 bool ds_conv_ws_eligible(const ConvArgs& a);   // conv3x3_ws.hip: weight-stationary 64 -> 64 bf16 kernel
-int ds_conv_ws_tiles(const ConvArgs& a);
 int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st);
 
 // GroupNorm: stats -> per-(b,c) scale/shift -> apply(+SiLU)(+FIR resample)
@@ -166,9 +172,9 @@ int ds_launch_gn_stats(const void* x, int ldx, const void* x2, int ldx2, int C1,
                        float eps, const float* gamma, const float* beta, void* ws, float* scale, float* shift,
                        int dtype, hipStream_t st);
 // scale/shift from per-tile channel partials written by the conv epilogue (two sources = concat view)
-int ds_launch_gn_finalize_parts(const double* p1, int nt1, int C1, const double* p2, int nt2, int C2, int B, long npix,
-                                int groups, float eps, const float* gamma, const float* beta, float* scale,
-                                float* shift, hipStream_t st);
+int ds_launch_gn_finalize_acc(const long long* a1, int C1, const long long* a2, int C2, int B, long npix, int groups,
+                              float eps, const float* gamma, const float* beta, float* scale, float* shift,
+                              hipStream_t st);
 // mode: 0 none, 1 up, 2 down. scale/shift null => identity & no activation (pure FIR on x -> xr only).
 int ds_launch_gn_apply(const void* x, int ldx, const float* scale, const float* shift, int C, void* y, int ldy,
                        void* xr, int ldxr, int B, int H, int W, int act, int mode, int dtype, hipStream_t st);

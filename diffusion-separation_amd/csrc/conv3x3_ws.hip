@@ -20,7 +20,7 @@
 //     of one wave execute in order); a lane then owns 8 consecutive couts of a pixel: bias / residual / scale /
 //     statistics / bf16 packing and full 128-byte-line stores;
 //   * GroupNorm statistics of the output are accumulated in 16 registers per lane over all tiles of the block
-//     and reduced once at the end (partials [B][G][64][2], G = blocks per image).
+//     and added once at the end to the [B][64][2] fixed-point accumulators of the tensor.
 //
 // K order (chunk, tap, 16-channel block) is the same as in conv_mfma.hip.
 #include <stdlib.h>
@@ -85,11 +85,12 @@ struct WsK {
   const bf16_t* x; long x_bs; int ldx;
   const bf16_t* w; int w_chunked;
   const float* gn_scale; const float* gn_shift;
+  const long long* gn_acc; const float* gn_gamma; const float* gn_beta; int gn_groups; float gn_inv_count; float gn_eps;
   const float* bias; const float* bias_b; int bias_b_ld;
   const bf16_t* res; long res_bs; int ldr;
   float out_scale;
   bf16_t* y; long y_bs; int ldy;
-  double* stats;
+  long long* stats;
   int H, W, G, tiles_x, tiles_per_img;
 };
 
@@ -159,8 +160,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsK p) {
       *reinterpret_cast<uint4*>(sW + dst) = wv[k];
     }
     if (tid < C) {
-      sTab[tid] = p.gn_scale ? p.gn_scale[(long)b * C + tid] : 1.f;
-      sTab[C + tid] = p.gn_shift ? p.gn_shift[(long)b * C + tid] : 0.f;
+      float sc = 1.f, sh = 0.f;
+      if (p.gn_acc) {  // GroupNorm statistics straight from the producer's channel-sum accumulators
+        const int cpg = C / p.gn_groups, g0 = (tid / cpg) * cpg;
+        long long ssum = 0, ssq = 0;
+        for (int j = 0; j < cpg; ++j) {
+          ssum += p.gn_acc[((long)b * C + g0 + j) * 2];
+          ssq += p.gn_acc[((long)b * C + g0 + j) * 2 + 1];
+        }
+        const double mean = (double)ssum * (1.0 / DS_STAT_SUM_SCALE) * (double)p.gn_inv_count;
+        double var = (double)ssq * (1.0 / DS_STAT_SQ_SCALE) * (double)p.gn_inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        sc = (float)(1.0 / sqrt(var + (double)p.gn_eps)) * (p.gn_gamma ? p.gn_gamma[tid] : 1.f);
+        sh = (p.gn_beta ? p.gn_beta[tid] : 0.f) - (float)mean * sc;
+      } else if (p.gn_scale) {
+        sc = p.gn_scale[(long)b * C + tid];
+        sh = p.gn_shift[(long)b * C + tid];
+      }
+      sTab[tid] = sc;
+      sTab[C + tid] = sh;
       sTab[2 * C + tid] =
           ((p.bias ? p.bias[tid] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + tid] : 0.f)) * p.out_scale;
     }
@@ -421,7 +439,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsK p) {
       double a = 0.0;
 #pragma unroll 8
       for (int i = 0; i < 64; ++i) a += (double)src[i * 8 * RED_ROW];
-      p.stats[(((long)b * p.G + part) * C + co) * 2 + st] = a;
+      atomicAdd(reinterpret_cast<unsigned long long*>(p.stats + ((long)b * C + co) * 2 + st),
+                (unsigned long long)(long long)llrint(a * (st ? DS_STAT_SQ_SCALE : DS_STAT_SUM_SCALE)));
     }
   }
   WT_MARK(5)
@@ -467,8 +486,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
       *reinterpret_cast<uint4*>(sW + dst) = wv[k];
     }
     if (tid < C) {
-      sTab[tid] = p.gn_scale ? p.gn_scale[(long)b * C + tid] : 1.f;
-      sTab[C + tid] = p.gn_shift ? p.gn_shift[(long)b * C + tid] : 0.f;
+      float sc = 1.f, sh = 0.f;
+      if (p.gn_acc) {  // GroupNorm statistics straight from the producer's channel-sum accumulators
+        const int cpg = C / p.gn_groups, g0 = (tid / cpg) * cpg;
+        long long ssum = 0, ssq = 0;
+        for (int j = 0; j < cpg; ++j) {
+          ssum += p.gn_acc[((long)b * C + g0 + j) * 2];
+          ssq += p.gn_acc[((long)b * C + g0 + j) * 2 + 1];
+        }
+        const double mean = (double)ssum * (1.0 / DS_STAT_SUM_SCALE) * (double)p.gn_inv_count;
+        double var = (double)ssq * (1.0 / DS_STAT_SQ_SCALE) * (double)p.gn_inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        sc = (float)(1.0 / sqrt(var + (double)p.gn_eps)) * (p.gn_gamma ? p.gn_gamma[tid] : 1.f);
+        sh = (p.gn_beta ? p.gn_beta[tid] : 0.f) - (float)mean * sc;
+      } else if (p.gn_scale) {
+        sc = p.gn_scale[(long)b * C + tid];
+        sh = p.gn_shift[(long)b * C + tid];
+      }
+      sTab[tid] = sc;
+      sTab[C + tid] = sh;
       sTab[2 * C + tid] =
           ((p.bias ? p.bias[tid] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + tid] : 0.f)) * p.out_scale;
     }
@@ -689,7 +725,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
       double a = 0.0;
 #pragma unroll 8
       for (int i = 0; i < 64; ++i) a += (double)src[i * 8 * RED_ROW];
-      p.stats[(((long)b * p.G + part) * C + co) * 2 + st] = a;
+      atomicAdd(reinterpret_cast<unsigned long long*>(p.stats + ((long)b * C + co) * 2 + st),
+                (unsigned long long)(long long)llrint(a * (st ? DS_STAT_SQ_SCALE : DS_STAT_SUM_SCALE)));
     }
   }
   WT_MARK(5)
@@ -723,7 +760,6 @@ bool ds_conv_ws_eligible(const ConvArgs& a) {
          a.bias_mode == 0 && !a.div_b && a.H % TH == 0 && a.W % TW == 0 && a.ldx >= C && a.ldy >= C &&
          (!a.res || a.ldr >= C);
 }
-int ds_conv_ws_tiles(const ConvArgs& a) { return ws_blocks_per_image(a); }
 
 int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st) {
   WsK k;
@@ -734,10 +770,12 @@ int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st) {
   k.res = reinterpret_cast<const bf16_t*>(a.res); k.res_bs = a.res_bs; k.ldr = a.ldr;
   k.out_scale = a.out_scale;
   k.y = reinterpret_cast<bf16_t*>(a.y); k.y_bs = a.y_bs; k.ldy = a.ldy;
-  k.stats = a.stats_out;
+  k.stats = a.stats_acc;
+  k.gn_acc = a.gn_acc1; k.gn_gamma = a.gn_gamma; k.gn_beta = a.gn_beta; k.gn_groups = a.gn_groups;
+  k.gn_inv_count = a.gn_inv_count; k.gn_eps = a.gn_eps;
   k.H = a.H; k.W = a.W; k.G = ws_blocks_per_image(a);
   k.tiles_x = a.W / TW; k.tiles_per_img = (a.H / TH) * (a.W / TW);
-  const int mode = (a.gn_scale && a.gn_act) ? 2 : 1;  // raw input = affine with scale 1, shift 0 (exact in bf16)
+  const int mode = ((a.gn_scale || a.gn_acc1) && a.gn_act) ? 2 : 1;  // raw input = affine with scale 1, shift 0 (exact in bf16)
   static bool attr_done = false;
   if (!attr_done) {
     DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<1>),

@@ -137,12 +137,16 @@ struct ConvK {  // kernel-side copy of ConvArgs (typed by the template)
   const void* sx; long sx_bs; int ldsx; const void* sx2; long sx2_bs; int ldsx2; int sC1; int sCin;
   const void* sw; int sw_chunked;
   const float* gn_scale; const float* gn_shift; int gn_act;
+  // GroupNorm from channel-sum accumulators of the producer(s) (fixed point, common.h): the block turns them
+  // into its per-channel scale / shift table while its first loads are in flight
+  const long long* gn_acc1; const long long* gn_acc2; const float* gn_gamma; const float* gn_beta;
+  int gn_groups; float gn_inv_count; float gn_eps;
   const float* bias; const float* bias_b; int bias_b_ld; int bias_mode;
   const float* div_b;
   const void* res; long res_bs; int ldr;
   float out_scale;
   void* y; long y_bs; int ldy;
-  double* stats;  // optional [B][gridDim.x][Cout][2]: per-tile sum / sum of squares of the OUTPUT channels
+  long long* stats;  // optional [B][Cout][2] fixed-point accumulators: sum / sum of squares of the OUTPUT channels
   int H, W, Cin, Cout;
   int tiles_x;
 };
@@ -220,7 +224,8 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     m0 = blockIdx.x * BM;
   }
 
-  const bool has_gn = p.gn_scale != nullptr;
+  const bool has_gn = p.gn_scale != nullptr || p.gn_acc1 != nullptr;
+  float* sGN = reinterpret_cast<float*>(smem + G::LDS);  // [Cin] scale, [Cin] shift (accumulator mode)
   const int C1 = p.C1, C2 = p.Cin - p.C1;
   const __amdgpu_buffer_rsrc_t rx1 =
       make_rsrc(reinterpret_cast<const T*>(p.x) + (long)b * p.x_bs, (unsigned)M * p.ldx * ESZ);
@@ -376,9 +381,16 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
       for (int k = 0; k < NB; ++k) pb[k] = buf_load16(rw, ch_ok ? vob[k] : DS_OOB, sw);
     }
-    if (has_gn && ch_ok) {  // KV consecutive floats each: 16-byte vector loads
-      const float4* ps = reinterpret_cast<const float4*>(p.gn_scale + (long)b * p.Cin + wb + vch);
-      const float4* ph = reinterpret_cast<const float4*>(p.gn_shift + (long)b * p.Cin + wb + vch);
+  };
+  auto load_gn = [&](int c) __attribute__((always_inline)) {  // scale / shift of this thread's KV channels of chunk c
+    const bool second = c >= nch1;
+    const int cb = (second ? c - nch1 : c) * KC;
+    const int wb = second ? C1 + cb : cb;
+    if (has_gn && vch < (second ? C2 : C1) - cb) {
+      const float4* ps = p.gn_acc1 ? reinterpret_cast<const float4*>(sGN + wb + vch)
+                                   : reinterpret_cast<const float4*>(p.gn_scale + (long)b * p.Cin + wb + vch);
+      const float4* ph = p.gn_acc1 ? reinterpret_cast<const float4*>(sGN + p.Cin + wb + vch)
+                                   : reinterpret_cast<const float4*>(p.gn_shift + (long)b * p.Cin + wb + vch);
 #pragma unroll
       for (int j = 0; j < KV / 4; ++j) {
         const float4 a = ps[j], cc = ph[j];
@@ -386,6 +398,28 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
         gsh[4 * j] = cc.x; gsh[4 * j + 1] = cc.y; gsh[4 * j + 2] = cc.z; gsh[4 * j + 3] = cc.w;
       }
     }
+  };
+  // accumulator mode: per-channel scale = rstd * gamma, shift = beta - mean * scale of image b, into LDS
+  auto build_gn_table = [&]() __attribute__((always_inline)) {
+    const int cpg = p.Cin / p.gn_groups;
+    for (int c = tid; c < p.Cin; c += 256) {
+      const int g0 = (c / cpg) * cpg;
+      long long ssum = 0, ssq = 0;
+      for (int j = 0; j < cpg; ++j) {
+        const int cj = g0 + j;
+        const long long* src = cj < C1 ? p.gn_acc1 + ((long)b * C1 + cj) * 2 : p.gn_acc2 + ((long)b * C2 + (cj - C1)) * 2;
+        ssum += src[0];
+        ssq += src[1];
+      }
+      const double mean = (double)ssum * (1.0 / DS_STAT_SUM_SCALE) * (double)p.gn_inv_count;
+      double var = (double)ssq * (1.0 / DS_STAT_SQ_SCALE) * (double)p.gn_inv_count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+      const float sc = rstd * (p.gn_gamma ? p.gn_gamma[c] : 1.f);
+      sGN[c] = sc;
+      sGN[p.Cin + c] = (p.gn_beta ? p.gn_beta[c] : 0.f) - (float)mean * sc;
+    }
+    __syncthreads();
   };
   // The chunk in flight is activated IN REGISTERS (GN affine + SiLU) while the matrix pipe works on the chunk
   // that is resident in LDS: the activation's VALU is spread over the MFMA loop of the same wave, so between
@@ -456,6 +490,8 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     };
     CT_MARK(0)
     load_chunk(0);
+    if (p.gn_acc1) build_gn_table();  // (behind the first chunk's loads: they are needed next anyway)
+    load_gn(0);
     CT_MARK(1)
     CT_WAIT
     CT_MARK(2)
@@ -469,6 +505,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
       CT_MARK(4)
       if (c + 1 < nch) {
         load_chunk(c + 1);  // in flight during the first third of the MFMA loop below
+        load_gn(c + 1);
         CT_MARK(5)
         mma_chunk(std::true_type{}, std::false_type{});
       } else {
@@ -687,9 +724,10 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
         a += (double)sr[(rr2 * BN + tid) * 2 + 0];
         q += (double)sr[(rr2 * BN + tid) * 2 + 1];
       }
-      double* o = p.stats + (((long)b * gridDim.x + blockIdx.x) * p.Cout + n0 + tid) * 2;
-      o[0] = a;
-      o[1] = q;
+      // integer (fixed-point) atomics: associative, so the image totals are bit-reproducible whatever the order
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stats + ((long)b * p.Cout + n0 + tid) * 2);
+      atomicAdd(o, (unsigned long long)(long long)llrint(a * DS_STAT_SUM_SCALE));
+      atomicAdd(o + 1, (unsigned long long)(long long)llrint(q * DS_STAT_SQ_SCALE));
     }
   }
   CT_MARK(10)
@@ -699,7 +737,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
 template <typename T, int TAPS, int TH, int TW, int BN, int WM, int WN, int KC, int EP = 1, int OCC = 2>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   using G = ConvGeom<T, TAPS, TH, TW, BN, KC, EP>;
-  constexpr int LDS = G::LDS;
+  constexpr int LDS = G::LDS + 4096;  // + the [2][Cin <= 512] GroupNorm table of the accumulator mode
   auto kern = conv_mfma_kernel<T, TAPS, TH, TW, BN, WM, WN, KC, EP, OCC>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -721,7 +759,11 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   k.gn_scale = a.gn_scale; k.gn_shift = a.gn_shift; k.gn_act = a.gn_act;
   k.bias = a.bias; k.bias_b = a.bias_b; k.bias_b_ld = a.bias_b_ld; k.bias_mode = a.bias_mode; k.div_b = a.div_b;
   k.res = a.res; k.res_bs = a.res_bs; k.ldr = a.ldr; k.out_scale = a.out_scale;
-  k.y = a.y; k.y_bs = a.y_bs; k.ldy = a.ldy; k.stats = a.stats_out;
+  k.y = a.y; k.y_bs = a.y_bs; k.ldy = a.ldy; k.stats = a.stats_acc;
+  k.gn_acc1 = a.gn_acc1; k.gn_acc2 = a.gn_acc2; k.gn_gamma = a.gn_gamma; k.gn_beta = a.gn_beta;
+  k.gn_groups = a.gn_groups; k.gn_inv_count = a.gn_inv_count; k.gn_eps = a.gn_eps;
+  DS_CHECK(!a.gn_acc1 || (a.Cin <= 512 && a.gn_groups > 0 && a.Cin % a.gn_groups == 0 && (!a.x2 || a.gn_acc2)),
+           "conv: bad GroupNorm accumulator arguments");
   k.H = a.H; k.W = a.W; k.Cin = a.Cin; k.Cout = a.Cout;
   dim3 grid;
   if (TAPS == 9) {
@@ -776,16 +818,6 @@ bool ds_conv_skip_supported(int H, int W, int Cout, int dtype) {
 int ds_conv_chunk(int taps, int dtype) {
   if (dtype == DS_F32) return taps == 9 ? 16 : 32;
   return taps == 9 ? 32 : 64;
-}
-
-// grid.x of the launch = number of output tiles per image (the stride of the statistics partials)
-int ds_conv_tiles(const ConvArgs& a) {
-  const int id = ds_conv_config_id(a);
-  if (id == 6) return ds_conv_ws_tiles(a);
-  if (id <= 1) return cdiv(a.W, 32) * cdiv(a.H, 8);
-  if (id == 2) return cdiv(a.W, 8) * cdiv(a.H, 8);
-  const long M = (long)a.H * a.W;
-  return id == 5 ? cdiv(M, 64) : cdiv(M, 256);
 }
 
 // Which instantiation ds_launch_conv picks (profiling label): 0/1/2 = 3x3 {8x32xBN64, 8x32xBN32, 8x8xBN64},

@@ -286,14 +286,14 @@ struct Tn {  // NHWC view; optionally the in-place channel concat of two tensors
   int C = 0, ld = 0, H = 0, W = 0;
   void* p2 = nullptr;
   int C1 = 0, ld2 = 0;
-  // per-tile channel statistics written by the producing conv ([B][nt][C][2] doubles), or null
-  double* st = nullptr; int nt = 0;
-  double* st2 = nullptr; int nt2 = 0;
+  // channel-sum accumulators filled by the producing conv ([B][C][2] fixed-point int64, common.h), or null
+  long long* sa = nullptr;
+  long long* sa2 = nullptr;
 };
 static Tn cat_view(const Tn& a, const Tn& b) {
   Tn t = a;
   t.C = a.C + b.C; t.C1 = a.C; t.p2 = b.p; t.ld2 = b.ld;
-  t.st2 = b.st; t.nt2 = b.nt;
+  t.sa2 = b.sa;
   return t;
 }
 
@@ -309,6 +309,8 @@ struct diffsep_engine {
   // arena
   char* arena = nullptr;
   size_t cap = 0, top = 0, fwd_base = 0;
+  size_t stats_need = 0, stats_used = 0;  // GroupNorm accumulator region of one forward (sized by the dry run)
+  char* stats_ptr = nullptr;
   bool dry = false;
   int planB = -1;
   long planT = -1;
@@ -402,6 +404,22 @@ static void* e_alloc(diffsep_engine* e, size_t bytes) {
   if (e->dry) return (void*)(uintptr_t)(a + 256);  // fake non-null
   return e->arena + a;
 }
+// GroupNorm accumulators live in one region at the start of a forward's allocations: ONE memset per forward
+// zeroes them all (they are filled by integer atomics)
+static long long* e_alloc_stats(diffsep_engine* e, size_t bytes) {
+  const size_t a = (e->stats_used + 255) & ~(size_t)255;
+  e->stats_used = a + bytes;
+  if (e->dry) { if (e->stats_used > e->stats_need) e->stats_need = e->stats_used; return (long long*)(uintptr_t)256; }
+  if (e->stats_used > e->stats_need) { ds_set_error("internal: GroupNorm accumulator region overflow"); return nullptr; }
+  return (long long*)(e->stats_ptr + a);
+}
+static int stats_begin(diffsep_engine* e, hipStream_t st) {  // call right after e->top = e->fwd_base
+  e->stats_used = 0;
+  if (e->dry) { e->stats_need = 0; return 0; }
+  e->stats_ptr = (char*)e_alloc(e, e->stats_need);
+  if (e->stats_need) DS_HIP(hipMemsetAsync(e->stats_ptr, 0, e->stats_need, st));
+  return 0;
+}
 static Tn e_tensor(diffsep_engine* e, int B, int H, int W, int C) {
   Tn t;
   t.C = C; t.ld = C; t.H = H; t.W = W;
@@ -413,7 +431,13 @@ static const float* P(diffsep_engine* e, const PRef& r) { return e->d_blob + r.o
 static const void* PK(diffsep_engine* e, long off) { return e->d_pack + off * e->esz; }
 
 // ---- launch helpers (skip when dry)
-struct GnAff { float* scale; float* shift; };
+// GroupNorm of a conv input: either materialised per-(b,c) scale / shift arrays, or (lazy) the producers'
+// accumulators + affine parameters, from which the consuming conv builds the table itself (no launch)
+struct GnAff {
+  float* scale = nullptr; float* shift = nullptr;
+  const long long* acc1 = nullptr; const long long* acc2 = nullptr;
+  const float* gamma = nullptr; const float* beta = nullptr; int groups = 0; float inv_count = 0.f;
+};
 struct SkipConv { const Tn* x; const void* w; int chunk; };  // fused 1x1 skip convolution on the raw block input
 static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias, const float* bias_b, int bias_b_ld,
                 const Tn* res, float scale, Tn& y, int Cout, int taps, int B, const float* div_b,
@@ -425,6 +449,10 @@ static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias
   a.x = x.p; a.x_bs = (long)x.H * x.W * x.ld; a.ldx = x.ld;
   a.x2 = x.p2; a.x2_bs = (long)x.H * x.W * x.ld2; a.ldx2 = x.ld2; a.C1 = x.C1;
   a.gn_scale = gn ? gn->scale : nullptr; a.gn_shift = gn ? gn->shift : nullptr; a.gn_act = gn_act;
+  if (gn && gn->acc1) {
+    a.gn_acc1 = gn->acc1; a.gn_acc2 = gn->acc2; a.gn_gamma = gn->gamma; a.gn_beta = gn->beta;
+    a.gn_groups = gn->groups; a.gn_inv_count = gn->inv_count; a.gn_eps = 1e-6f;
+  }
   a.w = w; a.w_bs = 0; a.w_chunked = weight_chunk(taps, x.C, e->cfg.dtype);
   a.bias = bias; a.bias_b = bias_b; a.bias_b_ld = bias_b_ld; a.bias_mode = 0; a.div_b = div_b;
   a.res = res ? res->p : nullptr; a.res_bs = res ? (long)res->H * res->W * res->ld : 0; a.ldr = res ? res->ld : 0;
@@ -437,23 +465,31 @@ static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias
     a.sw = skip->w; a.sw_chunked = skip->chunk;
   }
   if (want_stats) {  // the consumer's GroupNorm reads these partials instead of re-reading the tensor
-    y.nt = ds_conv_tiles(a);  // (depends on which kernel takes the launch: every field above matters)
-    y.st = (double*)e_alloc(e, (size_t)B * y.nt * Cout * 2 * sizeof(double));
-    a.stats_out = y.st;
+    y.sa = e_alloc_stats(e, (size_t)B * Cout * 2 * sizeof(long long));
+    if (!y.sa) return 1;
+    a.stats_acc = y.sa;
   }
   if (e->dry) return 0;
   return conv_launch_prof(e, a, st);
 }
 
 static int gn_stats(diffsep_engine* e, const Tn& x, const float* gamma, const float* beta, int B, GnAff& aff,
-                    hipStream_t st) {
+                    hipStream_t st, bool lazy = false) {
+  const int groups = (x.C / 4 < 32) ? x.C / 4 : 32;
+  aff = GnAff();
+  const bool have_acc = x.sa && (!x.p2 || x.sa2);
+  static const bool lazy_ok = !(getenv("DIFFSEP_GN_LAZY") && atoi(getenv("DIFFSEP_GN_LAZY")) == 0);  // A/B switch
+  if (have_acc && lazy && lazy_ok) {  // the consuming conv computes scale / shift in its prologue
+    aff.acc1 = x.sa; aff.acc2 = x.sa2; aff.gamma = gamma; aff.beta = beta; aff.groups = groups;
+    aff.inv_count = (float)(1.0 / ((double)x.H * x.W * (x.C / groups)));
+    return 0;
+  }
   aff.scale = e_f32(e, (size_t)B * x.C);
   aff.shift = e_f32(e, (size_t)B * x.C);
-  const int groups = (x.C / 4 < 32) ? x.C / 4 : 32;
-  if (x.st && (!x.p2 || x.st2)) {  // statistics came with the tensor(s): finalize only
+  if (have_acc) {
     if (e->dry) return 0;
-    return ds_launch_gn_finalize_parts(x.st, x.nt, x.p2 ? x.C1 : x.C, x.st2, x.nt2, x.p2 ? x.C - x.C1 : 0, B,
-                                       (long)x.H * x.W, groups, 1e-6f, gamma, beta, aff.scale, aff.shift, st);
+    return ds_launch_gn_finalize_acc(x.sa, x.p2 ? x.C1 : x.C, x.sa2, x.p2 ? x.C - x.C1 : 0, B, (long)x.H * x.W, groups,
+                                     1e-6f, gamma, beta, aff.scale, aff.shift, st);
   }
   void* ws = e_alloc(e, (size_t)ds_gn_workspace_bytes(B, x.H, x.W, x.C));
   if (e->dry) return 0;
@@ -479,7 +515,7 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
   const int Ho = m.up ? 2 * x.H : (m.down ? x.H / 2 : x.H);
   const int Wo = m.up ? 2 * x.W : (m.down ? x.W / 2 : x.W);
   GnAff a0, a1;
-  if (gn_stats(e, x, P(e, m.gn0_w), P(e, m.gn0_b), B, a0, st)) return 1;
+  if (gn_stats(e, x, P(e, m.gn0_w), P(e, m.gn0_b), B, a0, st, mode == 0)) return 1;  // resampling needs the arrays
   Tn h1 = e_tensor(e, B, Ho, Wo, m.out_ch);
   Tn xr = x, h0m;
   if (mode) {
@@ -500,7 +536,7 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
              m.out_ch, 9, B, nullptr, st, &a0, 1, true))
       return 1;
   }
-  if (gn_stats(e, h1, P(e, m.gn1_w), P(e, m.gn1_b), B, a1, st)) return 1;
+  if (gn_stats(e, h1, P(e, m.gn1_w), P(e, m.gn1_b), B, a1, st, true)) return 1;
   out = e_tensor(e, B, Ho, Wo, m.out_ch);
   if (m.has_conv2 && fuse_skip(m)) {
     DS_CHECK(ds_conv_skip_supported(Ho, Wo, m.out_ch, e->cfg.dtype), "internal: fused skip conv on an unsupported tile");
@@ -559,17 +595,19 @@ static int attn_block(diffsep_engine* e, const Module& m, const Tn& x, int B, Tn
   void* probs = e_alloc(e, (size_t)B * L * Lp * e->esz);
   Tn o = e_tensor(e, B, x.H, x.W, C);
   out = e_tensor(e, B, x.H, x.W, C);
-  if (e->dry) return 0;
-  ConvArgs a;
-  memset(&a, 0, sizeof(a));
-  a.dtype = e->cfg.dtype; a.B = B; a.taps = 1; a.out_scale = 1.f;
-  a.x = PK(e, m.pk_nin[2]); a.x_bs = 0; a.ldx = C;
-  a.w = h.p; a.w_bs = (long)L * C;
-  a.bias = P(e, m.nin_b[2]); a.bias_mode = 1;
-  a.y = vt; a.y_bs = (long)C * Lp; a.ldy = Lp;
-  a.H = 1; a.W = C; a.Cin = C; a.Cout = L;
-  if (ds_launch_conv(a, st)) return 1;
-  if (attention_core(q.p, k.p, vt, o.p, B, L, C, C, C, scores, probs, e->cfg.dtype, st)) return 1;
+  if (!e->dry) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dtype = e->cfg.dtype; a.B = B; a.taps = 1; a.out_scale = 1.f;
+    a.x = PK(e, m.pk_nin[2]); a.x_bs = 0; a.ldx = C;
+    a.w = h.p; a.w_bs = (long)L * C;
+    a.bias = P(e, m.nin_b[2]); a.bias_mode = 1;
+    a.y = vt; a.y_bs = (long)C * Lp; a.ldy = Lp;
+    a.H = 1; a.W = C; a.Cin = C; a.Cout = L;
+    if (ds_launch_conv(a, st)) return 1;
+    if (attention_core(q.p, k.p, vt, o.p, B, L, C, C, C, scores, probs, e->cfg.dtype, st)) return 1;
+  }
+  // (the dry run must see this call too: it sizes the accumulator region)
   return conv(e, o, PK(e, m.pk_nin[3]), P(e, m.nin_b[3]), nullptr, 0, &x, kInvSqrt2, out, C, 1, B, nullptr, st, nullptr,
               0, true);
 }
@@ -664,7 +702,7 @@ static int net_forward(diffsep_engine* e, const Tn& x0, const float* t, const Tn
     hipStream_t sp = sideb ? e->sideB : st;
     if (sideb && stream_dep(e, st, sp)) return 1;
     GnAff ga;
-    if (gn_stats(e, h, P(e, g.w0), P(e, g.b0), B, ga, sp)) return 1;
+    if (gn_stats(e, h, P(e, g.w0), P(e, g.b0), B, ga, sp, true)) return 1;
     Tn pnew = e_tensor(e, B, h.H, h.W, A.cpad_in);
     if (have_pyr) {
       Tn pu = e_tensor(e, B, h.H, h.W, A.cpad_in);
@@ -697,6 +735,7 @@ static int score_forward_impl(diffsep_engine* e, const float* xt, const float* t
   const int W = diffsep_padded_frames(&c, T), H = c.n_fft / 2 + 1, S = c.num_sources;
   e->top = e->fwd_base;
   e->fj_i = 0;
+  if (stats_begin(e, st)) return 1;
   Tn x0 = e_tensor(e, B, H, W, e->arch.cpad_in);
   Tn y = e_tensor(e, B, H, W, e->arch.cpad_out);
   float* ws_f = (float*)e_alloc(e, (size_t)ds_stft_workspace_bytes(B, S, T, c.n_fft, c.hop));
@@ -739,7 +778,7 @@ static int ensure_plan(diffsep_engine* e, int B, long T, hipStream_t st) {
   const int rc = score_forward_impl(e, nullptr, nullptr, nullptr, nullptr, B, T, st);
   e->dry = false;
   if (rc) return 1;
-  const size_t need = e->top + 4096;
+  const size_t need = e->top + e->stats_need + 8192;
   if (need > e->cap) {
     DS_HIP(hipStreamSynchronize(st));
     if (e->arena) DS_HIP(hipFree(e->arena));
@@ -914,6 +953,7 @@ extern "C" int32_t diffsep_backbone_forward(diffsep_engine* e, const void* x, co
   const int H = e->cfg.n_fft / 2 + 1;
   e->top = e->fwd_base;
   e->fj_i = 0;
+  if (stats_begin(e, st)) return 1;
   Tn xin; xin.p = (void*)x; xin.C = xin.ld = e->arch.cpad_in; xin.H = H; xin.W = W;
   Tn x0 = e_tensor(e, B, H, W, e->arch.cpad_in);
   float* sc = e_f32(e, (size_t)B * e->arch.cpad_in);
@@ -1105,12 +1145,19 @@ extern "C" int32_t diffsep_conv2d_fused(const void* x, const void* x2, int32_t C
                                         const float* gn_shift, int32_t gn_act, const void* w, const float* bias,
                                         const float* bias_b, const void* res, void* y, int32_t B, int32_t H, int32_t W,
                                         int32_t Cin, int32_t Cout, int32_t ksize, int32_t ldx, int32_t ldx2,
-                                        int32_t ldr, int32_t ldy, float out_scale, int32_t dtype, double* stats,
-                                        int32_t w_chunk, void* stream) {
+                                        int32_t ldr, int32_t ldy, float out_scale, int32_t dtype, int64_t* stats,
+                                        int32_t w_chunk, const int64_t* gn_acc1, const int64_t* gn_acc2,
+                                        const float* gn_gamma, const float* gn_beta, int32_t gn_groups, void* stream) {
   DS_CHECK(ksize == 1 || ksize == 3, "conv2d: ksize must be 1 or 3");
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.stats_out = stats;
+  a.stats_acc = (long long*)stats;
+  if (gn_acc1) {
+    DS_CHECK(gn_groups > 0 && Cin % gn_groups == 0, "conv2d: bad GroupNorm group count");
+    a.gn_acc1 = (const long long*)gn_acc1; a.gn_acc2 = (const long long*)gn_acc2; a.gn_gamma = gn_gamma;
+    a.gn_beta = gn_beta; a.gn_groups = gn_groups; a.gn_eps = 1e-6f;
+    a.gn_inv_count = (float)(1.0 / ((double)H * W * (Cin / gn_groups)));
+  }
   a.w_chunked = w_chunk;
   a.x = x; a.x_bs = (long)H * W * ldx; a.ldx = ldx;
   a.x2 = x2; a.x2_bs = (long)H * W * ldx2; a.ldx2 = ldx2; a.C1 = C1;
@@ -1125,15 +1172,6 @@ extern "C" int32_t diffsep_conv2d_fused(const void* x, const void* x2, int32_t C
 }
 
 extern "C" int32_t diffsep_conv2d_chunk(int32_t ksize, int32_t dtype) { return ds_conv_chunk(ksize == 3 ? 9 : 1, dtype); }
-
-extern "C" int32_t diffsep_conv2d_tiles(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
-                                        int32_t dtype) {
-  ConvArgs a;  // the unit entry point's launches: dense single-source input, shared weights, column bias
-  memset(&a, 0, sizeof(a));
-  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.taps = ksize == 3 ? 9 : 1; a.dtype = dtype;
-  a.ldx = Cin; a.ldy = (Cout + 7) & ~7; a.ldr = a.ldy;
-  return ds_conv_tiles(a);
-}
 
 extern "C" int32_t diffsep_attention(const void* q, const void* k, const void* vt, void* o, int32_t B, int32_t L,
                                      int32_t C, int32_t ld, int32_t dtype, void* workspace, int64_t workspace_bytes,

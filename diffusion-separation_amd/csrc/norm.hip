@@ -101,72 +101,42 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
   }
 }
 
-// GroupNorm scale/shift from the per-tile channel partials the conv epilogue wrote (no extra pass over the
-// activation).  grid (B) x 1024 threads split (channel, tile-slice); two partial sources = in-place concat.
-__global__ __launch_bounds__(1024) void gn_finalize_parts_kernel(const double* __restrict__ p1, int nt1, int C1,
-                                                                const double* __restrict__ p2, int nt2, int C2,
-                                                                int groups, double count, float eps,
-                                                                const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta,
-                                                                float* __restrict__ scale, float* __restrict__ shift) {
-  __shared__ double cs[1024], cq[1024];
-  __shared__ float gm[256], gr[256];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int C = C1 + C2;
-  const int Cw = C < 1024 ? C : 1024;
-  const int nsl = 1024 / Cw;  // tile slices summed in parallel (the loop below is a chain of L2 round trips)
-  const int cl = tid % Cw, sl = tid / Cw;
-  if (sl < nsl) {
-    for (int c = cl; c < C; c += Cw) {
-      const bool second = c >= C1;
-      const double* src = second ? p2 : p1;
-      const int nt = second ? nt2 : nt1, Cs = second ? C2 : C1, cc = second ? c - C1 : c;
-      double a = 0.0, q = 0.0;
-#pragma unroll 8
-      for (int t = sl; t < nt; t += nsl) {
-        const double* o = src + (((long)b * nt + t) * Cs + cc) * 2;
-        a += o[0];
-        q += o[1];
-      }
-      cs[sl * C + c] = a;
-      cq[sl * C + c] = q;
+// GroupNorm scale/shift from the channel-sum accumulators the conv epilogues fill (fixed point, common.h) — only
+// for consumers that are not convolutions (the FIR resampling / attention GroupNorm kernels); the convolutions
+// build the same table in their own prologue.  grid (B) x 256 threads; two sources = in-place concat.
+__global__ __launch_bounds__(256) void gn_finalize_acc_kernel(const long long* __restrict__ a1, int C1,
+                                                              const long long* __restrict__ a2, int C2, int groups,
+                                                              double inv_count, float eps,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              float* __restrict__ scale, float* __restrict__ shift) {
+  const int b = blockIdx.x, C = C1 + C2, cpg = C / groups;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g0 = (c / cpg) * cpg;
+    long long ssum = 0, ssq = 0;
+    for (int j = 0; j < cpg; ++j) {
+      const int cj = g0 + j;
+      const long long* src = cj < C1 ? a1 + ((long)b * C1 + cj) * 2 : a2 + ((long)b * C2 + (cj - C1)) * 2;
+      ssum += src[0];
+      ssq += src[1];
     }
-  }
-  __syncthreads();
-  for (int c = tid; c < C; c += 1024) {
-    double a = 0.0, q = 0.0;
-    for (int s = 0; s < nsl; ++s) { a += cs[s * C + c]; q += cq[s * C + c]; }
-    cs[c] = a;  // slot (0, c) is read by this thread only: no hazard with the other threads' reads
-    cq[c] = q;
-  }
-  __syncthreads();
-  const int cpg = C / groups;
-  for (int g = tid; g < groups; g += 1024) {
-    double a = 0.0, q = 0.0;
-    for (int j = 0; j < cpg; ++j) { a += cs[g * cpg + j]; q += cq[g * cpg + j]; }
-    const double mean = a / count;
-    double var = q / count - mean * mean;
+    const double mean = (double)ssum * (1.0 / DS_STAT_SUM_SCALE) * inv_count;
+    double var = (double)ssq * (1.0 / DS_STAT_SQ_SCALE) * inv_count - mean * mean;
     if (var < 0.0) var = 0.0;
-    gm[g] = (float)mean;
-    gr[g] = (float)(1.0 / sqrt(var + (double)eps));
-  }
-  __syncthreads();
-  for (int c = tid; c < C; c += 1024) {
-    const int g = c / cpg;
-    const float sc = gr[g] * (gamma ? gamma[c] : 1.f);
+    const float sc = (float)(1.0 / sqrt(var + (double)eps)) * (gamma ? gamma[c] : 1.f);
     scale[(long)b * C + c] = sc;
-    shift[(long)b * C + c] = (beta ? beta[c] : 0.f) - gm[g] * sc;
+    shift[(long)b * C + c] = (beta ? beta[c] : 0.f) - (float)mean * sc;
   }
 }
 
-int ds_launch_gn_finalize_parts(const double* p1, int nt1, int C1, const double* p2, int nt2, int C2, int B, long npix,
-                                int groups, float eps, const float* gamma, const float* beta, float* scale,
-                                float* shift, hipStream_t st) {
+int ds_launch_gn_finalize_acc(const long long* a1, int C1, const long long* a2, int C2, int B, long npix, int groups,
+                              float eps, const float* gamma, const float* beta, float* scale, float* shift,
+                              hipStream_t st) {
   const int C = C1 + C2;
-  DS_CHECK(C <= 1024 && C % groups == 0 && groups <= 256, "groupnorm(parts): unsupported channel / group count");
-  const double count = (double)npix * (double)(C / groups);
-  hipLaunchKernelGGL(gn_finalize_parts_kernel, dim3(B), dim3(1024), 0, st, p1, nt1, C1, p2, nt2, C2, groups, count, eps,
-                     gamma, beta, scale, shift);
+  DS_CHECK(C % groups == 0 && groups > 0, "groupnorm(acc): bad group count");
+  const double inv_count = 1.0 / ((double)npix * (double)(C / groups));
+  hipLaunchKernelGGL(gn_finalize_acc_kernel, dim3(B), dim3(256), 0, st, a1, C1, a2, C2, groups, inv_count, eps, gamma,
+                     beta, scale, shift);
   DS_LAUNCH_CHECK();
   return 0;
 }

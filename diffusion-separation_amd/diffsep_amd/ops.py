@@ -89,9 +89,14 @@ def groupnorm_stats(x, gamma, beta, groups, eps=1e-6, x2=None):
     return scale, shift
 
 
+STAT_SUM_SCALE, STAT_SQ_SCALE = 2.0 ** 24, 2.0 ** 16  # fixed-point scales of the GroupNorm accumulators
+
+
 def conv2d_fused(x, wpacked, bias, cout, ksize, x2=None, gn=None, gn_act=1, bias_b=None, res=None, out_scale=1.0,
-                 cout_pad=None, out=None, stats=False, w_chunk=0):
-    """stats=True additionally returns the per-tile float64 partials [B,tiles,cout,2] of the output."""
+                 cout_pad=None, out=None, stats=False, w_chunk=0, gn_acc=None):
+    """stats=True additionally returns the int64 channel-sum accumulators [B,cout,2] of the output (sum * 2^24,
+    sum of squares * 2^16); stats=<tensor> adds into it.  gn_acc=(acc1, acc2|None, gamma, beta, groups): GroupNorm of
+    the input from such accumulators instead of gn=(scale, shift)."""
     B, H, W, C1 = x.shape
     Cin = C1 + (x2.shape[-1] if x2 is not None else 0)
     cp = cout if cout_pad is None else cout_pad
@@ -99,15 +104,24 @@ def conv2d_fused(x, wpacked, bias, cout, ksize, x2=None, gn=None, gn_act=1, bias
     sc, sh = gn if gn is not None else (None, None)
     st = None
     if stats is True:
-        st = torch.zeros((B, lib().diffsep_conv2d_tiles(B, H, W, Cin, cout, ksize, _dt(x)), cout, 2), dtype=torch.float64,
-                         device=x.device)
+        st = torch.zeros((B, cout, 2), dtype=torch.int64, device=x.device)
     elif stats is not False:
         st = stats
+    a1, a2, gam, bet, grp = gn_acc if gn_acc is not None else (None, None, None, None, 0)
     check(lib().diffsep_conv2d_fused(_ptr(x), _ptr(x2), C1, _ptr(sc), _ptr(sh), gn_act, _ptr(wpacked), _ptr(bias),
                                      _ptr(bias_b), _ptr(res), _ptr(y), B, H, W, Cin, cout, ksize, C1,
                                      x2.shape[-1] if x2 is not None else 0, res.shape[-1] if res is not None else 0, cp,
-                                     out_scale, _dt(x), _ptr(st), w_chunk, _stream_ptr()))
+                                     out_scale, _dt(x), _ptr(st), w_chunk, _ptr(a1), _ptr(a2), _ptr(gam), _ptr(bet), grp,
+                                     _stream_ptr()))
     return (y, st) if stats is not False else y
+
+
+def stats_to_float(st):
+    """int64 accumulators [B,C,2] -> float64 (sum, sum of squares)."""
+    out = st.double()
+    out[..., 0] /= STAT_SUM_SCALE
+    out[..., 1] /= STAT_SQ_SCALE
+    return out
 
 
 def attention(q, k, vt):

@@ -185,15 +185,19 @@ int32_t diffsep_conv2d_fused(const void* x, const void* x2, int32_t C1, const fl
                              int32_t gn_act, const void* w, const float* bias, const float* bias_b, const void* res,
                              void* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize,
                              int32_t ldx, int32_t ldx2, int32_t ldr, int32_t ldy, float out_scale, int32_t dtype,
-                             double* stats, int32_t w_chunk, void* stream);
+                             int64_t* stats, int32_t w_chunk, const int64_t* gn_acc1, const int64_t* gn_acc2,
+                             const float* gn_gamma, const float* gn_beta, int32_t gn_groups, void* stream);
 /* `w_chunk` = 0: w is [Cout][k*k][Cin_pad]; = kc = diffsep_conv2d_chunk(ksize, dtype): w is chunk-major
  * [Cin_pad / kc][k*k][Cout][kc] (the layout the engine keeps its weights in: one K stage of the kernel is then
  * contiguous in memory and is fetched in full 128-byte lines). */
 int32_t diffsep_conv2d_chunk(int32_t ksize, int32_t dtype);
-/* `stats` (nullable): per-tile partial sums of the OUTPUT for the next GroupNorm, [B][tiles][Cout][2] float64
- * (sum, sum of squares) with tiles = diffsep_conv2d_tiles(...) of the same problem — the conv epilogue produces them so that no
- * separate pass over the tensor is needed (layerspp.py:313: GroupNorm_1 follows Conv_0). */
-int32_t diffsep_conv2d_tiles(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t ksize, int32_t dtype);
+/* `stats` (nullable): channel-sum accumulators of the OUTPUT for the next GroupNorm, [B][Cout][2] int64 fixed point
+ * (sum * 2^24, sum of squares * 2^16).  Every block ADDS its tile's totals with integer atomics (associative:
+ * bit-reproducible), the caller zeroes the buffer first — so no separate pass over the tensor is needed
+ * (layerspp.py:313: GroupNorm_1 follows Conv_0).
+ * `gn_acc1` (nullable, instead of gn_scale / gn_shift): such accumulators of x (and gn_acc2 of x2) plus the
+ * GroupNorm affine parameters gamma / beta [Cin] and the group count; the kernel derives scale / shift itself
+ * (eps = 1e-6, statistics over H * W * Cin / groups elements per group). */
 
 /* AttnBlockpp core (layerspp.py:83-87): o = softmax(q k^T * C^-0.5) v over L = H*W tokens.
  * q,k [B,L,C] (ld), vt [B,C,Lp] (V transposed, Lp = L rounded up to 8), o [B,L,C];

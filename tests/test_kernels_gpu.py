@@ -339,16 +339,16 @@ def test_gram_and_separation_metrics():
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("ksize,H,W", [(3, 16, 64), (3, 12, 40), (1, 16, 32), (3, 8, 8)])
 def test_conv_epilogue_statistics(dt, ksize, H, W):
-    # the per-tile partials the conv epilogue emits for the next GroupNorm sum to the statistics of its own output
+    # the channel-sum accumulators the conv epilogue fills for the next GroupNorm = statistics of its own output
     B, ci, co = 2, 16, 64
     x = rnd("cs.x", (B, H, W, ci)).to(DEV).to(dt)
     w = (rnd("cs.w", (co, ksize * ksize, ci)) / (ksize * ksize * ci) ** 0.5).to(DEV).to(dt)
     b = rnd("cs.b", (co,)).to(DEV)
     res = rnd("cs.r", (B, H, W, co)).to(DEV).to(dt)
     y, st = ops.conv2d_fused(x, w, b, co, ksize, res=res, out_scale=0.7071, stats=True)
-    s = st.sum(1)  # [B, co, 2]
+    s = ops.stats_to_float(st)  # [B, co, 2]
     yd = y.double()
-    tol = 1e-6 if dt == torch.float32 else 2e-3  # the partials are taken before the bf16 rounding of the output
+    tol = 2e-6 if dt == torch.float32 else 2e-3  # the sums are taken before the bf16 rounding of the output
     assert torch.allclose(s[..., 0], yd.sum((1, 2)), rtol=tol, atol=tol * H * W)
     assert torch.allclose(s[..., 1], (yd * yd).sum((1, 2)), rtol=tol, atol=tol * H * W)
 
@@ -379,7 +379,7 @@ def test_weight_stationary_conv3x3_64_to_64(B, H, W, act, variant, monkeypatch):
     y, st = ops.conv2d_fused(x, ops.pack_conv_weight(w, dt).to(DEV), bias, 64, 3, gn=None if act is None else (sc, sh),
                              gn_act=act or 0, bias_b=bb, res=res, out_scale=0.70710678, stats=True)
     assert rel_rms(y.float(), ref) < 4e-3
-    s = st.sum(1)
+    s = ops.stats_to_float(st)
     assert torch.allclose(s[..., 0], ref.double().sum((1, 2)), rtol=2e-3, atol=2e-3 * H * W)
     assert torch.allclose(s[..., 1], (ref.double() ** 2).sum((1, 2)), rtol=2e-3, atol=2e-3 * H * W)
     y2 = ops.conv2d_fused(x, ops.pack_conv_weight(w, dt).to(DEV), None, 64, 3)  # no bias / residual / statistics
@@ -401,3 +401,37 @@ def test_conv_chunk_major_weights_are_equivalent(dtype, tol, C1, C2, Cout, H, W,
     y0 = ops.conv2d_fused(a, ops.pack_conv_weight(w, dtype).to(DEV), bias, Cout, k, x2=bt)
     y1 = ops.conv2d_fused(a, ops.pack_conv_weight(w, dtype, chunk=kc).to(DEV), bias, Cout, k, x2=bt, w_chunk=kc)
     assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("C1,C2,Cout,H,W,k", [(64, 0, 64, 16, 64, 3), (64, 64, 64, 16, 32, 3), (128, 64, 64, 8, 32, 3),
+                                             (16, 16, 24, 8, 8, 3), (64, 64, 64, 16, 64, 1)])
+def test_conv_groupnorm_from_producer_accumulators(dtype, tol, C1, C2, Cout, H, W, k, monkeypatch):
+    # producer convs fill the channel-sum accumulators; the consumer derives GroupNorm scale / shift from them in its
+    # own prologue (no finalize launch), also across the seam of an in-place concat (groups of 6 for C = 192)
+    B = 2
+    C = C1 + C2
+    groups = min(C // 4, 32)
+    g, be = (1.0 + rnd(f"ga.g{C}", (C,), 0.2)).to(DEV), rnd(f"ga.be{C}", (C,), 0.1).to(DEV)
+
+    def produce(tag, Cp):
+        xi = rnd(f"ga.x{tag}{Cp}{H}", (B, H, W, 16)).to(DEV, dtype)
+        wi = ops.pack_conv_weight(rnd(f"ga.w{tag}{Cp}", (Cp, 16, 3, 3), 1.0 / 12.0), dtype).to(DEV)
+        return ops.conv2d_fused(xi, wi, rnd(f"ga.b{tag}{Cp}", (Cp,), 0.3).to(DEV), Cp, 3, stats=True)
+
+    a, sa = produce("a", C1)
+    (bt, sb) = produce("b", C2) if C2 else (None, None)
+    w = rnd(f"ga.w{C}{Cout}{k}", (Cout, C, k, k), 1.0 / math.sqrt(k * k * C))
+    bias = rnd(f"ga.bias{Cout}", (Cout,), 0.1).to(DEV)
+    wp = ops.pack_conv_weight(w, dtype).to(DEV)
+    sc, sh = ops.groupnorm_stats(a, g, be, groups, 1e-6, x2=bt)  # two-pass statistics over the stored tensor
+    y_ref = ops.conv2d_fused(a, wp, bias, Cout, k, x2=bt, gn=(sc, sh), gn_act=1)
+    y = ops.conv2d_fused(a, wp, bias, Cout, k, x2=bt, gn_acc=(sa, sb, g, be, groups), gn_act=1)
+    # (the accumulators hold the sums BEFORE the output was rounded to the storage dtype)
+    assert rel_rms(y.float(), y_ref.float()) < (1e-5 if dtype == torch.float32 else 1e-2)
+    xcat = torch.cat([a.float(), bt.float()], -1) if C2 else a.float()
+    hn = F.silu(F.group_norm(xcat.permute(0, 3, 1, 2), groups, g, be, eps=1e-6))
+    if dtype == torch.bfloat16:
+        hn = hn.to(dtype).float()
+    ref = F.conv2d(hn, w.to(DEV), bias, padding=k // 2).permute(0, 2, 3, 1)
+    assert rel_rms(y.float(), ref) < tol

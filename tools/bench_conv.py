@@ -43,7 +43,7 @@ def main():
         if FUSED and ci >= 64:  # GroupNorm + SiLU on the input, residual add: the shape of the engine's launches
             sc, sh = torch.rand(B, ci, device="cuda") + 0.5, torch.randn(B, ci, device="cuda") * 0.1
             res = torch.randn(B, H, W, cp, device="cuda").to(dt)
-            _, st = ops.conv2d_fused(x, w, b, co, k, cout_pad=cp, out=y, stats=True, w_chunk=kc)
+            _, st = ops.conv2d_fused(x, w, b, co, k, cout_pad=cp, out=y, stats=True, w_chunk=kc)  # int64 accumulators (keep adding: timing only)
             run = lambda: ops.conv2d_fused(x, w, b, co, k, gn=(sc, sh), gn_act=1, res=res, out_scale=0.7071, cout_pad=cp, out=y, stats=st, w_chunk=kc)
         else:
             run = lambda: ops.conv2d_fused(x, w, b, co, k, cout_pad=cp, out=y, w_chunk=kc)
