@@ -401,15 +401,23 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
   };
   // accumulator mode: per-channel scale = rstd * gamma, shift = beta - mean * scale of image b, into LDS
   auto build_gn_table = [&]() __attribute__((always_inline)) {
+    // one global round trip: every thread fetches the sums of ITS channel into LDS (the staging area is still
+    // unused), then the group totals come from LDS
+    long long* tmp = reinterpret_cast<long long*>(smem);  // [Cin][2]
+    for (int c = tid; c < p.Cin; c += 256) {
+      const long long* src = c < C1 ? p.gn_acc1 + ((long)b * C1 + c) * 2 : p.gn_acc2 + ((long)b * C2 + (c - C1)) * 2;
+      const longlong2 v = *reinterpret_cast<const longlong2*>(src);
+      tmp[2 * c] = v.x;
+      tmp[2 * c + 1] = v.y;
+    }
+    __syncthreads();
     const int cpg = p.Cin / p.gn_groups;
     for (int c = tid; c < p.Cin; c += 256) {
       const int g0 = (c / cpg) * cpg;
       long long ssum = 0, ssq = 0;
       for (int j = 0; j < cpg; ++j) {
-        const int cj = g0 + j;
-        const long long* src = cj < C1 ? p.gn_acc1 + ((long)b * C1 + cj) * 2 : p.gn_acc2 + ((long)b * C2 + (cj - C1)) * 2;
-        ssum += src[0];
-        ssq += src[1];
+        ssum += tmp[2 * (g0 + j)];
+        ssq += tmp[2 * (g0 + j) + 1];
       }
       const double mean = (double)ssum * (1.0 / DS_STAT_SUM_SCALE) * (double)p.gn_inv_count;
       double var = (double)ssq * (1.0 / DS_STAT_SQ_SCALE) * (double)p.gn_inv_count - mean * mean;
