@@ -4,6 +4,8 @@
 //   channel concat, row softmax.
 // Reference semantics: nn.GroupNorm(min(C/4,32), C, eps=1e-6) + SiLU  layerspp.py:264-266,292,313;
 // upsample_2d / downsample_2d  up_or_down_sampling.py:206-273 (closed forms: SURVEY.md §8a-15).
+#include <stdlib.h>
+
 #include "common.h"
 
 // ------------------------------------------------------------------ GroupNorm statistics
@@ -260,6 +262,94 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
+// Block variants of the resampling modes: one thread = a 2 x 2 OUTPUT block x 8 channels, built separably (rows of
+// horizontally filtered values, then the vertical taps).  SiLU(GN(.)) is evaluated 9 (up) / 36 (down) times per 4
+// outputs instead of 16 / 64, and the loads shrink likewise.  Same arithmetic as gn_apply_kernel up to fp32
+// summation order.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void gn_resample2x2_kernel(const T* __restrict__ x, int ldx,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int C, T* __restrict__ y,
+                                                             int ldy, T* __restrict__ xr, int ldxr, int B, int H, int W,
+                                                             int act) {
+  constexpr int NR = MODE == 1 ? 3 : 6;  // input rows / columns feeding one 2 x 2 output block
+  const int Hb = MODE == 1 ? H : H / 4, Wb = MODE == 1 ? W : W / 4;  // grid of output blocks
+  const int Ho = MODE == 1 ? 2 * H : H / 2, Wo = MODE == 1 ? 2 * W : W / 2;
+  const int ncg = C >> 3;
+  const long total = (long)B * Hb * Wb * ncg;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cg = (int)(i % ncg);
+    long r = i / ncg;
+    const int bx = (int)(r % Wb);
+    r /= Wb;
+    const int by = (int)(r % Hb);
+    const int b = (int)(r / Hb);
+    float sc[8], sf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sc[j] = scale[(long)b * C + cg * 8 + j];
+      sf[j] = shift[(long)b * C + cg * 8 + j];
+    }
+    const T* xb = x + (long)b * H * W * ldx + cg * 8;
+    const int iy0 = MODE == 1 ? by - 1 : 4 * by - 1, ix0 = MODE == 1 ? bx - 1 : 4 * bx - 1;
+    float oh[2][2][8], ox[2][2][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { oh[a][c][j] = 0.f; ox[a][c][j] = 0.f; }
+#pragma unroll
+    for (int ri = 0; ri < NR; ++ri) {
+      const int iy = iy0 + ri;
+      if (iy < 0 || iy >= H) continue;
+      float hh[2][8], hx[2][8];  // horizontally filtered activated / raw values for the two output columns
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { hh[c][j] = 0.f; hx[c][j] = 0.f; }
+#pragma unroll
+      for (int ci = 0; ci < NR; ++ci) {
+        const int ix = ix0 + ci;
+        // horizontal tap weights of input column ci for output columns 0 / 1
+        const float w0 = MODE == 1 ? (ci == 0 ? 0.25f : (ci == 1 ? 0.75f : 0.f))
+                                   : (ci == 0 || ci == 3 ? 0.125f : (ci == 1 || ci == 2 ? 0.375f : 0.f));
+        const float w1 = MODE == 1 ? (ci == 1 ? 0.75f : (ci == 2 ? 0.25f : 0.f))
+                                   : (ci == 2 || ci == 5 ? 0.125f : (ci == 3 || ci == 4 ? 0.375f : 0.f));
+        if (ix < 0 || ix >= W) continue;
+        float f[8];
+        load8<T>(xb + ((long)iy * W + ix) * ldx, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float v = f[j] * sc[j] + sf[j];
+          v = act ? silu_t<T>(v) : v;
+          if (w0 != 0.f) { hh[0][j] = fmaf(w0, v, hh[0][j]); hx[0][j] = fmaf(w0, f[j], hx[0][j]); }
+          if (w1 != 0.f) { hh[1][j] = fmaf(w1, v, hh[1][j]); hx[1][j] = fmaf(w1, f[j], hx[1][j]); }
+        }
+      }
+      const float v0 = MODE == 1 ? (ri == 0 ? 0.25f : (ri == 1 ? 0.75f : 0.f))
+                                 : (ri == 0 || ri == 3 ? 0.125f : (ri == 1 || ri == 2 ? 0.375f : 0.f));
+      const float v1 = MODE == 1 ? (ri == 1 ? 0.75f : (ri == 2 ? 0.25f : 0.f))
+                                 : (ri == 2 || ri == 5 ? 0.125f : (ri == 3 || ri == 4 ? 0.375f : 0.f));
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (v0 != 0.f) { oh[0][c][j] = fmaf(v0, hh[c][j], oh[0][c][j]); ox[0][c][j] = fmaf(v0, hx[c][j], ox[0][c][j]); }
+          if (v1 != 0.f) { oh[1][c][j] = fmaf(v1, hh[c][j], oh[1][c][j]); ox[1][c][j] = fmaf(v1, hx[c][j], ox[1][c][j]); }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const long opix = ((long)b * Ho + 2 * by + a) * Wo + 2 * bx + c;
+        store8<T>(y + opix * ldy + cg * 8, oh[a][c]);
+        if (xr) store8<T>(xr + opix * ldxr + cg * 8, ox[a][c]);
+      }
+  }
+}
+
 template <typename T>
 static int gn_apply_typed(const void* x, int ldx, const float* scale, const float* shift, int C, void* y, int ldy,
                           void* xr, int ldxr, int B, int H, int W, int act, int mode, hipStream_t st) {
@@ -270,6 +360,21 @@ static int gn_apply_typed(const void* x, int ldx, const float* scale, const floa
   if (nb > 16384) nb = 16384;
   if (nb < 1) nb = 1;
   const bool aff = scale != nullptr;
+  static const bool blk = !(getenv("DIFFSEP_RESAMPLE_BLOCK") && atoi(getenv("DIFFSEP_RESAMPLE_BLOCK")) == 0);
+  if (blk && aff && (mode == 1 || (mode == 2 && H % 4 == 0 && W % 4 == 0))) {  // 2 x 2 output blocks per thread
+    const long tot2 = (mode == 1 ? (long)B * H * W : (long)B * (H / 4) * (W / 4)) * (C >> 3);
+    long nb2 = (tot2 + 255) / 256;
+    if (nb2 > 16384) nb2 = 16384;
+    if (nb2 < 1) nb2 = 1;
+    if (mode == 1)
+      hipLaunchKernelGGL((gn_resample2x2_kernel<T, 1>), dim3((unsigned)nb2), dim3(256), 0, st, (const T*)x, ldx, scale,
+                         shift, C, (T*)y, ldy, (T*)xr, ldxr, B, H, W, act);
+    else
+      hipLaunchKernelGGL((gn_resample2x2_kernel<T, 2>), dim3((unsigned)nb2), dim3(256), 0, st, (const T*)x, ldx, scale,
+                         shift, C, (T*)y, ldy, (T*)xr, ldxr, B, H, W, act);
+    DS_LAUNCH_CHECK();
+    return 0;
+  }
 #define GA(M, A)                                                                                                    \
   hipLaunchKernelGGL((gn_apply_kernel<T, M, A>), dim3((unsigned)nb), dim3(256), 0, st, (const T*)x, ldx, scale, shift, \
                      C, (T*)y, ldy, (T*)xr, ldxr, B, H, W, act)
