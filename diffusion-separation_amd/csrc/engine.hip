@@ -479,7 +479,8 @@ static int gn_stats(diffsep_engine* e, const Tn& x, const float* gamma, const fl
   aff = GnAff();
   const bool have_acc = x.sa && (!x.p2 || x.sa2);
   static const bool lazy_ok = !(getenv("DIFFSEP_GN_LAZY") && atoi(getenv("DIFFSEP_GN_LAZY")) == 0);  // A/B switch
-  if (have_acc && lazy && lazy_ok) {  // the consuming conv computes scale / shift in its prologue
+  if (have_acc && lazy && lazy_ok && x.C <= 512) {  // the consuming conv computes scale / shift in its prologue
+    // (its LDS table holds 512 channels; wider inputs take the materialised arrays below)
     aff.acc1 = x.sa; aff.acc2 = x.sa2; aff.gamma = gamma; aff.beta = beta; aff.groups = groups;
     aff.inv_count = (float)(1.0 / ((double)x.H * x.W * (x.C / groups)));
     return 0;
