@@ -167,7 +167,7 @@ struct ConvGeom {
   static constexpr int LDS_OUT = (BM / EP) * OROW;  // the epilogue streams the tile out in EP passes
   static constexpr int LDS = LDS_STAGE > LDS_OUT ? LDS_STAGE : LDS_OUT;
   // fused 1x1 skip convolution: needs one weight staging pass per tap (256 / NVEC rows per pass == BN)
-  static constexpr bool SKIP_OK = TAPS == 9 && (256 / NVEC) == BN;
+  static constexpr bool SKIP_OK = TAPS == 9 && (256 / NVEC) <= BN && BN % (256 / NVEC) == 0;
 };
 
 // ---- buffer addressing (SRSRC): a wave-uniform descriptor + a 32-bit per-lane byte offset + a uniform
@@ -288,7 +288,8 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     // weights: [Cout][tap][Cin] or, chunk-major, [Cin / KC][tap][Cout][KC] (a stage's rows are then contiguous:
     // full 128-byte lines per request instead of 64-byte pieces)
     vob[k] = !ok ? DS_OOB
-                 : p.w_chunked ? (unsigned)((tap * p.Cout + n0 + col) * KC + vch) * ESZ
+                 : p.w_chunked ? (unsigned)((((vch / p.w_chunked) * TAPS + tap) * p.Cout + n0 + col) * p.w_chunked +
+                                            vch % p.w_chunked) * ESZ
                                : (unsigned)(((n0 + col) * TAPS + tap) * p.Cin + vch) * ESZ;
   }
 
@@ -324,8 +325,9 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
   const int nchs1 = p.sx ? (sC1 + KC - 1) / KC : 0;
   const int ncht = nch + nchs1 + (p.sx ? (sC2 + KC - 1) / KC : 0);
   // (supported by the instantiations whose weight staging makes one pass per tap; the launcher checks)
-  constexpr bool SKIP_OK = TAPS == 9 && B_TAPSTEP && RPS == BN;
-  constexpr int KSKIP = SKIP_OK ? 4 : 0;  // staging pass that holds the centre tap
+  constexpr bool SKIP_OK = G::SKIP_OK;
+  constexpr int QS = SKIP_OK ? BN / RPS : 1;   // staging passes per tap
+  constexpr int KSKIP = SKIP_OK ? 4 * QS : 0;  // first staging pass of the centre tap
   auto load_chunk = [&](int c) __attribute__((always_inline)) {
     if (SKIP_OK && c >= nch) {  // skip chunk: raw input, centre-tap weights only
       const int cs = c - nch;
@@ -342,11 +344,15 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
       const unsigned so = (unsigned)cb * ESZ;
 #pragma unroll
       for (int k = 0; k < NA; ++k) pa[k] = buf_load16(rs, (ch_ok && ain[k]) ? voa(k, lds_) : DS_OOB, so);
-      const int col = row0 % BN;
-      const bool okw = ch_ok && n0 + col < p.Cout;
-      const unsigned vo = p.sw_chunked ? (unsigned)(((wb / KC) * p.Cout + n0 + col) * KC + vch) * ESZ
-                                       : (unsigned)((n0 + col) * p.sCin + wb + vch) * ESZ;
-      pb[KSKIP] = buf_load16(rsw, okw ? vo : DS_OOB, 0);
+#pragma unroll
+      for (int q = 0; q < QS; ++q) {
+        const int col = row0 + q * RPS;  // (RPS == BN: row0 < BN)
+        const bool okw = ch_ok && col < BN && n0 + col < p.Cout;
+        const unsigned vo = p.sw_chunked ? (unsigned)((((wb + vch) / p.sw_chunked) * p.Cout + n0 + col) * p.sw_chunked +
+                                                      (wb + vch) % p.sw_chunked) * ESZ
+                                         : (unsigned)((n0 + col) * p.sCin + wb + vch) * ESZ;
+        pb[KSKIP + q] = buf_load16(rsw, okw ? vo : DS_OOB, 0);
+      }
       return;
     }
     const bool second = c >= nch1;
@@ -355,7 +361,8 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     const int wb = second ? C1 + cb : cb;                // channel offset inside the weights / GN tables
     ch_ok = vch < width;
     const unsigned so = (unsigned)cb * ESZ;
-    const unsigned sw = p.w_chunked ? (unsigned)(wb / KC) * (unsigned)(TAPS * p.Cout * KC * ESZ) : (unsigned)wb * ESZ;
+    const unsigned sw = p.w_chunked ? (unsigned)(wb / p.w_chunked) * (unsigned)(TAPS * p.Cout * p.w_chunked * ESZ)
+                                    : (unsigned)wb * ESZ;
 #ifdef ABL_NOLOAD
     return;
 #endif
@@ -440,7 +447,8 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     for (int k = 0; k < NA; ++k)
       if (a_in(k)) *reinterpret_cast<uint4*>(sA + lds0 + k * RPS * ROWB) = pa[k];
     if (skip) {  // only the centre tap's weight rows exist (and only they are read)
-      *reinterpret_cast<uint4*>(sB + lds0 + KSKIP * RPS * ROWB) = pb[KSKIP];
+#pragma unroll
+      for (int q = 0; q < QS; ++q) *reinterpret_cast<uint4*>(sB + lds0 + (KSKIP + q) * RPS * ROWB) = pb[KSKIP + q];
       return;
     }
 #pragma unroll
@@ -756,14 +764,16 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   k.x = a.x; k.x_bs = a.x_bs; k.ldx = a.ldx; k.C1 = a.x2 ? a.C1 : a.Cin;
   k.x2 = a.x2; k.x2_bs = a.x2_bs; k.ldx2 = a.ldx2;
   k.w = a.w; k.w_bs = a.w_bs;
-  DS_CHECK(a.w_chunked == 0 || (a.w_chunked == KC && a.Cin % KC == 0 && (!a.x2 || a.C1 % KC == 0)),
-           "conv: chunk-major weights need kc == the kernel's chunk width and whole chunks per source");
-  k.w_chunked = a.w_chunked ? 1 : 0;
+  // chunk-major weights [Cin/kc][taps][Cout][kc]: a K stage of KC channels is KC / kc consecutive layout chunks
+  DS_CHECK(a.w_chunked == 0 || (a.w_chunked >= 8 && KC % a.w_chunked == 0 && a.Cin % KC == 0 && (!a.x2 || a.C1 % KC == 0)),
+           "conv: chunk-major weights need kc | the kernel's chunk width and whole chunks per source");
+  k.w_chunked = a.w_chunked;
   DS_CHECK(!a.sx || (G::SKIP_OK && a.sw && a.sCin % 8 == 0 && a.ldsx % 8 == 0 &&
-                     (a.sw_chunked == 0 || (a.sw_chunked == KC && a.sCin % KC == 0 && (!a.sx2 || a.sC1 % KC == 0)))),
+                     (a.sw_chunked == 0 || (a.sw_chunked >= 8 && KC % a.sw_chunked == 0 && a.sCin % KC == 0 &&
+                                            (!a.sx2 || a.sC1 % KC == 0)))),
            "conv: bad fused skip convolution arguments");
   k.sx = a.sx; k.sx_bs = a.sx_bs; k.ldsx = a.ldsx; k.sx2 = a.sx2; k.sx2_bs = a.sx2_bs; k.ldsx2 = a.ldsx2;
-  k.sC1 = a.sx2 ? a.sC1 : a.sCin; k.sCin = a.sCin; k.sw = a.sw; k.sw_chunked = a.sw_chunked ? 1 : 0;
+  k.sC1 = a.sx2 ? a.sC1 : a.sCin; k.sCin = a.sCin; k.sw = a.sw; k.sw_chunked = a.sw_chunked;
   k.gn_scale = a.gn_scale; k.gn_shift = a.gn_shift; k.gn_act = a.gn_act;
   k.bias = a.bias; k.bias_b = a.bias_b; k.bias_b_ld = a.bias_b_ld; k.bias_mode = a.bias_mode; k.div_b = a.div_b;
   k.res = a.res; k.res_bs = a.res_bs; k.ldr = a.ldr; k.out_scale = a.out_scale;
@@ -801,15 +811,23 @@ static int launch_typed(const ConvArgs& a, hipStream_t st) {
       return launch_cfg<T, 9, 8, 32, 64, 2, 2, KC9>(a, st);
     }
     case 1: return launch_cfg<T, 9, 8, 32, 32, 2, 1, KC9>(a, st);
-    case 2: {  // small images: latency bound on the K pipeline -> twice the chunk depth (half the barriers)
-      static int alt2 = -1;
-      if (alt2 < 0) { const char* v = getenv("DIFFSEP_CONV_ALT2"); alt2 = v ? atoi(v) : 0; }
-      if (alt2 == 1) return launch_cfg<T, 9, 8, 8, 64, 1, 1, KC9 * 2>(a, st);
+    case 2: {  // small images: a chain of dependent chunk round trips (1.7 us each) -> chunks twice as deep
+      static int alt2 = -1;  // (+1 % end to end; DIFFSEP_CONV_ALT2=0 restores the single-depth chunks)
+      if (alt2 < 0) { const char* v = getenv("DIFFSEP_CONV_ALT2"); alt2 = v ? atoi(v) : 1; }
+      const bool deep = alt2 == 1 && a.Cin % (2 * KC9) == 0 && (!a.x2 || a.C1 % (2 * KC9) == 0) &&
+                        (!a.sx || (a.sCin % (2 * KC9) == 0 && (!a.sx2 || a.sC1 % (2 * KC9) == 0)));
+      if (deep) return launch_cfg<T, 9, 8, 8, 64, 1, 1, KC9 * 2>(a, st);
       return launch_cfg<T, 9, 8, 8, 64, 1, 1, KC9>(a, st);
     }
     case 3: return launch_cfg<T, 1, 8, 32, 64, 2, 2, KC1>(a, st);
     case 4: return launch_cfg<T, 1, 8, 32, 32, 2, 1, KC1>(a, st);
-    default: return launch_cfg<T, 1, 8, 8, 64, 1, 1, KC1>(a, st);
+    default: {
+      static int alt5 = -1;
+      if (alt5 < 0) { const char* v = getenv("DIFFSEP_CONV_ALT5"); alt5 = v ? atoi(v) : 0; }
+      if (alt5 == 1 && a.Cin % (2 * KC1) == 0 && (!a.x2 || a.C1 % (2 * KC1) == 0))
+        return launch_cfg<T, 1, 8, 8, 64, 1, 1, KC1 * 2>(a, st);
+      return launch_cfg<T, 1, 8, 8, 64, 1, 1, KC1>(a, st);
+    }
   }
 }
 
