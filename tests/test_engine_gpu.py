@@ -225,3 +225,26 @@ def test_other_samplers_match_reference_golden(golden):
     b, _ = eng.pc_sample(mix_norm, SDE, N=N, corrector_steps=cs, snr=0.5, eps=0.03, corrector="langevin",
                          noise=draws.to(DEV))
     assert rel_rms(b, g["g12_sep_rd_langevin"]) < 1e-4
+
+
+def test_edge_lengths_and_error_behaviour():
+    # shortest / odd signal lengths against the oracle, and loud failures with a message for bad arguments
+    eng, sd = engine(16, 2, _lib.F32)
+    cfg = O.default_config(16, 2)
+    p = O.to_torch(sd)
+    for T in (1, 127, 129, 383, 4001):  # 1 sample still makes F = 3 frames (center padding 255 each side)
+        xt, mix = rnd(f"edge.x{T}", (1, 2, T), 0.5), rnd(f"edge.m{T}", (1, 1, T), 0.5)
+        t = torch.tensor([0.31])
+        out = eng.score(xt.to(DEV), t.to(DEV), mix.to(DEV))
+        ref = O.score_forward(p, cfg, xt, t, mix)
+        assert out.shape == (1, 2, T) and rel_rms(out, ref) < 2e-4, T
+    with pytest.raises(_lib.DiffsepError) as ei:  # the engine names what is wrong instead of crashing
+        eng.backbone(torch.zeros(1, 256, 96, 8, device=DEV), torch.tensor([0.5], device=DEV))
+    assert "multiple of 64" in str(ei.value)
+    with pytest.raises(_lib.DiffsepError):
+        ops.conv2d_fused(torch.zeros(1, 8, 8, 12, device=DEV), torch.zeros(8, 9, 12, device=DEV), None, 8, 3)  # Cin % 8
+    with pytest.raises(_lib.DiffsepError):
+        ops.conv2d_fused(torch.zeros(1, 8, 8, 64, device=DEV), torch.zeros(8, 9, 64, device=DEV), None, 8, 3,
+                         w_chunk=24)  # chunk width that does not divide the kernel's K stage
+    with pytest.raises(AssertionError):
+        eng.score(torch.zeros(2, 2, 100, device=DEV), torch.zeros(1, device=DEV), torch.zeros(2, 1, 100, device=DEV))
