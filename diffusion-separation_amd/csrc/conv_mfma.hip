@@ -180,6 +180,13 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
+#ifndef DS_A_AUX
+#define DS_A_AUX 0  // cache-policy bits of the activation tile loads (experiment: 2 = nt)
+#endif
+__device__ inline uint4 buf_load16a(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, DS_A_AUX);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ inline uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
   return make_uint4(v.x, v.y, v.z, v.w);
@@ -370,10 +377,10 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     if (width >= KC) {  // uniform fast path
       if (!second) {
 #pragma unroll
-        for (int k = 0; k < NA; ++k) pa[k] = buf_load16(rx1, voa(k, ld_), so);
+        for (int k = 0; k < NA; ++k) pa[k] = buf_load16a(rx1, voa(k, ld_), so);
       } else {
 #pragma unroll
-        for (int k = 0; k < NA; ++k) pa[k] = buf_load16(rx2, voa(k, ld_), so);
+        for (int k = 0; k < NA; ++k) pa[k] = buf_load16a(rx2, voa(k, ld_), so);
       }
 #pragma unroll
       for (int k = 0; k < NB; ++k) pb[k] = buf_load16(rw, vob[k], sw);
