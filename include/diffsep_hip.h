@@ -192,7 +192,8 @@ int32_t diffsep_conv2d_fused(const void* x, const void* x2, int32_t C1, const fl
  * contiguous in memory and is fetched in full 128-byte lines). */
 int32_t diffsep_conv2d_chunk(int32_t ksize, int32_t dtype);
 /* `stats` (nullable): channel-sum accumulators of the OUTPUT for the next GroupNorm, [B][Cout][2] int64 fixed point
- * (sum * 2^24, sum of squares * 2^16).  Every block ADDS its tile's totals with integer atomics (associative:
+ * (sum * 2^24, sum of squares * 2^16; exact to 6e-8 / 1.5e-5 per tile, no overflow while the per-image sum of
+ * squares of a channel stays below 1.4e14).  Every block ADDS its tile's totals with integer atomics (associative:
  * bit-reproducible), the caller zeroes the buffer first — so no separate pass over the tensor is needed
  * (layerspp.py:313: GroupNorm_1 follows Conv_0).
  * `gn_acc1` (nullable, instead of gn_scale / gn_shift): such accumulators of x (and gn_acc2 of x2) plus the
