@@ -171,7 +171,7 @@ long ds_gn_workspace_bytes(int B, int H, int W, int C);
 int ds_launch_gn_stats(const void* x, int ldx, const void* x2, int ldx2, int C1, int B, int H, int W, int C, int groups,
                        float eps, const float* gamma, const float* beta, void* ws, float* scale, float* shift,
                        int dtype, hipStream_t st);
-// scale/shift from per-tile channel partials written by the conv epilogue (two sources = concat view)
+// scale/shift from the channel-sum accumulators filled by the conv epilogues (two sources = concat view)
 int ds_launch_gn_finalize_acc(const long long* a1, int C1, const long long* a2, int C2, int B, long npix, int groups,
                               float eps, const float* gamma, const float* beta, float* scale, float* shift,
                               hipStream_t st);
