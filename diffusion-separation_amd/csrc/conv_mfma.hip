@@ -823,6 +823,11 @@ static int launch_typed(const ConvArgs& a, hipStream_t st) {
       if (alt2 < 0) { const char* v = getenv("DIFFSEP_CONV_ALT2"); alt2 = v ? atoi(v) : 1; }
       const bool deep = alt2 == 1 && a.Cin % (2 * KC9) == 0 && (!a.x2 || a.C1 % (2 * KC9) == 0) &&
                         (!a.sx || (a.sCin % (2 * KC9) == 0 && (!a.sx2 || a.sC1 % (2 * KC9) == 0)));
+      // experiment (DIFFSEP_CONV_SMALL_NARROW=1): a 32-cout tile halves the weight slab one CU has to stream and
+      // doubles the CUs that share it — measured +0.3 % end to end, i.e. noise; off by default
+      static int narrow = -1;
+      if (narrow < 0) { const char* v = getenv("DIFFSEP_CONV_SMALL_NARROW"); narrow = v ? atoi(v) : 0; }
+      if (deep && narrow) return launch_cfg<T, 9, 8, 16, 32, 1, 1, KC9 * 2>(a, st);
       if (deep) return launch_cfg<T, 9, 8, 8, 64, 1, 1, KC9 * 2>(a, st);
       return launch_cfg<T, 9, 8, 8, 64, 1, 1, KC9>(a, st);
     }
