@@ -197,6 +197,8 @@ def test_full_size_sampler_nf64_N30_parity_with_oracle():
     s = si_sdr(out16, ref)
     print(f"[bf16 vs fp32 reference] rel rms {rel_rms(out16, ref):.3e}  SI-SDR(out16, ref) {s.flatten().tolist()}")
     assert torch.isfinite(out16).all()
+    # throughput mode after 60 NFE with identical noise: measured 2.4e-2 relative RMS, 30.8 / 32.7 dB per source
+    assert rel_rms(out16, ref) < 4e-2 and float(s.min()) > 27.0
 
 
 def test_priormix_sampler_matches_reference_golden(golden):
