@@ -353,11 +353,11 @@ def test_conv_epilogue_statistics(dt, ksize, H, W):
     assert torch.allclose(s[..., 1], (yd * yd).sum((1, 2)), rtol=tol, atol=tol * H * W)
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 16, 64), (5, 8, 32), (128, 16, 64), (256, 24, 32)])
+@pytest.mark.parametrize("B,H,W", [(2, 16, 64), (5, 8, 32), (128, 16, 64), (256, 24, 32), (64, 48, 64)])
 @pytest.mark.parametrize("act", [1, 0, None])
-@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
 def test_weight_stationary_conv3x3_64_to_64(B, H, W, act, variant, monkeypatch):
-    monkeypatch.setenv("DIFFSEP_CONV_WS", variant)  # experimental kernels, opt-in (1: ping-pong groups, 2: one phase)
+    monkeypatch.setenv("DIFFSEP_CONV_WS", variant)  # 1: ping-pong groups, 2: one phase (default), 3: 16 x 32 tiles
     # the persistent 64 -> 64 bf16 kernel (conv3x3_ws.hip): one or several tiles per block, image borders,
     # GN affine (+SiLU) on the input, conv bias + per-batch temb bias, residual, 1/sqrt(2), statistics partials
     dt = torch.bfloat16
