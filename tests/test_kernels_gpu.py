@@ -355,9 +355,9 @@ def test_conv_epilogue_statistics(dt, ksize, H, W):
 
 @pytest.mark.parametrize("B,H,W", [(2, 16, 64), (5, 8, 32), (128, 16, 64), (256, 24, 32), (64, 48, 64)])
 @pytest.mark.parametrize("act", [1, 0, None])
-@pytest.mark.parametrize("variant", ["1", "2", "3"])
+@pytest.mark.parametrize("variant", ["1", "2", "3", "4"])
 def test_weight_stationary_conv3x3_64_to_64(B, H, W, act, variant, monkeypatch):
-    monkeypatch.setenv("DIFFSEP_CONV_WS", variant)  # 1: ping-pong groups, 2: one phase (default), 3: 16 x 32 tiles
+    monkeypatch.setenv("DIFFSEP_CONV_WS", variant)  # 1: ping-pong groups, 2: one phase (default), 3: 16 x 32 tiles, 4: matrix / memory wave roles
     # the persistent 64 -> 64 bf16 kernel (conv3x3_ws.hip): one or several tiles per block, image borders,
     # GN affine (+SiLU) on the input, conv bias + per-batch temb bias, residual, 1/sqrt(2), statistics partials
     dt = torch.bfloat16
