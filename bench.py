@@ -99,28 +99,51 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+    # DIFFSEP_BENCH_DRYRUN=1: the same control flow (collectives, barriers, who prints) on CPU tensors over gloo with a
+    # stand-in for the engine — only for the world_size-2 test of the multi-rank sequencing, never a measurement
+    dry = os.environ.get("DIFFSEP_BENCH_DRYRUN") == "1"
+    dev = "cpu" if dry else "cuda"
+    if not dry:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from diffsep_amd import _lib, ops, synth
-    from diffsep_amd.engine import Engine, pack_state_dict, param_table
+    from diffsep_amd import synth
     torch.set_grad_enabled(False)
-
     B, T, S = args.batch, args.samples, 2
-    dt_flag = _lib.BF16 if args.dtype == "bf16" else _lib.F32
-    cfg = _lib.model_config(nf=args.nf, num_sources=S, dtype=dt_flag)
-    sd = synth.synth_state_dict([(n, s) for n, s, _ in param_table(cfg)], 7)
-    eng = Engine(cfg, pack_state_dict(cfg, sd))
-    if args.no_graph:
-        eng.set_graph(False)
-    sde = dict(ndim=S, d_lambda=2.0, sigma_min=0.05, sigma_max=0.5)
-    mix = torch.from_numpy(synth.synth_batch(B, T=T, start=rank * B)[0]).cuda()  # resident before timing
-    gathered = [torch.empty((B, S, T), dtype=torch.float32, device="cuda") for _ in range(world)] if rank == 0 else None
+    if dry:
+        import contextlib
+        import types
 
-    stream = torch.cuda.Stream()
+        class _Eng:  # records nothing, computes nothing
+            def pc_sample(self, mix_norm, sde, N, corrector_steps, **kw):
+                return torch.zeros((mix_norm.shape[0], S, mix_norm.shape[-1])), N * (corrector_steps + 1)
+            def profile_begin(self): pass
+            def profile_end(self): return {"conv3x3_8x32xN64": (1.0, 1.0, 1, 1.0)}
+            def device_bytes(self): return 0
+        eng = _Eng()
+        ops = types.SimpleNamespace(normalize_batch=lambda m: (m, None, None), scale_output=lambda m, s: s)
+        stream_ctx = contextlib.nullcontext()
+        sync = lambda: None
+    else:
+        from diffsep_amd import _lib, ops
+        from diffsep_amd.engine import Engine, pack_state_dict, param_table
+        dt_flag = _lib.BF16 if args.dtype == "bf16" else _lib.F32
+        cfg = _lib.model_config(nf=args.nf, num_sources=S, dtype=dt_flag)
+        sd = synth.synth_state_dict([(n, s) for n, s, _ in param_table(cfg)], 7)
+        eng = Engine(cfg, pack_state_dict(cfg, sd))
+        if args.no_graph:
+            eng.set_graph(False)
+        stream_ctx = torch.cuda.stream(torch.cuda.Stream())
+        sync = torch.cuda.synchronize
+    sde = dict(ndim=S, d_lambda=2.0, sigma_min=0.05, sigma_max=0.5)
+    mix = torch.from_numpy(synth.synth_batch(B, T=T, start=rank * B)[0]).to(dev)  # resident before timing
+    gathered = [torch.empty((B, S, T), dtype=torch.float32, device=dev) for _ in range(world)] if rank == 0 else None
 
     def step(i, collect=True):
         mix_norm, _, _ = ops.normalize_batch(mix)
@@ -132,12 +155,12 @@ def main():
         return out, nfe
 
     def fence():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
-    with torch.cuda.stream(stream):
+    with stream_ctx:
         for i in range(args.warmup):
             out, nfe = step(i)
         fence()
@@ -188,7 +211,7 @@ def main():
                     "all_mfma_kernels_tflops": round(sum(v[0] for v in prof.values()) / (tot_ms * 1e-3) / 1e12, 2)})
 
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -213,7 +236,7 @@ def main():
         }
         if roof is not None:
             res["roofline"] = roof
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not dry:
             t_nfe, n = cpu_baseline(args.nf, T)
             res["cpu_baseline"] = {"value": round(1.0 / (t_nfe * nfe), 5), "unit": "utterances/s",
                                    "cores": torch.get_num_threads(), "kind": "port",

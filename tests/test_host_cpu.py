@@ -167,3 +167,28 @@ def test_summarize_matches_reference_schema():
     from diffsep_amd.datasets import summarize
     s = summarize([{"si_sdr": 1.0, "pesq": None, "nfe": 60, "x": [1.0, 3.0]}, {"si_sdr": 3.0, "pesq": None, "nfe": 60, "x": [3.0, 5.0]}])
     assert s == {"si_sdr": 2.0, "nfe": 60.0, "x": 3.0, "number": 2}
+
+
+def test_bench_multi_rank_sequencing_gloo(tmp_path):
+    # bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), here with 2 CPU ranks
+    # over gloo and a stand-in engine (DIFFSEP_BENCH_DRYRUN=1): every rank must enter the same collectives (the
+    # untimed roofline pass of rank 0 must not), rank 0 prints exactly one JSON line, nobody hangs.
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, DIFFSEP_BENCH_DRYRUN="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                                       "--warmup", "1", "--batch", "2", "--samples", "800"], env=e, cwd=root,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-500:] for o in outs]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak" and "roofline" in res
+    assert res["config"]["sharding"] == "utterances/2" and res["value"] > 0
