@@ -16,6 +16,10 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 // fixed-point scales of the GroupNorm channel-sum accumulators (int64): sums 2^-24, sums of squares 2^-16
 #define DS_STAT_SUM_SCALE 16777216.0
 #define DS_STAT_SQ_SCALE 65536.0
+// Add into an accumulator (device-scope integer atomic: associative, so totals are bit-reproducible).
+__device__ inline void ds_stat_add(long long* acc, long long v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)v);
+}
 
 // ---------------------------------------------------------------- error plumbing (host)
 void ds_set_error(const std::string& s);

@@ -445,8 +445,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsK p) {
       double a = 0.0;
 #pragma unroll 8
       for (int i = 0; i < 64; ++i) a += (double)src[i * 8 * RED_ROW];
-      atomicAdd(reinterpret_cast<unsigned long long*>(p.stats + ((long)b * C + co) * 2 + st),
-                (unsigned long long)(long long)llrint(a * (st ? DS_STAT_SQ_SCALE : DS_STAT_SUM_SCALE)));
+      ds_stat_add(p.stats + ((long)b * C + co) * 2 + st, (long long)llrint(a * (st ? DS_STAT_SQ_SCALE : DS_STAT_SUM_SCALE)));
     }
   }
   WT_MARK(5)
@@ -752,8 +751,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws3_kernel(WsK p) {
       double a = 0.0;
 #pragma unroll 8
       for (int i = 0; i < 64; ++i) a += (double)src[i * 8 * RED_ROW];
-      atomicAdd(reinterpret_cast<unsigned long long*>(p.stats + ((long)b * C + co) * 2 + st),
-                (unsigned long long)(long long)llrint(a * (st ? DS_STAT_SQ_SCALE : DS_STAT_SUM_SCALE)));
+      ds_stat_add(p.stats + ((long)b * C + co) * 2 + st, (long long)llrint(a * (st ? DS_STAT_SQ_SCALE : DS_STAT_SUM_SCALE)));
     }
   }
 }
@@ -1061,8 +1059,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
       double a = 0.0;
 #pragma unroll 8
       for (int i = 0; i < 64; ++i) a += (double)src[i * 8 * RED_ROW];
-      atomicAdd(reinterpret_cast<unsigned long long*>(p.stats + ((long)b * C + co) * 2 + st),
-                (unsigned long long)(long long)llrint(a * (st ? DS_STAT_SQ_SCALE : DS_STAT_SUM_SCALE)));
+      ds_stat_add(p.stats + ((long)b * C + co) * 2 + st, (long long)llrint(a * (st ? DS_STAT_SQ_SCALE : DS_STAT_SUM_SCALE)));
     }
   }
   WT_MARK(5)
@@ -1357,8 +1354,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws2_kernel(WsK p) {
       double a = 0.0;
 #pragma unroll 8
       for (int i = 0; i < 64; ++i) a += (double)src[i * 8 * RED_ROW];
-      atomicAdd(reinterpret_cast<unsigned long long*>(p.stats + ((long)b * C + co) * 2 + st),
-                (unsigned long long)(long long)llrint(a * (st ? DS_STAT_SQ_SCALE : DS_STAT_SUM_SCALE)));
+      ds_stat_add(p.stats + ((long)b * C + co) * 2 + st, (long long)llrint(a * (st ? DS_STAT_SQ_SCALE : DS_STAT_SUM_SCALE)));
     }
   }
   WT_MARK(5)

@@ -718,8 +718,14 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
         const float keep = m < 0 ? 0.f : 1.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+          // the barriers keep these as scalar FMAs.  Without them the compiler pairs (sum, sum of squares) into
+          // v_mul_f32 + v_pk_fma_f32 op_sel sequences, and that code was measured returning a wrong SUM lane (the
+          // square lane and the stored output stayed right) in ~1 % of forwards once kernels of other hardware
+          // queues shared the CUs — never with a single stream (profiles/experiments/README.md, "streams")
           ssum[j] = fmaf(keep, v[j], ssum[j]);
+          asm volatile("" : "+v"(ssum[j]));
           ssq[j] = fmaf(keep * v[j], v[j], ssq[j]);
+          asm volatile("" : "+v"(ssq[j]));
         }
         pack8<T>(v, oraw[it]);
       }
@@ -748,9 +754,9 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
         q += (double)sr[(rr2 * BN + tid) * 2 + 1];
       }
       // integer (fixed-point) atomics: associative, so the image totals are bit-reproducible whatever the order
-      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.stats + ((long)b * p.Cout + n0 + tid) * 2);
-      atomicAdd(o, (unsigned long long)(long long)llrint(a * DS_STAT_SUM_SCALE));
-      atomicAdd(o + 1, (unsigned long long)(long long)llrint(q * DS_STAT_SQ_SCALE));
+      long long* o = p.stats + ((long)b * p.Cout + n0 + tid) * 2;
+      ds_stat_add(o, (long long)llrint(a * DS_STAT_SUM_SCALE));
+      ds_stat_add(o + 1, (long long)llrint(q * DS_STAT_SQ_SCALE));
     }
   }
   CT_MARK(10)

@@ -28,6 +28,7 @@ enum ModKind { MK_FOURIER, MK_LINEAR, MK_CONV3, MK_RES, MK_ATTN, MK_COMBINE, MK_
 struct Module {
   ModKind kind;
   int in_ch = 0, out_ch = 0;
+  int in_c1 = 0;  // residual blocks of the up path read an in-place concat: channels of its first source (0 = none)
   bool up = false, down = false, has_conv2 = false;
   int temb_off = 0;  // offset of this block's Dense_0 output inside the concatenated projection
   // fp32 parameter references
@@ -101,8 +102,8 @@ struct ArchBuilder {
     m.b0 = add(pfx() + "bias", {c});
     A.mods.push_back(m);
   }
-  void res(int in, int out, bool up, bool down, int temb_dim) {
-    Module m; m.kind = MK_RES; m.in_ch = in; m.out_ch = out; m.up = up; m.down = down;
+  void res(int in, int out, bool up, bool down, int temb_dim, int in_c1 = 0) {
+    Module m; m.kind = MK_RES; m.in_ch = in; m.out_ch = out; m.up = up; m.down = down; m.in_c1 = in_c1;
     const std::string p = pfx();
     m.gn0_w = add(p + "GroupNorm_0.weight", {in});
     m.gn0_b = add(p + "GroupNorm_0.bias", {in});
@@ -198,7 +199,7 @@ static int build_arch(const diffsep_model_config& c, Arch& A) {
       const int out_ch = nf * c.ch_mult[i];
       const int skip = hs_c.back();
       hs_c.pop_back();
-      b.res(in_ch + skip, out_ch, false, false, 4 * nf);
+      b.res(in_ch + skip, out_ch, false, false, 4 * nf, in_ch);
       in_ch = out_ch;
     }
     if (resl == c.attn_resolution) b.attn(in_ch);
@@ -275,8 +276,12 @@ __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ s
     Elt<T>::st(dst + d, v);
   }
 }
-// Which weights the engine keeps chunk-major: every conv whose input channels (and concat split) are multiples of 64
-static int weight_chunk(int taps, int cin, int dtype) { return (cin % 64 == 0) ? ds_conv_chunk(taps, dtype) : 0; }
+// Which weights the engine keeps chunk-major: every conv whose input channels are a multiple of 64 and whose concat
+// split (c1 channels from the first source, 0 = no concat) falls on a chunk boundary
+static int weight_chunk(int taps, int cin, int c1, int dtype) {
+  const int kc = ds_conv_chunk(taps, dtype);
+  return (cin % 64 == 0 && c1 % kc == 0) ? kc : 0;
+}
 // Conv_2 of a block is folded into its second 3x3 convolution when that one runs on a 64-cout tile
 static bool fuse_skip(const Module& m) { return m.has_conv2 && m.out_ch > 32; }
 
@@ -333,6 +338,7 @@ struct diffsep_engine {
   hipStream_t sideA = nullptr, sideB = nullptr;
   std::vector<hipEvent_t> fj_events;
   size_t fj_i = 0;
+  bool dbg_alloc = false;  // DIFFSEP_DBG_ALLOC=1: log every arena allocation (offset, bytes) to stderr
   int use_side = 0;  // measured on MI355X: parallel graph branches cost ~5 % here (DIFFSEP_SIDE=1|2|3 enables them)
   // optional per-launch timing of the MFMA kernels (HIP events on the launch stream)
   bool prof = false;
@@ -385,6 +391,9 @@ struct StreamScope {
   diffsep_engine* e; hipStream_t user; hipStream_t st;
   StreamScope(diffsep_engine* e_, void* s) : e(e_), user((hipStream_t)s), st((hipStream_t)s) {
     if (!user) {
+      // the private stream is only created for callers on the null stream: HIP maps streams onto its few hardware
+      // queues in creation order, and streams nobody uses would alias the caller's streams onto one queue
+      if (!e->own) hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking);
       st = e->own;
       hipEventRecord(e->ev_in, nullptr);
       hipStreamWaitEvent(st, e->ev_in, 0);
@@ -402,6 +411,7 @@ static void* e_alloc(diffsep_engine* e, size_t bytes) {
   const size_t a = (e->top + 255) & ~(size_t)255;
   e->top = a + bytes;
   if (e->dry) return (void*)(uintptr_t)(a + 256);  // fake non-null
+  if (e->dbg_alloc) fprintf(stderr, "[diffsep alloc] %zu %zu\n", a, bytes);
   return e->arena + a;
 }
 // GroupNorm accumulators live in one region at the start of a forward's allocations: ONE memset per forward
@@ -453,7 +463,7 @@ static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias
     a.gn_acc1 = gn->acc1; a.gn_acc2 = gn->acc2; a.gn_gamma = gn->gamma; a.gn_beta = gn->beta;
     a.gn_groups = gn->groups; a.gn_inv_count = gn->inv_count; a.gn_eps = 1e-6f;
   }
-  a.w = w; a.w_bs = 0; a.w_chunked = weight_chunk(taps, x.C, e->cfg.dtype);
+  a.w = w; a.w_bs = 0; a.w_chunked = weight_chunk(taps, x.C, x.p2 ? x.C1 : 0, e->cfg.dtype);
   a.bias = bias; a.bias_b = bias_b; a.bias_b_ld = bias_b_ld; a.bias_mode = 0; a.div_b = div_b;
   a.res = res ? res->p : nullptr; a.res_bs = res ? (long)res->H * res->W * res->ld : 0; a.ldr = res ? res->ld : 0;
   a.out_scale = scale;
@@ -468,6 +478,10 @@ static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias
     y.sa = e_alloc_stats(e, (size_t)B * Cout * 2 * sizeof(long long));
     if (!y.sa) return 1;
     a.stats_acc = y.sa;
+    if (e->dbg_alloc && !e->dry)
+      fprintf(stderr, "[diffsep stats] %ld Cin %d Cout %d taps %d HxW %dx%d res %d skip %d bias_b %d cfg %d\n",
+              (long)((char*)y.sa - e->stats_ptr), x.C, Cout, taps, x.H, x.W, res != nullptr, skip != nullptr,
+              bias_b != nullptr, ds_conv_config_id(a));
   }
   if (e->dry) return 0;
   return conv_launch_prof(e, a, st);
@@ -541,7 +555,7 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
   out = e_tensor(e, B, Ho, Wo, m.out_ch);
   if (m.has_conv2 && fuse_skip(m)) {
     DS_CHECK(ds_conv_skip_supported(Ho, Wo, m.out_ch, e->cfg.dtype), "internal: fused skip conv on an unsupported tile");
-    const SkipConv sk = {&xr, PK(e, m.pk2), weight_chunk(9, m.in_ch, e->cfg.dtype)};
+    const SkipConv sk = {&xr, PK(e, m.pk2), weight_chunk(9, m.in_ch, m.in_c1, e->cfg.dtype)};
     // conv bias + Conv_2 bias: the second goes in as a "per-batch" bias with stride 0
     return conv(e, h1, PK(e, m.pk1), P(e, m.conv1_b), P(e, m.conv2_b), 0, nullptr, kInvSqrt2, out, m.out_ch, 9, B,
                 nullptr, st, &a1, 1, true, &sk);
@@ -828,18 +842,20 @@ extern "C" int32_t diffsep_engine_create(const diffsep_model_config* cfg, const 
   DS_HIP(hipMalloc((void**)&e->d_dense_b, (size_t)A.dense_total * 4));
   e->weight_bytes = (int64_t)A.total * 4 + (int64_t)A.pack_total * e->esz + (int64_t)A.dense_total * (4 * cfg->nf + 1) * 4;
   if (ds_build_stft_table(cfg->n_fft, &e->d_tab)) { delete e; return 1; }
-  DS_HIP(hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
   if (const char* sv = getenv("DIFFSEP_SIDE")) e->use_side = atoi(sv);
-  DS_HIP(hipStreamCreateWithFlags(&e->sideA, hipStreamNonBlocking));
-  DS_HIP(hipStreamCreateWithFlags(&e->sideB, hipStreamNonBlocking));
+  if (const char* sv = getenv("DIFFSEP_DBG_ALLOC")) e->dbg_alloc = atoi(sv) != 0;
+  if (e->use_side) {
+    DS_HIP(hipStreamCreateWithFlags(&e->sideA, hipStreamNonBlocking));
+    DS_HIP(hipStreamCreateWithFlags(&e->sideB, hipStreamNonBlocking));
+  }
   DS_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
   DS_HIP(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
 
   auto repack = [&](const PRef& src, long pk, int O, int I, int taps, long so, long si, long stp,
-                    bool allow_chunk = true, int kc_taps = 0) -> int {
+                    bool allow_chunk = true, int kc_taps = 0, int c1 = 0) -> int {
     const int Ipad = rup8(I);
     // kc_taps: the kernel that will READ these weights (the fused skip conv is read by the 3x3 kernel)
-    const int kc = allow_chunk ? weight_chunk(kc_taps ? kc_taps : taps, I, cfg->dtype) : 0;
+    const int kc = allow_chunk ? weight_chunk(kc_taps ? kc_taps : taps, I, c1, cfg->dtype) : 0;
     const long total = (long)O * taps * Ipad;
     long nb = (total + 255) / 256;
     if (nb > 4096) nb = 4096;
@@ -859,9 +875,10 @@ extern "C" int32_t diffsep_engine_create(const diffsep_model_config* cfg, const 
       case MK_CONV3: rc |= repack(m.w0, m.pk0, m.out_ch, m.in_ch, 9, (long)m.in_ch * 9, 9, 1); break;
       case MK_COMBINE: rc |= repack(m.w0, m.pk0, m.out_ch, m.in_ch, 1, m.in_ch, 1, 0); break;
       case MK_RES:
-        rc |= repack(m.conv0_w, m.pk0, m.out_ch, m.in_ch, 9, (long)m.in_ch * 9, 9, 1);
+        rc |= repack(m.conv0_w, m.pk0, m.out_ch, m.in_ch, 9, (long)m.in_ch * 9, 9, 1, true, 0, m.in_c1);
         rc |= repack(m.conv1_w, m.pk1, m.out_ch, m.out_ch, 9, (long)m.out_ch * 9, 9, 1);
-        if (m.has_conv2) rc |= repack(m.conv2_w, m.pk2, m.out_ch, m.in_ch, 1, m.in_ch, 1, 0, true, fuse_skip(m) ? 9 : 0);
+        if (m.has_conv2)
+          rc |= repack(m.conv2_w, m.pk2, m.out_ch, m.in_ch, 1, m.in_ch, 1, 0, true, fuse_skip(m) ? 9 : 0, m.in_c1);
         // Dense_0 rows -> concatenated projection [dense_total][4 nf]
         DS_HIP(hipMemcpy(e->d_dense_w + (size_t)m.temb_off * 4 * cfg->nf, e->d_blob + m.dense_w.off,
                          (size_t)m.dense_w.numel * 4, hipMemcpyDeviceToDevice));
@@ -893,6 +910,11 @@ extern "C" void diffsep_engine_destroy(diffsep_engine* e) {
   if (e->ev_in) hipEventDestroy(e->ev_in);
   if (e->ev_out) hipEventDestroy(e->ev_out);
   delete e;
+}
+extern "C" int32_t diffsep_engine_debug_arena(const diffsep_engine* e, void** base, int64_t* bytes, int64_t* fwd_base) {
+  DS_CHECK(e && base && bytes && fwd_base, "debug_arena: null argument");
+  *base = e->arena; *bytes = (int64_t)e->cap; *fwd_base = (int64_t)e->fwd_base;
+  return 0;
 }
 extern "C" int64_t diffsep_engine_device_bytes(const diffsep_engine* e) { return e ? e->weight_bytes + (int64_t)e->cap : 0; }
 extern "C" int32_t diffsep_engine_set_graph(diffsep_engine* e, int32_t enable) {

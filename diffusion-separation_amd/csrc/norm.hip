@@ -119,8 +119,8 @@ __global__ __launch_bounds__(256) void gn_finalize_acc_kernel(const long long* _
     for (int j = 0; j < cpg; ++j) {
       const int cj = g0 + j;
       const long long* src = cj < C1 ? a1 + ((long)b * C1 + cj) * 2 : a2 + ((long)b * C2 + (cj - C1)) * 2;
-      ssum += src[0];
-      ssq += src[1];
+      ssum += __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ssq += __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const double mean = (double)ssum * (1.0 / DS_STAT_SUM_SCALE) * inv_count;
     double var = (double)ssq * (1.0 / DS_STAT_SQ_SCALE) * inv_count - mean * mean;

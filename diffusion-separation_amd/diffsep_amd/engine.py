@@ -120,6 +120,16 @@ class Engine:
                                               _stream_ptr(self.device)))
         return out
 
+    def debug_arena(self):
+        """(uint8 view of the workspace arena, offset of the forward region): every intermediate tensor of the last
+        forward, in launch order.  Debug / test aid."""
+        base, nb, fb = C.c_void_p(), C.c_int64(), C.c_int64()
+        check(lib().diffsep_engine_debug_arena(self._h, C.byref(base), C.byref(nb), C.byref(fb)))
+
+        class _Raw:
+            __cuda_array_interface__ = {"shape": (nb.value,), "typestr": "|u1", "data": (base.value, False), "version": 2}
+        return torch.as_tensor(_Raw(), device=f"cuda:{self.device.index or 0}" if hasattr(self.device, "index") else "cuda"), fb.value
+
     def backbone(self, x_nhwc, t):
         """NCSNpp.forward on a packed NHWC input [B,256,W,Cpad] (engine dtype storage)."""
         B, H, W, Cp = x_nhwc.shape

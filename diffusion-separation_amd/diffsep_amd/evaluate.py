@@ -79,10 +79,23 @@ def main(argv=None):
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("-o", "--output-dir", type=Path, default=Path("results"))
     ap.add_argument("--save-wav", action="store_true")
+    ap.add_argument("--seed", type=int, default=0, help="torch.manual_seed before the first utterance: the i-th "
+                                                         "utterance gets the i-th draw as its device RNG seed")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="utterances in flight per GPU: K engines on K HIP streams (results are bit-identical for any "
+                         "K).  One utterance at a time (the reference's evaluation loop) leaves most of the GPU idle: "
+                         "measured 6.0 utt/s with 1 stream, 10.4 / 13.5 / 18.5 with 2 / 3 / 4 (4 s utterances, "
+                         "nf=64); more than 4 is slower again (streams share hardware queues).  Per-utterance "
+                         "'runtime' is then the latency of an utterance that shared the GPU with K-1 others.")
     ap.add_argument("--enhance", action="store_true",
                     help="speech enhancement (evaluate.py:173-176,268-271): PriorMixSDE model, metrics on the first "
                          "source (clean speech) only")
     args = ap.parse_args(argv)
+    if args.streams > 1:
+        # HIP maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, one of which the null stream holds:
+        # with the default, two of four worker streams share a queue (measured 10.7 instead of 18.5 utt/s).  Read
+        # by the HIP runtime when it initialises, i.e. this must precede the first torch.cuda call.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -93,12 +106,21 @@ def main(argv=None):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if args.synthetic_weights or args.ckpt is None:
-        cfg = (enhancement_config(nf=args.synthetic_weights or 128) if args.enhance
-               else default_config(nf=args.synthetic_weights or 64, n_speakers=args.n_speakers))
-        model = DiffSepModel(cfg, dtype=args.dtype)
-    else:
-        model = DiffSepModel.load_from_checkpoint(args.ckpt, dtype=args.dtype)
+    def make_model():
+        if args.synthetic_weights or args.ckpt is None:
+            cfg = (enhancement_config(nf=args.synthetic_weights or 128) if args.enhance
+                   else default_config(nf=args.synthetic_weights or 64, n_speakers=args.n_speakers))
+            return DiffSepModel(cfg, dtype=args.dtype)
+        return DiffSepModel.load_from_checkpoint(args.ckpt, dtype=args.dtype)
+
+    K = max(1, args.streams)
+    models = [make_model() for _ in range(K)]  # one engine (weights copy + workspace) per stream
+    for m in models:
+        # engines are created BEFORE the worker streams: HIP hands out hardware queues in stream-creation order, and
+        # engines created lazily in between left the workers sharing queues (measured 7.0 instead of 17 utt/s, K=4)
+        m.score_model.engine()
+    streams = [torch.cuda.Stream() for _ in range(K)]
+    model = models[0]
     fs = cfg_get(model.config, "model.fs", 8000)
     N = cfg_get(model.config, "model.sampler.N", 30) if args.N is None else args.N
     cs = cfg_get(model.config, "model.sampler.corrector_steps", 1) if args.corrector_steps is None else args.corrector_steps
@@ -106,22 +128,33 @@ def main(argv=None):
 
     n, get = load_dataset(args, fs)
     lo, hi = shard_range(n, world, rank)
+    # warm every worker up on the first utterance's shape (engine creation, workspace plan, graph capture), then fix
+    # the RNG state: results do not depend on the number of streams
+    if hi > lo:
+        m0, _ = get(lo)
+        for w in range(K):
+            with torch.cuda.stream(streams[w]):
+                mw = m0[None].cuda()
+                (mw_n, _), *_ = models[w].normalize_batch((mw, None))
+                models[w].get_pc_sampler("reverse_diffusion", "ald2", mw_n, N=N, corrector_steps=cs, snr=snr, denoise=True,
+                                         intermediate=False, schedule=args.schedule)()
+        torch.cuda.synchronize()
+    torch.manual_seed(args.seed + rank)
     records = []
-    for i in range(lo, hi):
-        mix, tgt = get(i)
-        mix, tgt = mix[None].cuda(), tgt[None].cuda()
-        (mix_n, tgt_n), *_ = model.normalize_batch((mix, tgt))
-        sampler = model.get_pc_sampler("reverse_diffusion", "ald2", mix_n, N=N, corrector_steps=cs, snr=snr,
-                                       denoise=True, intermediate=False, schedule=args.schedule)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        est, nfe, *_ = sampler()
-        torch.cuda.synchronize()
+    pending = [None] * K  # per worker: the utterance whose sampler is running on its stream
+
+    def finish(w):
+        if pending[w] is None:
+            return
+        i, mix, tgt_n, est, nfe, t0, _alive = pending[w]
+        pending[w] = None
+        streams[w].synchronize()
         runtime = time.perf_counter() - t0
-        if args.enhance:  # n_src = 1: only the clean-speech estimate is scored (evaluate.py:270)
-            met = compute_metrics(est[0, :1], tgt_n[0, :1])
-        else:
-            met = compute_metrics(est[0], tgt_n[0])
+        with torch.cuda.stream(streams[w]):
+            if args.enhance:  # n_src = 1: only the clean-speech estimate is scored (evaluate.py:270)
+                met = compute_metrics(est[0, :1], tgt_n[0, :1])
+            else:
+                met = compute_metrics(est[0], tgt_n[0])
         records.append({"batch_idx": i, **met, "pesq": None, "stoi": None, "nfe": int(nfe), "runtime": runtime,
                         "len_s": mix.shape[-1] / fs})
         if args.save_wav:
@@ -129,6 +162,29 @@ def main(argv=None):
             d.mkdir(parents=True, exist_ok=True)
             for k in range(est.shape[1]):
                 wavio.save(d / f"{i:05d}_s{k}.wav", est[0, k:k + 1].cpu() * 0.1, fs)
+
+    t_all = time.perf_counter()
+    for i in range(lo, hi):
+        w = (i - lo) % K
+        finish(w)  # the worker's previous utterance (oldest in flight)
+        mix, tgt = get(i)
+        with torch.cuda.stream(streams[w]):
+            # pinned staging + asynchronous copies: a pageable host->device copy serialises the whole device
+            mix = mix[None].contiguous().pin_memory().to("cuda", non_blocking=True)
+            tgt = tgt[None].contiguous().pin_memory().to("cuda", non_blocking=True)
+            (mix_n, tgt_n), *_ = models[w].normalize_batch((mix, tgt))
+            sampler = models[w].get_pc_sampler("reverse_diffusion", "ald2", mix_n, N=N, corrector_steps=cs, snr=snr,
+                                               denoise=True, intermediate=False, schedule=args.schedule)
+            if K == 1:
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            est, nfe, *_ = sampler()  # enqueues the whole sampler on the worker's stream
+        # (every tensor the asynchronous sampler reads stays referenced until the worker's stream has drained)
+        pending[w] = (i, mix, tgt_n, est, nfe, t0, (mix_n, tgt, sampler))
+    for w in range(K):
+        finish(w)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t_all
     allrec = gather_objects(records)
     if rank == 0:
         flat = sorted([r for part in allrec for r in part], key=lambda r: r["batch_idx"])
@@ -137,7 +193,8 @@ def main(argv=None):
             json.dump(flat, f, indent=2)
         summary = datasets.summarize([{k: v for k, v in r.items() if k not in ("batch_idx", "perm")} for r in flat])
         tot_rt = sum(r["runtime"] for r in flat)
-        summary.update({"rtf": tot_rt / max(sum(r["len_s"] for r in flat), 1e-9), "world_size": world})
+        summary.update({"rtf": tot_rt / max(sum(r["len_s"] for r in flat), 1e-9), "world_size": world,
+                        "streams": K, "utt_per_s_rank0": (hi - lo) / max(wall, 1e-9)})
         with open(args.output_dir / f"{args.split}_summary.json", "w") as f:
             json.dump(summary, f, indent=2)
         print(json.dumps(summary))

@@ -24,7 +24,12 @@ def _db(num, den):
 def si_bss_eval_sources(ref, est, clamp_db=100.0):
     """ref, est [B,S,T] device tensors -> (si_sdr, si_sir, si_sar [B,S] numpy, perm [B,S] int) with est[:, perm] aligned
     to ref."""
-    G = ops.gram(ref.float(), est.float()).cpu().numpy()
+    Gd = ops.gram(ref.float(), est.float())
+    # device -> pinned host on the CURRENT stream only (a pageable copy would stall every other stream's work)
+    Gh = torch.empty(Gd.shape, dtype=Gd.dtype, pin_memory=True)
+    Gh.copy_(Gd, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    G = Gh.numpy()
     B, _, S, _ = G.shape
     sdr = np.zeros((B, S, S)); sir = np.zeros((B, S, S)); sar = np.zeros((B, S, S))
     for b in range(B):

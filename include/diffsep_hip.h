@@ -104,6 +104,9 @@ int32_t diffsep_engine_create(const diffsep_model_config* cfg, const float* weig
 void diffsep_engine_destroy(diffsep_engine* e);
 /* bytes of device memory currently held (weights + workspace). */
 int64_t diffsep_engine_device_bytes(const diffsep_engine* e);
+/* Debug aid: the engine's workspace arena (sampler state, then one forward's activations in launch order from
+ * fwd_base).  Lets a test snapshot every intermediate tensor of a forward; no reference counterpart. */
+int32_t diffsep_engine_debug_arena(const diffsep_engine* e, void** base, int64_t* bytes, int64_t* fwd_base);
 /* frames F = 1 + (T + n_fft - hop)/hop and padded width W = 64*ceil(F/64) for T samples
  * (score_models.py:83-91,107-112). Pure host arithmetic. */
 int32_t diffsep_num_frames(const diffsep_model_config* cfg, int64_t T);

@@ -139,6 +139,21 @@ def test_evaluate_cli_writes_reference_style_results(tmp_path):
     assert all({"batch_idx", "si_sdr", "si_sir", "si_sar", "pesq", "stoi", "nfe", "runtime", "len_s"} <= set(r) for r in rec)
 
 
+def test_evaluate_streams_do_not_change_results(tmp_path):
+    # --streams K keeps K utterances in flight; the records must not depend on K (seeds are drawn per utterance)
+    import json
+    from diffsep_amd import evaluate as ev
+    recs = []
+    for k in (1, 3):
+        ev.main(["--synthetic", "7", "--samples", "6000", "--synthetic-weights", "16", "-N", "2", "--streams", str(k),
+                 "-o", str(tmp_path / f"k{k}")])
+        recs.append(json.load(open(tmp_path / f"k{k}" / "test.json")))
+        summ = json.load(open(tmp_path / f"k{k}" / "test_summary.json"))
+        assert summ["streams"] == k and summ["number"] == 7 and summ["utt_per_s_rank0"] > 0
+    strip = lambda r: {k: v for k, v in r.items() if k != "runtime"}
+    assert [strip(r) for r in recs[0]] == [strip(r) for r in recs[1]]
+
+
 def test_evaluate_cli_on_wsj0_mix_tree(tmp_path):
     # WSJ0-mix on-disk layout -> evaluate: file order, (mix, tgt) shapes, variable lengths
     import json

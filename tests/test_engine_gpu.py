@@ -153,6 +153,59 @@ def test_batch_entries_do_not_interact():
     assert rel_rms(one, full[1:2]) < 1e-6
 
 
+@pytest.mark.parametrize("nf", [16, 32])
+def test_narrow_backbones_bf16_follow_fp32(nf):
+    # nf = 16 / 32: concat splits (32 + 32, 64 + 32 ...) that do not fall on the 64-channel chunk of the 1x1 kernels,
+    # and 32-cout tiles without the fused skip convolution
+    ef, _ = engine(nf, 2, _lib.F32)
+    eb, _ = engine(nf, 2, _lib.BF16)
+    T = 6000
+    xt, mix = rnd("nb.xt", (2, 2, T), 0.5).to(DEV), rnd("nb.mix", (2, 1, T), 0.5).to(DEV)
+    t = torch.tensor([0.4, 0.8], device=DEV)
+    a, b = ef.score(xt, t, mix), eb.score(xt, t, mix)
+    assert torch.isfinite(b).all() and rel_rms(b, a) < 5e-2
+
+
+@pytest.mark.parametrize("dtype", [_lib.BF16, _lib.F32])
+def test_concurrent_streams_are_bit_identical_to_one_stream(dtype):
+    # K engines on K HIP streams (evaluate --streams): kernels of different hardware queues share the CUs.  Every
+    # output must equal the single-stream result bit for bit (this caught a code-generation-dependent wrong
+    # GroupNorm sum that only appeared with co-resident kernels: profiles/experiments/README.md, "streams")
+    K, M, T = 4, 100 if dtype == _lib.BF16 else 30, 32000
+    cfg = _lib.model_config(nf=64, num_sources=2, dtype=dtype)
+    blob = pack_state_dict(cfg, synth.synth_state_dict([(n, s) for n, s, _ in param_table(cfg)], 7))
+    engs = [Engine(cfg, blob) for _ in range(K)]
+    streams = [torch.cuda.Stream() for _ in range(K)]
+    mix = [rnd(f"cs.mix{w}", (1, 1, T), 0.5).to(DEV) for w in range(K)]
+    xt = [rnd(f"cs.xt{w}", (1, 2, T), 0.5).to(DEV) for w in range(K)]
+    ts = [torch.full((1,), 0.3 + 0.1 * w, device=DEV) for w in range(K)]
+    ref = []
+    for w in range(K):
+        engs[w].score(xt[w], ts[w], mix[w])
+        ref.append(engs[w].score(xt[w], ts[w], mix[w]))
+        torch.cuda.synchronize()
+    bad = [torch.zeros((), device=DEV, dtype=torch.int64) for _ in range(K)]
+    for _ in range(M):
+        for w in range(K):
+            with torch.cuda.stream(streams[w]):
+                bad[w] += (engs[w].score(xt[w], ts[w], mix[w]) != ref[w]).any()
+    torch.cuda.synchronize()
+    assert sum(int(b) for b in bad) == 0
+    # the sampler (graph replay) too
+    outs = []
+    for rep in range(2):
+        o = []
+        for i in range(2 * K):
+            w = i % K
+            with torch.cuda.stream(streams[w] if rep else torch.cuda.current_stream()):
+                o.append(engs[w].pc_sample(mix[i % K], SDE, N=3, seed=100 + i)[0])
+        torch.cuda.synchronize()
+        outs.append(o)
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    for e in engs:
+        e.close()
+
+
 def test_full_size_score_nf64_fp32_and_bf16_vs_oracle():
     # BASELINE config: nf=64, T=32000 (253 frames -> W=256), one network evaluation
     cfg = O.default_config(64, 2)

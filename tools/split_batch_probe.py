@@ -33,5 +33,5 @@ def run(parts):
     print(f"{parts} stream(s) x B={B // parts}: {dt*1e3:.1f} ms per sampler call -> {B/dt:.2f} utt/s", flush=True)
     del engs
 
-for parts in (1, 2, 4):
+for parts in [int(v) for v in (sys.argv[1].split(',') if len(sys.argv) > 1 else '1,2,4'.split(','))]:
     run(parts)
