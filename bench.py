@@ -79,8 +79,8 @@ def cpu_baseline(nf, T, budget_s=12.0, max_nfe=12):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16, help="utterances per GPU")
     ap.add_argument("--nf", type=int, default=64)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -90,7 +90,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=4,
+                    help="batches in flight per GPU: step i runs on engine / HIP stream i %% K, so consecutive steps overlap "
+                         "(the ~110 small launches of one batch's NFE leave the chip mostly idle; another batch's large "
+                         "convolutions fill it).  1 = one batch at a time.  Every step is still a full batch through the "
+                         "whole path and all timed steps finish inside the timed region.")
     args = ap.parse_args()
+    # HIP maps streams onto GPU_MAX_HW_QUEUES (default 4, one taken by the null stream) hardware queues; read when the
+    # runtime initialises, i.e. before the first torch.cuda call
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -126,9 +134,10 @@ def main():
             def profile_begin(self): pass
             def profile_end(self): return {"conv3x3_8x32xN64": (1.0, 1.0, 1, 1.0)}
             def device_bytes(self): return 0
-        eng = _Eng()
+        K = max(1, args.in_flight)
+        engs = [_Eng() for _ in range(K)]
         ops = types.SimpleNamespace(normalize_batch=lambda m: (m, None, None), scale_output=lambda m, s: s)
-        stream_ctx = contextlib.nullcontext()
+        on_stream = lambda w: contextlib.nullcontext()
         sync = lambda: None
     else:
         from diffsep_amd import _lib, ops
@@ -136,22 +145,33 @@ def main():
         dt_flag = _lib.BF16 if args.dtype == "bf16" else _lib.F32
         cfg = _lib.model_config(nf=args.nf, num_sources=S, dtype=dt_flag)
         sd = synth.synth_state_dict([(n, s) for n, s, _ in param_table(cfg)], 7)
-        eng = Engine(cfg, pack_state_dict(cfg, sd))
+        K = max(1, args.in_flight)
+        blob = pack_state_dict(cfg, sd)
+        engs = [Engine(cfg, blob) for _ in range(K)]  # (engines before streams: hardware queues go in creation order)
         if args.no_graph:
-            eng.set_graph(False)
-        stream_ctx = torch.cuda.stream(torch.cuda.Stream())
+            for e in engs:
+                e.set_graph(False)
+        streams = [torch.cuda.Stream() for _ in range(K)]
+        on_stream = lambda w: torch.cuda.stream(streams[w])
         sync = torch.cuda.synchronize
     sde = dict(ndim=S, d_lambda=2.0, sigma_min=0.05, sigma_max=0.5)
     mix = torch.from_numpy(synth.synth_batch(B, T=T, start=rank * B)[0]).to(dev)  # resident before timing
-    gathered = [torch.empty((B, S, T), dtype=torch.float32, device=dev) for _ in range(world)] if rank == 0 else None
+    eng = engs[0]
+    # one set of gather buffers per batch in flight (rank 0)
+    gathered = [[torch.empty((B, S, T), dtype=torch.float32, device=dev) for _ in range(world)] if rank == 0 else None
+                for _ in range(K)]
+    keep = [None] * K  # the tensors of a worker's last step stay referenced until its stream has drained
 
-    def step(i, collect=True):
-        mix_norm, _, _ = ops.normalize_batch(mix)
-        sep, nfe = eng.pc_sample(mix_norm, sde, N=args.N, corrector_steps=args.corrector_steps, snr=0.5, eps=0.03,
-                                 denoise=True, seed=1000 + i)
-        out = ops.scale_output(mix, sep)
-        if world > 1 and collect:
-            dist.gather(out, gathered, dst=0)  # RCCL over xGMI: the only collective on the path
+    def step(i, collect=True, w=None):
+        w = i % K if w is None else w
+        with on_stream(w):
+            mix_norm, _, _ = ops.normalize_batch(mix)
+            sep, nfe = engs[w].pc_sample(mix_norm, sde, N=args.N, corrector_steps=args.corrector_steps, snr=0.5,
+                                         eps=0.03, denoise=True, seed=1000 + i)
+            out = ops.scale_output(mix, sep)
+            if world > 1 and collect:
+                dist.gather(out, gathered[w], dst=0)  # RCCL over xGMI: the only collective on the path
+        keep[w] = (mix_norm, sep, out)
         return out, nfe
 
     def fence():
@@ -160,55 +180,68 @@ def main():
             dist.barrier()
         sync()
 
-    with stream_ctx:
-        for i in range(args.warmup):
-            out, nfe = step(i)
-        fence()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            out, nfe = step(args.warmup + i)
-        fence()
-        elapsed = time.perf_counter() - t0
-        finite = bool(torch.isfinite(out).all())
+    # engine preparation (not a step of the benchmark): workspace plan, then hipGraph capture, for every engine
+    for w in range(K):
+        for _ in range(2):
+            step(w, collect=False)
+    fence()
+    for i in range(args.warmup):
+        out, nfe = step(i)
+    fence()
+    t0 = time.perf_counter()
+    outs = []
+    for i in range(args.steps):
+        out, nfe = step(args.warmup + i)
+        outs.append(out)
+    fence()
+    elapsed = time.perf_counter() - t0
+    finite = all(bool(torch.isfinite(o).all()) for o in outs[-K:])
+    del outs
+    # latency of ONE batch with nothing else in flight (untimed extra)
+    fence()
+    t1 = time.perf_counter()
+    step(0, collect=False, w=0)
+    sync()
+    alone_ms = (time.perf_counter() - t1) * 1e3
 
-        roof = None
-        if not args.no_roofline and rank == 0:
-            eng.profile_begin()
-            step(10_000, collect=False)  # rank 0 only: no collective in this untimed pass
-            prof = eng.profile_end()
-            dom = max(prof, key=lambda k: prof[k][1])  # the kernel instantiation with the most GPU time
-            fl, ms, n, by = prof[dom]
-            tot_ms = sum(v[1] for v in prof.values())
-            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            peak = PEAK_TFLOPS[args.dtype]
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_conv3x3.json")
-            if os.path.exists(pmc):
-                try:
-                    tkey = {"conv3x3_8x32xN64": f"hbm_bytes_per_launch_{args.dtype}_B{B}",
-                            "conv3x3_ws_64to64": f"hbm_bytes_per_launch_ws_{args.dtype}_B{B}"}.get(dom)
-                    traffic = json.load(open(pmc)).get(tkey) if tkey else None
-                    traffic = round(traffic) if traffic else None
-                except Exception:
-                    traffic = None
-            # the bound is whichever floor of an average launch is higher: HBM at 8 TB/s or dense MFMA at `peak`
-            hbm_floor_us = by / max(n, 1) / HBM_PEAK_BPS * 1e6
-            mfma_floor_us = fl / max(n, 1) / (peak * 1e12) * 1e6
-            kname = KERNEL_NAMES.get(dom, dom) % {"dt": args.dtype}
-            if hbm_floor_us > mfma_floor_us:
-                gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-                roof = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": HBM_PEAK_BPS / 1e9,
-                        "unit": "GB/s", "frac": round(gbs / (HBM_PEAK_BPS / 1e9), 4)}
-            else:
-                roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4)}
-            roof.update({"traffic": traffic, "launches": n, "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
-                    "flops_per_launch": fl / max(n, 1), "algorithmic_bytes_per_launch": by / max(n, 1),
-                    "hbm_floor_us": round(hbm_floor_us, 2), "mfma_floor_us": round(mfma_floor_us, 2),
-                    "achieved_tflops": round(ach, 2),
-                    "per_kernel_ms": {k: round(v[1], 2) for k, v in prof.items() if v[2]},
-                    "all_mfma_kernels_ms": round(tot_ms, 2),
-                    "all_mfma_kernels_tflops": round(sum(v[0] for v in prof.values()) / (tot_ms * 1e-3) / 1e12, 2)})
+    roof = None
+    if not args.no_roofline and rank == 0:
+        eng.profile_begin()
+        step(10_000, collect=False, w=0)  # rank 0 only: no collective in this untimed pass
+        prof = eng.profile_end()
+        dom = max(prof, key=lambda k: prof[k][1])  # the kernel instantiation with the most GPU time
+        fl, ms, n, by = prof[dom]
+        tot_ms = sum(v[1] for v in prof.values())
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        peak = PEAK_TFLOPS[args.dtype]
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_conv3x3.json")
+        if os.path.exists(pmc):
+            try:
+                tkey = {"conv3x3_8x32xN64": f"hbm_bytes_per_launch_{args.dtype}_B{B}",
+                        "conv3x3_ws_64to64": f"hbm_bytes_per_launch_ws_{args.dtype}_B{B}"}.get(dom)
+                traffic = json.load(open(pmc)).get(tkey) if tkey else None
+                traffic = round(traffic) if traffic else None
+            except Exception:
+                traffic = None
+        # the bound is whichever floor of an average launch is higher: HBM at 8 TB/s or dense MFMA at `peak`
+        hbm_floor_us = by / max(n, 1) / HBM_PEAK_BPS * 1e6
+        mfma_floor_us = fl / max(n, 1) / (peak * 1e12) * 1e6
+        kname = KERNEL_NAMES.get(dom, dom) % {"dt": args.dtype}
+        if hbm_floor_us > mfma_floor_us:
+            gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            roof = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": HBM_PEAK_BPS / 1e9,
+                    "unit": "GB/s", "frac": round(gbs / (HBM_PEAK_BPS / 1e9), 4)}
+        else:
+            roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4)}
+        roof.update({"traffic": traffic, "launches": n, "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
+                "flops_per_launch": fl / max(n, 1), "algorithmic_bytes_per_launch": by / max(n, 1),
+                "hbm_floor_us": round(hbm_floor_us, 2), "mfma_floor_us": round(mfma_floor_us, 2),
+                "achieved_tflops": round(ach, 2),
+                "per_kernel_ms": {k: round(v[1], 2) for k, v in prof.items() if v[2]},
+                "all_mfma_kernels_ms": round(tot_ms, 2),
+                "all_mfma_kernels_tflops": round(sum(v[0] for v in prof.values()) / (tot_ms * 1e-3) / 1e12, 2)})
 
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -227,12 +260,14 @@ def main():
                                    "per GPU, NCSN++ nf=%d random-init, %d NFE/step" %
                                    (args.N, args.corrector_steps, B, T / 8000.0, args.nf, nfe),
                        "batch_per_gpu": B, "samples": T, "N": args.N, "corrector_steps": args.corrector_steps,
-                       "nf": args.nf, "sharding": "utterances/%d" % world, "graph": not args.no_graph},
+                       "nf": args.nf, "sharding": "utterances/%d" % world, "graph": not args.no_graph,
+                       "batches_in_flight": K},
+            "one_batch_alone_ms": round(alone_ms, 2),
             "realtime_factor": round(value * T / 8000.0, 2),
             "nfe_per_s": round(value * nfe, 1),
             "model_tflops": round(value * nfe * GFLOP_PER_NFE.get(args.nf, float("nan")) * (T / 32000.0) / 1e3, 2),
             "finite": finite,
-            "device_bytes": eng.device_bytes(),
+            "device_bytes": sum(e.device_bytes() for e in engs),
         }
         if roof is not None:
             res["roofline"] = roof

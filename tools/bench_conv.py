@@ -19,6 +19,8 @@ SHAPES = [  # (ksize, Cin, Cout, H, W, count per forward)
 ]
 
 
+if os.environ.get("BENCH_CONV_SHAPES"):  # "k,Cin,Cout,H,W;..." replaces the table
+    SHAPES = [tuple(int(v) for v in t.split(",")) + (1,) for t in os.environ["BENCH_CONV_SHAPES"].split(";")]
 FUSED = os.environ.get("BENCH_CONV_PLAIN", "0") != "1"
 CHUNKED = os.environ.get("BENCH_CONV_CHUNKED", "0") == "1"
 

@@ -15,23 +15,33 @@ sde = dict(ndim=S, d_lambda=2.0, sigma_min=0.05, sigma_max=0.5)
 mix = torch.from_numpy(synth.synth_batch(B, T=T)[0]).cuda()
 mix_norm, _, _ = ops.normalize_batch(mix)
 
-def run(parts):
+def run(parts, full=False):
     engs = [Engine(cfg, blob) for _ in range(parts)]
     streams = [torch.cuda.Stream() for _ in range(parts)]
-    chunks = list(mix_norm.chunk(parts, 0))
+    chunks = [mix_norm] * parts if full else list(mix_norm.chunk(parts, 0))
     def once(seed):
         outs = []
         for e, s, c in zip(engs, streams, chunks):
             with torch.cuda.stream(s):
                 outs.append(e.pc_sample(c.contiguous(), sde, N=N, corrector_steps=1, snr=0.5, eps=0.03, denoise=True, seed=seed)[0])
         return outs
-    once(1); torch.cuda.synchronize()
+    once(1); once(1); torch.cuda.synchronize()   # eager pass, then graph capture
     t0 = time.perf_counter()
-    for i in range(2): once(2 + i)
+    for i in range(3): once(2 + i)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 2
-    print(f"{parts} stream(s) x B={B // parts}: {dt*1e3:.1f} ms per sampler call -> {B/dt:.2f} utt/s", flush=True)
+    dt = (time.perf_counter() - t0) / 3
+    nb = sum(c.shape[0] for c in chunks)
+    print(f"{parts} stream(s) x B={chunks[0].shape[0]}: {dt*1e3:.1f} ms per round -> {nb/dt:.2f} utt/s", flush=True)
     del engs
 
+if len(sys.argv) > 1 and sys.argv[1] == "grid":   # K concurrent samplers of batch Bk each
+    for Bk, Ks in ((48, (1,)), (32, (1, 2)), (16, (3, 4, 6)), (8, (4, 6, 8)), (4, (8,))):
+        mix = torch.from_numpy(synth.synth_batch(Bk, T=T)[0]).cuda()
+        mix_norm, _, _ = ops.normalize_batch(mix)
+        for k in Ks:
+            run(k, full=True)
+    sys.exit(0)
 for parts in [int(v) for v in (sys.argv[1].split(',') if len(sys.argv) > 1 else '1,2,4'.split(','))]:
     run(parts)
+for parts in (2, 3):
+    run(parts, full=True)
