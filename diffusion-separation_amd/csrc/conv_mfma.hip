@@ -819,7 +819,6 @@ static int launch_typed(const ConvArgs& a, hipStream_t st) {
     case 0: {
       static int alt = -1;
       if (alt < 0) { const char* v = getenv("DIFFSEP_CONV_ALT"); alt = v ? atoi(v) : 0; }
-      if (alt == 1) return launch_cfg<T, 9, 8, 32, 64, 2, 2, KC9 / 2, 2, 3>(a, st);  // 44 KB LDS, 3 blocks / CU
       if (alt == 2) return launch_cfg<T, 9, 8, 32, 64, 2, 2, KC9, 2, 2>(a, st);      // 2-pass epilogue only
       return launch_cfg<T, 9, 8, 32, 64, 2, 2, KC9>(a, st);
     }
