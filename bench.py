@@ -162,12 +162,12 @@ def main():
                 for _ in range(K)]
     keep = [None] * K  # the tensors of a worker's last step stay referenced until its stream has drained
 
-    def step(i, collect=True, w=None):
+    def step(i, collect=True, w=None, seed=None):
         w = i % K if w is None else w
         with on_stream(w):
             mix_norm, _, _ = ops.normalize_batch(mix)
             sep, nfe = engs[w].pc_sample(mix_norm, sde, N=args.N, corrector_steps=args.corrector_steps, snr=0.5,
-                                         eps=0.03, denoise=True, seed=1000 + i)
+                                         eps=0.03, denoise=True, seed=1000 + i if seed is None else seed)
             out = ops.scale_output(mix, sep)
             if world > 1 and collect:
                 dist.gather(out, gathered[w], dst=0)  # RCCL over xGMI: the only collective on the path
@@ -200,9 +200,14 @@ def main():
     # latency of ONE batch with nothing else in flight (untimed extra)
     fence()
     t1 = time.perf_counter()
-    step(0, collect=False, w=0)
+    ref_out, _ = step(0, collect=False, w=0, seed=77)
     sync()
     alone_ms = (time.perf_counter() - t1) * 1e3
+    # the same batch and seed again with K-1 other batches in flight: must be bit-identical (untimed check)
+    again = [step(j, collect=False, w=j, seed=77 + j)[0] for j in range(K)]
+    sync()
+    same_bits = bool(torch.equal(again[0], ref_out))
+    del again, ref_out
 
     roof = None
     if not args.no_roofline and rank == 0:
@@ -263,6 +268,7 @@ def main():
                        "nf": args.nf, "sharding": "utterances/%d" % world, "graph": not args.no_graph,
                        "batches_in_flight": K},
             "one_batch_alone_ms": round(alone_ms, 2),
+            "in_flight_bit_identical": same_bits,
             "realtime_factor": round(value * T / 8000.0, 2),
             "nfe_per_s": round(value * nfe, 1),
             "model_tflops": round(value * nfe * GFLOP_PER_NFE.get(args.nf, float("nan")) * (T / 32000.0) / 1e3, 2),

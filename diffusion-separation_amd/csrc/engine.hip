@@ -429,7 +429,11 @@ static int stats_begin(diffsep_engine* e, hipStream_t st) {  // call right after
   e->stats_used = 0;
   if (e->dry) { e->stats_need = 0; return 0; }
   e->stats_ptr = (char*)e_alloc(e, e->stats_need);
-  if (e->stats_need) DS_HIP(hipMemsetAsync(e->stats_ptr, 0, e->stats_need, st));
+  // zeroed by a kernel, not hipMemsetAsync: as a captured memset NODE it made every engine but the first return
+  // different samples when the graph was replayed on another stream (B >= 4; DIFFSEP_STATS_MEMSET=1 reproduces it)
+  static const bool use_memset = getenv("DIFFSEP_STATS_MEMSET") != nullptr;
+  if (e->stats_need && use_memset) DS_HIP(hipMemsetAsync(e->stats_ptr, 0, e->stats_need, st));
+  else if (e->stats_need && ds_launch_fill((float*)e->stats_ptr, 0.f, (long)(e->stats_need / 4), st)) return 1;
   return 0;
 }
 static Tn e_tensor(diffsep_engine* e, int B, int H, int W, int C) {

@@ -202,6 +202,21 @@ def test_concurrent_streams_are_bit_identical_to_one_stream(dtype):
         torch.cuda.synchronize()
         outs.append(o)
     assert all(torch.equal(a, b) for a, b in zip(*outs))
+    # ... and with a batch (B = 4: a hipMemsetAsync node for the accumulators made every engine but the first one
+    # return different samples under graph replay on its own stream; the accumulators are now zeroed by a kernel)
+    mixb = rnd("cs.mixb", (4, 1, T), 0.5).to(DEV)
+    alone = []
+    for w in range(K):
+        engs[w].pc_sample(mixb, SDE, N=2, seed=5 + w)
+        engs[w].pc_sample(mixb, SDE, N=2, seed=5 + w)  # (graph captured)
+        alone.append(engs[w].pc_sample(mixb, SDE, N=2, seed=5 + w)[0])
+        torch.cuda.synchronize()
+    both = []
+    for w in range(K):
+        with torch.cuda.stream(streams[w]):
+            both.append(engs[w].pc_sample(mixb, SDE, N=2, seed=5 + w)[0])
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(alone, both))
     for e in engs:
         e.close()
 
