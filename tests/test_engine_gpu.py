@@ -297,6 +297,24 @@ def test_other_samplers_match_reference_golden(golden):
     assert rel_rms(b, g["g12_sep_rd_langevin"]) < 1e-4
 
 
+def test_long_three_speaker_utterance_matches_oracle():
+    # BASELINE configs[4] shape: 3 speakers (Cin 8 / Cout 6), a 12.5 s utterance (785 frames -> W = 832, attention over
+    # 16 x 52 tokens), 2 corrector steps per predictor step
+    eng, sd = engine(16, 3, _lib.F32)
+    cfg = O.default_config(16, 3)
+    p = O.to_torch(sd)
+    T = 100000
+    xt, mix = rnd("long.x", (1, 3, T), 0.5), rnd("long.m", (1, 1, T), 0.5)
+    t = torch.tensor([0.47])
+    out = eng.score(xt.to(DEV), t.to(DEV), mix.to(DEV))
+    ref = O.score_forward(p, cfg, xt, t, mix)
+    assert out.shape == (1, 3, T) and rel_rms(out, ref) < 2e-4
+    sde3 = dict(ndim=3, d_lambda=2.0, sigma_min=0.05, sigma_max=0.5)
+    a, nfe = eng.pc_sample(mix.to(DEV), sde3, N=2, corrector_steps=2, seed=3)
+    b, _ = eng.pc_sample(mix.to(DEV), sde3, N=2, corrector_steps=2, seed=3)
+    assert nfe == 6 and torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_edge_lengths_and_error_behaviour():
     # shortest / odd signal lengths against the oracle, and loud failures with a message for bad arguments
     eng, sd = engine(16, 2, _lib.F32)
