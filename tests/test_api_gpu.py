@@ -98,6 +98,20 @@ def test_separate_cli_on_wav_folder(tmp_path):
             assert sr == 8000 and y.shape == (1, 4000) and torch.isfinite(y).all()
 
 
+def test_separate_cli_streams_do_not_change_the_files(tmp_path):
+    # --streams K: K files in flight; with --seed the written wavs are identical for any K
+    ind = tmp_path / "in"
+    ind.mkdir()
+    for i in range(5):
+        wavio.save(ind / f"utt{i}.wav", torch.from_numpy(synth.synth_mixture(i, T=4000 + 640 * (i % 2))[0]), 8000)
+    outs = []
+    for k in (1, 3):
+        outd = tmp_path / f"out{k}"
+        sep_cli.main([str(ind), str(outd), "--synthetic-weights", "16", "-N", "2", "--seed", "4", "--streams", str(k)])
+        outs.append([wavio.load(outd / s / f"utt{i}.wav")[0] for i in range(5) for s in ("s0", "s1")])
+    assert all(a.shape == b.shape and torch.equal(a, b) for a, b in zip(*outs))
+
+
 def test_enhancement_model_api(golden):
     # config/model/nr.yaml shaped model: PriorMixSDE behind the same DiffSepModel / registry surface
     from diffsep_amd.pl_model import enhancement_config
