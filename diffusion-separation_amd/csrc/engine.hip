@@ -416,7 +416,7 @@ static void* e_alloc(diffsep_engine* e, size_t bytes) {
   if (e->dbg_alloc) fprintf(stderr, "[diffsep alloc] %zu %zu\n", a, bytes);
   return e->arena + a;
 }
-// GroupNorm accumulators live in one region at the start of a forward's allocations: ONE memset per forward
+// GroupNorm accumulators live in one region at the start of a forward's allocations: ONE fill launch per forward
 // zeroes them all (they are filled by integer atomics)
 static long long* e_alloc_stats(diffsep_engine* e, size_t bytes) {
   const size_t a = (e->stats_used + 255) & ~(size_t)255;
