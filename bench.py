@@ -268,6 +268,7 @@ def main():
                        "nf": args.nf, "sharding": "utterances/%d" % world, "graph": not args.no_graph,
                        "batches_in_flight": K},
             "one_batch_alone_ms": round(alone_ms, 2),
+            "utt_per_s_per_gpu_one_batch_at_a_time": round(B / (alone_ms * 1e-3), 2),
             "in_flight_bit_identical": same_bits,
             "realtime_factor": round(value * T / 8000.0, 2),
             "nfe_per_s": round(value * nfe, 1),
