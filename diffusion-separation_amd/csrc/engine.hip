@@ -338,8 +338,13 @@ struct diffsep_engine {
   hipStream_t sideA = nullptr, sideB = nullptr;
   std::vector<hipEvent_t> fj_events;
   size_t fj_i = 0;
+  float* ts_pin = nullptr;    // pinned staging buffer of the time-step upload (+ the event of its last use)
+  size_t ts_pin_cap = 0;
+  hipEvent_t ts_ev = nullptr;
+  bool ts_ev_rec = false;
   std::vector<float> ts_dev;  // time steps currently in st_ts (for ts_B batch rows): re-uploaded only when they change
   int ts_B = 0;
+  bool had_arena = false;
   bool dbg_alloc = false;  // DIFFSEP_DBG_ALLOC=1: log every arena allocation (offset, bytes) to stderr
   int use_side = 0;  // measured on MI355X: parallel graph branches cost ~5 % here (DIFFSEP_SIDE=1|2|3 enables them)
   // optional per-launch timing of the MFMA kernels (HIP events on the launch stream)
@@ -805,8 +810,12 @@ static int ensure_plan(diffsep_engine* e, int B, long T, hipStream_t st) {
     if (e->arena) DS_HIP(hipFree(e->arena));
     e->arena = nullptr;
     e->cap = 0;
-    DS_HIP(hipMalloc((void**)&e->arena, need));
-    e->cap = need;
+    // (hipFree / hipMalloc synchronise the whole device: grow with headroom so that a stream of utterances of
+    // slowly increasing length does not reallocate — and stall every other stream — at each new maximum)
+    const size_t grown = e->had_arena ? need + need / 4 : need;
+    DS_HIP(hipMalloc((void**)&e->arena, grown));
+    e->cap = grown;
+    e->had_arena = true;
   }
   DS_HIP(hipMemsetAsync(e->arena, 0, e->cap, st));  // channel / K padding must read as zero
   e->top = 0;
@@ -822,7 +831,10 @@ static int ensure_plan(diffsep_engine* e, int B, long T, hipStream_t st) {
   e->planB = B;
   e->planT = T;
   e->ts_dev.clear();
-  e->warmed = false;
+  // a new plan is captured at its first score evaluation (hipFuncSetAttribute inside the launchers is not a stream
+  // operation and is legal during capture); DIFFSEP_EAGER_FIRST=1 restores one eager evaluation before the capture
+  static const bool eager_first = getenv("DIFFSEP_EAGER_FIRST") != nullptr;
+  e->warmed = !eager_first;
   return 0;
 }
 
@@ -914,9 +926,21 @@ extern "C" void diffsep_engine_destroy(diffsep_engine* e) {
   if (e->sideA) hipStreamDestroy(e->sideA);
   if (e->sideB) hipStreamDestroy(e->sideB);
   for (auto v : e->fj_events) hipEventDestroy(v);
+  if (e->ts_ev) hipEventDestroy(e->ts_ev);
+  if (e->ts_pin) hipHostFree(e->ts_pin);
   if (e->ev_in) hipEventDestroy(e->ev_in);
   if (e->ev_out) hipEventDestroy(e->ev_out);
   delete e;
+}
+extern "C" int32_t diffsep_engine_reserve(diffsep_engine* e, int32_t B, int64_t T, void* stream) {
+  DS_CHECK(e && B >= 1 && T >= 1, "reserve: bad argument");
+  // size the workspace for a B x T batch now: plans of that size or smaller never reallocate afterwards
+  // (hipFree / hipMalloc synchronise the whole device, i.e. every other stream's work)
+  // (on the caller's stream — the null stream included: no private stream is created here, see StreamScope)
+  hipStream_t st = (hipStream_t)stream;
+  if (ensure_plan(e, B, T, st)) return 1;
+  DS_HIP(hipStreamSynchronize(st));  // the workspace is zeroed before any other stream may use the plan
+  return 0;
 }
 extern "C" int32_t diffsep_engine_debug_arena(const diffsep_engine* e, void** base, int64_t* bytes, int64_t* fwd_base) {
   DS_CHECK(e && base && bytes && fwd_base, "debug_arena: null argument");
@@ -1065,10 +1089,23 @@ extern "C" int32_t diffsep_pc_sample(diffsep_engine* e, const diffsep_sde_config
   if (timesteps_host) for (int i = 0; i < N; ++i) ts[i] = timesteps_host[i];
   else linspace_f32(1.0f, smp->eps, N, ts.data());
   if (e->ts_dev != ts || e->ts_B != B) {  // (same schedule as the last call: the device rows are already there)
-    std::vector<float> rows((size_t)N * B);
-    for (int i = 0; i < N; ++i) for (int b = 0; b < B; ++b) rows[(size_t)i * B + b] = ts[i];
-    DS_HIP(hipMemcpyAsync(e->st_ts, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
-    DS_HIP(hipStreamSynchronize(st));  // `rows` is pageable host memory about to go out of scope
+    // through a pinned staging buffer, stream-ordered: a pageable hipMemcpyAsync + stream sync was measured waiting for
+    // the work of OTHER streams (200 ms per new utterance length with four samplers in flight)
+    const size_t nrow = (size_t)N * B;
+    if (e->ts_ev_rec) DS_HIP(hipEventSynchronize(e->ts_ev));  // the previous upload has left the staging buffer
+    if (nrow > e->ts_pin_cap) {
+      if (e->ts_pin) DS_HIP(hipHostFree(e->ts_pin));
+      e->ts_pin = nullptr;
+      e->ts_pin_cap = 0;
+      const size_t cap = nrow < 4096 ? 4096 : nrow;
+      DS_HIP(hipHostMalloc((void**)&e->ts_pin, cap * sizeof(float), hipHostMallocDefault));
+      e->ts_pin_cap = cap;
+    }
+    if (!e->ts_ev) DS_HIP(hipEventCreateWithFlags(&e->ts_ev, hipEventDisableTiming));
+    for (int i = 0; i < N; ++i) for (int b = 0; b < B; ++b) e->ts_pin[(size_t)i * B + b] = ts[i];
+    DS_HIP(hipMemcpyAsync(e->st_ts, e->ts_pin, nrow * 4, hipMemcpyHostToDevice, st));
+    DS_HIP(hipEventRecord(e->ts_ev, st));
+    e->ts_ev_rec = true;
     e->ts_dev = ts;
     e->ts_B = B;
   }

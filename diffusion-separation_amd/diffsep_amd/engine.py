@@ -120,6 +120,11 @@ class Engine:
                                               _stream_ptr(self.device)))
         return out
 
+    def reserve(self, B, T):
+        """Size the workspace for batches of up to B x T samples now (later, smaller plans never reallocate)."""
+        with torch.cuda.device(self.device):
+            check(lib().diffsep_engine_reserve(self._h, int(B), int(T), _stream_ptr(self.device)))
+
     def debug_arena(self):
         """(uint8 view of the workspace arena, offset of the forward region): every intermediate tensor of the last
         forward, in launch order.  Debug / test aid."""

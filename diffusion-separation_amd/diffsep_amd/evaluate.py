@@ -39,7 +39,7 @@ def load_dataset(args, fs):
     if args.dataset_dir and args.enhance:
         ds = datasets.NoisyDataset(args.dataset_dir, fs=fs, split=args.split)
         n = len(ds) if args.limit is None else min(len(ds), args.limit)
-        return n, lambda i: tuple(t[..., : min(ds[i][0].shape[-1], ds[i][1].shape[-1])] for t in ds[i])
+        return n, (lambda i: tuple(t[..., : min(ds[i][0].shape[-1], ds[i][1].shape[-1])] for t in ds[i])), None
     if args.dataset_dir:
         root = Path(args.dataset_dir)
         if (root / "mix").is_dir():  # flat folder: mix/, s1/, s2/ ...
@@ -49,16 +49,16 @@ def load_dataset(args, fs):
                 mix, _ = wavio.load(root / "mix" / names[i])
                 tgt = torch.cat([wavio.load(root / f"s{k + 1}" / names[i])[0][:1] for k in range(args.n_speakers)], 0)
                 return mix[:1], tgt
-            return len(names), get_flat
+            return len(names), get_flat, max((wavio.info(root / "mix" / nm)[1] for nm in names), default=None)
         ds = datasets.WSJ0_mix(root, n_spkr=args.n_speakers, fs=fs, cut=args.cut, split=args.split,
                                max_n_samples=args.limit)
-        return len(ds), lambda i: ds[i]
+        return len(ds), (lambda i: ds[i]), max((wavio.info(ds.path_mix / nm)[1] for nm in ds.file_list), default=None)
     n = args.synthetic
 
     def get(i):
         mix, tgt = synth.synth_mixture(i, T=args.samples, fs=fs, n_src=args.n_speakers)
         return torch.from_numpy(mix), torch.from_numpy(tgt)
-    return n, get
+    return n, get, args.samples
 
 
 def main(argv=None):
@@ -119,14 +119,17 @@ def main(argv=None):
         # engines are created BEFORE the worker streams: HIP hands out hardware queues in stream-creation order, and
         # engines created lazily in between left the workers sharing queues (measured 7.0 instead of 17 utt/s, K=4)
         m.score_model.engine()
-    streams = [torch.cuda.Stream() for _ in range(K)]
     model = models[0]
     fs = cfg_get(model.config, "model.fs", 8000)
     N = cfg_get(model.config, "model.sampler.N", 30) if args.N is None else args.N
     cs = cfg_get(model.config, "model.sampler.corrector_steps", 1) if args.corrector_steps is None else args.corrector_steps
     snr = cfg_get(model.config, "model.sampler.snr", 0.5) if args.snr is None else args.snr
 
-    n, get = load_dataset(args, fs)
+    n, get, max_len = load_dataset(args, fs)  # max_len: longest utterance in samples when the headers tell (else None)
+    if max_len:
+        for m in models:  # workspace for the longest utterance now: growing it later would stall every stream
+            m.score_model.engine().reserve(1, max_len)
+    streams = [torch.cuda.Stream() for _ in range(K)]
     lo, hi = shard_range(n, world, rank)
     # warm every worker up on the first utterance's shape (engine creation, workspace plan, graph capture), then fix
     # the RNG state: results do not depend on the number of streams
@@ -140,6 +143,8 @@ def main(argv=None):
                                          intermediate=False, schedule=args.schedule)()
         torch.cuda.synchronize()
     torch.manual_seed(args.seed + rank)
+    # the i-th utterance of this rank gets the i-th draw as its device RNG seed, whatever K is
+    seeds = [int(torch.randint(0, 2 ** 62, (1,)).item()) for _ in range(lo, hi)]
     records = []
     pending = [None] * K  # per worker: the utterance whose sampler is running on its stream
 
@@ -163,6 +168,8 @@ def main(argv=None):
             for k in range(est.shape[1]):
                 wavio.save(d / f"{i:05d}_s{k}.wav", est[0, k:k + 1].cpu() * 0.1, fs)
 
+    # One host thread drives all K streams (a thread per stream was measured SLOWER: 10.7 instead of 17 utt/s at K = 4;
+    # concurrent launches serialise inside the HIP runtime and a launch that waits for queue space holds them all up).
     t_all = time.perf_counter()
     for i in range(lo, hi):
         w = (i - lo) % K
@@ -174,7 +181,8 @@ def main(argv=None):
             tgt = tgt[None].contiguous().pin_memory().to("cuda", non_blocking=True)
             (mix_n, tgt_n), *_ = models[w].normalize_batch((mix, tgt))
             sampler = models[w].get_pc_sampler("reverse_diffusion", "ald2", mix_n, N=N, corrector_steps=cs, snr=snr,
-                                               denoise=True, intermediate=False, schedule=args.schedule)
+                                               denoise=True, intermediate=False, schedule=args.schedule,
+                                               seed=seeds[i - lo])
             if K == 1:
                 torch.cuda.synchronize()
             t0 = time.perf_counter()

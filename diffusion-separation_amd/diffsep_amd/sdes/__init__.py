@@ -38,7 +38,7 @@ def _engine_of(score_fn):
 
 
 def _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, denoise, eps, snr, corrector_steps,
-                  probability_flow, intermediate, schedule):
+                  probability_flow, intermediate, schedule, seed=None):
     predictor = PredictorRegistry.get_by_name(predictor_name)(sde, score_fn, probability_flow=probability_flow)
     corrector = CorrectorRegistry.get_by_name(corrector_name)(sde, score_fn, snr=snr, n_steps=corrector_steps)
     eng = _engine_of(score_fn)
@@ -51,11 +51,13 @@ def _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, d
         with torch.no_grad():
             ns = sde.N * (corrector.n_steps + 1)
             if fused:
-                seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # torch.manual_seed() governs reproducibility
+                # torch.manual_seed() governs reproducibility; seed=... (an extension) fixes the device RNG seed of
+                # this sampler explicitly, e.g. when several samplers are driven from different threads
+                s_ = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
                 ts = None if schedule is None else _timesteps(sde, eps, schedule, "cpu").numpy()
                 x, _ = eng.pc_sample(y, sde.engine_config(), N=sde.N, corrector_steps=corrector.n_steps, snr=snr,
                                      eps=eps, denoise=denoise, predictor=predictor_name, corrector=corrector_name,
-                                     seed=seed, timesteps=ts)
+                                     seed=s_, timesteps=ts)
                 return x, ns
             im = []
             xt = sde.prior_sampling((true_mean if true_mean is not None else y).shape,
@@ -78,7 +80,7 @@ def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean=N
                    corrector_steps=1, probability_flow=False, intermediate=False, **kwargs):
     """Reference: sdes/__init__.py:132-190."""
     return _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, denoise, eps, snr,
-                         corrector_steps, probability_flow, intermediate, None)
+                         corrector_steps, probability_flow, intermediate, None, seed=kwargs.get("seed"))
 
 
 def get_pc_scheduled_sampler(predictor_name, corrector_name, sde, score_fn, y, denoise=True, true_mean=None, eps=3e-2,
@@ -86,4 +88,4 @@ def get_pc_scheduled_sampler(predictor_name, corrector_name, sde, score_fn, y, d
                              schedule="linear", **kwargs):
     """Reference: sdes/__init__.py:46-129."""
     return _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, denoise, eps, snr,
-                         corrector_steps, probability_flow, intermediate, schedule)
+                         corrector_steps, probability_flow, intermediate, schedule, seed=kwargs.get("seed"))

@@ -91,7 +91,6 @@ def main(argv=None):
     models = [model] + [get_model(args)[0] for _ in range(K - 1)]
     for m in models:
         m.score_model.engine()  # engines before streams (hardware queues are handed out in creation order)
-    streams = [torch.cuda.Stream() for _ in range(K)] if K > 1 else [torch.cuda.current_stream()]
     if args.seed is not None:
         torch.manual_seed(args.seed)
     model_sr = cfg_get(model.config, "model.fs", 8000)
@@ -99,6 +98,11 @@ def main(argv=None):
         raise ValueError("Output directory is a file")
     args.output_dir.mkdir(parents=True, exist_ok=True)
     files = sorted(args.input_dir.glob("*.wav"))
+    if files:  # workspace for the longest file now (growing it later synchronises the whole device)
+        longest = max(wavio.info(p)[1] for p in files)
+        for m in models:
+            m.score_model.engine().reserve(args.batch, longest)
+    streams = [torch.cuda.Stream() for _ in range(K)] if K > 1 else [torch.cuda.current_stream()]
     pending = []
     in_flight = [None] * K  # per worker: (group, device result) of the batch running on its stream
     n_groups = 0

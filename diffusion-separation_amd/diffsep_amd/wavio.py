@@ -35,6 +35,30 @@ def load(path):
     return torch.from_numpy(np.ascontiguousarray(x)), sr
 
 
+def info(path):
+    """(sample_rate, frames per channel) from the header only."""
+    with open(path, "rb") as f:
+        head = f.read(12)
+        if head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+            raise ValueError(f"{path}: not a RIFF/WAVE file")
+        fmt = None
+        while True:
+            ch = f.read(8)
+            if len(ch) < 8:
+                raise ValueError(f"{path}: missing fmt/data chunk")
+            cid, size = ch[:4], struct.unpack("<I", ch[4:])[0]
+            if cid == b"fmt ":
+                fmt = struct.unpack("<HHIIHH", f.read(size)[:16])
+                if size & 1:
+                    f.read(1)
+            elif cid == b"data":
+                if fmt is None:
+                    raise ValueError(f"{path}: data chunk before fmt")
+                return fmt[2], size // (fmt[1] * (fmt[5] // 8))
+            else:
+                f.seek(size + (size & 1), 1)
+
+
 def save(path, wav, sr, bits=16):
     x = wav.detach().cpu().float().numpy() if isinstance(wav, torch.Tensor) else np.asarray(wav, np.float32)
     if x.ndim == 1:

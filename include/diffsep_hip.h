@@ -104,6 +104,10 @@ int32_t diffsep_engine_create(const diffsep_model_config* cfg, const float* weig
 void diffsep_engine_destroy(diffsep_engine* e);
 /* bytes of device memory currently held (weights + workspace). */
 int64_t diffsep_engine_device_bytes(const diffsep_engine* e);
+/* Size the workspace for batches of up to B utterances of T samples now (the engine otherwise grows it on demand, and
+ * hipFree / hipMalloc synchronise the whole device — i.e. every other stream).  Host-side counterpart in the
+ * reference: none (torch's caching allocator). */
+int32_t diffsep_engine_reserve(diffsep_engine* e, int32_t B, int64_t T, void* stream);
 /* Debug aid: the engine's workspace arena (sampler state, then one forward's activations in launch order from
  * fwd_base).  Lets a test snapshot every intermediate tensor of a forward; no reference counterpart. */
 int32_t diffsep_engine_debug_arena(const diffsep_engine* e, void** base, int64_t* bytes, int64_t* fwd_base);

@@ -168,6 +168,30 @@ def test_evaluate_streams_do_not_change_results(tmp_path):
     assert [strip(r) for r in recs[0]] == [strip(r) for r in recs[1]]
 
 
+def test_evaluate_streams_on_files_of_different_length(tmp_path):
+    # a flat mix/ s1/ s2/ folder with utterances of different lengths: every utterance is a new workspace plan and a new
+    # graph capture on its worker's stream; the records must not depend on the number of streams
+    import json
+    from diffsep_amd import evaluate as ev
+    root = tmp_path / "data"
+    for sub in ("mix", "s1", "s2"):
+        (root / sub).mkdir(parents=True)
+    for i in range(7):
+        mix, tgt = synth.synth_mixture(i, T=3000 + 517 * ((i * 3) % 7), fs=8000, n_src=2)
+        wavio.save(root / "mix" / f"u{i}.wav", torch.from_numpy(mix), 8000)
+        for k in range(2):
+            wavio.save(root / f"s{k + 1}" / f"u{i}.wav", torch.from_numpy(tgt[k:k + 1]), 8000)
+    assert wavio.info(root / "mix" / "u1.wav") == (8000, 3000 + 517 * 3)
+    recs = []
+    for k in (1, 3):
+        ev.main(["--dataset-dir", str(root), "--synthetic-weights", "16", "-N", "2", "--streams", str(k), "-o",
+                 str(tmp_path / f"k{k}")])
+        recs.append(json.load(open(tmp_path / f"k{k}" / "test.json")))
+    strip = lambda r: {k: v for k, v in r.items() if k != "runtime"}
+    assert len(recs[0]) == 7 and [strip(r) for r in recs[0]] == [strip(r) for r in recs[1]]
+    assert [r["len_s"] for r in recs[0]] == [(3000 + 517 * ((i * 3) % 7)) / 8000 for i in range(7)]
+
+
 def test_evaluate_cli_on_wsj0_mix_tree(tmp_path):
     # WSJ0-mix on-disk layout -> evaluate: file order, (mix, tgt) shapes, variable lengths
     import json
