@@ -262,8 +262,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "configs[1]: 2-spk N=%d PC sampler (+%d ald2 corrector step), batch=%d x %.1f s @ 8 kHz "
-                                   "per GPU, NCSN++ nf=%d random-init, %d NFE/step" %
-                                   (args.N, args.corrector_steps, B, T / 8000.0, args.nf, nfe),
+                                   "per GPU and step, NCSN++ nf=%d random-init, %d NFE/step; %d consecutive steps (batches) in "
+                                   "flight per GPU" % (args.N, args.corrector_steps, B, T / 8000.0, args.nf, nfe, K),
                        "batch_per_gpu": B, "samples": T, "N": args.N, "corrector_steps": args.corrector_steps,
                        "nf": args.nf, "sharding": "utterances/%d" % world, "graph": not args.no_graph,
                        "batches_in_flight": K},
