@@ -15,6 +15,15 @@ def shard_range(n_items, world, rank):
     return start, end
 
 
+def rank_indices(n_items, world, rank, lengths=None, balance=False):
+    """Utterance indices of one rank, ascending: the reference's contiguous range (evaluate_mp.py:495-503), or with
+    balance=True and known lengths the length-balanced deal."""
+    if balance and lengths and world > 1:
+        return sorted(length_balanced_order(lengths, world)[rank])
+    lo, hi = shard_range(n_items, world, rank)
+    return list(range(lo, hi))
+
+
 def length_balanced_order(lengths, world):
     """Optional better balance for variable-length sets: sort by length, deal round-robin.
     Returns one index list per rank."""

@@ -22,7 +22,7 @@ import torch
 import torch.distributed as dist
 
 from . import datasets, metrics, synth, wavio
-from .dist_utils import gather_objects, shard_range
+from .dist_utils import gather_objects, rank_indices
 from .pl_model import DiffSepModel, cfg_get, default_config, enhancement_config
 
 
@@ -49,16 +49,16 @@ def load_dataset(args, fs):
                 mix, _ = wavio.load(root / "mix" / names[i])
                 tgt = torch.cat([wavio.load(root / f"s{k + 1}" / names[i])[0][:1] for k in range(args.n_speakers)], 0)
                 return mix[:1], tgt
-            return len(names), get_flat, max((wavio.info(root / "mix" / nm)[1] for nm in names), default=None)
+            return len(names), get_flat, [wavio.info(root / "mix" / nm)[1] for nm in names]
         ds = datasets.WSJ0_mix(root, n_spkr=args.n_speakers, fs=fs, cut=args.cut, split=args.split,
                                max_n_samples=args.limit)
-        return len(ds), (lambda i: ds[i]), max((wavio.info(ds.path_mix / nm)[1] for nm in ds.file_list), default=None)
+        return len(ds), (lambda i: ds[i]), [wavio.info(ds.path_mix / nm)[1] for nm in ds.file_list]
     n = args.synthetic
 
     def get(i):
         mix, tgt = synth.synth_mixture(i, T=args.samples, fs=fs, n_src=args.n_speakers)
         return torch.from_numpy(mix), torch.from_numpy(tgt)
-    return n, get, args.samples
+    return n, get, [args.samples] * n
 
 
 def main(argv=None):
@@ -81,6 +81,9 @@ def main(argv=None):
     ap.add_argument("--save-wav", action="store_true")
     ap.add_argument("--seed", type=int, default=0, help="torch.manual_seed before the first utterance: the i-th "
                                                          "utterance gets the i-th draw as its device RNG seed")
+    ap.add_argument("--balance", action="store_true",
+                    help="multi-GPU: deal the utterances to the ranks by length (longest first, round-robin) instead of "
+                         "the reference's contiguous index ranges; needs the lengths (wav headers)")
     ap.add_argument("--streams", type=int, default=1,
                     help="utterances in flight per GPU: K engines on K HIP streams (results are bit-identical for any "
                          "K).  One utterance at a time (the reference's evaluation loop) leaves most of the GPU idle: "
@@ -125,15 +128,18 @@ def main(argv=None):
     cs = cfg_get(model.config, "model.sampler.corrector_steps", 1) if args.corrector_steps is None else args.corrector_steps
     snr = cfg_get(model.config, "model.sampler.snr", 0.5) if args.snr is None else args.snr
 
-    n, get, max_len = load_dataset(args, fs)  # max_len: longest utterance in samples when the headers tell (else None)
+    n, get, lengths = load_dataset(args, fs)  # lengths: samples per utterance when the wav headers tell (else None)
+    max_len = max(lengths) if lengths else None
     if max_len:
         for m in models:  # workspace for the longest utterance now: growing it later would stall every stream
             m.score_model.engine().reserve(1, max_len)
     streams = [torch.cuda.Stream() for _ in range(K)]
-    lo, hi = shard_range(n, world, rank)
+    # the reference's contiguous ranges (evaluate_mp.py:495-503), or sorted by length and dealt round-robin
+    mine = rank_indices(n, world, rank, lengths, args.balance)
+    lo = mine[0] if mine else 0
     # warm every worker up on the first utterance's shape (engine creation, workspace plan, graph capture), then fix
     # the RNG state: results do not depend on the number of streams
-    if hi > lo:
+    if mine:
         m0, _ = get(lo)
         for w in range(K):
             with torch.cuda.stream(streams[w]):
@@ -142,9 +148,9 @@ def main(argv=None):
                 models[w].get_pc_sampler("reverse_diffusion", "ald2", mw_n, N=N, corrector_steps=cs, snr=snr, denoise=True,
                                          intermediate=False, schedule=args.schedule)()
         torch.cuda.synchronize()
-    torch.manual_seed(args.seed + rank)
-    # the i-th utterance of this rank gets the i-th draw as its device RNG seed, whatever K is
-    seeds = [int(torch.randint(0, 2 ** 62, (1,)).item()) for _ in range(lo, hi)]
+    # utterance i of the data set gets the i-th draw of a generator seeded with --seed as its device RNG seed: the
+    # records do not depend on the number of streams, of ranks, or on how the utterances are dealt to them
+    seeds = torch.randint(0, 2 ** 62, (max(n, 1),), generator=torch.Generator().manual_seed(args.seed)).tolist()
     records = []
     pending = [None] * K  # per worker: the utterance whose sampler is running on its stream
 
@@ -171,8 +177,8 @@ def main(argv=None):
     # One host thread drives all K streams (a thread per stream was measured SLOWER: 10.7 instead of 17 utt/s at K = 4;
     # concurrent launches serialise inside the HIP runtime and a launch that waits for queue space holds them all up).
     t_all = time.perf_counter()
-    for i in range(lo, hi):
-        w = (i - lo) % K
+    for j, i in enumerate(mine):
+        w = j % K
         finish(w)  # the worker's previous utterance (oldest in flight)
         mix, tgt = get(i)
         with torch.cuda.stream(streams[w]):
@@ -182,7 +188,7 @@ def main(argv=None):
             (mix_n, tgt_n), *_ = models[w].normalize_batch((mix, tgt))
             sampler = models[w].get_pc_sampler("reverse_diffusion", "ald2", mix_n, N=N, corrector_steps=cs, snr=snr,
                                                denoise=True, intermediate=False, schedule=args.schedule,
-                                               seed=seeds[i - lo])
+                                               seed=seeds[i])
             if K == 1:
                 torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -202,7 +208,7 @@ def main(argv=None):
         summary = datasets.summarize([{k: v for k, v in r.items() if k not in ("batch_idx", "perm")} for r in flat])
         tot_rt = sum(r["runtime"] for r in flat)
         summary.update({"rtf": tot_rt / max(sum(r["len_s"] for r in flat), 1e-9), "world_size": world,
-                        "streams": K, "utt_per_s_rank0": (hi - lo) / max(wall, 1e-9)})
+                        "streams": K, "utt_per_s_rank0": len(mine) / max(wall, 1e-9)})
         with open(args.output_dir / f"{args.split}_summary.json", "w") as f:
             json.dump(summary, f, indent=2)
         print(json.dumps(summary))

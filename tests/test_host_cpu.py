@@ -86,6 +86,15 @@ def test_shard_range_matches_reference_partition():
         assert all(e - s == n // w for s, e in rs[:-1])
     parts = dist_utils.length_balanced_order([5, 1, 9, 3, 7, 2], 2)
     assert sorted(parts[0] + parts[1]) == list(range(6))
+    # evaluate --balance: every utterance exactly once, per-rank work within one utterance of each other
+    lens = [3 + (i * 37) % 11 for i in range(50)]
+    for w in (1, 3, 8):
+        got = [dist_utils.rank_indices(50, w, r, lens, balance=True) for r in range(w)]
+        assert sorted(i for g in got for i in g) == list(range(50)) and all(g == sorted(g) for g in got)
+        loads = [sum(lens[i] for i in g) for g in got]
+        assert max(loads) - min(loads) <= max(lens)
+        assert [dist_utils.rank_indices(50, w, r, lens) for r in range(w)] == \
+               [list(range(*dist_utils.shard_range(50, w, r))) for r in range(w)]
 
 
 def _free_port():
