@@ -199,13 +199,25 @@ int ds_build_stft_table(int n_fft, float** dev_tab);
 struct SdeP { int kind; int ndim; float d_lambda, sigma_min, sigma_max; };
 // smix: per-sample sigma_mix [B][T] of PriorMixSDE (kind 1), null for MixSDE (kind 0)
 int ds_launch_sigma_mix(const float* mix, float* out, int B, long T, int avg_len, hipStream_t st);
+// lens (nullable): per-utterance lengths [B] (device); the state beyond lens[b] is kept at zero
 int ds_launch_sde_prior(const SdeP& s, const float* y, const float* z, float* x, int B, int S, long T,
-                        const float* smix, hipStream_t st);
+                        const float* smix, hipStream_t st, const int* lens = nullptr);
 int ds_launch_sde_corrector(const SdeP& s, float snr, const float* x, const float* t, const float* score,
                             const float* z, float* xo, float* xm, int B, int S, long T, const float* smix,
-                            int variant, hipStream_t st);  // variant 0 = ald2, 1 = ald
+                            int variant, hipStream_t st, const int* lens = nullptr);  // variant 0 = ald2, 1 = ald
 int ds_launch_sde_predictor(const SdeP& s, int N, const float* x, const float* t, const float* score, const float* z,
-                            float* xo, float* xm, int B, int S, long T, const float* smix, int pflow, hipStream_t st);
+                            float* xo, float* xm, int B, int S, long T, const float* smix, int pflow, hipStream_t st,
+                            const int* lens = nullptr);
+// the SDE object surface (sde / marginal_prob / mult_std / discretize / reverse) as unit kernels
+int ds_launch_sde_coeff(const SdeP& s, const float* x, const float* t, const float* smix, float* drift,
+                        float* diffusion, int B, int S, long T, float fs, float gs, hipStream_t st);
+int ds_launch_sde_mean(const SdeP& s, const float* x0, const float* t, float* out, int B, int S, long T, hipStream_t st);
+int ds_launch_sde_std(const SdeP& s, const float* t, const float* smix, float* L, int B, int S, long T, hipStream_t st);
+int ds_launch_sde_mult_std(const float* L, const float* x, float* out, int B, int S, long T, int per_t, hipStream_t st);
+int ds_launch_sde_reverse(const float* f, const float* G, const float* score, float* out, int B, long n_per_batch,
+                          int g_full, int pflow, hipStream_t st);
+int ds_launch_randn_batch(float* out, int B, int S, long T, const uint64_t* seeds, const int* lens, uint64_t stream_id,
+                          hipStream_t st);
 // Langevin corrector step; ws >= 16*B + 16 bytes
 int ds_launch_langevin(float snr, const float* x, const float* score, const float* z, float* xo, float* xm, int B,
                        long n_per_batch, void* ws, hipStream_t st);

@@ -322,6 +322,12 @@ struct diffsep_engine {
   // sampler state (inside the arena, below fwd_base)
   float *st_x = nullptr, *st_xm = nullptr, *st_score = nullptr, *st_t = nullptr, *st_noise = nullptr,
         *st_ts = nullptr, *st_mix = nullptr, *st_smix = nullptr, *st_lang = nullptr;
+  int* st_lens = nullptr;             // per-utterance lengths of a mixed-length batch (diffsep_sampler_ext)
+  unsigned long long* st_seeds = nullptr;
+  char* ext_pin = nullptr;            // pinned staging of (lengths, seeds) + the event of its last upload
+  size_t ext_pin_cap = 0;
+  hipEvent_t ext_ev = nullptr;
+  bool ext_ev_rec = false;
   // graph of one NFE: (st_x, st_t, st_mix) -> st_score
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
@@ -800,6 +806,7 @@ static int ensure_plan(diffsep_engine* e, int B, long T, hipStream_t st) {
   e_alloc(e, nst * 4); e_alloc(e, nst * 4); e_alloc(e, nst * 4); e_alloc(e, nst * 4);
   e_alloc(e, (size_t)B * 4); e_alloc(e, (size_t)B * T * 4); e_alloc(e, (size_t)B * T * 4);
   e_alloc(e, 4096 * (size_t)B * 4); e_alloc(e, 16 * (size_t)B + 64);
+  e_alloc(e, (size_t)B * 4); e_alloc(e, (size_t)B * 8);
   e->fwd_base = (e->top + 255) & ~(size_t)255;
   const int rc = score_forward_impl(e, nullptr, nullptr, nullptr, nullptr, B, T, st);
   e->dry = false;
@@ -828,6 +835,8 @@ static int ensure_plan(diffsep_engine* e, int B, long T, hipStream_t st) {
   e->st_smix = (float*)e_alloc(e, (size_t)B * T * 4);
   e->st_ts = (float*)e_alloc(e, 4096 * (size_t)B * 4);
   e->st_lang = (float*)e_alloc(e, 16 * (size_t)B + 64);
+  e->st_lens = (int*)e_alloc(e, (size_t)B * 4);
+  e->st_seeds = (unsigned long long*)e_alloc(e, (size_t)B * 8);
   e->planB = B;
   e->planT = T;
   e->ts_dev.clear();
@@ -928,6 +937,8 @@ extern "C" void diffsep_engine_destroy(diffsep_engine* e) {
   for (auto v : e->fj_events) hipEventDestroy(v);
   if (e->ts_ev) hipEventDestroy(e->ts_ev);
   if (e->ts_pin) hipHostFree(e->ts_pin);
+  if (e->ext_ev) hipEventDestroy(e->ext_ev);
+  if (e->ext_pin) hipHostFree(e->ext_pin);
   if (e->ev_in) hipEventDestroy(e->ev_in);
   if (e->ev_out) hipEventDestroy(e->ev_out);
   delete e;
@@ -1061,9 +1072,19 @@ static int run_nfe(diffsep_engine* e, int B, long T, hipStream_t st) {
   return rc;
 }
 
-extern "C" int32_t diffsep_pc_sample(diffsep_engine* e, const diffsep_sde_config* sde, const diffsep_sampler_config* smp,
-                                     const float* mix_norm, float* out, int32_t B, int64_t T, const float* noise,
-                                     uint64_t seed, const float* timesteps_host, int32_t* nfe_out, void* stream) {
+// zero the tail t >= lens[b] of [B][rows][T] rows (mixture of a mixed-length batch)
+__global__ __launch_bounds__(256) void mask_tail_kernel(float* __restrict__ v, int rows, long T,
+                                                        const int* __restrict__ lens) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= T || t < lens[b]) return;
+  for (int r = 0; r < rows; ++r) v[((long)b * rows + r) * T + t] = 0.f;
+}
+
+extern "C" int32_t diffsep_pc_sample_ex(diffsep_engine* e, const diffsep_sde_config* sde,
+                                        const diffsep_sampler_config* smp, const diffsep_sampler_ext* ext,
+                                        const float* mix_norm, float* out, int32_t B, int64_t T, const float* noise,
+                                        uint64_t seed, const float* timesteps_host, int32_t* nfe_out, void* stream) {
   DS_CHECK(e && sde && smp && mix_norm && out, "pc_sample: null argument");
   DS_CHECK(sde->kind == DIFFSEP_SDE_MIX || sde->kind == DIFFSEP_SDE_PRIORMIX, "pc_sample: unknown SDE kind");
   DS_CHECK(sde->kind == DIFFSEP_SDE_MIX || sde->avg_len >= 1, "pc_sample: PriorMixSDE needs avg_len >= 1");
@@ -1077,11 +1098,33 @@ extern "C" int32_t diffsep_pc_sample(diffsep_engine* e, const diffsep_sde_config
            "pc_sample: corrector must be ald2, ald, langevin or none");
   DS_CHECK(smp->corrector != DIFFSEP_CORR_ALD || sde->kind == DIFFSEP_SDE_MIX,
            "pc_sample: the 'ald' corrector supports MixSDE only (sdes/correctors.py:64-67)");
+  const int64_t* lengths = ext ? ext->lengths_host : nullptr;
+  const uint64_t* seeds = ext ? ext->seeds_host : nullptr;
+  diffsep_engine* tail = (ext && ext->tail_steps > 0) ? ext->tail_engine : nullptr;
+  const int tail_steps = tail ? ext->tail_steps : 0;
+  if (tail) {
+    DS_CHECK(tail != e, "pc_sample: the tail engine must be a different engine");
+    diffsep_model_config a = e->cfg, b2 = tail->cfg;
+    a.dtype = b2.dtype = 0;
+    DS_CHECK(memcmp(&a, &b2, sizeof(a)) == 0, "pc_sample: the tail engine must have the same architecture");
+  }
+  DS_CHECK(!lengths || smp->corrector != DIFFSEP_CORR_LANGEVIN,
+           "pc_sample: the 'langevin' corrector couples the batch entries; it cannot run on a mixed-length batch");
+  DS_CHECK(!seeds || !noise, "pc_sample: per-utterance seeds are for device noise (noise == NULL)");
+  if (lengths) {
+    const int Wp = diffsep_padded_frames(&e->cfg, T);
+    for (int b = 0; b < B; ++b) {
+      DS_CHECK(lengths[b] >= 1 && lengths[b] <= T, "pc_sample: utterance length outside [1, T]");
+      DS_CHECK(diffsep_padded_frames(&e->cfg, lengths[b]) == Wp,
+               "pc_sample: every utterance of a mixed-length batch must have the padded frame count of T");
+    }
+  }
   StreamScope sc_(e, stream);
   hipStream_t st = sc_.st;
   const int S = e->cfg.num_sources, N = smp->N;
   const int csteps = smp->corrector == DIFFSEP_CORR_NONE ? 0 : smp->corrector_steps;
   if (ensure_plan(e, B, T, st)) return 1;
+  if (tail && ensure_plan(tail, B, T, st)) return 1;
   const size_t nst = (size_t)B * S * T;
   SdeP sp{sde->kind, sde->ndim, sde->d_lambda, sde->sigma_min, sde->sigma_max};
   // time steps -> device rows [N][B]
@@ -1110,12 +1153,47 @@ extern "C" int32_t diffsep_pc_sample(diffsep_engine* e, const diffsep_sde_config
     e->ts_B = B;
   }
   DS_HIP(hipMemcpyAsync(e->st_mix, mix_norm, (size_t)B * T * 4, hipMemcpyDeviceToDevice, st));
+  const int* lens = nullptr;
+  if (lengths || seeds) {  // per-utterance lengths / seeds -> device (pinned staging, stream-ordered)
+    const size_t need = (size_t)B * 16;
+    if (e->ext_ev_rec) DS_HIP(hipEventSynchronize(e->ext_ev));
+    if (need > e->ext_pin_cap) {
+      if (e->ext_pin) DS_HIP(hipHostFree(e->ext_pin));
+      e->ext_pin = nullptr;
+      e->ext_pin_cap = 0;
+      const size_t cap = need < 4096 ? 4096 : need;
+      DS_HIP(hipHostMalloc((void**)&e->ext_pin, cap, hipHostMallocDefault));
+      e->ext_pin_cap = cap;
+    }
+    if (!e->ext_ev) DS_HIP(hipEventCreateWithFlags(&e->ext_ev, hipEventDisableTiming));
+    unsigned long long* ps = reinterpret_cast<unsigned long long*>(e->ext_pin);
+    int* pl = reinterpret_cast<int*>(e->ext_pin + (size_t)B * 8);
+    for (int b = 0; b < B; ++b) {
+      ps[b] = seeds ? seeds[b] : seed + 0x9E3779B97F4A7C15ull * (unsigned long long)b;  // (b = 0: the B = 1 stream of `seed`)
+      pl[b] = lengths ? (int)lengths[b] : (int)T;
+    }
+    DS_HIP(hipMemcpyAsync(e->st_seeds, ps, (size_t)B * 8, hipMemcpyHostToDevice, st));
+    DS_HIP(hipMemcpyAsync(e->st_lens, pl, (size_t)B * 4, hipMemcpyHostToDevice, st));
+    DS_HIP(hipEventRecord(e->ext_ev, st));
+    e->ext_ev_rec = true;
+    if (lengths) {
+      lens = e->st_lens;
+      hipLaunchKernelGGL(mask_tail_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, e->st_mix, 1, (long)T, lens);
+      DS_LAUNCH_CHECK();
+    }
+  }
+  const bool batch_rng = !noise && (seeds || lengths);
 
   long draw = 0;
   auto next_noise = [&](const float** z) -> int {
     if (noise) { *z = noise + (size_t)draw * nst; }
     else {
-      if (ds_launch_randn(e->st_noise, (long)nst, seed, (uint64_t)draw, st)) return 1;
+      if (batch_rng) {
+        if (ds_launch_randn_batch(e->st_noise, B, S, T, (const uint64_t*)e->st_seeds, e->st_lens, (uint64_t)draw, st))
+          return 1;
+      } else if (ds_launch_randn(e->st_noise, (long)nst, seed, (uint64_t)draw, st)) {
+        return 1;
+      }
       *z = e->st_noise;
     }
     ++draw;
@@ -1128,30 +1206,48 @@ extern "C" int32_t diffsep_pc_sample(diffsep_engine* e, const diffsep_sde_config
     if (ds_launch_sigma_mix(e->st_mix, e->st_smix, B, T, sde->avg_len, st)) return 1;
     smix = e->st_smix;
   }
-  if (ds_launch_sde_prior(sp, e->st_mix, z, e->st_x, B, S, T, smix, st)) return 1;
+  if (ds_launch_sde_prior(sp, e->st_mix, z, e->st_x, B, S, T, smix, st, lens)) return 1;
   DS_HIP(hipMemcpyAsync(e->st_xm, e->st_x, nst * 4, hipMemcpyDeviceToDevice, st));
+  // one score evaluation of reverse step i: on this engine, or — in the last tail_steps steps — on the tail engine
+  // (state and time step copied over, the score read from there)
+  bool tail_ready = false;
+  const float* score = e->st_score;
+  auto eval_score = [&](int i) -> int {
+    if (tail && i >= N - tail_steps) {
+      if (!tail_ready) {
+        DS_HIP(hipMemcpyAsync(tail->st_mix, e->st_mix, (size_t)B * T * 4, hipMemcpyDeviceToDevice, st));
+        tail_ready = true;
+      }
+      DS_HIP(hipMemcpyAsync(tail->st_x, e->st_x, nst * 4, hipMemcpyDeviceToDevice, st));
+      DS_HIP(hipMemcpyAsync(tail->st_t, e->st_t, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+      score = tail->st_score;
+      return run_nfe(tail, B, T, st);
+    }
+    score = e->st_score;
+    return run_nfe(e, B, T, st);
+  };
   int nfe = 0;
   for (int i = 0; i < N; ++i) {
     DS_HIP(hipMemcpyAsync(e->st_t, e->st_ts + (size_t)i * B, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     for (int k = 0; k < csteps; ++k) {
-      if (run_nfe(e, B, T, st)) return 1;
+      if (eval_score(i)) return 1;
       ++nfe;
       if (next_noise(&z)) return 1;
       if (smp->corrector == DIFFSEP_CORR_LANGEVIN) {
-        if (ds_launch_langevin(smp->snr, e->st_x, e->st_score, z, e->st_x, e->st_xm, B, (long)S * T, e->st_lang, st))
+        if (ds_launch_langevin(smp->snr, e->st_x, score, z, e->st_x, e->st_xm, B, (long)S * T, e->st_lang, st))
           return 1;
-      } else if (ds_launch_sde_corrector(sp, smp->snr, e->st_x, e->st_t, e->st_score, z, e->st_x, e->st_xm, B, S, T,
-                                         smix, smp->corrector == DIFFSEP_CORR_ALD ? 1 : 0, st)) {
+      } else if (ds_launch_sde_corrector(sp, smp->snr, e->st_x, e->st_t, score, z, e->st_x, e->st_xm, B, S, T,
+                                         smix, smp->corrector == DIFFSEP_CORR_ALD ? 1 : 0, st, lens)) {
         return 1;
       }
     }
     if (smp->predictor != DIFFSEP_PRED_NONE) {
       // euler_maruyama (sdes/predictors.py:39-52) takes x + f*dt with the reverse drift f = drift - g^2 score and
       // noise g sqrt(dt): algebraically the reverse_diffusion step (dt = 1/N, G = g sqrt(dt)) — one kernel for both
-      if (run_nfe(e, B, T, st)) return 1;
+      if (eval_score(i)) return 1;
       ++nfe;
       if (next_noise(&z)) return 1;
-      if (ds_launch_sde_predictor(sp, N, e->st_x, e->st_t, e->st_score, z, e->st_x, e->st_xm, B, S, T, smix, 0, st))
+      if (ds_launch_sde_predictor(sp, N, e->st_x, e->st_t, score, z, e->st_x, e->st_xm, B, S, T, smix, 0, st, lens))
         return 1;
     } else {
       DS_HIP(hipMemcpyAsync(e->st_xm, e->st_x, nst * 4, hipMemcpyDeviceToDevice, st));
@@ -1161,6 +1257,12 @@ extern "C" int32_t diffsep_pc_sample(diffsep_engine* e, const diffsep_sde_config
   if (nfe_out) *nfe_out = N * (csteps + 1);
   (void)nfe;
   return 0;
+}
+
+extern "C" int32_t diffsep_pc_sample(diffsep_engine* e, const diffsep_sde_config* sde, const diffsep_sampler_config* smp,
+                                     const float* mix_norm, float* out, int32_t B, int64_t T, const float* noise,
+                                     uint64_t seed, const float* timesteps_host, int32_t* nfe_out, void* stream) {
+  return diffsep_pc_sample_ex(e, sde, smp, nullptr, mix_norm, out, B, T, noise, seed, timesteps_host, nfe_out, stream);
 }
 
 // ------------------------------------------------------------------ unit entry points
@@ -1320,6 +1422,34 @@ extern "C" int32_t diffsep_sde_predictor_update(const diffsep_sde_config* sde, i
   return ds_launch_sde_predictor(to_sdep(sde), N, x, t, score, z, x_out, x_mean_out, B, S, T, sigma_mix,
                                  probability_flow, (hipStream_t)stream);
 }
+extern "C" int32_t diffsep_sde_coefficients(const diffsep_sde_config* sde, const float* x, const float* t,
+                                            const float* sigma_mix, float* drift_out, float* diffusion_out, int32_t B,
+                                            int32_t S, int64_t T, float f_scale, float g_scale, void* stream) {
+  DS_CHECK(sde && x && t && drift_out && diffusion_out, "sde_coefficients: null pointer");
+  return ds_launch_sde_coeff(to_sdep(sde), x, t, sigma_mix, drift_out, diffusion_out, B, S, T, f_scale, g_scale,
+                             (hipStream_t)stream);
+}
+extern "C" int32_t diffsep_sde_mean(const diffsep_sde_config* sde, const float* x0, const float* t, float* mean_out,
+                                    int32_t B, int32_t S, int64_t T, void* stream) {
+  DS_CHECK(sde && x0 && t && mean_out, "sde_mean: null pointer");
+  return ds_launch_sde_mean(to_sdep(sde), x0, t, mean_out, B, S, T, (hipStream_t)stream);
+}
+extern "C" int32_t diffsep_sde_std(const diffsep_sde_config* sde, const float* t, const float* sigma_mix, float* std_out,
+                                   int32_t B, int32_t S, int64_t T, void* stream) {
+  DS_CHECK(sde && t && std_out, "sde_std: null pointer");
+  return ds_launch_sde_std(to_sdep(sde), t, sigma_mix, std_out, B, S, T, (hipStream_t)stream);
+}
+extern "C" int32_t diffsep_sde_mult_std(const float* std, const float* x, float* out, int32_t B, int32_t S, int64_t T,
+                                        int32_t per_sample, void* stream) {
+  DS_CHECK(std && x && out, "sde_mult_std: null pointer");
+  return ds_launch_sde_mult_std(std, x, out, B, S, T, per_sample, (hipStream_t)stream);
+}
+extern "C" int32_t diffsep_sde_reverse_drift(const float* f, const float* G, const float* score, float* rev_f_out,
+                                             int32_t B, int64_t n_per_batch, int32_t g_full, int32_t probability_flow,
+                                             void* stream) {
+  DS_CHECK(f && G && score && rev_f_out, "sde_reverse_drift: null pointer");
+  return ds_launch_sde_reverse(f, G, score, rev_f_out, B, n_per_batch, g_full, probability_flow, (hipStream_t)stream);
+}
 extern "C" int32_t diffsep_sde_langevin_update(float snr, const float* x, const float* score, const float* z,
                                                float* x_out, float* x_mean_out, int32_t B, int64_t n_per_batch,
                                                void* workspace, int64_t workspace_bytes, void* stream) {
@@ -1344,6 +1474,11 @@ extern "C" int32_t diffsep_gram(const float* ref, const float* est, double* out,
 extern "C" int32_t diffsep_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream) {
   DS_CHECK(out, "randn: null pointer");
   return ds_launch_randn(out, n, seed, stream_id, (hipStream_t)stream);
+}
+extern "C" int32_t diffsep_randn_batch(float* out, int32_t B, int32_t S, int64_t T, const uint64_t* seeds,
+                                       const int32_t* lengths, uint64_t stream_id, void* stream) {
+  DS_CHECK(out && seeds && lengths && B >= 1 && S >= 1 && T >= 1, "randn_batch: bad argument");
+  return ds_launch_randn_batch(out, B, S, T, seeds, lengths, stream_id, (hipStream_t)stream);
 }
 extern "C" int32_t diffsep_convert(const void* src, void* dst, int64_t n, int32_t sd, int32_t dd, void* stream) {
   DS_CHECK(src && dst, "convert: null pointer");

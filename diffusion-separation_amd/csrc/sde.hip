@@ -48,12 +48,20 @@ int ds_launch_sigma_mix(const float* mix, float* out, int B, long T, int avg_len
 
 // x_T = c*y + L(T=1) @ z          MixSDE.prior_sampling  sdes.py:334-346 (c = 0.5 hard-coded for S = 2: quirk Q2)
 // PriorMixSDE (smix != null): L is scaled per sample by sigma_mix, mean is 0.5*mix for any S (sdes.py:564-587)
+// lens (nullable, here and in the two updates below): per-utterance lengths of a batch of utterances of different
+// lengths that share one padded frame count; samples t >= lens[b] of the state are kept at exactly zero, which makes
+// every utterance of the batch evolve bit-for-bit as it would alone (the STFT of the zero tail is the zero padding).
 __global__ __launch_bounds__(256) void sde_prior_kernel(SdeP s, const float* __restrict__ y,
                                                         const float* __restrict__ z, float* __restrict__ x, int S,
-                                                        long T, const float* __restrict__ smix) {
+                                                        long T, const float* __restrict__ smix,
+                                                        const int* __restrict__ lens) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   if (t >= T) return;
+  if (lens && t >= lens[b]) {
+    for (int i = 0; i < S; ++i) x[((long)b * S + i) * T + t] = 0.f;
+    return;
+  }
   float ev1, ev2;
   mix_eig(s, 1.0f, ev1, ev2);
   const float sm = smix ? smix[(long)b * T + t] : 1.0f;
@@ -68,15 +76,24 @@ __global__ __launch_bounds__(256) void sde_prior_kernel(SdeP s, const float* __r
 
 // ald2 corrector step given score g:  x_mean = x + 2 snr^2 L L g ;  x = x_mean + (2 snr L) z
 // sdes/correctors.py:115-126
-__global__ __launch_bounds__(256) void sde_corrector_kernel(SdeP s, float snr, const float* __restrict__ x,
+// (x may alias xo — the engine updates its state in place — so x / xo / xm carry no __restrict__)
+__global__ __launch_bounds__(256) void sde_corrector_kernel(SdeP s, float snr, const float* x,
                                                             const float* __restrict__ tt,
                                                             const float* __restrict__ score,
-                                                            const float* __restrict__ z, float* __restrict__ xo,
-                                                            float* __restrict__ xm, int S, long T,
-                                                            const float* __restrict__ smix, int variant) {
+                                                            const float* __restrict__ z, float* xo, float* xm, int S,
+                                                            long T, const float* __restrict__ smix, int variant,
+                                                            const int* __restrict__ lens) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   if (t >= T) return;
+  if (lens && t >= lens[b]) {
+    for (int i = 0; i < S; ++i) {
+      const long o = ((long)b * S + i) * T + t;
+      if (xm) xm[o] = 0.f;
+      xo[o] = 0.f;
+    }
+    return;
+  }
   float ev1, ev2;
   mix_eig(s, tt[b], ev1, ev2);
   // variant 1 = 'ald' (sdes/correctors.py:58-91): a scalar std = sqrt(sum_j (L L)[0, j]) = sqrt(ev1) for every source,
@@ -108,15 +125,23 @@ __global__ __launch_bounds__(256) void sde_corrector_kernel(SdeP s, float snr, c
 
 // reverse-diffusion predictor given score:  f = -lambda P x dt ; rev_f = f - G^2 score ;
 // x_mean = x - rev_f ; x = x_mean + G z          sdes/predictors.py:60-66, sdes/sdes.py:163-171
-__global__ __launch_bounds__(256) void sde_predictor_kernel(SdeP s, int N, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void sde_predictor_kernel(SdeP s, int N, const float* x,
                                                             const float* __restrict__ tt,
                                                             const float* __restrict__ score,
-                                                            const float* __restrict__ z, float* __restrict__ xo,
-                                                            float* __restrict__ xm, int S, long T,
-                                                            const float* __restrict__ smix, int pflow) {
+                                                            const float* __restrict__ z, float* xo, float* xm, int S,
+                                                            long T, const float* __restrict__ smix, int pflow,
+                                                            const int* __restrict__ lens) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   if (t >= T) return;
+  if (lens && t >= lens[b]) {
+    for (int i = 0; i < S; ++i) {
+      const long o = ((long)b * S + i) * T + t;
+      if (xm) xm[o] = 0.f;
+      xo[o] = 0.f;
+    }
+    return;
+  }
   const float r = s.sigma_max / s.sigma_min;
   const float dt = 1.0f / (float)N;
   const float sigma = s.sigma_min * powf(r, tt[b]);
@@ -139,31 +164,160 @@ __global__ __launch_bounds__(256) void sde_predictor_kernel(SdeP s, int N, const
 }
 
 int ds_launch_sde_prior(const SdeP& s, const float* y, const float* z, float* x, int B, int S, long T,
-                        const float* smix, hipStream_t st) {
+                        const float* smix, hipStream_t st, const int* lens) {
   DS_CHECK((s.kind == 1) == (smix != nullptr), "sde: PriorMixSDE needs sigma_mix, MixSDE must not get one");
   DS_CHECK(S >= 1 && S <= DS_MAX_SRC, "sde: too many sources");
-  hipLaunchKernelGGL(sde_prior_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, s, y, z, x, S, T, smix);
+  hipLaunchKernelGGL(sde_prior_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, s, y, z, x, S, T, smix, lens);
   DS_LAUNCH_CHECK();
   return 0;
 }
 int ds_launch_sde_corrector(const SdeP& s, float snr, const float* x, const float* t, const float* score,
                             const float* z, float* xo, float* xm, int B, int S, long T, const float* smix,
-                            int variant, hipStream_t st) {
+                            int variant, hipStream_t st, const int* lens) {
   DS_CHECK((s.kind == 1) == (smix != nullptr), "sde: PriorMixSDE needs sigma_mix, MixSDE must not get one");
   DS_CHECK(S >= 1 && S <= DS_MAX_SRC, "sde: too many sources");
   DS_CHECK(variant == 0 || (variant == 1 && s.kind == 0), "sde: corrector variant must be ald2 (0) or ald on MixSDE (1)");
   hipLaunchKernelGGL(sde_corrector_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, s, snr, x, t, score, z, xo, xm, S,
-                     T, smix, variant);
+                     T, smix, variant, lens);
   DS_LAUNCH_CHECK();
   return 0;
 }
 int ds_launch_sde_predictor(const SdeP& s, int N, const float* x, const float* t, const float* score, const float* z,
                             float* xo, float* xm, int B, int S, long T, const float* smix, int pflow,
-                            hipStream_t st) {
+                            hipStream_t st, const int* lens) {
   DS_CHECK((s.kind == 1) == (smix != nullptr), "sde: PriorMixSDE needs sigma_mix, MixSDE must not get one");
   DS_CHECK(S >= 1 && S <= DS_MAX_SRC && N >= 1, "sde: bad arguments");
   hipLaunchKernelGGL(sde_predictor_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, s, N, x, t, score, z, xo, xm, S, T,
-                     smix, pflow);
+                     smix, pflow, lens);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ SDE object surface (the L3 plug point)
+// The pieces a user-written Predictor / Corrector reaches through the reference's SDE API — sde(), marginal_prob()
+// (= _mean, _std), mult_std(), discretize(), reverse().discretize() (sdes/sdes.py:61-66,93-173,275-328,451-470,
+// 515-537) — as unit kernels.  The fused sampler above never calls them; they exist so that code written against
+// the reference interface runs on the mirror (diffsep_amd/sdes/sdes.py).
+
+// drift_out = fs * (-lambda P x);  diffusion = gs * g(t) [* sigma_mix]:  MixSDE.sde (sdes.py:275-284) with
+// fs = gs = 1, SDE.discretize (sdes.py:93-107) with fs = dt, gs = sqrt(dt).  diffusion is [B] for MixSDE and
+// [B,S,T] for PriorMixSDE (sdes.py:451-470).
+__global__ __launch_bounds__(256) void sde_coeff_kernel(SdeP s, const float* x, const float* __restrict__ tt,
+                                                        const float* __restrict__ smix, float* drift,
+                                                        float* __restrict__ diffusion, int S, long T, float fs,
+                                                        float gs) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= T) return;
+  const float r = s.sigma_max / s.sigma_min;
+  const float g = s.sigma_min * powf(r, tt[b]) * sqrtf(2.0f * logf(r));
+  float xv[DS_MAX_SRC], mx = 0.f;
+  for (int i = 0; i < S; ++i) { xv[i] = x[((long)b * S + i) * T + t]; mx += xv[i]; }
+  mx /= (float)S;
+  for (int i = 0; i < S; ++i) {
+    const long o = ((long)b * S + i) * T + t;
+    drift[o] = (-s.d_lambda * (xv[i] - mx)) * fs;
+    if (smix) diffusion[o] = (g * smix[(long)b * T + t]) * gs;
+  }
+  if (!smix && t == 0) diffusion[b] = g * gs;
+}
+// mean = (A + exp(-lambda t) P) x0          MixSDE._mean / _mean_mix_mat (sdes.py:286-294)
+__global__ __launch_bounds__(256) void sde_mean_kernel(SdeP s, const float* __restrict__ x0,
+                                                       const float* __restrict__ tt, float* __restrict__ out, int S,
+                                                       long T) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= T) return;
+  const float decay = expf(-tt[b] * s.d_lambda);
+  float xv[DS_MAX_SRC], mx = 0.f;
+  for (int i = 0; i < S; ++i) { xv[i] = x0[((long)b * S + i) * T + t]; mx += xv[i]; }
+  mx /= (float)S;
+  for (int i = 0; i < S; ++i) out[((long)b * S + i) * T + t] = mx + decay * (xv[i] - mx);
+}
+// L = sqrt(ev1) A + sqrt(ev2) P as a dense tensor: [B,S,S] (MixSDE._std, sdes.py:315-320) or, scaled per sample by
+// sigma_mix, [B,S,S,T] (PriorMixSDE._std, sdes.py:515-532)
+__global__ __launch_bounds__(256) void sde_std_kernel(SdeP s, const float* __restrict__ tt,
+                                                      const float* __restrict__ smix, float* __restrict__ L, int S,
+                                                      long T) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  const long Tn = smix ? T : 1;
+  if (t >= Tn) return;
+  float ev1, ev2;
+  mix_eig(s, tt[b], ev1, ev2);
+  const float a = sqrtf(ev1), p = sqrtf(ev2);
+  const float sm = smix ? smix[(long)b * T + t] : 1.0f;
+  const float inv = 1.0f / (float)S;
+  for (int c = 0; c < S; ++c)
+    for (int d = 0; d < S; ++d) {
+      const float A = inv, Pn = (c == d ? 1.0f : 0.0f) - inv;
+      L[(((long)b * S + c) * S + d) * Tn + t] = (a * A + p * Pn) * sm;
+    }
+}
+// out[b,c,t] = sum_d std[b,c,d(,t)] x[b,d,t]      MixSDE.mult_std (std @ x, sdes.py:326-328) /
+// PriorMixSDE.mult_std (einsum "bcdt,bdt->bct", sdes.py:534-537) for ANY dense std the caller built
+__global__ __launch_bounds__(256) void sde_mult_std_kernel(const float* __restrict__ L, const float* __restrict__ x,
+                                                           float* __restrict__ out, int S, long T, int per_t) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (t >= T) return;
+  float xv[DS_MAX_SRC];
+  for (int d = 0; d < S; ++d) xv[d] = x[((long)b * S + d) * T + t];
+  for (int c = 0; c < S; ++c) {
+    float acc = 0.f;
+    for (int d = 0; d < S; ++d) {
+      const long li = ((long)b * S + c) * S + d;
+      acc = fmaf(per_t ? L[li * T + t] : L[li], xv[d], acc);
+    }
+    out[((long)b * S + c) * T + t] = acc;
+  }
+}
+// rev_f = f - G^2 score (x 0.5 for the probability-flow ODE)      RSDE.discretize (sdes.py:163-171); G is [B] or [B,S,T]
+__global__ __launch_bounds__(256) void sde_reverse_kernel(const float* __restrict__ f, const float* __restrict__ G,
+                                                          const float* __restrict__ score, float* __restrict__ out,
+                                                          long n_per_batch, int g_full, float half) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (i >= n_per_batch) return;
+  const long o = (long)b * n_per_batch + i;
+  const float g = g_full ? G[o] : G[b];
+  out[o] = f[o] - g * g * score[o] * half;
+}
+int ds_launch_sde_coeff(const SdeP& s, const float* x, const float* t, const float* smix, float* drift,
+                        float* diffusion, int B, int S, long T, float fs, float gs, hipStream_t st) {
+  DS_CHECK((s.kind == 1) == (smix != nullptr), "sde: PriorMixSDE needs sigma_mix, MixSDE must not get one");
+  DS_CHECK(S >= 1 && S <= DS_MAX_SRC, "sde: too many sources");
+  hipLaunchKernelGGL(sde_coeff_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, s, x, t, smix, drift, diffusion, S, T,
+                     fs, gs);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+int ds_launch_sde_mean(const SdeP& s, const float* x0, const float* t, float* out, int B, int S, long T,
+                       hipStream_t st) {
+  DS_CHECK(S >= 1 && S <= DS_MAX_SRC, "sde: too many sources");
+  hipLaunchKernelGGL(sde_mean_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, s, x0, t, out, S, T);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+int ds_launch_sde_std(const SdeP& s, const float* t, const float* smix, float* L, int B, int S, long T,
+                      hipStream_t st) {
+  DS_CHECK((s.kind == 1) == (smix != nullptr), "sde: PriorMixSDE needs sigma_mix, MixSDE must not get one");
+  DS_CHECK(S >= 1 && S <= DS_MAX_SRC, "sde: too many sources");
+  hipLaunchKernelGGL(sde_std_kernel, dim3(cdiv(smix ? T : 1, 256), B), dim3(256), 0, st, s, t, smix, L, S, T);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+int ds_launch_sde_mult_std(const float* L, const float* x, float* out, int B, int S, long T, int per_t,
+                           hipStream_t st) {
+  DS_CHECK(S >= 1 && S <= DS_MAX_SRC, "sde: too many sources");
+  hipLaunchKernelGGL(sde_mult_std_kernel, dim3(cdiv(T, 256), B), dim3(256), 0, st, L, x, out, S, T, per_t);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+int ds_launch_sde_reverse(const float* f, const float* G, const float* score, float* out, int B, long n_per_batch,
+                          int g_full, int pflow, hipStream_t st) {
+  hipLaunchKernelGGL(sde_reverse_kernel, dim3(cdiv(n_per_batch, 256), B), dim3(256), 0, st, f, G, score, out,
+                     n_per_batch, g_full, pflow ? 0.5f : 1.0f);
   DS_LAUNCH_CHECK();
   return 0;
 }
@@ -204,10 +358,10 @@ __global__ void langevin_step_kernel(const double* __restrict__ norms, int B, fl
     step[0] = r * r * 2.0f;
   }
 }
-__global__ __launch_bounds__(256) void langevin_update_kernel(const float* __restrict__ x, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void langevin_update_kernel(const float* x, const float* __restrict__ g,
                                                               const float* __restrict__ z,
-                                                              const float* __restrict__ step, float* __restrict__ xo,
-                                                              float* __restrict__ xm, long n) {
+                                                              const float* __restrict__ step, float* xo, float* xm,
+                                                              long n) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float st = step[0];
@@ -377,6 +531,54 @@ __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, lon
   v[0] *= r0; v[1] *= r0; v[2] *= r1; v[3] *= r1;
   for (int j = 0; j < 4; ++j)
     if (q * 4 + j < n) out[q * 4 + j] = v[j];
+}
+// Batch of utterances with their own seeds and lengths: utterance b gets exactly the draws a single-utterance call
+// with (seed[b], stream id, S * lens[b] values) produces — element (s, t) is value s * lens[b] + t of that stream — laid
+// out in rows of T; the tail t >= lens[b] is zero.
+__global__ __launch_bounds__(256) void randn_batch_kernel(float* __restrict__ out, int S, long T,
+                                                          const uint64_t* __restrict__ seeds,
+                                                          const int* __restrict__ lens, uint64_t sid) {
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;  // one thread = 4 values of utterance blockIdx.y's stream
+  const int b = blockIdx.y;
+  const long len = lens[b], n = (long)S * len;
+  // (zero tail: element index space of the padded rows that no stream value maps to)
+  if (q * 4 < (long)S * T) {
+    for (int j = 0; j < 4; ++j) {
+      const long e = q * 4 + j;
+      if (e < (long)S * T && e % T >= len) out[(long)b * S * T + e] = 0.f;
+    }
+  }
+  if (q * 4 >= n) return;
+  const uint64_t seed = seeds[b];
+  uint32_t c0 = (uint32_t)q, c1 = (uint32_t)((uint64_t)q >> 32), c2 = (uint32_t)sid, c3 = (uint32_t)(sid >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u1 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u3 = ((float)(c3 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
+  float v[4];
+  sincosf(6.28318530718f * u1, &v[1], &v[0]);
+  sincosf(6.28318530718f * u3, &v[3], &v[2]);
+  v[0] *= r0; v[1] *= r0; v[2] *= r1; v[3] *= r1;
+  for (int j = 0; j < 4; ++j) {
+    const long i = q * 4 + j;
+    if (i < n) out[((long)b * S + i / len) * T + i % len] = v[j];
+  }
+}
+int ds_launch_randn_batch(float* out, int B, int S, long T, const uint64_t* seeds, const int* lens, uint64_t stream_id,
+                          hipStream_t st) {
+  const long n = (long)S * T;
+  hipLaunchKernelGGL(randn_batch_kernel, dim3(cdiv((n + 3) / 4, 256), B), dim3(256), 0, st, out, S, T, seeds, lens,
+                     stream_id);
+  DS_LAUNCH_CHECK();
+  return 0;
 }
 int ds_launch_randn(float* out, long n, uint64_t seed, uint64_t stream_id, hipStream_t st) {
   if (n <= 0) return 0;

@@ -29,6 +29,11 @@ class SamplerConfig(C.Structure):
                 ("denoise", C.c_int32), ("predictor", C.c_int32), ("corrector", C.c_int32)]
 
 
+class SamplerExt(C.Structure):
+    _fields_ = [("lengths_host", C.POINTER(C.c_int64)), ("seeds_host", C.POINTER(C.c_uint64)),
+                ("tail_engine", C.c_void_p), ("tail_steps", C.c_int32)]
+
+
 class DiffsepError(RuntimeError):
     pass
 
@@ -54,6 +59,8 @@ _SIGS = {
     "diffsep_backbone_forward": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "diffsep_pc_sample": (_I, [_P, C.POINTER(SdeConfig), C.POINTER(SamplerConfig), _P, _P, _I, _L, _P, _U64, _P,
                                C.POINTER(_I), _P]),
+    "diffsep_pc_sample_ex": (_I, [_P, C.POINTER(SdeConfig), C.POINTER(SamplerConfig), C.POINTER(SamplerExt), _P, _P, _I,
+                                  _L, _P, _U64, _P, C.POINTER(_I), _P]),
     "diffsep_engine_set_graph": (_I, [_P, _I]),
     "diffsep_engine_profile_begin": (_I, [_P]),
     "diffsep_engine_profile_end": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L),
@@ -72,11 +79,17 @@ _SIGS = {
     "diffsep_sde_prior": (_I, [C.POINTER(SdeConfig), _P, _P, _P, _I, _I, _L, _P, _P]),
     "diffsep_sde_corrector_update": (_I, [C.POINTER(SdeConfig), _F, _P, _P, _P, _P, _P, _P, _I, _I, _L, _P, _I, _P]),
     "diffsep_sde_predictor_update": (_I, [C.POINTER(SdeConfig), _I, _P, _P, _P, _P, _P, _P, _I, _I, _L, _P, _I, _P]),
+    "diffsep_sde_coefficients": (_I, [C.POINTER(SdeConfig), _P, _P, _P, _P, _P, _I, _I, _L, _F, _F, _P]),
+    "diffsep_sde_mean": (_I, [C.POINTER(SdeConfig), _P, _P, _P, _I, _I, _L, _P]),
+    "diffsep_sde_std": (_I, [C.POINTER(SdeConfig), _P, _P, _P, _I, _I, _L, _P]),
+    "diffsep_sde_mult_std": (_I, [_P, _P, _P, _I, _I, _L, _I, _P]),
+    "diffsep_sde_reverse_drift": (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _P]),
     "diffsep_sde_langevin_update": (_I, [_F, _P, _P, _P, _P, _P, _I, _L, _P, _L, _P]),
     "diffsep_normalize_batch": (_I, [_P, _P, _P, _P, _I, _L, _P]),
     "diffsep_scale_output": (_I, [_P, _P, _I, _I, _L, _P]),
     "diffsep_gram": (_I, [_P, _P, _P, _I, _I, _L, _P]),
     "diffsep_randn": (_I, [_P, _L, _U64, _U64, _P]),
+    "diffsep_randn_batch": (_I, [_P, _I, _I, _L, _P, _P, _U64, _P]),
     "diffsep_convert": (_I, [_P, _P, _L, _I, _I, _P]),
 }
 EXPORTS = tuple(_SIGS.keys())

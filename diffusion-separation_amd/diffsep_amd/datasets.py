@@ -1,98 +1,112 @@
-"""On-disk data contracts of the evaluation path (host side, no torchaudio/lightning dependency).
+"""Readers of the two evaluation corpora, inference only (host side; no torchaudio / lightning).
 
-* WSJ0_mix        <root>/{2,3}speakers/wav{8,16}k/{min,max}/{tr,cv,tt}/{mix,s1,s2[,s3]}/*.wav -> (mix [1,T], tgt [S,T])
-                  (reference datasets/wsj0_mix.py:24-92; same ctor arguments, same errors, same sorted file order)
-* NoisyDataset    <root>/{train,test}/{noisy,clean}/*.wav -> (noisy [1,T], [clean, noisy - clean] [2,T])
-                  (reference datasets/vctk_demand.py:22-79)
-* max_collator    centre-pads every tensor of a batch to the longest item (datasets/wsj0_mix.py:95-111)
+The contract is a directory layout -> `(mixture [1,T], targets [S,T])` float32 items:
+
+* WSJ0-mix         `<root>/{2,3}speakers/wav{8,16}k/{min,max}/{tr,cv,tt}/{mix,s1..sS}/<name>.wav`; item = (mix, [s1..sS]);
+                   names sorted (reference datasets/wsj0_mix.py:64-92)
+* VoiceBank-DEMAND `<root>/{train,test}/{noisy,clean}/<name>.wav`; item = (noisy, [clean, noisy - clean]); directory
+                   order (reference datasets/vctk_demand.py:33-61)
+
+Both are one index class, `WavPairs` — a list of utterance names plus a mixture folder and the folders / rule the
+targets come from — built by a layout resolver (`wsj0_mix`, `voicebank_demand`).  `WSJ0_mix` / `NoisyDataset` keep the
+reference's constructor keywords so that its hydra `datamodule` entries resolve, but only the evaluation behaviour
+exists: whole utterances, file order, `max_n_samples`.  The training-time behaviour of the reference classes (random
+crops to `max_len_s` / `audio_len`, tiling of short files, noise shuffling) is out of scope
+and asking for it raises.
 """
 import os
-import random
 from pathlib import Path
 
 import torch
 
 from . import wavio
 
-split_map = {"test": "tt", "val": "cv", "train": "tr", "libri2mix_test": "test"}
+_WSJ0_SPLITS = {"train": "tr", "val": "cv", "test": "tt", "libri2mix_test": "test"}
 
 
-class WSJ0_mix(torch.utils.data.Dataset):
-    def __init__(self, path, n_spkr=2, fs=16000, cut="max", split="train", max_len_s=None, max_n_samples=None,
-                 mix_dir="mix"):
-        super().__init__()
-        if fs not in [8000, 16000]:
-            raise ValueError(f"The sampling frequency fs can be only 8000 or 16000 (passed {fs})")
-        if n_spkr not in [2, 3]:
-            raise ValueError(f"The number of speakers can only be 2 or 3 (passed {n_spkr})")
-        if cut not in ["min", "max"]:
-            raise ValueError(f"The cut parameter has to be 'min' or 'max' (passed {cut})")
-        if split not in split_map:
-            raise ValueError(f"The split parameter must be 'train', 'val', or 'test' (passed {split})")
-        self.base_folder = Path(path).absolute()
-        self.n_spkr, self.fs, self.cut = n_spkr, int(fs), cut
-        self.max_len = int(self.fs * max_len_s) if max_len_s is not None else None
-        self.path = self.base_folder / f"{n_spkr}speakers/wav{self.fs // 1000}k/{cut}/{split_map[split]}"
-        self.path_mix = self.path / mix_dir
-        self.path_src = [self.path / f"s{i + 1}" for i in range(n_spkr)]
-        self.file_list = sorted(os.listdir(self.path_mix))
-        if max_n_samples is not None:
-            self.file_list = self.file_list[:max_n_samples]
+class WavPairs(torch.utils.data.Dataset):
+    """names[i] -> (mixture [1,T], targets [S,T]).  `target_dirs`: one folder per target channel; `residual=True`
+    appends mixture - sum(targets) as a last channel (the noise of an enhancement pair)."""
+
+    def __init__(self, mix_dir, target_dirs, names, fs, residual=False):
+        self.mix_dir, self.target_dirs = Path(mix_dir), [Path(d) for d in target_dirs]
+        self.file_list, self.fs, self.residual = list(names), int(fs), bool(residual)
 
     def __len__(self):
         return len(self.file_list)
+
+    def num_samples(self, idx):
+        """length of item idx from the wav header alone (evaluate sorts / buckets by it without decoding audio)"""
+        return wavio.info(self.mix_dir / self.file_list[idx])[1]
 
     def __getitem__(self, idx):
         name = self.file_list[idx]
-        mix, _ = wavio.load(self.path_mix / name)
-        tgt = torch.cat([wavio.load(p / name)[0] for p in self.path_src], dim=0)
-        if self.max_len is not None and tgt.shape[-1] > self.max_len:
-            p = int(torch.randint(0, tgt.shape[-1] - self.max_len, size=(1,)))  # random cut of the right size
-            tgt, mix = tgt[..., p:p + self.max_len], mix[..., p:p + self.max_len]
-        return mix, tgt
+        mix, sr = wavio.load(self.mix_dir / name)
+        if sr != self.fs:
+            raise ValueError(f"{self.mix_dir / name}: sample rate {sr}, the dataset was opened for {self.fs}")
+        rows = [wavio.load(d / name)[0] for d in self.target_dirs]
+        if self.residual:
+            rows.append(mix - torch.stack(rows).sum(0))
+        return mix, torch.cat(rows, dim=0)
 
 
-class NoisyDataset(torch.utils.data.Dataset):
-    def __init__(self, audio_path, audio_len=4, fs=16000, augmentation=False, split="train"):
-        if split not in ("test", "train"):
-            raise ValueError(f"The split parameter must be 'train' or 'test' (passed {split})")
-        root = Path(audio_path).absolute() / split
-        self.noisy_path, self.clean_path = root / "noisy", root / "clean"
-        self.file_list = os.listdir(self.noisy_path)  # directory order, as the reference (not sorted)
-        self.audio_len, self.fs, self.aug, self.split = int(audio_len * fs), fs, augmentation, split
+def wsj0_mix(root, n_spkr=2, fs=16000, cut="max", split="test", max_n_samples=None, mix_dir="mix"):
+    """Resolve the WSJ0-2mix / 3mix layout (pywsj0-mix output) to a WavPairs index."""
+    if fs not in (8000, 16000):
+        raise ValueError(f"The sampling frequency fs can be only 8000 or 16000 (passed {fs})")
+    if n_spkr not in (2, 3):
+        raise ValueError(f"The number of speakers can only be 2 or 3 (passed {n_spkr})")
+    if cut not in ("min", "max"):
+        raise ValueError(f"The cut parameter has to be 'min' or 'max' (passed {cut})")
+    if split not in _WSJ0_SPLITS:
+        raise ValueError(f"The split parameter must be 'train', 'val', or 'test' (passed {split})")
+    base = Path(root).absolute() / f"{n_spkr}speakers" / f"wav{int(fs) // 1000}k" / cut / _WSJ0_SPLITS[split]
+    names = sorted(os.listdir(base / mix_dir))
+    if max_n_samples is not None:
+        names = names[:max_n_samples]
+    return WavPairs(base / mix_dir, [base / f"s{k}" for k in range(1, n_spkr + 1)], names, fs)
 
-    def __len__(self):
-        return len(self.file_list)
 
-    def __getitem__(self, idx):
-        noisy, _ = wavio.load(self.noisy_path / self.file_list[idx])
-        clean, _ = wavio.load(self.clean_path / self.file_list[idx])
-        if self.split == "test":
-            return noisy, torch.cat([clean, noisy - clean], dim=0)
-        n = noisy.shape[-1]
-        if n < self.audio_len:
-            noisy = torch.tile(noisy, dims=(2,))[..., :self.audio_len]
-            clean = torch.tile(clean, dims=(2,))[..., :self.audio_len]
-        else:
-            st = random.randint(0, n - self.audio_len)
-            noisy, clean = noisy[..., st:st + self.audio_len], clean[..., st:st + self.audio_len]
-        if self.aug:
-            noise = noisy - clean
-            noisy = noise[torch.randperm(clean.size(0))] + clean
-        return noisy, torch.cat([clean, noisy - clean], dim=0)
+def voicebank_demand(root, fs=16000, split="test"):
+    """Resolve the VoiceBank-DEMAND layout to a WavPairs index: targets = [clean, noisy - clean]."""
+    if split not in ("test", "train"):
+        raise ValueError(f"The split parameter must be 'train' or 'test' (passed {split})")
+    base = Path(root).absolute() / split
+    return WavPairs(base / "noisy", [base / "clean"], os.listdir(base / "noisy"), fs, residual=True)
+
+
+def WSJ0_mix(path, n_spkr=2, fs=16000, cut="max", split="train", max_len_s=None, max_n_samples=None, mix_dir="mix"):
+    """The reference's constructor keywords (datasets/wsj0_mix.py:24-62) over `wsj0_mix`."""
+    if max_len_s is not None:
+        raise NotImplementedError("max_len_s (random training crops) is not part of the inference path")
+    return wsj0_mix(path, n_spkr=n_spkr, fs=fs, cut=cut, split=split, max_n_samples=max_n_samples, mix_dir=mix_dir)
+
+
+def NoisyDataset(audio_path, audio_len=None, fs=16000, augmentation=False, split="test"):
+    """The reference's constructor keywords (datasets/vctk_demand.py:22-32) over `voicebank_demand`; only whole
+    utterances are served (the reference does that for split == "test"; `audio_len` is ignored there too)."""
+    if augmentation:
+        raise NotImplementedError("augmentation is a training-time feature; not part of the inference path")
+    return voicebank_demand(audio_path, fs=fs, split=split)
+
+
+def pad_batch(items, side="center"):
+    """[(mix [1,T_i], tgt [S,T_i])] -> (mix [B,1,Tmax], tgt [B,S,Tmax], lengths [B]).  side="center" spreads the padding
+    on both ends (left half rounded down) like the reference's max_collator (datasets/wsj0_mix.py:95-111); side="right"
+    appends it (what the engine's mixed-length batches take: Engine.pc_sample(lengths=...))."""
+    lengths = [int(m.shape[-1]) for m, _ in items]
+    Tmax = max(lengths)
+    out_m, out_t = [], []
+    for (m, t), n in zip(items, lengths):
+        left = (Tmax - n) // 2 if side == "center" else 0
+        out_m.append(torch.nn.functional.pad(m, (left, Tmax - n - left)))
+        out_t.append(torch.nn.functional.pad(t, (left, Tmax - n - left)))
+    return torch.stack(out_m), torch.stack(out_t), lengths
 
 
 def max_collator(batch):
-    max_len = max(s[0].shape[-1] for s in batch)
-    rows = []
-    for row in batch:
-        new = []
-        for el in row:
-            if isinstance(el, torch.Tensor):
-                off = max_len - el.shape[-1]
-                new.append(torch.nn.functional.pad(el, (off // 2, off - off // 2)))
-        rows.append(tuple(new))
-    return torch.utils.data.default_collate(rows)
+    m, t, _ = pad_batch(batch, side="center")
+    return m, t
 
 
 def summarize(results):

@@ -5,12 +5,19 @@
     python -m torch.distributed.run --nproc-per-node 8 -m diffsep_amd.evaluate ...          (8 GPUs)
 
 Utterances are sharded over ranks in contiguous ranges (evaluate_mp.py:495-503); each rank separates its
-share, records {batch_idx, si_sdr, nfe, runtime, len_s} per utterance (evaluate.py:394-405; runtime is
-measured WITH a device sync, unlike evaluate.py:374-376) and rank 0 gathers everything (RCCL) and writes
+share, records {batch_idx, si_sdr, si_sir, si_sar, pesq, stoi, nfe, runtime, len_s} per utterance (evaluate.py:394-405;
+runtime is measured WITH a device sync, unlike evaluate.py:374-376) and rank 0 gathers everything (RCCL) and writes
 <split>.json + <split>_summary.json (evaluate.py:436-443).  Dataset: --dataset-dir ROOT in the WSJ0-mix layout
 (datasets/wsj0_mix.py:64-92; with --enhance the VoiceBank-DEMAND layout, datasets/vctk_demand.py:33-36), a flat
 ROOT/{mix,s1,s2} folder, or --synthetic N speech-like mixtures.  SI-SDR (scale-invariant
 SDR with the best source permutation) is computed in the normalised domain like evaluate.py:360,382.
+
+The reference separates one utterance per sampler call (batch_size=1, evaluate.py:328) because lengths differ.  Here
+utterances whose padded spectrogram width W = 64 ceil(F / 64) is equal ride in ONE engine call (--batch, default 16):
+the batch is zero-padded on the right to its longest member, the engine keeps every utterance's tail at exactly zero
+(diffsep_sampler_ext.lengths_host) and draws its noise from the utterance's own seed, so an utterance's record does
+not depend on which batch, stream or rank it was separated in (bit-for-bit with --dtype f32; to the rounding of the
+GroupNorm sums of the weight-stationary bf16 convolution otherwise).
 """
 import argparse
 import json
@@ -21,44 +28,59 @@ from pathlib import Path
 import torch
 import torch.distributed as dist
 
-from . import datasets, metrics, synth, wavio
+from . import datasets, metrics, ops, synth, wavio
 from .dist_utils import gather_objects, rank_indices
 from .pl_model import DiffSepModel, cfg_get, default_config, enhancement_config
 
 
-def compute_metrics(est, ref):
-    """est, ref [S,T] -> dict with the reference's record fields (evaluate.py:103-132): si_sdr / si_sir / si_sar
-    (mean over sources at the best permutation), per-source SI-SDR and the permutation.  The waveform reductions run
-    in the HIP Gram kernel."""
-    sdr, sir, sar, perm = metrics.si_bss_eval_sources(ref[None], est[None])
-    return {"si_sdr": float(sdr.mean()), "si_sir": float(sir.mean()), "si_sar": float(sar.mean()),
-            "si_sdr_per_source": [float(v) for v in sdr[0]], "perm": [int(v) for v in perm[0]]}
+def compute_metrics(est, ref, n_src=None):
+    """est, ref [B,S,T] (zero-padded batches are fine: the zero tails add nothing to the Gram sums) -> per utterance a
+    dict with the reference's metric fields (evaluate.py:103-132): the FULL source set is scored with the best
+    permutation, then the first n_src entries are kept (n_src = 1 with --enhance: the clean speech; its permutation
+    against the noise channel is still searched, evaluate.py:105-111,125-127).  The waveform reductions run in the HIP
+    Gram kernel."""
+    sdr, sir, sar, perm = metrics.si_bss_eval_sources(ref, est)
+    k = sdr.shape[1] if n_src is None else n_src
+    return [{"si_sdr": [[float(v) for v in sdr[b, :k]]], "si_sir": [[float(v) for v in sir[b, :k]]],
+             "si_sar": [[float(v) for v in sar[b, :k]]], "perm": [int(v) for v in perm[b]]}
+            for b in range(sdr.shape[0])]
 
 
 def load_dataset(args, fs):
+    """-> (number of utterances, get(i) -> (mix [1,T], tgt [S,T]) CPU tensors, lengths in samples)"""
     if args.dataset_dir and args.enhance:
         ds = datasets.NoisyDataset(args.dataset_dir, fs=fs, split=args.split)
         n = len(ds) if args.limit is None else min(len(ds), args.limit)
-        return n, (lambda i: tuple(t[..., : min(ds[i][0].shape[-1], ds[i][1].shape[-1])] for t in ds[i])), None
+        return n, (lambda i: ds[i]), [ds.num_samples(i) for i in range(n)]
     if args.dataset_dir:
         root = Path(args.dataset_dir)
         if (root / "mix").is_dir():  # flat folder: mix/, s1/, s2/ ...
             names = sorted(p.name for p in (root / "mix").glob("*.wav"))[: args.limit]
-
-            def get_flat(i):
-                mix, _ = wavio.load(root / "mix" / names[i])
-                tgt = torch.cat([wavio.load(root / f"s{k + 1}" / names[i])[0][:1] for k in range(args.n_speakers)], 0)
-                return mix[:1], tgt
-            return len(names), get_flat, [wavio.info(root / "mix" / nm)[1] for nm in names]
-        ds = datasets.WSJ0_mix(root, n_spkr=args.n_speakers, fs=fs, cut=args.cut, split=args.split,
-                               max_n_samples=args.limit)
-        return len(ds), (lambda i: ds[i]), [wavio.info(ds.path_mix / nm)[1] for nm in ds.file_list]
+            ds = datasets.WavPairs(root / "mix", [root / f"s{k + 1}" for k in range(args.n_speakers)], names, fs)
+        else:
+            ds = datasets.WSJ0_mix(root, n_spkr=args.n_speakers, fs=fs, cut=args.cut, split=args.split,
+                                   max_n_samples=args.limit)
+        return len(ds), (lambda i: tuple(t[..., : ds.num_samples(i)] for t in ds[i])), \
+            [ds.num_samples(i) for i in range(len(ds))]
     n = args.synthetic
 
     def get(i):
         mix, tgt = synth.synth_mixture(i, T=args.samples, fs=fs, n_src=args.n_speakers)
         return torch.from_numpy(mix), torch.from_numpy(tgt)
     return n, get, [args.samples] * n
+
+
+def plan_batches(indices, lengths, width_of, batch):
+    """Group utterance indices into engine batches: equal padded width W, at most `batch` per call, longest first
+    inside a width (deterministic: ties by index).  Returns a list of index lists."""
+    by_w = {}
+    for i in indices:
+        by_w.setdefault(width_of(lengths[i]), []).append(i)
+    out = []
+    for w in sorted(by_w):
+        g = sorted(by_w[w], key=lambda i: (-lengths[i], i))
+        out += [g[k:k + batch] for k in range(0, len(g), batch)]
+    return out
 
 
 def main(argv=None):
@@ -76,7 +98,7 @@ def main(argv=None):
     ap.add_argument("--snr", type=float, default=None)
     ap.add_argument("--corrector-steps", type=int, default=None)
     ap.add_argument("--schedule", type=str, default=None)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "hybrid"])
     ap.add_argument("-o", "--output-dir", type=Path, default=Path("results"))
     ap.add_argument("--save-wav", action="store_true")
     ap.add_argument("--seed", type=int, default=0, help="torch.manual_seed before the first utterance: the i-th "
@@ -84,12 +106,14 @@ def main(argv=None):
     ap.add_argument("--balance", action="store_true",
                     help="multi-GPU: deal the utterances to the ranks by length (longest first, round-robin) instead of "
                          "the reference's contiguous index ranges; needs the lengths (wav headers)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="utterances in flight per GPU: K engines on K HIP streams (results are bit-identical for any "
-                         "K).  One utterance at a time (the reference's evaluation loop) leaves most of the GPU idle: "
-                         "measured 6.0 utt/s with 1 stream, 10.4 / 13.5 / 18.5 with 2 / 3 / 4 (4 s utterances, "
-                         "nf=64); more than 4 is slower again (streams share hardware queues).  Per-utterance "
-                         "'runtime' is then the latency of an utterance that shared the GPU with K-1 others.")
+    ap.add_argument("--batch", type=int, default=16,
+                    help="utterances per engine call: those with the same padded spectrogram width share a call "
+                         "(zero-padded to the longest; --batch 1 = the reference's one-utterance loop)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="engine calls (batches) in flight per GPU: K engines on K HIP streams; the records do not "
+                         "depend on K.  'runtime' of an utterance is its batch's latency / batch size.")
+    ap.add_argument("--tail-steps", type=int, default=None,
+                    help="with --dtype hybrid: reverse steps evaluated by the fp32 engine (default: pl_model.HYBRID_TAIL_STEPS)")
     ap.add_argument("--enhance", action="store_true",
                     help="speech enhancement (evaluate.py:173-176,268-271): PriorMixSDE model, metrics on the first "
                          "source (clean speech) only")
@@ -113,8 +137,8 @@ def main(argv=None):
         if args.synthetic_weights or args.ckpt is None:
             cfg = (enhancement_config(nf=args.synthetic_weights or 128) if args.enhance
                    else default_config(nf=args.synthetic_weights or 64, n_speakers=args.n_speakers))
-            return DiffSepModel(cfg, dtype=args.dtype)
-        return DiffSepModel.load_from_checkpoint(args.ckpt, dtype=args.dtype)
+            return DiffSepModel(cfg, dtype=args.dtype, tail_steps=args.tail_steps)
+        return DiffSepModel.load_from_checkpoint(args.ckpt, dtype=args.dtype, tail_steps=args.tail_steps)
 
     K = max(1, args.streams)
     models = [make_model() for _ in range(K)]  # one engine (weights copy + workspace) per stream
@@ -122,79 +146,91 @@ def main(argv=None):
         # engines are created BEFORE the worker streams: HIP hands out hardware queues in stream-creation order, and
         # engines created lazily in between left the workers sharing queues (measured 7.0 instead of 17 utt/s, K=4)
         m.score_model.engine()
+        if m.tail_engine() is not None:
+            m.tail_engine()
     model = models[0]
+    eng0 = model.score_model.engine()
     fs = cfg_get(model.config, "model.fs", 8000)
     N = cfg_get(model.config, "model.sampler.N", 30) if args.N is None else args.N
     cs = cfg_get(model.config, "model.sampler.corrector_steps", 1) if args.corrector_steps is None else args.corrector_steps
     snr = cfg_get(model.config, "model.sampler.snr", 0.5) if args.snr is None else args.snr
+    n_src = 1 if args.enhance else None  # (evaluate.py:268-271)
 
-    n, get, lengths = load_dataset(args, fs)  # lengths: samples per utterance when the wav headers tell (else None)
-    max_len = max(lengths) if lengths else None
-    if max_len:
-        for m in models:  # workspace for the longest utterance now: growing it later would stall every stream
-            m.score_model.engine().reserve(1, max_len)
-    streams = [torch.cuda.Stream() for _ in range(K)]
+    n, get, lengths = load_dataset(args, fs)
     # the reference's contiguous ranges (evaluate_mp.py:495-503), or sorted by length and dealt round-robin
     mine = rank_indices(n, world, rank, lengths, args.balance)
-    lo = mine[0] if mine else 0
-    # warm every worker up on the first utterance's shape (engine creation, workspace plan, graph capture), then fix
-    # the RNG state: results do not depend on the number of streams
-    if mine:
-        m0, _ = get(lo)
-        for w in range(K):
-            with torch.cuda.stream(streams[w]):
-                mw = m0[None].cuda()
-                (mw_n, _), *_ = models[w].normalize_batch((mw, None))
-                models[w].get_pc_sampler("reverse_diffusion", "ald2", mw_n, N=N, corrector_steps=cs, snr=snr, denoise=True,
-                                         intermediate=False, schedule=args.schedule)()
-        torch.cuda.synchronize()
+    batches = plan_batches(mine, lengths, eng0.padded_frames, max(1, args.batch))
+    if batches:  # workspace for the largest call now: growing it later would stall every stream
+        bmax = max(len(g) for g in batches)
+        tmax = max(lengths[i] for i in mine)
+        for m in models:
+            m.score_model.engine().reserve(bmax, tmax)
+            if m.tail_engine() is not None:
+                m.tail_engine().reserve(bmax, tmax)
+    streams = [torch.cuda.Stream() for _ in range(K)]
     # utterance i of the data set gets the i-th draw of a generator seeded with --seed as its device RNG seed: the
-    # records do not depend on the number of streams, of ranks, or on how the utterances are dealt to them
+    # records do not depend on the number of streams, of ranks, or on how the utterances are batched or dealt
     seeds = torch.randint(0, 2 ** 62, (max(n, 1),), generator=torch.Generator().manual_seed(args.seed)).tolist()
     records = []
-    pending = [None] * K  # per worker: the utterance whose sampler is running on its stream
+    pending = [None] * K  # per worker: the batch whose sampler is running on its stream
+
+    def stage(group, w):
+        """load, pad, upload and normalise one batch on worker w's stream -> (mix, mix_n, tgt_n, lens)"""
+        items = [get(i) for i in group]
+        mix, tgt, lens = datasets.pad_batch(items, side="right")
+        # pinned staging + asynchronous copies: a pageable host->device copy serialises the whole device
+        mix = mix.contiguous().pin_memory().to("cuda", non_blocking=True)
+        tgt = tgt.contiguous().pin_memory().to("cuda", non_blocking=True)
+        mix_n, tgt_n = torch.zeros_like(mix), torch.zeros_like(tgt)
+        for b, L in enumerate(lens):  # every utterance is normalised over ITS samples (pl_model.py:81-88)
+            (m_b, t_b), *_ = models[w].normalize_batch((mix[b:b + 1, :, :L], tgt[b:b + 1, :, :L]))
+            mix_n[b, :, :L], tgt_n[b, :, :L] = m_b[0], t_b[0]
+        return mix, mix_n, tgt_n, lens
+
+    def launch(group, w):
+        mix, mix_n, tgt_n, lens = stage(group, w)
+        sampler = models[w].get_pc_sampler("reverse_diffusion", "ald2", mix_n, N=N, corrector_steps=cs, snr=snr,
+                                           denoise=True, intermediate=False, schedule=args.schedule,
+                                           lengths=lens, seeds=[seeds[i] for i in group])
+        if K == 1:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        est, nfe, *_ = sampler()  # enqueues the whole sampler on the worker's stream
+        # (every tensor the asynchronous sampler reads stays referenced until the worker's stream has drained)
+        return (group, lens, tgt_n, est, nfe, t0, (mix, mix_n, sampler))
 
     def finish(w):
         if pending[w] is None:
             return
-        i, mix, tgt_n, est, nfe, t0, _alive = pending[w]
+        group, lens, tgt_n, est, nfe, t0, _alive = pending[w]
         pending[w] = None
         streams[w].synchronize()
-        runtime = time.perf_counter() - t0
+        runtime = (time.perf_counter() - t0) / len(group)
         with torch.cuda.stream(streams[w]):
-            if args.enhance:  # n_src = 1: only the clean-speech estimate is scored (evaluate.py:270)
-                met = compute_metrics(est[0, :1], tgt_n[0, :1])
-            else:
-                met = compute_metrics(est[0], tgt_n[0])
-        records.append({"batch_idx": i, **met, "pesq": None, "stoi": None, "nfe": int(nfe), "runtime": runtime,
-                        "len_s": mix.shape[-1] / fs})
-        if args.save_wav:
-            d = args.output_dir / "wav"
-            d.mkdir(parents=True, exist_ok=True)
-            for k in range(est.shape[1]):
-                wavio.save(d / f"{i:05d}_s{k}.wav", est[0, k:k + 1].cpu() * 0.1, fs)
+            mets = compute_metrics(est, tgt_n, n_src)
+        for b, i in enumerate(group):
+            records.append({"batch_idx": i, **mets[b], "pesq": None, "stoi": None, "nfe": int(nfe),
+                            "runtime": runtime, "len_s": lens[b] / fs})
+            if args.save_wav:
+                d = args.output_dir / "wav"
+                d.mkdir(parents=True, exist_ok=True)
+                for k in range(est.shape[1]):
+                    wavio.save(d / f"{i:05d}_s{k}.wav", est[b, k:k + 1, :lens[b]].cpu() * 0.1, fs, bits=32)
 
+    # warm every worker up on the first batch's shape (workspace plan, graph capture) outside the timed region
+    if batches:
+        for w in range(K):
+            with torch.cuda.stream(streams[w]):
+                launch(batches[0], w)
+        torch.cuda.synchronize()
     # One host thread drives all K streams (a thread per stream was measured SLOWER: 10.7 instead of 17 utt/s at K = 4;
     # concurrent launches serialise inside the HIP runtime and a launch that waits for queue space holds them all up).
     t_all = time.perf_counter()
-    for j, i in enumerate(mine):
+    for j, group in enumerate(batches):
         w = j % K
-        finish(w)  # the worker's previous utterance (oldest in flight)
-        mix, tgt = get(i)
+        finish(w)  # the worker's previous batch (oldest in flight)
         with torch.cuda.stream(streams[w]):
-            # pinned staging + asynchronous copies: a pageable host->device copy serialises the whole device
-            mix = mix[None].contiguous().pin_memory().to("cuda", non_blocking=True)
-            tgt = tgt[None].contiguous().pin_memory().to("cuda", non_blocking=True)
-            (mix_n, tgt_n), *_ = models[w].normalize_batch((mix, tgt))
-            sampler = models[w].get_pc_sampler("reverse_diffusion", "ald2", mix_n, N=N, corrector_steps=cs, snr=snr,
-                                               denoise=True, intermediate=False, schedule=args.schedule,
-                                               seed=seeds[i])
-            if K == 1:
-                torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            est, nfe, *_ = sampler()  # enqueues the whole sampler on the worker's stream
-        # (every tensor the asynchronous sampler reads stays referenced until the worker's stream has drained)
-        pending[w] = (i, mix, tgt_n, est, nfe, t0, (mix_n, tgt, sampler))
+            pending[w] = launch(group, w)
     for w in range(K):
         finish(w)
     torch.cuda.synchronize()
@@ -208,7 +244,10 @@ def main(argv=None):
         summary = datasets.summarize([{k: v for k, v in r.items() if k not in ("batch_idx", "perm")} for r in flat])
         tot_rt = sum(r["runtime"] for r in flat)
         summary.update({"rtf": tot_rt / max(sum(r["len_s"] for r in flat), 1e-9), "world_size": world,
-                        "streams": K, "utt_per_s_rank0": len(mine) / max(wall, 1e-9)})
+                        "streams": K, "batch": args.batch, "engine_calls_rank0": len(batches), "dtype": args.dtype,
+                        "utt_per_s_rank0": len(mine) / max(wall, 1e-9),
+                        # metrics this build does not compute (third-party C code, out of scope: DESIGN.md section 7)
+                        "not_computed": ["pesq", "stoi"]})
         with open(args.output_dir / f"{args.split}_summary.json", "w") as f:
             json.dump(summary, f, indent=2)
         print(json.dumps(summary))

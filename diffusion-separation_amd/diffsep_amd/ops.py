@@ -2,6 +2,7 @@
 Activations are NHWC torch tensors on the GPU; bf16 is torch.bfloat16 storage."""
 import ctypes as C
 
+import numpy as np
 import torch
 
 from ._lib import F32, BF16, SdeConfig, SDE_MIX, check, lib
@@ -197,6 +198,57 @@ def sde_predictor_update(sde, N, x, t, score, z, sigma_mix=None, probability_flo
     return xo, xm
 
 
+def sde_coefficients(sde, x, t, sigma_mix=None, f_scale=1.0, g_scale=1.0):
+    """(f_scale * drift [B,S,T], g_scale * diffusion): diffusion is [B] for MixSDE, [B,S,T] for PriorMixSDE."""
+    B, S, T = x.shape
+    drift = torch.empty_like(x)
+    diff = torch.empty_like(x) if sigma_mix is not None else torch.empty(B, dtype=torch.float32, device=x.device)
+    sc = _sde(sde)
+    check(lib().diffsep_sde_coefficients(C.byref(sc), _ptr(x), _ptr(t), _ptr(sigma_mix), _ptr(drift), _ptr(diff), B, S, T,
+                                         f_scale, g_scale, _stream_ptr()))
+    return drift, diff
+
+
+def sde_mean(sde, x0, t):
+    B, S, T = x0.shape
+    out = torch.empty_like(x0)
+    sc = _sde(sde)
+    check(lib().diffsep_sde_mean(C.byref(sc), _ptr(x0), _ptr(t), _ptr(out), B, S, T, _stream_ptr()))
+    return out
+
+
+def sde_std(sde, t, S, T=1, sigma_mix=None):
+    """Dense matrix square root of the perturbation covariance: [B,S,S], or [B,S,S,T] with sigma_mix [B,T]."""
+    B = t.shape[0]
+    shape = (B, S, S, T) if sigma_mix is not None else (B, S, S)
+    out = torch.empty(shape, dtype=torch.float32, device=t.device)
+    sc = _sde(sde)
+    check(lib().diffsep_sde_std(C.byref(sc), _ptr(t), _ptr(sigma_mix), _ptr(out), B, S, T, _stream_ptr()))
+    return out
+
+
+def sde_mult_std(std, x):
+    """std [B,S,S] or [B,S,S,T] applied to x [B,S,T]."""
+    B, S, T = x.shape
+    per = std.dim() == 4
+    assert std.shape == ((B, S, S, T) if per else (B, S, S)), "std must be [B,S,S] or [B,S,S,T]"
+    out = torch.empty_like(x)
+    check(lib().diffsep_sde_mult_std(_ptr(std.contiguous()), _ptr(x), _ptr(out), B, S, T, int(per), _stream_ptr()))
+    return out
+
+
+def sde_reverse_drift(f, G, score, probability_flow=False):
+    """rev_f = f - G^2 score (x 0.5 for the probability-flow ODE); G [B] or the shape of f."""
+    B = f.shape[0]
+    n = f.numel() // B
+    full = G.numel() != B
+    assert (not full) or G.shape == f.shape
+    out = torch.empty_like(f)
+    check(lib().diffsep_sde_reverse_drift(_ptr(f), _ptr(G.contiguous()), _ptr(score), _ptr(out), B, n, int(full),
+                                          int(bool(probability_flow)), _stream_ptr()))
+    return out
+
+
 def sde_langevin_update(snr, x, score, z):
     B = x.shape[0]
     n = x.numel() // B
@@ -226,6 +278,15 @@ def scale_output(mix, sep):
 def randn(n, seed, stream_id, device="cuda"):
     out = torch.empty(n, dtype=torch.float32, device=device)
     check(lib().diffsep_randn(_ptr(out), n, seed, stream_id, _stream_ptr()))
+    return out
+
+
+def randn_batch(B, S, T, seeds, lengths, stream_id, device="cuda"):
+    """[B,S,T] draws: row (b, s) = values s*len_b .. of randn(S*len_b, seeds[b], stream_id), zero beyond len_b."""
+    out = torch.empty((B, S, T), dtype=torch.float32, device=device)
+    sd = torch.as_tensor(np.asarray(seeds, dtype=np.uint64).view(np.int64), device=device)
+    ln = torch.as_tensor(np.asarray(lengths, dtype=np.int32), device=device)
+    check(lib().diffsep_randn_batch(_ptr(out), B, S, T, _ptr(sd), _ptr(ln), stream_id, _stream_ptr()))
     return out
 
 

@@ -64,14 +64,28 @@ def default_config(nf=64, n_speakers=2, fs=8000, spec_factor=0.33):
         "sampler": {"N": 30, "snr": 0.5, "corrector_steps": 1}}}
 
 
+# Reverse steps whose score the fp32 engine evaluates in dtype="hybrid" (the rest run in bf16).  Derivation in
+# the bf16 network's rounding noise only matters once the injected noise G z is small.
+HYBRID_TAIL_STEPS = 5
+
+
 class DiffSepModel:
-    def __init__(self, config, dtype="bf16", device=None, init_seed=0):
+    def __init__(self, config, dtype="bf16", device=None, init_seed=0, tail_steps=None):
+        """dtype: "bf16" (throughput), "f32" (parity with the reference to 1e-3 RMS) or "hybrid": bf16 for the first
+        N - tail_steps reverse steps, the fp32 engine for the last tail_steps (an extension: the reference has one
+        precision)."""
         self.config = config
         sm = dict(cfg_get(config, "model.score_model"))
         sm.pop("_target_", None)
         sm["stft_args"] = dict(sm["stft_args"])
         sm["backbone_args"] = {k: v for k, v in dict(sm["backbone_args"]).items()}
-        self.score_model = ScoreModelNCSNpp(dtype=dtype, device=device, init_seed=init_seed, **sm)
+        self.dtype = dtype
+        self.score_model = ScoreModelNCSNpp(dtype="bf16" if dtype == "hybrid" else dtype, device=device,
+                                            init_seed=init_seed, **sm)
+        self.tail_model, self.tail_steps = None, 0
+        if dtype == "hybrid":
+            self.tail_model = ScoreModelNCSNpp(dtype="f32", device=device, init_seed=init_seed, **sm)
+            self.tail_steps = HYBRID_TAIL_STEPS if tail_steps is None else int(tail_steps)
         sd = dict(cfg_get(config, "model.sde"))
         target = str(sd.pop("_target_", "sdes.sdes.MixSDE"))
         if target.endswith("PriorMixSDE"):
@@ -87,12 +101,12 @@ class DiffSepModel:
 
     # ---- checkpoint ----------------------------------------------------------------------
     @classmethod
-    def load_from_checkpoint(cls, path, dtype="bf16", device=None, use_ema=True):
+    def load_from_checkpoint(cls, path, dtype="bf16", device=None, use_ema=True, tail_steps=None):
         """Lightning .ckpt / HF checkpoint.pt: {'state_dict', 'hyper_parameters': {'config'}, 'ema'}
         (pl_model.py:100,642-673).  Inference runs on the EMA shadow weights (pl_model.py:655-660)."""
         ckpt = torch.load(str(path), map_location="cpu", weights_only=False)
         config = ckpt["hyper_parameters"]["config"]
-        model = cls(config, dtype=dtype, device=device)
+        model = cls(config, dtype=dtype, device=device, tail_steps=tail_steps)
         state = {k[len("score_model."):]: v for k, v in ckpt["state_dict"].items() if k.startswith("score_model.")}
         ema = ckpt.get("ema", None) if use_ema else None
         if ema is not None:
@@ -107,11 +121,19 @@ class DiffSepModel:
                     raise ValueError(f"EMA shadow parameter for '{n}' has shape {tuple(v.shape)}")
                 state[n] = v
         model.score_model.load_state_dict(state)
+        if model.tail_model is not None:
+            model.tail_model.load_state_dict(state)
         return model
 
     def to(self, device):
         self.score_model.to(device)
+        if self.tail_model is not None:
+            self.tail_model.to(device)
         return self
+
+    def tail_engine(self):
+        """the fp32 engine of dtype="hybrid" (None otherwise)"""
+        return self.tail_model.engine() if self.tail_model is not None and self.tail_steps > 0 else None
 
     def eval(self, no_ema=False):
         return self
@@ -140,9 +162,17 @@ class DiffSepModel:
         if minibatch is None:
             return make(y)
 
+        seed0 = kwargs.pop("seed", None)
+        if kwargs.get("lengths") is not None or kwargs.get("seeds") is not None:
+            raise ValueError("lengths= / seeds= describe one engine batch; they cannot be combined with minibatch=")
+
         def batched_sampling_fn():
             samples, ns, inter = [], [], []
             for i in range(int(math.ceil(y.shape[0] / minibatch))):
+                # an explicit seed is advanced per minibatch: the same seed would give every minibatch of the same
+                # shape the same device noise
+                if seed0 is not None:
+                    kwargs["seed"] = (int(seed0) + 0x9E3779B97F4A7C15 * i) % (1 << 64)
                 sample, n, *other = make(y[i * minibatch:(i + 1) * minibatch])()
                 samples.append(sample)
                 ns.append(n)

@@ -23,6 +23,25 @@ class ScoreModelNCSNpp:
         if not stft_args.get("center", True) or stft_args.get("pad_mode", "constant") != "constant":
             raise NotImplementedError("STFT must be center=True, pad_mode='constant' (config/model/default.yaml:21-22)")
         ba = {k: v for k, v in dict(backbone_args).items() if k != "_target_"}
+        # Every backbone argument that changes NCSNpp.forward and is not a parameter of the engine must hold the value
+        # the engine implements (models/ncsnpp.py:45-70 constructor defaults): a checkpoint trained otherwise would
+        # load and silently produce wrong scores.
+        supported = dict(scale_by_sigma=True, nonlinearity="swish", dropout=0.0, resamp_with_conv=True,
+                         conditional=True, fir=True, fir_kernel=[1, 3, 3, 1], skip_rescale=True,
+                         resblock_type="biggan", progressive="output_skip", progressive_input="input_skip",
+                         progressive_combine="sum", init_scale=0.0, fourier_scale=16, image_size=256,
+                         embedding_type="fourier", centered=False)
+        for k, want in supported.items():
+            if k in ba and (list(ba[k]) if isinstance(want, list) else ba[k]) != want and k != "init_scale":
+                raise NotImplementedError(f"backbone_args.{k}={ba[k]!r}: the engine implements {want!r} only")
+        # (arguments NCSNpp does not know are swallowed by its **unused_kwargs, ncsnpp.py:68: ignored here too)
+        if len(tuple(ba.get("attn_resolutions", (16,)))) != 1:
+            raise NotImplementedError("the engine implements exactly one attention resolution")
+        for k, want in (("num_channels_in", 2 * num_sources + 2), ("num_channels_out", 2 * num_sources)):
+            if k in ba and ba[k] != want:
+                raise NotImplementedError(f"backbone_args.{k}={ba[k]} (ScoreModelNCSNpp sets {want}, score_models.py:24-26)")
+        if stft_args["n_fft"] != 510 or stft_args["n_fft"] // 2 + 1 != 256:
+            raise NotImplementedError("n_fft must be 510 (image height 256 = NCSNpp image_size; the DFT tables hold 510 taps)")
         self.num_sources = num_sources
         self.stft_args = dict(stft_args)
         self.spec_abs_exponent, self.spec_factor = spec_abs_exponent, spec_factor

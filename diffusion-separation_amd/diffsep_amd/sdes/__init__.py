@@ -38,7 +38,7 @@ def _engine_of(score_fn):
 
 
 def _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, denoise, eps, snr, corrector_steps,
-                  probability_flow, intermediate, schedule, seed=None):
+                  probability_flow, intermediate, schedule, seed=None, lengths=None, seeds=None):
     predictor = PredictorRegistry.get_by_name(predictor_name)(sde, score_fn, probability_flow=probability_flow)
     corrector = CorrectorRegistry.get_by_name(corrector_name)(sde, score_fn, snr=snr, n_steps=corrector_steps)
     eng = _engine_of(score_fn)
@@ -46,6 +46,12 @@ def _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, d
              and predictor_name in ("reverse_diffusion", "euler_maruyama", "none")
              and corrector_name in ("ald2", "ald", "langevin", "none") and isinstance(sde, MixSDE)
              and not (corrector_name == "ald" and type(sde) is not MixSDE))
+
+    if not fused and (seed is not None or lengths is not None or seeds is not None):
+        # the step-by-step loop draws from torch's global generator like the reference (torch.manual_seed governs it)
+        # and has no notion of a zero-padded batch
+        raise ValueError("seed= / seeds= / lengths= are extensions of the fused engine sampler; this request "
+                         "(intermediate, true_mean or a user predictor / corrector) runs the generic loop")
 
     def pc_sampler():
         with torch.no_grad():
@@ -55,9 +61,11 @@ def _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, d
                 # this sampler explicitly, e.g. when several samplers are driven from different threads
                 s_ = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
                 ts = None if schedule is None else _timesteps(sde, eps, schedule, "cpu").numpy()
+                tail = getattr(score_fn, "tail_engine", lambda: None)()
                 x, _ = eng.pc_sample(y, sde.engine_config(), N=sde.N, corrector_steps=corrector.n_steps, snr=snr,
                                      eps=eps, denoise=denoise, predictor=predictor_name, corrector=corrector_name,
-                                     seed=s_, timesteps=ts)
+                                     seed=s_, timesteps=ts, lengths=lengths, seeds=seeds, tail=tail,
+                                     tail_steps=getattr(score_fn, "tail_steps", 0) if tail is not None else 0)
                 return x, ns
             im = []
             xt = sde.prior_sampling((true_mean if true_mean is not None else y).shape,
@@ -78,9 +86,11 @@ def _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, d
 
 def get_pc_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean=None, denoise=True, eps=3e-2, snr=0.1,
                    corrector_steps=1, probability_flow=False, intermediate=False, **kwargs):
-    """Reference: sdes/__init__.py:132-190."""
+    """Reference: sdes/__init__.py:132-190.  Extensions through **kwargs (fused engine path only): seed, and for a
+    zero-padded batch of utterances of different lengths lengths=[B] (+ seeds=[B], per-utterance RNG seeds)."""
     return _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, denoise, eps, snr,
-                         corrector_steps, probability_flow, intermediate, None, seed=kwargs.get("seed"))
+                         corrector_steps, probability_flow, intermediate, None, seed=kwargs.get("seed"),
+                         lengths=kwargs.get("lengths"), seeds=kwargs.get("seeds"))
 
 
 def get_pc_scheduled_sampler(predictor_name, corrector_name, sde, score_fn, y, denoise=True, true_mean=None, eps=3e-2,
@@ -88,4 +98,5 @@ def get_pc_scheduled_sampler(predictor_name, corrector_name, sde, score_fn, y, d
                              schedule="linear", **kwargs):
     """Reference: sdes/__init__.py:46-129."""
     return _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, denoise, eps, snr,
-                         corrector_steps, probability_flow, intermediate, schedule, seed=kwargs.get("seed"))
+                         corrector_steps, probability_flow, intermediate, schedule, seed=kwargs.get("seed"),
+                         lengths=kwargs.get("lengths"), seeds=kwargs.get("seeds"))

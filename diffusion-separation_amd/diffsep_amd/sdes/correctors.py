@@ -13,6 +13,7 @@ CorrectorRegistry = Registry("Corrector")
 class Corrector(abc.ABC):
     def __init__(self, sde, score_fn, snr, n_steps):
         self.sde, self.score_fn, self.snr, self.n_steps = sde, score_fn, snr, n_steps
+        self.rsde = sde.reverse(score_fn)  # (sdes/correctors.py:14-19)
 
     @abc.abstractmethod
     def update_fn(self, x, t, *args, **kwargs):

@@ -16,6 +16,8 @@ class Predictor(abc.ABC):
         # (sdes/predictors.py:15-18: `self.rsde = sde.reverse(score_fn)`), so the flag never changes a PC-sampler
         # update there; it is accepted and ignored here for the same behaviour.
         self.sde, self.score_fn, self.probability_flow = sde, score_fn, probability_flow
+        # user subclasses written against the reference API step through self.rsde.discretize / self.rsde.sde
+        self.rsde = sde.reverse(score_fn)
 
     @abc.abstractmethod
     def update_fn(self, x, t, *args, **kwargs):

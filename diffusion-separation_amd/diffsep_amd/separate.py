@@ -6,10 +6,12 @@
 For every *.wav in input_dir: load -> normalize_batch -> reverse-diffusion PC sampler on the HIP engine ->
 scale_output -> write output_dir/s{i}/name.wav (directories s0, s1 like separate.py:157-158).
 Additions: --synthetic-weights NF runs with random-init weights of width NF when no checkpoint is
-available (there is no network here: the HF default 'fakufaku/diffsep' cannot be downloaded), --dtype,
---batch to separate several equal-length files per engine call, --streams K to keep K files (or batches) in flight on
-K engines / HIP streams (one file at a time leaves most of the GPU idle: 6.0 -> 18.5 files/s at K = 4 for 4 s files)
-and --seed (with it the outputs do not depend on K).
+available (there is no network here: the HF default 'fakufaku/diffsep' cannot be downloaded), --dtype (bf16 / f32 /
+hybrid), --batch B: files whose padded spectrogram width is equal share one engine call (zero-padded to the longest,
+each file's tail kept at zero by the engine: evaluate.py has the details), --streams K engine calls in flight on K
+engines / HIP streams, and --seed (file i of the sorted folder then gets the i-th draw of that generator as its device
+RNG seed: the written files do not depend on --batch or --streams).  Output files are 32-bit float WAV like
+torchaudio.save of a float tensor (separate.py:160-162).
 """
 import argparse
 import os
@@ -17,7 +19,7 @@ from pathlib import Path
 
 import torch
 
-from . import ops, wavio
+from . import datasets, ops, wavio
 from .pl_model import DiffSepModel, cfg_get, default_config
 
 DEFAULT_MODEL = "fakufaku/diffsep"
@@ -25,13 +27,15 @@ DEFAULT_MODEL = "fakufaku/diffsep"
 
 def get_model(args):
     if args.synthetic_weights:
-        model = DiffSepModel(default_config(nf=args.synthetic_weights), dtype=args.dtype, device=args.device)
+        model = DiffSepModel(default_config(nf=args.synthetic_weights), dtype=args.dtype, device=args.device,
+                             tail_steps=getattr(args, "tail_steps", None))
     else:
         path = Path(args.model)
         if not path.exists():
             raise FileNotFoundError(f"checkpoint '{args.model}' not found (Hugging Face download needs network access; "
                                     "pass a local Lightning checkpoint or --synthetic-weights NF)")
-        model = DiffSepModel.load_from_checkpoint(str(path), dtype=args.dtype, device=args.device)
+        model = DiffSepModel.load_from_checkpoint(str(path), dtype=args.dtype, device=args.device,
+                                                  tail_steps=getattr(args, "tail_steps", None))
     model.to(args.device)
     model.eval()
     N = cfg_get(model.config, "model.sampler.N", 30) if args.N is None else args.N
@@ -47,16 +51,30 @@ def scale_output(mix, sep):
     return ops.scale_output(mix.contiguous(), sep.contiguous())
 
 
-def separate_on_device(mix, model, sampler_kwargs, device):
-    """Enqueue the separation of mix [1,T] / [B,1,T] on the current stream; returns the device tensor [B,S,T]."""
+def separate_on_device(mix, model, sampler_kwargs, device, lengths=None, seeds=None):
+    """Enqueue the separation of mix [1,T] / [B,1,T] on the current stream; returns the device tensor [B,S,T].
+    lengths [B]: mix is a right-zero-padded batch of files of those lengths (normalised and rescaled per file)."""
     mix = mix.to(device)
     if mix.dim() == 2:
         mix = mix[None]
-    (mix_norm, _), *_ = model.normalize_batch((mix, None))
-    sampler = model.get_pc_sampler("reverse_diffusion", "ald2", mix_norm, **sampler_kwargs)
+    if lengths is None:
+        (mix_norm, _), *_ = model.normalize_batch((mix, None))
+    else:
+        mix_norm = torch.zeros_like(mix)
+        for b, L in enumerate(lengths):
+            mix_norm[b, :, :L] = model.normalize_batch((mix[b:b + 1, :, :L], None))[0][0][0]
+    extra = {} if lengths is None else {"lengths": list(lengths)}
+    if seeds is not None:
+        extra["seeds"] = list(seeds)
+    sampler = model.get_pc_sampler("reverse_diffusion", "ald2", mix_norm, **sampler_kwargs, **extra)
     with torch.no_grad():
         sep, nfe, *_ = sampler()
-    return scale_output(mix, sep)
+    if lengths is None:
+        return scale_output(mix, sep)
+    out = torch.zeros_like(sep)
+    for b, L in enumerate(lengths):  # the least-squares scale of separate.py:73-78 is per file, over ITS samples
+        out[b, :, :L] = scale_output(mix[b:b + 1, :, :L], sep[b:b + 1, :, :L])[0]
+    return out
 
 
 def separate(mix, model, sampler_kwargs, device):
@@ -76,10 +94,12 @@ def main(argv=None):
     ap.add_argument("--denoise", type=bool, default=True)
     ap.add_argument("-s", "--schedule", type=str, default=None)
     ap.add_argument("--synthetic-weights", type=int, default=0, metavar="NF")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=1, help="files (batches) in flight: K engines on K HIP streams")
-    ap.add_argument("--seed", type=int, default=None, help="torch.manual_seed before the first file")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "hybrid"])
+    ap.add_argument("--tail-steps", type=int, default=None, help="--dtype hybrid: reverse steps on the fp32 engine")
+    ap.add_argument("--batch", type=int, default=1, help="files per engine call (equal padded width)")
+    ap.add_argument("--streams", type=int, default=1, help="engine calls in flight: K engines on K HIP streams")
+    ap.add_argument("--seed", type=int, default=None,
+                    help="file i (sorted) gets the i-th draw of a generator with this seed as its device RNG seed")
     args = ap.parse_args(argv)
     K = max(1, args.streams)
     if K > 1:  # (see evaluate.py: hardware queues; must precede the first torch.cuda call)
@@ -91,57 +111,57 @@ def main(argv=None):
     models = [model] + [get_model(args)[0] for _ in range(K - 1)]
     for m in models:
         m.score_model.engine()  # engines before streams (hardware queues are handed out in creation order)
-    if args.seed is not None:
-        torch.manual_seed(args.seed)
+        if m.tail_engine() is not None:
+            m.tail_engine()
     model_sr = cfg_get(model.config, "model.fs", 8000)
     if args.output_dir.is_file():
         raise ValueError("Output directory is a file")
     args.output_dir.mkdir(parents=True, exist_ok=True)
     files = sorted(args.input_dir.glob("*.wav"))
-    if files:  # workspace for the longest file now (growing it later synchronises the whole device)
-        longest = max(wavio.info(p)[1] for p in files)
+    lengths = [wavio.info(p)[1] for p in files]
+    eng = model.score_model.engine()
+    from .evaluate import plan_batches
+    batches = plan_batches(range(len(files)), lengths, eng.padded_frames, max(1, args.batch))
+    if batches:  # workspace for the largest call now (growing it later synchronises the whole device)
         for m in models:
-            m.score_model.engine().reserve(args.batch, longest)
+            m.score_model.engine().reserve(max(len(g) for g in batches), max(lengths))
+            if m.tail_engine() is not None:
+                m.tail_engine().reserve(max(len(g) for g in batches), max(lengths))
+    seeds = None
+    if args.seed is not None:
+        seeds = torch.randint(0, 2 ** 62, (max(len(files), 1),),
+                              generator=torch.Generator().manual_seed(args.seed)).tolist()
     streams = [torch.cuda.Stream() for _ in range(K)] if K > 1 else [torch.cuda.current_stream()]
-    pending = []
-    in_flight = [None] * K  # per worker: (group, device result) of the batch running on its stream
-    n_groups = 0
+    in_flight = [None] * K  # per worker: (file indices, lengths, sample rates, device result) of its running batch
 
     def finish(w):
         if in_flight[w] is None:
             return
-        group, sep = in_flight[w]
+        group, lens, srs, sep = in_flight[w]
         in_flight[w] = None
         streams[w].synchronize()
-        for (p, _, sr), s in zip(group, sep.cpu()):
-            for i in range(s.shape[0]):
-                d = args.output_dir / f"s{i}"
+        sep = sep.cpu()
+        for b, i in enumerate(group):
+            for k in range(sep.shape[1]):
+                d = args.output_dir / f"s{k}"
                 d.mkdir(parents=True, exist_ok=True)
-                wavio.save(d / f"{p.stem}.wav", s[i:i + 1], sr)
+                wavio.save(d / f"{files[i].stem}.wav", sep[b, k:k + 1, :lens[b]], srs[b], bits=32)
 
-    def flush():
-        nonlocal n_groups
-        if not pending:
-            return
-        w = n_groups % K
-        n_groups += 1
+    for j, group in enumerate(batches):
+        w = j % K
         finish(w)  # the worker's previous batch
-        mix = torch.stack([wv for _, wv, _ in pending])  # [B,1,T]
+        items, srs = [], []
+        for i in group:
+            wav, sr = wavio.load(files[i])
+            if sr != model_sr:  # the reference only warns (separate.py:151-155, quirk Q9)
+                print(f"Warning: {files[i].stem}: this model expects {model_sr} Hz, but the file is {sr} Hz.")
+            items.append((wav[:1], wav[:1]))
+            srs.append(sr)
+        mix, _, lens = datasets.pad_batch(items, side="right")
         with torch.cuda.stream(streams[w]):
-            in_flight[w] = (list(pending), separate_on_device(mix, models[w], kw, args.device))
-        pending.clear()
-
-    for p in files:
-        wav, sr = wavio.load(p)
-        if sr != model_sr:  # the reference only warns (separate.py:151-155, quirk Q9)
-            print(f"Warning: {p.stem}: this model expects {model_sr} Hz, but the file is {sr} Hz.")
-        wav = wav[:1]
-        if pending and (pending[0][1].shape[-1] != wav.shape[-1] or len(pending) >= args.batch):
-            flush()
-        pending.append((p, wav, sr))
-        if len(pending) >= args.batch:
-            flush()
-    flush()
+            sep = separate_on_device(mix.pin_memory().to(args.device, non_blocking=True), models[w], kw, args.device,
+                                     lengths=lens, seeds=[seeds[i] for i in group] if seeds is not None else None)
+        in_flight[w] = (group, lens, srs, sep)
     for w in range(K):
         finish(w)
     print(f"separated {len(files)} files into {args.output_dir}")

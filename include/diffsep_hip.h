@@ -20,7 +20,9 @@
  *     DIFFSEP_F32 or DIFFSEP_BF16 (raw bfloat16 bits), C and ld multiples of 8;
  *   - an engine handle is bound to the device that was current at creation, owns the repacked
  *     weights + workspace, and is not thread-safe (the reference is one Python thread per process
- *     per GPU: evaluate_mp.py:339,510-513).
+ *     per GPU: evaluate_mp.py:339,510-513).  The parameter-table queries (diffsep_param_count / _info /
+ *     _total) share ONE process-wide cache of the last architecture asked about: call them from one
+ *     thread at a time.
  */
 #ifndef DIFFSEP_HIP_H
 #define DIFFSEP_HIP_H
@@ -143,6 +145,32 @@ int32_t diffsep_pc_sample(diffsep_engine* e, const diffsep_sde_config* sde, cons
                           const float* mix_norm, float* out, int32_t B, int64_t T, const float* noise,
                           uint64_t seed, const float* timesteps_host, int32_t* nfe_out, void* stream);
 
+/* Extensions of the sampler call that have no counterpart in the reference (which runs one utterance at a time in
+ * one precision: evaluate.py:348-376).  All fields optional (zero / NULL = diffsep_pc_sample behaviour).
+ *   lengths_host [B]  : utterance b has lengths_host[b] <= T samples; the batch is zero-padded to T and every
+ *                       utterance must have the padded frame count of T (diffsep_padded_frames).  Samples beyond an
+ *                       utterance's length stay exactly zero through the whole sampler, so each utterance comes out
+ *                       bit-for-bit as a B = 1 call on it alone with the same seed (fp32 engine; within the
+ *                       GroupNorm-sum rounding of the weight-stationary bf16 kernel otherwise).  The 'langevin'
+ *                       corrector couples the batch entries and is refused with lengths.
+ *   seeds_host [B]    : per-utterance Philox seeds (with noise == NULL): utterance b draws exactly what a B = 1 call
+ *                       with seed = seeds_host[b] draws, whatever batch it rides in.  Without it `seed` keys the
+ *                       whole batch as in diffsep_pc_sample (with lengths: utterance b uses seed + b * 0x9E3779B97F4A7C15).
+ *   tail_engine/steps : evaluate the score of the LAST tail_steps reverse steps (their corrector and predictor
+ *                       evaluations) with another engine of the same architecture and weights — the fp32 engine
+ *                       behind a bf16 one: rounding noise of the bf16 network only matters once the injected noise
+ *                       G z has become small, i.e. in the last steps. */
+typedef struct {
+  const int64_t* lengths_host;
+  const uint64_t* seeds_host;
+  diffsep_engine* tail_engine;
+  int32_t tail_steps;
+} diffsep_sampler_ext;
+int32_t diffsep_pc_sample_ex(diffsep_engine* e, const diffsep_sde_config* sde, const diffsep_sampler_config* smp,
+                             const diffsep_sampler_ext* ext, const float* mix_norm, float* out, int32_t B, int64_t T,
+                             const float* noise, uint64_t seed, const float* timesteps_host, int32_t* nfe_out,
+                             void* stream);
+
 /* Use hipGraph replay of the per-NFE launch sequence inside diffsep_pc_sample (default 1). */
 int32_t diffsep_engine_set_graph(diffsep_engine* e, int32_t enable);
 
@@ -253,6 +281,32 @@ int32_t diffsep_sde_predictor_update(const diffsep_sde_config* sde, int32_t N, c
                                      const float* score, const float* z, float* x_out, float* x_mean_out,
                                      int32_t B, int32_t S, int64_t T, const float* sigma_mix,
                                      int32_t probability_flow, void* stream);
+/* ---- the SDE object surface a user-written Predictor / Corrector reaches through the reference API.  The fused
+ * sampler never calls these; diffsep_amd/sdes/sdes.py builds sde() / marginal_prob() / mult_std() / discretize() /
+ * reverse() on them. ----
+ * SDE.sde (MixSDE sdes/sdes.py:275-284, PriorMixSDE :451-470) scaled for SDE.discretize (:93-107):
+ *   drift_out [B,S,T] = f_scale * (-lambda P x);  diffusion_out = g_scale * g(t) [B]  (MixSDE)
+ *                                                              or g_scale * g(t) sigma_mix [B,S,T] (PriorMixSDE).
+ *   sde(): f_scale = g_scale = 1; discretize(): f_scale = dt, g_scale = sqrt(dt), dt = 1/N (quirk Q1). */
+int32_t diffsep_sde_coefficients(const diffsep_sde_config* sde, const float* x, const float* t, const float* sigma_mix,
+                                 float* drift_out, float* diffusion_out, int32_t B, int32_t S, int64_t T, float f_scale,
+                                 float g_scale, void* stream);
+/* MixSDE._mean (sdes/sdes.py:286-294): (A + exp(-lambda t) P) x0, the mean of marginal_prob (:322-324). */
+int32_t diffsep_sde_mean(const diffsep_sde_config* sde, const float* x0, const float* t, float* mean_out, int32_t B,
+                         int32_t S, int64_t T, void* stream);
+/* MixSDE._std (sdes/sdes.py:315-320) -> std_out [B,S,S]; PriorMixSDE._std (:515-532, sigma_mix != NULL) ->
+ * std_out [B,S,S,T]: the second member of marginal_prob. */
+int32_t diffsep_sde_std(const diffsep_sde_config* sde, const float* t, const float* sigma_mix, float* std_out, int32_t B,
+                        int32_t S, int64_t T, void* stream);
+/* MixSDE.mult_std (std @ x, sdes/sdes.py:326-328; per_sample = 0, std [B,S,S]) / PriorMixSDE.mult_std
+ * (einsum "bcdt,bdt->bct", :534-537; per_sample = 1, std [B,S,S,T]) for any dense std. */
+int32_t diffsep_sde_mult_std(const float* std, const float* x, float* out, int32_t B, int32_t S, int64_t T,
+                             int32_t per_sample, void* stream);
+/* RSDE.discretize (sdes/sdes.py:163-171) given the forward discretisation: rev_f = f - G^2 score (x 0.5 when
+ * probability_flow); G is [B] (g_full = 0) or [B, n_per_batch] (g_full = 1). */
+int32_t diffsep_sde_reverse_drift(const float* f, const float* G, const float* score, float* rev_f_out, int32_t B,
+                                  int64_t n_per_batch, int32_t g_full, int32_t probability_flow, void* stream);
+
 /* LangevinCorrector.update_fn body for one step (sdes/correctors.py:43-53): step = 2 (snr <||z_b||> / <||g_b||>)^2
  * from batch-mean norms, x_mean = x + step g, x = x_mean + sqrt(2 step) z.  x etc. are [B, n_per_batch];
  * ws >= 16*B + 16 bytes. */
@@ -274,6 +328,10 @@ int32_t diffsep_gram(const float* ref, const float* est, double* out, int32_t B,
 
 /* on-device standard normal draws (Philox4x32-10 + Box-Muller); used when noise == NULL. */
 int32_t diffsep_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+/* the same for a zero-padded batch of utterances with their own seeds and lengths (device arrays [B]): row (b, s) of
+ * out [B,S,T] holds values s*len_b .. (s+1)*len_b - 1 of the stream diffsep_randn(seed_b, stream_id) draws, then zeros. */
+int32_t diffsep_randn_batch(float* out, int32_t B, int32_t S, int64_t T, const uint64_t* seeds, const int32_t* lengths,
+                            uint64_t stream_id, void* stream);
 
 /* float32 <-> engine dtype conversion helper for the tests (n elements). */
 int32_t diffsep_convert(const void* src, void* dst, int64_t n, int32_t src_dtype, int32_t dst_dtype, void* stream);

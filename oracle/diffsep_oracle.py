@@ -8,7 +8,7 @@ ONLY tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may impor
 only as the checker / the timed CPU baseline.  The product path (diffsep_amd + libdiffsep_hip.so)
 never imports it and fails loudly when the HIP library is missing.
 
-Parity status: PINNED.  The reference has no tests or golden vectors of its own, so
+Parity status: PINNED — except si_bss_eval_sources (third-party fast_bss_eval, source absent: unpinned, see there).  The reference has no tests or golden vectors of its own, so
 this oracle is pinned against outputs of the reference itself, imported in the build container
 from /root/reference with stubs for its missing third-party packages
 (tests/golden/gen_golden.py -> tests/golden/*.npz, checked by tests/test_oracle_golden.py).
@@ -416,6 +416,102 @@ def pc_sampler(p, cfg, y, noise, N=None, corrector_steps=None, snr=None, eps=Non
                     xt, xm = corrector_langevin(xt, sc, next(it), snr)
             xt, xm = predictor_reverse_diffusion(cfg, xt, vec_t, score_fn(xt, vec_t, y), next(it), N, smix)
     return (xm if denoise else xt), N * (cs + 1)
+
+
+# ----------------------------------------------------------------------------- SDE object surface
+def sde_coefficients(cfg, x, t, smix=None):
+    """MixSDE.sde  sdes/sdes.py:275-284 / PriorMixSDE.sde :451-470: drift = -lambda P x, diffusion = sigma_min r^t
+    sqrt(2 ln r) [B] (x sigma_mix broadcast to [B,S,T] for PriorMixSDE)."""
+    S = x.shape[1]
+    _, P = mix_mats(S, x.dtype)
+    drift = -cfg["d_lambda"] * (P @ x)
+    r = cfg["sigma_max"] / cfg["sigma_min"]
+    diffusion = cfg["sigma_min"] * r ** t * math.sqrt(2.0 * math.log(r))
+    if smix is not None:
+        diffusion = diffusion[:, None, None] * smix[:, None, :].expand(-1, S, -1)
+    return drift, diffusion
+
+
+def sde_discretize(cfg, x, t, N, smix=None):
+    """SDE.discretize  sdes/sdes.py:93-107 with dt = 1/N always (quirk Q1)."""
+    dt = 1.0 / N
+    drift, diffusion = sde_coefficients(cfg, x, t, smix)
+    return drift * dt, diffusion * torch.sqrt(torch.tensor(dt))
+
+
+def sde_mean(cfg, x0, t):
+    """MixSDE._mean  sdes/sdes.py:286-294: (A + exp(-lambda t) P) x0."""
+    A, P = mix_mats(x0.shape[1], x0.dtype)
+    return (A + torch.exp(-t[:, None, None] * cfg["d_lambda"]) * P) @ x0
+
+
+def sde_std(cfg, t, S, smix=None):
+    """MixSDE._std  sdes/sdes.py:315-320 -> [B,S,S]; PriorMixSDE._std :515-532 -> [B,S,S,T]."""
+    L = mix_std(cfg, t, S)
+    return L if smix is None else L[..., None] * smix[:, None, None, :]
+
+
+def sde_mult_std(std, x):
+    """mult_std  sdes/sdes.py:326-328 (std @ x) / :534-537 (einsum bcdt,bdt->bct)."""
+    return std @ x if std.dim() == 3 else torch.einsum("bcdt,bdt->bct", std, x)
+
+
+def rsde_discretize(cfg, x, t, score, N, smix=None, probability_flow=False):
+    """RSDE.discretize  sdes/sdes.py:163-171."""
+    f, G = sde_discretize(cfg, x, t, N, smix)
+    Gp = G if G.dim() == 3 else G[:, None, None]
+    rev_f = f - Gp ** 2 * score * (0.5 if probability_flow else 1.0)
+    return rev_f, (torch.zeros_like(G) if probability_flow else G)
+
+
+# ----------------------------------------------------------------------------- separation metrics
+def si_bss_eval_sources(ref, est, clamp_db=100.0):
+    """SI-SDR / SI-SIR / SI-SAR with the best permutation as the reference's compute_metrics obtains them
+    (evaluate.py:103-111: fast_bss_eval.si_bss_eval_sources(ref, est, zero_mean=False, compute_permutation=True,
+    clamp_db=100)).  fast_bss_eval is a third-party package (environment.yaml:32, unpinned) that is NOT under
+    /root/reference and not installed here: PARITY UNPINNED for this function.  It restates the package's published
+    algorithm (Scheibler, "SDR - medium rare with fast computations", ICASSP 2022, scale-invariant case): with
+    unit-norm references r_i and estimates e_j (time domain, float64),
+        c_ij  = <r_i, e_j>^2                                  coherence of estimate j with reference i
+        p_j   = |projection of e_j on span{r_1..r_S}|^2        (normal equations  R a = <r, e_j>,  R = r r^T)
+        SI-SDR_ij = c_ij / (1 - c_ij),  SI-SIR_ij = c_ij / (p_j - c_ij),  SI-SAR_j = p_j / (1 - p_j)
+    each mapped to dB through a coherence clamped to [eps', 1 - eps'], eps' = e / (1 + e), e = 10^(-clamp_db / 10)
+    (so every figure lies in [-clamp_db, clamp_db]); the permutation maximises the mean SI-SDR.
+    ref, est: [B,S,T] arrays.  Returns (sdr, sir, sar [B,S] at the best permutation, perm [B,S]: est[:, perm] ~ ref)."""
+    import itertools
+    r = np.asarray(ref, dtype=np.float64)
+    e = np.asarray(est, dtype=np.float64)
+    B, S, _ = r.shape
+    tiny = np.finfo(np.float64).tiny
+    rn = r / np.maximum(np.linalg.norm(r, axis=-1, keepdims=True), tiny)
+    en = e / np.maximum(np.linalg.norm(e, axis=-1, keepdims=True), tiny)
+    eps = 10.0 ** (-clamp_db / 10.0)
+    eps = eps / (1.0 + eps)
+
+    def to_db(coh):  # coherence -> ratio in dB (10 log10(coh / (1 - coh))), clamped
+        coh = np.clip(coh, eps, 1.0 - eps)
+        return 10.0 * np.log10(coh / (1.0 - coh))
+
+    sdr = np.zeros((B, S, S)); sir = np.zeros((B, S, S)); sar = np.zeros((B, S, S))
+    for b in range(B):
+        xc = rn[b] @ en[b].T                      # [ref i, est j]
+        R = rn[b] @ rn[b].T
+        a = np.linalg.lstsq(R, xc, rcond=None)[0]  # projection coefficients (pseudo-inverse: silent / equal refs)
+        p = np.einsum("ij,ij->j", xc, a)          # |proj e_j|^2
+        c = xc ** 2
+        sdr[b] = to_db(c)
+        sir[b] = to_db(c / np.maximum(p[None, :], tiny))
+        sar[b] = to_db(p)[None, :].repeat(S, axis=0)
+    perms = list(itertools.permutations(range(S)))
+    out = [np.zeros((B, S)) for _ in range(3)]
+    best = np.zeros((B, S), dtype=np.int64)
+    for b in range(B):
+        k = int(np.argmax([np.mean([sdr[b, i, q[i]] for i in range(S)]) for q in perms]))
+        best[b] = perms[k]
+        for i in range(S):
+            j = perms[k][i]
+            out[0][b, i], out[1][b, i], out[2][b, i] = sdr[b, i, j], sir[b, i, j], sar[b, i, j]
+    return out[0], out[1], out[2], best
 
 
 def normalize_batch(mix):

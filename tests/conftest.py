@@ -24,3 +24,10 @@ def golden():
     with open(os.path.join(GOLDEN_DIR, "golden_meta.json")) as f:
         meta = json.load(f)
     return data, meta
+
+
+@pytest.fixture(scope="session")
+def golden2():
+    """round-2 vectors (tests/golden/gen_golden_r2.py): SDE surface, nf = 128, three sources"""
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN_DIR, "golden_ref2.npz")))

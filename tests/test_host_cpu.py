@@ -148,14 +148,20 @@ def test_wsj0_mix_and_noisy_dataset_layouts(tmp_path):
     assert mix.shape == (1, 1200) and tgt.shape == (3, 1200)
     assert (mix - tgt.sum(0, keepdim=True)).abs().max() < 3e-4  # 16-bit quantisation
     assert len(datasets.WSJ0_mix(tmp_path, n_spkr=3, fs=16000, split="val", max_n_samples=1)) == 1
-    cut = datasets.WSJ0_mix(tmp_path, n_spkr=3, fs=16000, split="val", max_len_s=0.05)[0]
-    assert cut[0].shape == (1, 800) and cut[1].shape == (3, 800)
+    assert ds.num_samples(0) == 1200 and ds.num_samples(1) == 900  # from the wav headers alone
+    with pytest.raises(NotImplementedError):  # random training crops are not part of the inference path
+        datasets.WSJ0_mix(tmp_path, n_spkr=3, fs=16000, split="val", max_len_s=0.05)
+    with pytest.raises(ValueError):  # a corpus opened at the wrong rate must not be read silently
+        datasets.WSJ0_mix(tmp_path, n_spkr=3, fs=16000, split="val").__class__(
+            ds.mix_dir, ds.target_dirs, ds.file_list, 8000)[0]
     for bad in (dict(fs=44100), dict(n_spkr=4), dict(cut="mid"), dict(split="dev")):
         with pytest.raises(ValueError):
             datasets.WSJ0_mix(tmp_path, **{**dict(n_spkr=3, fs=16000, split="val"), **bad})
     mb, tb = datasets.max_collator([ds[0], ds[1]])
     assert mb.shape == (2, 1, 1200) and tb.shape == (2, 3, 1200)
     assert mb[1, 0, :150].abs().max() == 0 and mb[1, 0, 150] == ds[1][0][0, 0]  # centre padding
+    mr, tr_, lens_ = datasets.pad_batch([ds[0], ds[1]], side="right")               # the engine's mixed-length batches
+    assert lens_ == [1200, 900] and mr[1, 0, 0] == ds[1][0][0, 0] and mr[1, 0, 900:].abs().max() == 0
     for split in ("train", "test"):
         for d in ("noisy", "clean"):
             (tmp_path / "vb" / split / d).mkdir(parents=True)
@@ -166,8 +172,10 @@ def test_wsj0_mix_and_noisy_dataset_layouts(tmp_path):
     noisy_t, tgt_t = datasets.NoisyDataset(tmp_path / "vb", split="test")[0]
     assert noisy_t.shape == (1, 700) and tgt_t.shape == (2, 700)
     assert torch.equal(tgt_t[0:1] + tgt_t[1:2], noisy_t) or (tgt_t.sum(0, keepdim=True) - noisy_t).abs().max() < 1e-6
-    noisy_tr, tgt_tr = datasets.NoisyDataset(tmp_path / "vb", audio_len=0.05, split="train")[0]
-    assert noisy_tr.shape == (1, 800) and tgt_tr.shape == (2, 800)   # shorter than audio_len: tiled x2 then cut
+    noisy_tr, tgt_tr = datasets.NoisyDataset(tmp_path / "vb", split="train")[0]      # whole utterances on every split
+    assert noisy_tr.shape == (1, 700) and tgt_tr.shape == (2, 700)
+    with pytest.raises(NotImplementedError):
+        datasets.NoisyDataset(tmp_path / "vb", augmentation=True)
     with pytest.raises(ValueError):
         datasets.NoisyDataset(tmp_path / "vb", split="val")
 

@@ -201,3 +201,98 @@ def test_remaining_sampler_surface(golden):
     assert rel_rms(a.numpy(), g["g12_sep_em_ald_log"]) < 1e-4
     b, _ = O.pc_sampler(p, cfg, mix_norm, draws, N=N, corrector_steps=cs, snr=0.5, eps=0.03, corrector="langevin")
     assert rel_rms(b.numpy(), g["g12_sep_rd_langevin"]) < 1e-4
+
+
+def test_sde_object_surface(golden, golden2):
+    """sde / marginal_prob / mult_std / discretize / reverse().discretize of MixSDE and PriorMixSDE
+    (sdes/sdes.py:93-173,275-328,451-537) against the reference's own outputs."""
+    g, g2 = golden[0], golden2
+    cfg = O.default_config(16, 2)
+    p = weights(cfg, 7)
+    B, S, T, N = 2, 2, 4000, 3
+    mix_norm = torch.from_numpy(g["g10_mix_norm"])
+    x0 = torch.from_numpy(synth.synth_noise("g9.x0", (B, S, T))) * 0.5
+    tv = torch.tensor([0.8, 0.2])
+    sc = O.score_forward(p, cfg, x0, tv, mix_norm)
+    for tag, smix in (("mix", None), ("pmix", O.sigma_mix(mix_norm, 510)[:, 0])):
+        drift, diff = O.sde_coefficients(cfg, x0, tv, smix)
+        assert rel_rms(drift.numpy(), g2[f"g13_{tag}_drift"]) < 1e-6 and rel_rms(diff.numpy(), g2[f"g13_{tag}_diffusion"]) < 1e-6
+        assert diff.shape == g2[f"g13_{tag}_diffusion"].shape
+        assert rel_rms(O.sde_mean(cfg, x0, tv).numpy(), g2[f"g13_{tag}_mean"]) < 1e-6
+        std = O.sde_std(cfg, tv, S, smix)
+        assert std.shape == g2[f"g13_{tag}_std"].shape and rel_rms(std.numpy(), g2[f"g13_{tag}_std"]) < 1e-6
+        assert rel_rms(O.sde_mult_std(std, x0).numpy(), g2[f"g13_{tag}_mult_std"]) < 1e-6
+        f, G = O.sde_discretize(cfg, x0, tv, N, smix)
+        assert rel_rms(f.numpy(), g2[f"g13_{tag}_f"]) < 1e-6 and rel_rms(G.numpy(), g2[f"g13_{tag}_G"]) < 1e-6
+        rf, rG = O.rsde_discretize(cfg, x0, tv, sc, N, smix)
+        assert rel_rms(rf.numpy(), g2[f"g13_{tag}_rev_f"]) < 2e-5 and rel_rms(rG.numpy(), g2[f"g13_{tag}_rev_G"]) < 1e-6
+        dp = diff if diff.dim() == 3 else diff[:, None, None]
+        assert rel_rms((drift - dp ** 2 * sc).numpy(), g2[f"g13_{tag}_rsde_drift"]) < 2e-5
+
+
+def test_published_width_nf128(golden, golden2):
+    """nf = 128, spec_factor 0.15 (icassp-separation.yaml:14-18, nr.yaml): one score evaluation and the PriorMixSDE
+    sampler against the reference."""
+    g, g2 = golden[0], golden2
+    cfg = O.default_config(128, 2, spec_factor=0.15)
+    p = weights(cfg, 7)
+    S, T = 2, 4000
+    xt = torch.from_numpy(synth.synth_noise("g7.xt", (1, S, T))) * 0.5
+    mx = torch.from_numpy(synth.synth_noise("g7.mix", (1, 1, T))) * 0.5
+    assert rel_rms(O.score_forward(p, cfg, xt, torch.tensor([0.6]), mx).numpy(), g2["g14_score_nf128"]) < 2e-5
+    mix_norm = torch.from_numpy(g["g10_mix_norm"])[:1]
+    draws = [torch.from_numpy(synth.synth_noise(f"g14.z{i}", (1, S, T))) for i in range(5)]
+    sep, nfe = O.pc_sampler(p, cfg, mix_norm, draws, N=2, corrector_steps=1, snr=0.5, eps=0.03, denoise=True,
+                            priormix_avg_len=510)
+    assert nfe == 4 and rel_rms(sep.numpy(), g2["g14_priormix_sep_nf128"]) < 1e-4
+
+
+def test_three_source_updates(golden, golden2):
+    """S = 3: std matrix, ald2 corrector and reverse-diffusion predictor updates against the reference (its
+    MixSDE.prior_sampling is undefined for S = 3 — quirk Q2 — so the full 3-source sampler has no reference vector)."""
+    g, g2 = golden[0], golden2
+    cfg = O.default_config(16, 3)
+    p = weights(cfg, 7)
+    B, T, N = 2, 4000, 3
+    mix_norm = torch.from_numpy(g["g10_mix_norm"])
+    x0 = torch.from_numpy(synth.synth_noise("g15.x0", (B, 3, T))) * 0.5
+    z = [torch.from_numpy(synth.synth_noise(f"g15.z{i}", (B, 3, T))) for i in range(2)]
+    tv = torch.tensor([0.8, 0.2])
+    assert rel_rms(O.mix_std(cfg, tv, 3).numpy(), g2["g15_std"]) < 1e-6
+    sc = O.score_forward(p, cfg, x0, tv, mix_norm)
+    xc, xcm = O.corrector_ald2(cfg, x0, tv, sc, z[0], 0.5)
+    xp, xpm = O.predictor_reverse_diffusion(cfg, x0, tv, sc, z[1], N)
+    for a, k in ((xc, "g15_corr_x"), (xcm, "g15_corr_mean"), (xp, "g15_pred_x"), (xpm, "g15_pred_mean")):
+        assert rel_rms(a.numpy(), g2[k]) < 2e-5, k
+
+
+def test_separation_metrics_restatement():
+    """oracle.si_bss_eval_sources (parity unpinned: fast_bss_eval is absent) against closed forms and its own
+    definitions in the time domain, incl. the degenerate cases."""
+    rng = np.random.default_rng(3)
+    T = 8000
+    r = rng.standard_normal((1, 3, T))
+    # estimates = permuted references + orthogonal noise of relative power 1e-2 -> SI-SDR = 20 dB each
+    n = rng.standard_normal((1, 3, T))
+    for k in range(3):
+        for j in range(3):
+            n[0, k] -= (n[0, k] @ r[0, j]) / (r[0, j] @ r[0, j]) * r[0, j]
+        n[0, k] *= 0.1 * np.linalg.norm(r[0, k]) / np.linalg.norm(n[0, k])
+    # (the references are only approximately orthogonal to each other: the projection on r_k is taken exactly)
+    est = (r + n)[:, [2, 0, 1]]
+    sdr, sir, sar, perm = O.si_bss_eval_sources(r, est)
+    assert perm.tolist() == [[1, 2, 0]]
+    assert np.allclose(sar, 20.0, atol=0.05) and (sir > 25).all() and (np.abs(sdr - 20.0) < 0.3).all()
+    # identical estimate: everything saturates at +clamp_db
+    sdr, sir, sar, _ = O.si_bss_eval_sources(r, r.copy(), clamp_db=100.0)
+    assert np.allclose(sdr, 100.0) and np.allclose(sar, 100.0)
+    # a silent reference / a silent estimate: clamped at -clamp_db, no NaN
+    r0 = r.copy(); r0[0, 1] = 0.0
+    out = O.si_bss_eval_sources(r0, est)
+    assert all(np.isfinite(v).all() for v in out[:3]) and out[0].min() == -100.0
+    e0 = est.copy(); e0[0, 0] = 0.0
+    out = O.si_bss_eval_sources(r, e0)
+    assert all(np.isfinite(v).all() for v in out[:3]) and out[0].min() == -100.0
+    # two identical references (singular Gram matrix): finite
+    r2 = r.copy(); r2[0, 2] = r2[0, 1]
+    assert all(np.isfinite(v).all() for v in O.si_bss_eval_sources(r2, est)[:3])
