@@ -13,6 +13,11 @@ scaling) and the only collective is the result gather.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+--scaling strong: a FIXED set of --utterances synthetic mixtures of different lengths (3 .. 6 s) is split over the
+ranks (length-balanced deal, evaluate_mp.py:495-518 semantics with the imbalance included), every rank separates its
+share in width-bucketed batches, and ONE gather at the end collects the per-utterance results; a step = one pass over
+the whole set; the line carries per-rank busy times and their imbalance.
+
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     — the dominant kernel (3x3 implicit-GEMM conv on MFMA, 8x32 pixel x 64 cout tile):
                  algorithmic FLOPs of its launches / their summed durations, measured with HIP events
@@ -20,6 +25,11 @@ Prints ONE JSON line (rank 0).  Extra objects:
                  timed region (diffsep_engine_profile_begin/end).
   cpu_baseline — the CPU oracle (torch fp32, this repo's restatement of the reference path) timed on
                  the host cores for a bounded number of network evaluations and scaled to utt/s.
+  fp32_parity_mode — the same step on the fp32 engine (the mode that meets the 1e-3 RMS parity bar), timed after the
+                 main region: utt/s and the roofline fraction of its dominant kernel (fp32 MFMA peak).
+  hybrid       — bf16 for the first N - K reverse steps, the fp32 engine for the last K (pl_model.HYBRID_TAIL_STEPS):
+                 utt/s, and SI-SDR of its output against the fp32 engine's output on the same seeds (the quality the
+                 throughput mode gives up).
 """
 import argparse
 import json
@@ -76,6 +86,92 @@ def cpu_baseline(nf, T, budget_s=12.0, max_nfe=12):
     return dt, n
 
 
+def run_strong(args, engs, ops, on_stream, sync, fence, dist, world, rank, dev, sde, dry):
+    """--scaling strong: a fixed set of utterances of different lengths split over the ranks; a step = one pass over
+    the whole set; one gather of the separated waveforms at the end of a step."""
+    from diffsep_amd import synth
+    from diffsep_amd.dist_utils import rank_indices
+    from diffsep_amd.evaluate import plan_batches
+    n, S, K = args.utterances, 2, len(engs)
+    lengths = [24000 + (i * 7919) % 24001 for i in range(n)]          # 3 .. 6 s at 8 kHz
+    mine = rank_indices(n, world, rank, lengths, balance=True)          # sorted by length, dealt round-robin
+    e0 = engs[0]
+    batches = plan_batches(mine, lengths, e0.padded_frames, args.batch)
+    staged = []
+    for g in batches:                                                    # resident in HBM before timing
+        Tb = e0.bucket_length(e0.padded_frames(max(lengths[i] for i in g)))
+        mix = torch.zeros((len(g), 1, Tb))
+        for b, i in enumerate(g):
+            mix[b, :, :lengths[i]] = torch.from_numpy(synth.synth_mixture(i, T=lengths[i])[0])
+        staged.append((g, [lengths[i] for i in g], mix.to(dev)))
+    if batches:
+        for e in engs:
+            e.reserve(max(len(g) for g in batches), max(m.shape[-1] for _, _, m in staged))
+    nloc_max = (n + world - 1) // world
+    Tmax = e0.bucket_length(e0.padded_frames(max(lengths)))
+    block = torch.zeros((nloc_max, S, Tmax), dtype=torch.float32, device=dev)
+    blocks = [torch.empty_like(block) for _ in range(world)] if rank == 0 and world > 1 else None
+    keep = [None] * K
+    nfe = 0
+
+    def one_pass(p):
+        nonlocal nfe
+        row = 0
+        for j, (g, lens, mix) in enumerate(staged):
+            w = j % K
+            with on_stream(w):
+                mixn = torch.zeros_like(mix)
+                for b, L in enumerate(lens):
+                    mixn[b, :, :L] = ops.normalize_batch(mix[b:b + 1, :, :L])[0][0]
+                sep, nfe = engs[w].pc_sample(mixn, sde, N=args.N, corrector_steps=args.corrector_steps, snr=0.5, eps=0.03,
+                                             denoise=True, lengths=lens, seeds=[10_000 * p + i for i in g])
+                for b, L in enumerate(lens):
+                    block[row + b, :, :L] = ops.scale_output(mix[b:b + 1, :, :L], sep[b:b + 1, :, :L])[0]
+            keep[w] = (mixn, sep)
+            row += len(g)
+        sync()
+
+    for p in range(max(1, args.warmup)):   # plans + graph captures for every (B, W) of this rank's share
+        one_pass(-1 - p)
+    fence()
+    busy = 0.0
+    t0 = time.perf_counter()
+    for p in range(args.steps):
+        tb = time.perf_counter()
+        one_pass(p)
+        busy += time.perf_counter() - tb
+        if world > 1:
+            dist.gather(block, blocks, dst=0)   # ONE collective per pass (RCCL over xGMI)
+    fence()
+    elapsed = time.perf_counter() - t0
+    finite = bool(torch.isfinite(block).all())
+    busy_all = [busy]
+    if world > 1:
+        tt = torch.tensor([elapsed, busy], dtype=torch.float64, device=dev)
+        parts = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(parts, tt)
+        elapsed = max(float(q[0]) for q in parts)
+        busy_all = [float(q[1]) for q in parts]
+    if rank == 0:
+        value = n * args.steps / elapsed
+        secs = sum(lengths) / 8000.0
+        print(json.dumps({
+            "metric": "separated utterances/sec (3-6 s, 8 kHz, 2-spk, N=30 PC steps), fixed set split over the GPUs",
+            "value": round(value, 4), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs[2]-shaped: %d utterances of 3-6 s @ 8 kHz (mean %.2f s), N=%d + %d ald2 corrector "
+                                   "step, NCSN++ nf=%d random-init; length-balanced deal to the ranks, width-bucketed batches "
+                                   "of <= %d, %d batches in flight per GPU, one gather per pass"
+                                   % (n, secs / n, args.N, args.corrector_steps, args.nf, args.batch, K),
+                       "utterances": n, "batch_per_gpu": args.batch, "N": args.N, "corrector_steps": args.corrector_steps,
+                       "nf": args.nf, "sharding": "utterances/%d (length-balanced)" % world, "batches_in_flight": K},
+            "realtime_factor": round(secs * args.steps / elapsed, 2),
+            "rank_busy_s_per_step": [round(b / args.steps, 4) for b in busy_all],
+            "imbalance_max_over_mean": round(max(busy_all) / (sum(busy_all) / len(busy_all)), 4),
+            "engine_calls_rank0_per_step": len(staged), "nfe_per_call": int(nfe), "finite": finite}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,6 +186,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-extra-modes", action="store_true", help="skip the fp32_parity_mode / hybrid sections")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--utterances", type=int, default=128, help="--scaling strong: size of the fixed utterance set")
     ap.add_argument("--in-flight", type=int, default=4,
                     help="batches in flight per GPU: step i runs on engine / HIP stream i %% K, so consecutive steps overlap "
                          "(the ~110 small launches of one batch's NFE leave the chip mostly idle; another batch's large "
@@ -131,6 +230,9 @@ def main():
         class _Eng:  # records nothing, computes nothing
             def pc_sample(self, mix_norm, sde, N, corrector_steps, **kw):
                 return torch.zeros((mix_norm.shape[0], S, mix_norm.shape[-1])), N * (corrector_steps + 1)
+            def padded_frames(self, T): return 64 * ((1 + (T + 382) // 128 + 63) // 64)
+            def bucket_length(self, W): return 128 * W - 383
+            def reserve(self, B, T): pass
             def profile_begin(self): pass
             def profile_end(self): return {"conv3x3_8x32xN64": (1.0, 1.0, 1, 1.0)}
             def device_bytes(self): return 0
@@ -139,6 +241,7 @@ def main():
         ops = types.SimpleNamespace(normalize_batch=lambda m: (m, None, None), scale_output=lambda m, s: s)
         on_stream = lambda w: contextlib.nullcontext()
         sync = lambda: None
+        gstream = None
     else:
         from diffsep_amd import _lib, ops
         from diffsep_amd.engine import Engine, pack_state_dict, param_table
@@ -154,7 +257,23 @@ def main():
         streams = [torch.cuda.Stream() for _ in range(K)]
         on_stream = lambda w: torch.cuda.stream(streams[w])
         sync = torch.cuda.synchronize
+        # the result gather runs on ONE dedicated stream per rank (after an event of the producing stream): every
+        # rank issues its collectives in step order on a single stream, whatever the number of batches in flight
+        gstream = torch.cuda.Stream() if world > 1 else None
     sde = dict(ndim=S, d_lambda=2.0, sigma_min=0.05, sigma_max=0.5)
+
+    def fence():
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+
+    if args.scaling == "strong":
+        run_strong(args, engs, ops, on_stream, sync, fence, dist, world, rank, dev, sde, dry)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     mix = torch.from_numpy(synth.synth_batch(B, T=T, start=rank * B)[0]).to(dev)  # resident before timing
     eng = engs[0]
     # one set of gather buffers per batch in flight (rank 0)
@@ -170,15 +289,16 @@ def main():
                                          eps=0.03, denoise=True, seed=1000 + i if seed is None else seed)
             out = ops.scale_output(mix, sep)
             if world > 1 and collect:
-                dist.gather(out, gathered[w], dst=0)  # RCCL over xGMI: the only collective on the path
+                if gstream is None:
+                    dist.gather(out, gathered[w], dst=0)
+                else:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    gstream.wait_event(ev)
+                    with torch.cuda.stream(gstream):
+                        dist.gather(out, gathered[w], dst=0)  # RCCL over xGMI: the only collective on the path
         keep[w] = (mix_norm, sep, out)
         return out, nfe
-
-    def fence():
-        sync()
-        if world > 1:
-            dist.barrier()
-        sync()
 
     # engine preparation (not a step of the benchmark): workspace plan, then hipGraph capture, for every engine
     for w in range(K):
@@ -219,14 +339,18 @@ def main():
         tot_ms = sum(v[1] for v in prof.values())
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
-        traffic = None
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_conv3x3.json")
         if os.path.exists(pmc):
             try:
                 tkey = {"conv3x3_8x32xN64": f"hbm_bytes_per_launch_{args.dtype}_B{B}",
                         "conv3x3_ws_64to64": f"hbm_bytes_per_launch_ws_{args.dtype}_B{B}"}.get(dom)
-                traffic = json.load(open(pmc)).get(tkey) if tkey else None
+                pj = json.load(open(pmc))
+                traffic = pj.get(tkey) if tkey else None
                 traffic = round(traffic) if traffic else None
+                traffic_source = ("profiles/pmc_conv3x3.json: rocprofv3 --pmc passes of tools/pmc_bench.sh (FETCH_SIZE and "
+                                  "WRITE_SIZE in separate runs, guide correction 2*FETCH + WRITE), measured at commit %s — "
+                                  "NOT collected in this run" % pj.get("commit", "unrecorded (round 1)")) if traffic else None
             except Exception:
                 traffic = None
         # the bound is whichever floor of an average launch is higher: HBM at 8 TB/s or dense MFMA at `peak`
@@ -240,13 +364,76 @@ def main():
         else:
             roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4)}
-        roof.update({"traffic": traffic, "launches": n, "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
+        roof.update({"traffic": traffic, "traffic_source": traffic_source, "launches": n, "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
                 "flops_per_launch": fl / max(n, 1), "algorithmic_bytes_per_launch": by / max(n, 1),
                 "hbm_floor_us": round(hbm_floor_us, 2), "mfma_floor_us": round(mfma_floor_us, 2),
                 "achieved_tflops": round(ach, 2),
                 "per_kernel_ms": {k: round(v[1], 2) for k, v in prof.items() if v[2]},
                 "all_mfma_kernels_ms": round(tot_ms, 2),
                 "all_mfma_kernels_tflops": round(sum(v[0] for v in prof.values()) / (tot_ms * 1e-3) / 1e12, 2)})
+
+    extra = {}
+    if world == 1 and not dry and not args.no_extra_modes and args.dtype == "bf16":
+        # ---- the other two precision modes of the same step, on the driver's clock (after the main timed region)
+        from diffsep_amd.pl_model import HYBRID_TAIL_STEPS
+        cfg32 = _lib.model_config(nf=args.nf, num_sources=S, dtype=_lib.F32)
+        K2 = min(K, 2)
+        e32 = [Engine(cfg32, blob) for _ in range(K2)]
+        mix_norm0 = ops.normalize_batch(mix)[0]
+
+        def run_mode(kind, i, w):
+            with on_stream(w):
+                mn, _, _ = ops.normalize_batch(mix)
+                if kind == "f32":
+                    sep, _ = e32[w].pc_sample(mn, sde, N=args.N, corrector_steps=args.corrector_steps, snr=0.5, eps=0.03,
+                                              denoise=True, seed=2000 + i)
+                else:
+                    sep, _ = engs[w].pc_sample(mn, sde, N=args.N, corrector_steps=args.corrector_steps, snr=0.5, eps=0.03,
+                                               denoise=True, seed=2000 + i, tail=e32[w], tail_steps=HYBRID_TAIL_STEPS)
+                out = ops.scale_output(mix, sep)
+            keep[w] = (mn, sep, out)
+            return out
+
+        for kind, nstep in (("f32", 4), ("hybrid", 6)):
+            for w in range(K2):           # plans + graph capture
+                run_mode(kind, w, w)
+                run_mode(kind, w, w)
+            sync()
+            t2 = time.perf_counter()
+            for i in range(nstep):
+                run_mode(kind, i, i % K2)
+            sync()
+            extra[kind] = B * nstep / (time.perf_counter() - t2)
+        # quality of the throughput modes against the fp32 engine's output, same seeds (SI-SDR of the separated waveforms)
+        def si_sdr_db(est, ref):
+            est, ref = est.double(), ref.double()
+            a = (est * ref).sum(-1, keepdim=True) / (ref * ref).sum(-1, keepdim=True)
+            return 10 * torch.log10(((a * ref) ** 2).sum(-1) / ((est - a * ref) ** 2).sum(-1))
+        kw = dict(N=args.N, corrector_steps=args.corrector_steps, snr=0.5, eps=0.03, denoise=True, seed=4242)
+        o32 = e32[0].pc_sample(mix_norm0, sde, **kw)[0]
+        ohy = engs[0].pc_sample(mix_norm0, sde, tail=e32[0], tail_steps=HYBRID_TAIL_STEPS, **kw)[0]
+        o16 = engs[0].pc_sample(mix_norm0, sde, **kw)[0]
+        q_hy, q_16 = si_sdr_db(ohy, o32), si_sdr_db(o16, o32)
+        e32[0].profile_begin()
+        run_mode("f32", 10_000, 0)
+        p32 = e32[0].profile_end()
+        d32 = max(p32, key=lambda k: p32[k][1])
+        fl32, ms32, n32, _ = p32[d32]
+        extra_json = {
+            "fp32_parity_mode": {"utt_per_s": round(extra["f32"], 3), "batches_in_flight": K2,
+                                 "kernel": KERNEL_NAMES.get(d32, d32) % {"dt": "f32"},
+                                 "frac": round(fl32 / (ms32 * 1e-3) / 1e12 / PEAK_TFLOPS["f32"], 4) if ms32 > 0 else None,
+                                 "bound": "mfma", "peak_tflops": PEAK_TFLOPS["f32"],
+                                 "note": "the mode that meets the 1e-3 RMS parity bar (tests/test_engine_gpu.py)"},
+            "hybrid": {"K": HYBRID_TAIL_STEPS, "utt_per_s": round(extra["hybrid"], 3), "batches_in_flight": K2,
+                       "si_sdr_db": round(float(q_hy.mean()), 2), "si_sdr_db_min": round(float(q_hy.min()), 2),
+                       "bf16_only_si_sdr_db": round(float(q_16.mean()), 2),
+                       "bf16_only_si_sdr_db_min": round(float(q_16.min()), 2),
+                       "note": "SI-SDR of the separated waveforms against the fp32 engine's output on the same seeds"}}
+        for e in e32:
+            e.close()
+    else:
+        extra_json = {}
 
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -278,6 +465,7 @@ def main():
         }
         if roof is not None:
             res["roofline"] = roof
+        res.update(extra_json)
         if not args.no_cpu_baseline and world == 1 and not dry:
             t_nfe, n = cpu_baseline(args.nf, T)
             res["cpu_baseline"] = {"value": round(1.0 / (t_nfe * nfe), 5), "unit": "utterances/s",

@@ -121,642 +121,7 @@ __device__ inline uint4 gn8(const uint4& u, const float* sc, const float* sh) {
   return o;
 }
 
-template <int MODE>  // 1: GN affine (identity tables when the input is raw), 2: GN affine + SiLU
-__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsK p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sW = smem;
-  char* sA = smem + LDS_W;
-  float* sTab = reinterpret_cast<float*>(smem + LDS_W + 2 * LDS_A);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int l32 = lane & 31, h = lane >> 5;
-  const int b = blockIdx.x / p.G, part = blockIdx.x % p.G;
-  const int t0 = (int)((long)part * p.tiles_per_img / p.G);
-  const int nt = (int)((long)(part + 1) * p.tiles_per_img / p.G) - t0;
-  // the two wave groups take alternating tiles of the block's range
-#ifdef WS_GROUP_INTERLEAVED
-  const int group = wave & 1, gw = wave >> 1, gtid = (gw << 6) | lane;
-#else
-  const int group = wave >> 2, gw = wave & 3, gtid = tid & 255;
-#endif
-  const int ntg = (nt - group + 1) >> 1;   // tiles of this group
-  const int Qg = 2 * ntg;                  // chunks this group walks through
-  const int steps = 2 * ((nt + 1) >> 1);   // phase pairs both groups execute (barrier counts must match)
-
-  // ---- one-time: weights [cout][tap][cin] -> LDS [tap][cout] rows, per-image tables
-  {
-    const __amdgpu_buffer_rsrc_t rw = rsrc(p.w, 9u * C * C * 2u);
-    uint4 wv[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) wv[k] = ld16(rw, (unsigned)(tid + 512 * k) * 16u, 0);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int v = tid + 512 * k;
-      int dst;
-      if (p.w_chunked) {  // [chunk][tap][cout][32 ch]
-        const int row = v >> 2, piece = v & 3;
-        const int co = row & (C - 1), tap = (row >> 6) % 9, chunk = row / (9 * C);
-        dst = (tap * C + co) * WROW + chunk * (KC * 2) + piece * 16;
-      } else {            // [cout][tap][64 ch]
-        const int row = v >> 3, piece = v & 7;
-        const int co = row / 9, tap = row - co * 9;
-        dst = (tap * C + co) * WROW + piece * 16;
-      }
-      *reinterpret_cast<uint4*>(sW + dst) = wv[k];
-    }
-    if (tid < C) {
-      float sc = 1.f, sh = 0.f;
-      if (p.gn_acc) {  // GroupNorm statistics straight from the producer's channel-sum accumulators
-        const int cpg = C / p.gn_groups, g0 = (tid / cpg) * cpg;
-        long long ssum = 0, ssq = 0;
-        for (int j = 0; j < cpg; ++j) {
-          ssum += p.gn_acc[((long)b * C + g0 + j) * 2];
-          ssq += p.gn_acc[((long)b * C + g0 + j) * 2 + 1];
-        }
-        const double mean = (double)ssum * (1.0 / DS_STAT_SUM_SCALE) * (double)p.gn_inv_count;
-        double var = (double)ssq * (1.0 / DS_STAT_SQ_SCALE) * (double)p.gn_inv_count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        sc = (float)(1.0 / sqrt(var + (double)p.gn_eps)) * (p.gn_gamma ? p.gn_gamma[tid] : 1.f);
-        sh = (p.gn_beta ? p.gn_beta[tid] : 0.f) - (float)mean * sc;
-      } else if (p.gn_scale) {
-        sc = p.gn_scale[(long)b * C + tid];
-        sh = p.gn_shift[(long)b * C + tid];
-      }
-      sTab[tid] = sc;
-      sTab[C + tid] = sh;
-      sTab[2 * C + tid] =
-          ((p.bias ? p.bias[tid] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + tid] : 0.f)) * p.out_scale;
-    }
-  }
-
-  // ---- staging descriptors: vector v = gtid + 256 k -> halo pixel v / 4, 16-byte slot v % 4 (= tid % 4).
-  // Kept in LDS (one 4-byte word per vector: byte offset relative to the tile origin, multiple of 16, with the
-  // border flags in the low 4 bits) so that they do not occupy 18 registers for the whole kernel.
-  const int slot = tid & 3;
-  int* sDesc = reinterpret_cast<int*>(smem + LDS_MAIN + 8 * LDS_E);
-  if (group == 0) {
-#pragma unroll
-    for (int k = 0; k < NA; ++k) {
-      const int v = gtid + 256 * k;
-      const int pix = v >> 2, hy = pix / HW_, hx = pix - hy * HW_;
-      const int rel = (((hy - 1) * p.W + (hx - 1)) * p.ldx + slot * 8) * 2;
-      const int flg = (hy == 0 ? 1 : 0) | (hy == HH_ - 1 ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx == HW_ - 1 ? 8 : 0);
-      sDesc[k * 256 + gtid] = rel | flg;
-    }
-  }
-  const int ldo0 = (gtid >> 2) * AROW + slot * 16;  // LDS offset of vector 0; vector k is 64 pixels further
-  const bool in_last = gtid + 256 * (NA - 1) < HP * 4;
-  const __amdgpu_buffer_rsrc_t rx = rsrc(p.x + (long)b * p.x_bs, (unsigned)(p.H * p.W) * p.ldx * 2u);
-  const __amdgpu_buffer_rsrc_t ry = rsrc(p.y + (long)b * p.y_bs, (unsigned)(p.H * p.W) * p.ldy * 2u);
-  const __amdgpu_buffer_rsrc_t rr =
-      rsrc(p.res ? p.res + (long)b * p.res_bs : p.y, p.res ? (unsigned)(p.H * p.W) * p.ldr * 2u : 0u);
-  char* sAg = sA + group * LDS_A;  // the group's staging slot
-
-  auto tile_of = [&](int q) { return t0 + group + 2 * (q >> 1); };  // chunk q of the group -> tile index
-  uint4 pa[NA];
-  bool pval[NA];
-  auto issue = [&](int q) {  // global loads of the group's chunk q into registers
-    const int t = tile_of(q);
-    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
-    const int y0 = ty * TH, x0 = tx * TW;
-    const unsigned edge = (y0 == 0 ? 1u : 0u) | (y0 + TH == p.H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) |
-                          (x0 + TW == p.W ? 8u : 0u);
-    const int tbase = (y0 * p.W + x0) * p.ldx * 2;
-#pragma unroll
-    for (int k = 0; k < NA; ++k) {
-      const int d = sDesc[k * 256 + gtid];
-      pval[k] = (k < NA - 1 || in_last) && !((unsigned)d & edge);
-#ifdef ABL_NOLOAD
-      pa[k] = make_uint4(tbase, tbase, tbase, tbase);
-#else
-      pa[k] = ld16(rx, pval[k] ? (unsigned)((d & ~15) + tbase) : OOB, (unsigned)(q & 1) * (KC * 2));
-#endif
-    }
-  };
-  float gsc[8], gsh[8];  // GN scale / shift of this thread's 8 channels of the chunk in flight
-  auto act_tab = [&](int c) {
-    const float4* ts = reinterpret_cast<const float4*>(sTab + c * KC + slot * 8);
-    const float4* th = reinterpret_cast<const float4*>(sTab + C + c * KC + slot * 8);
-    const float4 s0 = ts[0], s1 = ts[1], h0 = th[0], h1 = th[1];
-    gsc[0] = s0.x; gsc[1] = s0.y; gsc[2] = s0.z; gsc[3] = s0.w; gsc[4] = s1.x; gsc[5] = s1.y; gsc[6] = s1.z; gsc[7] = s1.w;
-    gsh[0] = h0.x; gsh[1] = h0.y; gsh[2] = h0.z; gsh[3] = h0.w; gsh[4] = h1.x; gsh[5] = h1.y; gsh[6] = h1.z; gsh[7] = h1.w;
-  };
-  auto act_one = [&](int k) {  // zero padding stays zero: the activation applies to inside pixels only
-#ifdef ABL_NOACT
-    return;
-#endif
-    uint4 r = gn8<MODE == 2>(pa[k], gsc, gsh);
-    asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));  // unconditional: no branch inside the MFMA loop
-    pa[k].x = pval[k] ? r.x : pa[k].x;
-    pa[k].y = pval[k] ? r.y : pa[k].y;
-    pa[k].z = pval[k] ? r.z : pa[k].z;
-    pa[k].w = pval[k] ? r.w : pa[k].w;
-  };
-  auto write = [&]() {
-#ifdef ABL_NOLDSW
-    return;
-#endif
-#pragma unroll
-    for (int k = 0; k < NA; ++k)
-      if (k < NA - 1 || in_last) *reinterpret_cast<uint4*>(sAg + ldo0 + k * 64 * AROW) = pa[k];
-  };
-
-  f32x16 acc[2][2];  // [pixel row of the wave][cout half]
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float ssum[8], ssq[8];  // statistics of the 8 couts this lane writes (row-oriented epilogue role)
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
-
-  // fragment addresses: the wave owns output rows 2 gw, 2 gw + 1 of its group's tile; lane = pixel l32 (B
-  // operand) / cout l32 (A operand)
-  const int aoff = ((2 * gw) * HW_ + l32) * AROW + h * 16;
-  const int woff = l32 * WROW + h * 16;
-  auto mma = [&](int c, auto NEXT_) {  // 72 MFMAs on the group's slot; activates the chunk in flight meanwhile
-    constexpr bool NEXT = decltype(NEXT_)::value;
-    if constexpr (NEXT) act_tab(c ^ 1);
-    const char* a = sAg + aoff;
-    const char* w = sW + woff + c * (KC * 2);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-#ifdef ABL_NOMFMA
-        continue;
-#endif
-        const int po = ((tap / 3) * HW_ + (tap % 3)) * AROW + kb * 32;
-        const bf16x8 p0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a + po));
-        const bf16x8 p1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a + po + HW_ * AROW));
-        const bf16x8 w0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(w + tap * C * WROW + kb * 32));
-        const bf16x8 w1 =
-            __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(w + (tap * C + 32) * WROW + kb * 32));
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, p0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p0, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, p1, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p1, acc[1][1], 0, 0, 0);
-        if constexpr (NEXT) {
-          const int s = tap * 2 + kb;
-          if (s >= 4 && s < 4 + 2 * NA && (s & 1) == 0) act_one((s - 4) >> 1);
-        }
-      }
-    }
-  };
-
-  // epilogue roles: lane = (pixel epx of an 8-pixel group, 8-cout group ecg)
-  char* sE = smem + LDS_MAIN + wave * LDS_E;
-  const int epx = lane >> 3, ecg = lane & 7;
-  const bool has_res = p.res != nullptr, has_stats = p.stats != nullptr;
-  const float osc = p.out_scale;
-  // All residual loads of a tile are issued before its first store: vmcnt retires in order and counts stores on
-  // gfx950, so a load issued between two stores could only be waited for together with the older store's
-  // round trip to L2.
-  uint4 rres[8];
-  auto issue_res = [&](int t) {
-    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
-    const unsigned o = (unsigned)((((ty * TH + 2 * gw) * p.W + tx * TW + epx) * p.ldr + ecg * 8) * 2);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-        rres[i * 4 + s4] = ld16(rr, o + (unsigned)((i * p.W + s4 * 8) * p.ldr * 2), 0);
-  };
-  // lane layout of the 32x32 result: column = pixel l32, rows (couts) = (r & 3) + 8 (r >> 2) + 4 h
-  auto epilogue = [&](int t) {
-    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
-    const unsigned o = (unsigned)((((ty * TH + 2 * gw) * p.W + tx * TW + epx) * p.ldy + ecg * 8) * 2);
-    float bz[8];  // (bias + temb bias) * out_scale of this lane's 8 couts
-    {
-      const float4 b0 = *reinterpret_cast<const float4*>(sTab + 2 * C + ecg * 8);
-      const float4 b1 = *reinterpret_cast<const float4*>(sTab + 2 * C + ecg * 8 + 4);
-      bz[0] = b0.x; bz[1] = b0.y; bz[2] = b0.z; bz[3] = b0.w; bz[4] = b1.x; bz[5] = b1.y; bz[6] = b1.z; bz[7] = b1.w;
-    }
-#ifdef ABL_NOEPI
-    if (acc[0][0][0] + acc[1][1][3] == 12345.678f) reinterpret_cast<float*>(p.y)[tid] = acc[0][1][1];
-    return;
-#endif
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        if ((l32 >> 3) == s4) {  // the 8 pixels of this pass hand over their 8 quads (all 64 couts)
-          char* dst = sE + (l32 & 7) * EROW + h * 16;
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-              *reinterpret_cast<float4*>(dst + (j * 32 + g * 8) * 4) = make_float4(
-                  acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        const float4 a0 = *reinterpret_cast<const float4*>(sE + epx * EROW + ecg * 32);
-        const float4 a1 = *reinterpret_cast<const float4*>(sE + epx * EROW + ecg * 32 + 16);
-        __builtin_amdgcn_wave_barrier();
-        float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], osc, bz[j]);
-        if (has_res) {
-          const uint4 u = rres[i * 4 + s4];
-          v[0] = fmaf(__uint_as_float(u.x << 16), osc, v[0]); v[1] = fmaf(__uint_as_float(u.x & 0xffff0000u), osc, v[1]);
-          v[2] = fmaf(__uint_as_float(u.y << 16), osc, v[2]); v[3] = fmaf(__uint_as_float(u.y & 0xffff0000u), osc, v[3]);
-          v[4] = fmaf(__uint_as_float(u.z << 16), osc, v[4]); v[5] = fmaf(__uint_as_float(u.z & 0xffff0000u), osc, v[5]);
-          v[6] = fmaf(__uint_as_float(u.w << 16), osc, v[6]); v[7] = fmaf(__uint_as_float(u.w & 0xffff0000u), osc, v[7]);
-        }
-        if (has_stats) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            ssum[j] += v[j];
-            ssq[j] = fmaf(v[j], v[j], ssq[j]);
-          }
-        }
-        u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                      pack_bf16x2(v[6], v[7])};
-        WS_STORE(ov, ry, o + (unsigned)((i * p.W + s4 * 8) * p.ldy * 2), 0, 0);
-      }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  };
-
-  // ---- pipeline.  Phase P1 = multiply the chunk in the group's slot; phase P2 = activate + stage the next chunk,
-  // fetch the one after, finish the tile.  Group 1 starts one barrier late, so P1 of one group runs beside P2 of
-  // the other.
-  WT_DECL
-  sync_lds();  // weights, tables and descriptors visible
-  if (Qg > 0) {
-    issue(0);
-    act_tab(0);
-#pragma unroll
-    for (int k = 0; k < NA; ++k) act_one(k);
-    write();
-    issue(1);
-  }
-  sync_lds();
-  if (group == 1) sync_lds();
-  WT_MARK(4)
-  for (int s = 0; s < steps; ++s) {
-    for (int c = 0; c < 2; ++c) {
-      const int q = 2 * s + c;
-      const bool live = q < Qg;
-      if (live) {
-        if (q + 1 < Qg) mma(c, std::true_type{});
-        else mma(c, std::false_type{});
-      }
-      WT_MARK(0)
-      sync_lds();
-      WT_MARK(1)
-      if (live) {
-        if (c == 1 && has_res) issue_res(tile_of(q));
-        WT_MARK(6)
-        if (q + 1 < Qg) {
-          WT_MARK(7)
-          write();
-          WT_MARK(8)
-          if (q + 2 < Qg) issue(q + 2);
-          WT_MARK(9)
-        }
-        if (c == 1) epilogue(tile_of(q));
-      }
-      WT_MARK(2)
-      sync_lds();
-      WT_MARK(3)
-    }
-  }
-  if (group == 0) sync_lds();
-
-  // ---- statistics: 64 threads (8 per wave) share a cout group; reduce them in fp64
-  if (has_stats) {  // (the loop above ends on a block barrier: LDS is free now)
-    float* red = reinterpret_cast<float*>(smem);
-    *reinterpret_cast<float4*>(red + tid * RED_ROW) = make_float4(ssum[0], ssum[1], ssum[2], ssum[3]);
-    *reinterpret_cast<float4*>(red + tid * RED_ROW + 4) = make_float4(ssum[4], ssum[5], ssum[6], ssum[7]);
-    *reinterpret_cast<float4*>(red + tid * RED_ROW + 8) = make_float4(ssq[0], ssq[1], ssq[2], ssq[3]);
-    *reinterpret_cast<float4*>(red + tid * RED_ROW + 12) = make_float4(ssq[4], ssq[5], ssq[6], ssq[7]);
-    __syncthreads();
-    if (tid < 128) {
-      const int co = tid >> 1, st = tid & 1;
-      const float* src = red + (co >> 3) * RED_ROW + st * 8 + (co & 7);
-      double a = 0.0;
-#pragma unroll 8
-      for (int i = 0; i < 64; ++i) a += (double)src[i * 8 * RED_ROW];
-      ds_stat_add(p.stats + ((long)b * C + co) * 2 + st, (long long)llrint(a * (st ? DS_STAT_SQ_SCALE : DS_STAT_SUM_SCALE)));
-    }
-  }
-  WT_MARK(5)
-  WT_FLUSH
-}
-
-// ---- variant D (DIFFSEP_CONV_WS=4): role-specialised waves.  Waves 0-3 only multiply (MFMA + LDS fragment reads)
-// and run the epilogue of their 2 rows x 64 couts; waves 4-7 only move data: global loads, GroupNorm affine + SiLU,
-// LDS writes of every chunk of every tile.  A matrix wave never blocks on a global load of the staging path.
-template <int MODE>  // 1: GN affine (identity tables when the input is raw), 2: GN affine + SiLU
-__global__ __launch_bounds__(512, 2) void conv3x3_ws3_kernel(WsK p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sW = smem;
-  char* sA = smem + LDS_W;
-  float* sTab = reinterpret_cast<float*>(smem + LDS_W + 2 * LDS_A);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int l32 = lane & 31, h = lane >> 5;
-  const int b = blockIdx.x / p.G, part = blockIdx.x % p.G;
-  const int t0 = (int)((long)part * p.tiles_per_img / p.G);
-  const int nt = (int)((long)(part + 1) * p.tiles_per_img / p.G) - t0;
-  // the two wave groups take alternating tiles of the block's range
-#ifdef WS_GROUP_INTERLEAVED
-  const int group = wave & 1, gw = wave >> 1, gtid = (gw << 6) | lane;
-#else
-  const int group = wave >> 2, gw = wave & 3, gtid = tid & 255;
-#endif
-  const int Qg = 2 * nt;  // chunks of the block (every tile goes through both roles)
-
-  // ---- one-time: weights [cout][tap][cin] -> LDS [tap][cout] rows, per-image tables
-  {
-    const __amdgpu_buffer_rsrc_t rw = rsrc(p.w, 9u * C * C * 2u);
-    uint4 wv[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) wv[k] = ld16(rw, (unsigned)(tid + 512 * k) * 16u, 0);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int v = tid + 512 * k;
-      int dst;
-      if (p.w_chunked) {  // [chunk][tap][cout][32 ch]
-        const int row = v >> 2, piece = v & 3;
-        const int co = row & (C - 1), tap = (row >> 6) % 9, chunk = row / (9 * C);
-        dst = (tap * C + co) * WROW + chunk * (KC * 2) + piece * 16;
-      } else {            // [cout][tap][64 ch]
-        const int row = v >> 3, piece = v & 7;
-        const int co = row / 9, tap = row - co * 9;
-        dst = (tap * C + co) * WROW + piece * 16;
-      }
-      *reinterpret_cast<uint4*>(sW + dst) = wv[k];
-    }
-    if (tid < C) {
-      float sc = 1.f, sh = 0.f;
-      if (p.gn_acc) {  // GroupNorm statistics straight from the producer's channel-sum accumulators
-        const int cpg = C / p.gn_groups, g0 = (tid / cpg) * cpg;
-        long long ssum = 0, ssq = 0;
-        for (int j = 0; j < cpg; ++j) {
-          ssum += p.gn_acc[((long)b * C + g0 + j) * 2];
-          ssq += p.gn_acc[((long)b * C + g0 + j) * 2 + 1];
-        }
-        const double mean = (double)ssum * (1.0 / DS_STAT_SUM_SCALE) * (double)p.gn_inv_count;
-        double var = (double)ssq * (1.0 / DS_STAT_SQ_SCALE) * (double)p.gn_inv_count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        sc = (float)(1.0 / sqrt(var + (double)p.gn_eps)) * (p.gn_gamma ? p.gn_gamma[tid] : 1.f);
-        sh = (p.gn_beta ? p.gn_beta[tid] : 0.f) - (float)mean * sc;
-      } else if (p.gn_scale) {
-        sc = p.gn_scale[(long)b * C + tid];
-        sh = p.gn_shift[(long)b * C + tid];
-      }
-      sTab[tid] = sc;
-      sTab[C + tid] = sh;
-      sTab[2 * C + tid] =
-          ((p.bias ? p.bias[tid] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + tid] : 0.f)) * p.out_scale;
-    }
-  }
-
-  // ---- staging descriptors: vector v = gtid + 256 k -> halo pixel v / 4, 16-byte slot v % 4 (= tid % 4).
-  // Kept in LDS (one 4-byte word per vector: byte offset relative to the tile origin, multiple of 16, with the
-  // border flags in the low 4 bits) so that they do not occupy 18 registers for the whole kernel.
-  const int slot = tid & 3;
-  int* sDesc = reinterpret_cast<int*>(smem + LDS_MAIN + 8 * LDS_E);
-  if (group == 1) {
-#pragma unroll
-    for (int k = 0; k < NA; ++k) {
-      const int v = gtid + 256 * k;
-      const int pix = v >> 2, hy = pix / HW_, hx = pix - hy * HW_;
-      const int rel = (((hy - 1) * p.W + (hx - 1)) * p.ldx + slot * 8) * 2;
-      const int flg = (hy == 0 ? 1 : 0) | (hy == HH_ - 1 ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx == HW_ - 1 ? 8 : 0);
-      sDesc[k * 256 + gtid] = rel | flg;
-    }
-  }
-  const int ldo0 = (gtid >> 2) * AROW + slot * 16;  // LDS offset of vector 0; vector k is 64 pixels further
-  const bool in_last = gtid + 256 * (NA - 1) < HP * 4;
-  const __amdgpu_buffer_rsrc_t rx = rsrc(p.x + (long)b * p.x_bs, (unsigned)(p.H * p.W) * p.ldx * 2u);
-  const __amdgpu_buffer_rsrc_t ry = rsrc(p.y + (long)b * p.y_bs, (unsigned)(p.H * p.W) * p.ldy * 2u);
-  const __amdgpu_buffer_rsrc_t rr =
-      rsrc(p.res ? p.res + (long)b * p.res_bs : p.y, p.res ? (unsigned)(p.H * p.W) * p.ldr * 2u : 0u);
-
-  auto tile_of = [&](int q) { return t0 + (q >> 1); };  // chunk q -> tile index; chunk q lives in ring slot q & 1
-  uint4 pa[NA];
-  bool pval[NA];
-  auto issue = [&](int q) {  // global loads of the group's chunk q into registers
-    const int t = tile_of(q);
-    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
-    const int y0 = ty * TH, x0 = tx * TW;
-    const unsigned edge = (y0 == 0 ? 1u : 0u) | (y0 + TH == p.H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) |
-                          (x0 + TW == p.W ? 8u : 0u);
-    const int tbase = (y0 * p.W + x0) * p.ldx * 2;
-#pragma unroll
-    for (int k = 0; k < NA; ++k) {
-      const int d = sDesc[k * 256 + gtid];
-      pval[k] = (k < NA - 1 || in_last) && !((unsigned)d & edge);
-#ifdef ABL_NOLOAD
-      pa[k] = make_uint4(tbase, tbase, tbase, tbase);
-#else
-      pa[k] = ld16(rx, pval[k] ? (unsigned)((d & ~15) + tbase) : OOB, (unsigned)(q & 1) * (KC * 2));
-#endif
-    }
-  };
-  float gsc[8], gsh[8];  // GN scale / shift of this thread's 8 channels of the chunk in flight
-  auto act_tab = [&](int c) {
-    const float4* ts = reinterpret_cast<const float4*>(sTab + c * KC + slot * 8);
-    const float4* th = reinterpret_cast<const float4*>(sTab + C + c * KC + slot * 8);
-    const float4 s0 = ts[0], s1 = ts[1], h0 = th[0], h1 = th[1];
-    gsc[0] = s0.x; gsc[1] = s0.y; gsc[2] = s0.z; gsc[3] = s0.w; gsc[4] = s1.x; gsc[5] = s1.y; gsc[6] = s1.z; gsc[7] = s1.w;
-    gsh[0] = h0.x; gsh[1] = h0.y; gsh[2] = h0.z; gsh[3] = h0.w; gsh[4] = h1.x; gsh[5] = h1.y; gsh[6] = h1.z; gsh[7] = h1.w;
-  };
-  auto act_one = [&](int k) {  // zero padding stays zero: the activation applies to inside pixels only
-#ifdef ABL_NOACT
-    return;
-#endif
-    uint4 r = gn8<MODE == 2>(pa[k], gsc, gsh);
-    asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));  // unconditional: no branch inside the MFMA loop
-    pa[k].x = pval[k] ? r.x : pa[k].x;
-    pa[k].y = pval[k] ? r.y : pa[k].y;
-    pa[k].z = pval[k] ? r.z : pa[k].z;
-    pa[k].w = pval[k] ? r.w : pa[k].w;
-  };
-  auto write = [&](int sl) {
-    char* dst = sA + sl * LDS_A;
-#pragma unroll
-    for (int k = 0; k < NA; ++k)
-      if (k < NA - 1 || in_last) *reinterpret_cast<uint4*>(dst + ldo0 + k * 64 * AROW) = pa[k];
-  };
-
-  f32x16 acc[2][2];  // [pixel row of the wave][cout half]
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float ssum[8], ssq[8];  // statistics of the 8 couts this lane writes (row-oriented epilogue role)
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
-
-  // fragment addresses: the wave owns output rows 2 gw, 2 gw + 1 of its group's tile; lane = pixel l32 (B
-  // operand) / cout l32 (A operand)
-  const int aoff = ((2 * gw) * HW_ + l32) * AROW + h * 16;
-  const int woff = l32 * WROW + h * 16;
-  auto mma = [&](int c, int sl) {  // 72 MFMAs on ring slot sl: LDS reads and matrix instructions only
-    const char* a = sA + sl * LDS_A + aoff;
-    const char* w = sW + woff + c * (KC * 2);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const int po = ((tap / 3) * HW_ + (tap % 3)) * AROW + kb * 32;
-        const bf16x8 p0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a + po));
-        const bf16x8 p1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a + po + HW_ * AROW));
-        const bf16x8 w0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(w + tap * C * WROW + kb * 32));
-        const bf16x8 w1 =
-            __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(w + (tap * C + 32) * WROW + kb * 32));
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, p0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p0, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, p1, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p1, acc[1][1], 0, 0, 0);
-      }
-    }
-  };
-
-  // epilogue roles: lane = (pixel epx of an 8-pixel group, 8-cout group ecg)
-  char* sE = smem + LDS_MAIN + wave * LDS_E;
-  const int epx = lane >> 3, ecg = lane & 7;
-  const bool has_res = p.res != nullptr, has_stats = p.stats != nullptr;
-  const float osc = p.out_scale;
-  // All residual loads of a tile are issued before its first store: vmcnt retires in order and counts stores on
-  // gfx950, so a load issued between two stores could only be waited for together with the older store's
-  // round trip to L2.
-  uint4 rres[8];
-  auto issue_res = [&](int t) {
-    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
-    const unsigned o = (unsigned)((((ty * TH + 2 * gw) * p.W + tx * TW + epx) * p.ldr + ecg * 8) * 2);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-        rres[i * 4 + s4] = ld16(rr, o + (unsigned)((i * p.W + s4 * 8) * p.ldr * 2), 0);
-  };
-  // lane layout of the 32x32 result: column = pixel l32, rows (couts) = (r & 3) + 8 (r >> 2) + 4 h
-  auto epilogue = [&](int t) {
-    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
-    const unsigned o = (unsigned)((((ty * TH + 2 * gw) * p.W + tx * TW + epx) * p.ldy + ecg * 8) * 2);
-    float bz[8];  // (bias + temb bias) * out_scale of this lane's 8 couts
-    {
-      const float4 b0 = *reinterpret_cast<const float4*>(sTab + 2 * C + ecg * 8);
-      const float4 b1 = *reinterpret_cast<const float4*>(sTab + 2 * C + ecg * 8 + 4);
-      bz[0] = b0.x; bz[1] = b0.y; bz[2] = b0.z; bz[3] = b0.w; bz[4] = b1.x; bz[5] = b1.y; bz[6] = b1.z; bz[7] = b1.w;
-    }
-#ifdef ABL_NOEPI
-    if (acc[0][0][0] + acc[1][1][3] == 12345.678f) reinterpret_cast<float*>(p.y)[tid] = acc[0][1][1];
-    return;
-#endif
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        if ((l32 >> 3) == s4) {  // the 8 pixels of this pass hand over their 8 quads (all 64 couts)
-          char* dst = sE + (l32 & 7) * EROW + h * 16;
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-              *reinterpret_cast<float4*>(dst + (j * 32 + g * 8) * 4) = make_float4(
-                  acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        const float4 a0 = *reinterpret_cast<const float4*>(sE + epx * EROW + ecg * 32);
-        const float4 a1 = *reinterpret_cast<const float4*>(sE + epx * EROW + ecg * 32 + 16);
-        __builtin_amdgcn_wave_barrier();
-        float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], osc, bz[j]);
-        if (has_res) {
-          const uint4 u = rres[i * 4 + s4];
-          v[0] = fmaf(__uint_as_float(u.x << 16), osc, v[0]); v[1] = fmaf(__uint_as_float(u.x & 0xffff0000u), osc, v[1]);
-          v[2] = fmaf(__uint_as_float(u.y << 16), osc, v[2]); v[3] = fmaf(__uint_as_float(u.y & 0xffff0000u), osc, v[3]);
-          v[4] = fmaf(__uint_as_float(u.z << 16), osc, v[4]); v[5] = fmaf(__uint_as_float(u.z & 0xffff0000u), osc, v[5]);
-          v[6] = fmaf(__uint_as_float(u.w << 16), osc, v[6]); v[7] = fmaf(__uint_as_float(u.w & 0xffff0000u), osc, v[7]);
-        }
-        if (has_stats) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            ssum[j] += v[j];
-            ssq[j] = fmaf(v[j], v[j], ssq[j]);
-          }
-        }
-        u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                      pack_bf16x2(v[6], v[7])};
-        WS_STORE(ov, ry, o + (unsigned)((i * p.W + s4 * 8) * p.ldy * 2), 0, 0);
-      }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  };
-
-  // ---- pipeline.  Phase P1 = multiply the chunk in the group's slot; phase P2 = activate + stage the next chunk,
-  // fetch the one after, finish the tile.  Group 1 starts one barrier late, so P1 of one group runs beside P2 of
-  // the other.
-  // ---- pipeline: one block barrier per chunk.  Phase q: the matrix waves multiply chunk q (ring slot q & 1; after
-  // the tile's second chunk they run its epilogue), the memory waves activate + store chunk q + 1 into the other
-  // slot (its reader finished in phase q - 1) and fetch chunk q + 2.
-  sync_lds();  // weights, tables and descriptors visible
-  if (group == 1) {
-    issue(0);
-    act_tab(0);
-#pragma unroll
-    for (int k = 0; k < NA; ++k) act_one(k);
-    write(0);
-    if (Qg > 1) issue(1);
-  }
-  for (int q = 0; q < Qg; ++q) {
-    sync_lds();
-    const int c = q & 1;
-    if (group == 0) {
-      if (c == 1 && has_res) issue_res(tile_of(q));
-      mma(c, c);
-      if (c == 1) epilogue(tile_of(q));
-    } else if (q + 1 < Qg) {
-      act_tab(c ^ 1);
-#pragma unroll
-      for (int k = 0; k < NA; ++k) act_one(k);
-      write(c ^ 1);
-      if (q + 2 < Qg) issue(q + 2);
-    }
-  }
-  sync_lds();
-
-  // ---- statistics: 64 threads (8 per wave) share a cout group; reduce them in fp64
-  if (has_stats) {  // (the loop above ends on a block barrier: LDS is free now)
-    float* red = reinterpret_cast<float*>(smem);
-    *reinterpret_cast<float4*>(red + tid * RED_ROW) = make_float4(ssum[0], ssum[1], ssum[2], ssum[3]);
-    *reinterpret_cast<float4*>(red + tid * RED_ROW + 4) = make_float4(ssum[4], ssum[5], ssum[6], ssum[7]);
-    *reinterpret_cast<float4*>(red + tid * RED_ROW + 8) = make_float4(ssq[0], ssq[1], ssq[2], ssq[3]);
-    *reinterpret_cast<float4*>(red + tid * RED_ROW + 12) = make_float4(ssq[4], ssq[5], ssq[6], ssq[7]);
-    __syncthreads();
-    if (tid < 128) {
-      const int co = tid >> 1, st = tid & 1;
-      const float* src = red + (co >> 3) * RED_ROW + st * 8 + (co & 7);
-      double a = 0.0;
-#pragma unroll 8
-      for (int i = 0; i < 64; ++i) a += (double)src[i * 8 * RED_ROW];
-      ds_stat_add(p.stats + ((long)b * C + co) * 2 + st, (long long)llrint(a * (st ? DS_STAT_SQ_SCALE : DS_STAT_SUM_SCALE)));
-    }
-  }
-}
-
-// ---- variant B (DIFFSEP_CONV_WS=2): all 8 waves in the same phase.  A wave owns ONE pixel row x 64 couts
+// ---- the kernel: all 8 waves in the same phase.  A wave owns ONE pixel row x 64 couts
 // (36 MFMAs per chunk); the halo chunks go through a 2-slot ring with ONE barrier per chunk; the chunk in flight
 // is activated in registers between the MFMAs of the same wave; the next tile's first chunk is loading while
 // this tile's epilogue runs.
@@ -1066,301 +431,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
   WT_FLUSH
 }
 
-// ---- variant C (DIFFSEP_CONV_WS=3): 16 x 32 pixel tiles.  A wave owns TWO pixel rows x 64 couts (2 x 2 MFMA tiles,
-// 72 MFMAs per chunk, one LDS fragment read per MFMA instead of 1.5); the 18 x 34 halo chunk (49 KB) has a single
-// LDS slot, so a chunk costs two barriers (write | multiply); the next chunk is fetched, activated and held in
-// registers during the multiply phase (one register set: 64 accumulators leave no room for two).
-constexpr int TH2 = 16, HH2 = TH2 + 2, HP2 = HW_ * HH2;  // 612 halo pixels
-constexpr int LDS_A2 = HP2 * AROW;                       // 48,960
-constexpr int NA2 = (HP2 * (KC / 8) + 511) / 512;        // 16-byte vectors per thread per chunk: 5
-constexpr int LDS_TOTAL2 = LDS_W + LDS_A2 + LDS_TAB + 8 * LDS_E + NA2 * 512 * 4;
-static_assert(LDS_TOTAL2 <= 160 * 1024, "LDS budget of one CU");
-template <int MODE>
-__global__ __launch_bounds__(512, 2) void conv3x3_ws2_kernel(WsK p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sW = smem;
-  char* sA = smem + LDS_W;
-  float* sTab = reinterpret_cast<float*>(smem + LDS_W + LDS_A2);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int l32 = lane & 31, h = lane >> 5;
-  const int b = blockIdx.x / p.G, part = blockIdx.x % p.G;
-  const int t0 = (int)((long)part * p.tiles_per_img / p.G);
-  const int nt = (int)((long)(part + 1) * p.tiles_per_img / p.G) - t0;
-  const int Q = 2 * nt;
-  {
-    const __amdgpu_buffer_rsrc_t rw = rsrc(p.w, 9u * C * C * 2u);
-    uint4 wv[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) wv[k] = ld16(rw, (unsigned)(tid + 512 * k) * 16u, 0);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int v = tid + 512 * k;
-      int dst;
-      if (p.w_chunked) {  // [chunk][tap][cout][32 ch]
-        const int row = v >> 2, piece = v & 3;
-        const int co = row & (C - 1), tap = (row >> 6) % 9, chunk = row / (9 * C);
-        dst = (tap * C + co) * WROW + chunk * (KC * 2) + piece * 16;
-      } else {            // [cout][tap][64 ch]
-        const int row = v >> 3, piece = v & 7;
-        const int co = row / 9, tap = row - co * 9;
-        dst = (tap * C + co) * WROW + piece * 16;
-      }
-      *reinterpret_cast<uint4*>(sW + dst) = wv[k];
-    }
-    if (tid < C) {
-      float sc = 1.f, sh = 0.f;
-      if (p.gn_acc) {  // GroupNorm statistics straight from the producer's channel-sum accumulators
-        const int cpg = C / p.gn_groups, g0 = (tid / cpg) * cpg;
-        long long ssum = 0, ssq = 0;
-        for (int j = 0; j < cpg; ++j) {
-          ssum += p.gn_acc[((long)b * C + g0 + j) * 2];
-          ssq += p.gn_acc[((long)b * C + g0 + j) * 2 + 1];
-        }
-        const double mean = (double)ssum * (1.0 / DS_STAT_SUM_SCALE) * (double)p.gn_inv_count;
-        double var = (double)ssq * (1.0 / DS_STAT_SQ_SCALE) * (double)p.gn_inv_count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        sc = (float)(1.0 / sqrt(var + (double)p.gn_eps)) * (p.gn_gamma ? p.gn_gamma[tid] : 1.f);
-        sh = (p.gn_beta ? p.gn_beta[tid] : 0.f) - (float)mean * sc;
-      } else if (p.gn_scale) {
-        sc = p.gn_scale[(long)b * C + tid];
-        sh = p.gn_shift[(long)b * C + tid];
-      }
-      sTab[tid] = sc;
-      sTab[C + tid] = sh;
-      sTab[2 * C + tid] =
-          ((p.bias ? p.bias[tid] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + tid] : 0.f)) * p.out_scale;
-    }
-  }
-  const int slot = tid & 3;
-  char* sEbase = smem + LDS_W + LDS_A2 + LDS_TAB;
-  int* sDesc = reinterpret_cast<int*>(sEbase + 8 * LDS_E);
-#pragma unroll
-  for (int k = 0; k < NA2; ++k) {
-    const int v = tid + 512 * k;
-    const int pix = v >> 2, hy = pix / HW_, hx = pix - hy * HW_;
-    const int rel = (((hy - 1) * p.W + (hx - 1)) * p.ldx + slot * 8) * 2;
-    const int flg = (hy == 0 ? 1 : 0) | (hy == HH2 - 1 ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx == HW_ - 1 ? 8 : 0);
-    sDesc[k * 512 + tid] = rel | flg;
-  }
-  const int ldo0 = (tid >> 2) * AROW + slot * 16;  // vector k is 128 pixels further
-  const bool in_last = tid + 512 * (NA2 - 1) < HP2 * 4;
-  const __amdgpu_buffer_rsrc_t rx = rsrc(p.x + (long)b * p.x_bs, (unsigned)(p.H * p.W) * p.ldx * 2u);
-  const __amdgpu_buffer_rsrc_t ry = rsrc(p.y + (long)b * p.y_bs, (unsigned)(p.H * p.W) * p.ldy * 2u);
-  const __amdgpu_buffer_rsrc_t rr =
-      rsrc(p.res ? p.res + (long)b * p.res_bs : p.y, p.res ? (unsigned)(p.H * p.W) * p.ldr * 2u : 0u);
-
-  uint4 pa[NA2];
-  bool pval[NA2];
-  // global loads are issued ONE per k-step inside the MFMA loop: the texture addresser takes ~25 cycles per
-  // 16-byte wave load, and a burst of them right after the barrier would hold back every wave's first MFMA
-  unsigned ld_edge = 0, ld_soff = 0;
-  int ld_tbase = 0;
-  auto prep = [&](int q) {  // geometry of chunk q (tile q / 2, channels 32 (q & 1) ...)
-    const int t = t0 + (q >> 1);
-    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
-    const int y0 = ty * TH2, x0 = tx * TW;
-    ld_edge = (y0 == 0 ? 1u : 0u) | (y0 + TH2 == p.H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + TW == p.W ? 8u : 0u);
-    ld_tbase = (y0 * p.W + x0) * p.ldx * 2;
-    ld_soff = (unsigned)(q & 1) * (KC * 2);
-  };
-  auto issue_one = [&](int k) {
-    const int d = sDesc[k * 512 + tid];
-    pval[k] = (k < NA2 - 1 || in_last) && !((unsigned)d & ld_edge);
-    pa[k] = ld16(rx, pval[k] ? (unsigned)((d & ~15) + ld_tbase) : OOB, ld_soff);
-  };
-  float gsc[8], gsh[8];
-  auto act_tab = [&](int c) {
-    const float4* ts = reinterpret_cast<const float4*>(sTab + c * KC + slot * 8);
-    const float4* th = reinterpret_cast<const float4*>(sTab + C + c * KC + slot * 8);
-    const float4 s0 = ts[0], s1 = ts[1], h0 = th[0], h1 = th[1];
-    gsc[0] = s0.x; gsc[1] = s0.y; gsc[2] = s0.z; gsc[3] = s0.w; gsc[4] = s1.x; gsc[5] = s1.y; gsc[6] = s1.z; gsc[7] = s1.w;
-    gsh[0] = h0.x; gsh[1] = h0.y; gsh[2] = h0.z; gsh[3] = h0.w; gsh[4] = h1.x; gsh[5] = h1.y; gsh[6] = h1.z; gsh[7] = h1.w;
-  };
-  auto act_one = [&](int k) {
-    uint4 r = gn8<MODE == 2>(pa[k], gsc, gsh);
-    asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
-    pa[k].x = pval[k] ? r.x : pa[k].x;
-    pa[k].y = pval[k] ? r.y : pa[k].y;
-    pa[k].z = pval[k] ? r.z : pa[k].z;
-    pa[k].w = pval[k] ? r.w : pa[k].w;
-  };
-  auto write = [&]() {  // single LDS slot
-#pragma unroll
-    for (int k = 0; k < NA2; ++k)
-      if (k < NA2 - 1 || in_last) *reinterpret_cast<uint4*>(sA + ldo0 + k * 128 * AROW) = pa[k];
-  };
-  f32x16 acc[2][2];  // [pixel row of the wave][cout half]
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float ssum[8], ssq[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
-  const int aoff = (2 * wave * HW_ + l32) * AROW + h * 16;
-  const int woff = l32 * WROW + h * 16;
-  char* sE = sEbase + wave * LDS_E;
-  const int epx = lane >> 3, ecg = lane & 7;
-  const bool has_res = p.res != nullptr, has_stats = p.stats != nullptr;
-  const float osc = p.out_scale;
-  unsigned res_o = 0;
-  uint4 rres[8];
-  auto mma = [&](int c, int sl, auto NEXT_, bool loads, bool resl) {
-    constexpr bool NEXT = decltype(NEXT_)::value;
-    if constexpr (NEXT) act_tab(c ^ 1);  // (the chunk fetched during this phase is the other channel half)
-    const char* a = sA + aoff;
-    const char* w = sW + woff + c * (KC * 2);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const int po = ((tap / 3) * HW_ + (tap % 3)) * AROW + kb * 32;
-        const bf16x8 p0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a + po));
-        const bf16x8 p1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a + po + HW_ * AROW));
-        const bf16x8 w0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(w + tap * C * WROW + kb * 32));
-        const bf16x8 w1 =
-            __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(w + (tap * C + 32) * WROW + kb * 32));
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, p0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p0, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, p1, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, p1, acc[1][1], 0, 0, 0);
-        const int s = tap * 2 + kb;
-        if (s < NA2 && loads) issue_one(s);                       // chunk q + 1
-        if (s >= NA2 && s < NA2 + 8 && resl) {                    // the tile's residual rows (2 per wave)
-          const int q8 = s - NA2;
-          rres[q8] = ld16(rr, res_o + (unsigned)(((q8 >> 2) * p.W + (q8 & 3) * 8) * p.ldr * 2), 0);
-        }
-        if constexpr (NEXT) {
-          if (s >= 8 && s < 8 + 2 * NA2 && (s & 1) == 0) act_one((s - 8) >> 1);
-        }
-      }
-    }
-  };
-  auto prep_res = [&](int t) {
-    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
-    res_o = (unsigned)((((ty * TH2 + 2 * wave) * p.W + tx * TW + epx) * p.ldr + ecg * 8) * 2);
-  };
-  auto epilogue = [&](int t) {
-    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
-    const unsigned o = (unsigned)((((ty * TH2 + 2 * wave) * p.W + tx * TW + epx) * p.ldy + ecg * 8) * 2);
-    float bz[8];
-    {
-      const float4 b0 = *reinterpret_cast<const float4*>(sTab + 2 * C + ecg * 8);
-      const float4 b1 = *reinterpret_cast<const float4*>(sTab + 2 * C + ecg * 8 + 4);
-      bz[0] = b0.x; bz[1] = b0.y; bz[2] = b0.z; bz[3] = b0.w; bz[4] = b1.x; bz[5] = b1.y; bz[6] = b1.z; bz[7] = b1.w;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        if ((l32 >> 3) == s4) {
-          char* dst = sE + (l32 & 7) * EROW + h * 16;
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-              *reinterpret_cast<float4*>(dst + (j * 32 + g * 8) * 4) = make_float4(
-                  acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        const float4 a0 = *reinterpret_cast<const float4*>(sE + epx * EROW + ecg * 32);
-        const float4 a1 = *reinterpret_cast<const float4*>(sE + epx * EROW + ecg * 32 + 16);
-        __builtin_amdgcn_wave_barrier();
-        float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], osc, bz[j]);
-        if (has_res) {
-          const uint4 u = rres[i * 4 + s4];
-          v[0] = fmaf(__uint_as_float(u.x << 16), osc, v[0]); v[1] = fmaf(__uint_as_float(u.x & 0xffff0000u), osc, v[1]);
-          v[2] = fmaf(__uint_as_float(u.y << 16), osc, v[2]); v[3] = fmaf(__uint_as_float(u.y & 0xffff0000u), osc, v[3]);
-          v[4] = fmaf(__uint_as_float(u.z << 16), osc, v[4]); v[5] = fmaf(__uint_as_float(u.z & 0xffff0000u), osc, v[5]);
-          v[6] = fmaf(__uint_as_float(u.w << 16), osc, v[6]); v[7] = fmaf(__uint_as_float(u.w & 0xffff0000u), osc, v[7]);
-        }
-        if (has_stats) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            ssum[j] += v[j];
-            ssq[j] = fmaf(v[j], v[j], ssq[j]);
-          }
-        }
-        u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                      pack_bf16x2(v[6], v[7])};
-        WS_STORE(ov, ry, o + (unsigned)((i * p.W + s4 * 8) * p.ldy * 2), 0, 0);
-      }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  };
-
-  WT_DECL
-  sync_lds();  // weights, tables, descriptors visible
-  prep(0);
-#pragma unroll
-  for (int k = 0; k < NA2; ++k) issue_one(k);
-  act_tab(0);
-#pragma unroll
-  for (int k = 0; k < NA2; ++k) act_one(k);
-  write();
-  WT_MARK(4)
-  for (int q = 0; q < Q; q += 2) {
-    const int t = t0 + (q >> 1);
-    const bool more = q + 2 < Q;
-    // ---- chunk 0 in LDS; the tile's second chunk is fetched + activated meanwhile
-    sync_lds();                                   // slot written
-    WT_MARK(0)
-    prep(q + 1);
-    if (has_res) prep_res(t);
-    mma(0, 0, std::true_type{}, true, has_res);
-    WT_MARK(2)
-    sync_lds();                                   // slot read by everybody
-    WT_MARK(0)
-    write();
-    WT_MARK(3)
-    // ---- chunk 1 in LDS; the next tile's first chunk is fetched + activated meanwhile
-    sync_lds();
-    WT_MARK(0)
-    if (more) {
-      prep(q + 2);
-      mma(1, 0, std::true_type{}, true, false);
-      WT_MARK(2)
-      sync_lds();
-      WT_MARK(0)
-      write();
-      WT_MARK(3)
-    } else {
-      mma(1, 0, std::false_type{}, false, false);
-      WT_MARK(2)
-    }
-    epilogue(t);
-    WT_MARK(6)
-  }
-  if (has_stats) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);
-    *reinterpret_cast<float4*>(red + tid * RED_ROW) = make_float4(ssum[0], ssum[1], ssum[2], ssum[3]);
-    *reinterpret_cast<float4*>(red + tid * RED_ROW + 4) = make_float4(ssum[4], ssum[5], ssum[6], ssum[7]);
-    *reinterpret_cast<float4*>(red + tid * RED_ROW + 8) = make_float4(ssq[0], ssq[1], ssq[2], ssq[3]);
-    *reinterpret_cast<float4*>(red + tid * RED_ROW + 12) = make_float4(ssq[4], ssq[5], ssq[6], ssq[7]);
-    __syncthreads();
-    if (tid < 128) {
-      const int co = tid >> 1, st = tid & 1;
-      const float* src = red + (co >> 3) * RED_ROW + st * 8 + (co & 7);
-      double a = 0.0;
-#pragma unroll 8
-      for (int i = 0; i < 64; ++i) a += (double)src[i * 8 * RED_ROW];
-      ds_stat_add(p.stats + ((long)b * C + co) * 2 + st, (long long)llrint(a * (st ? DS_STAT_SQ_SCALE : DS_STAT_SUM_SCALE)));
-    }
-  }
-  WT_MARK(5)
-  WT_FLUSH
-}
-
 int ws_blocks_per_image(const ConvArgs& a) {
   static int cus = 0;
   if (!cus) {
@@ -1379,11 +449,9 @@ int ws_blocks_per_image(const ConvArgs& a) {
 
 }  // namespace
 
-// The layers these kernels take over from conv_mfma.hip (DIFFSEP_CONV_WS=0 switches them off for A/B runs).
+// The layers this kernel takes over from conv_mfma.hip.
 bool ds_conv_ws_eligible(const ConvArgs& a) {
-  const char* v = getenv("DIFFSEP_CONV_WS");  // 0: off, 1: ping-pong variant, 2 (default): one-phase variant
-  const int on = v ? atoi(v) : 2;
-  return on && a.dtype == DS_BF16 && a.taps == 9 && a.Cin == C && a.Cout == C && !a.x2 && a.w_bs == 0 &&
+  return a.dtype == DS_BF16 && a.taps == 9 && a.Cin == C && a.Cout == C && !a.x2 && a.w_bs == 0 &&
          (a.w_chunked == 0 || a.w_chunked == KC) && !a.sx &&
          a.bias_mode == 0 && !a.div_b && a.H % TH == 0 && a.W % TW == 0 && a.ldx >= C && a.ldy >= C &&
          (!a.res || a.ldr >= C);
@@ -1406,61 +474,15 @@ int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st) {
   const int mode = ((a.gn_scale || a.gn_acc1) && a.gn_act) ? 2 : 1;  // raw input = affine with scale 1, shift 0 (exact in bf16)
   static bool attr_done = false;
   if (!attr_done) {
-    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<1>),
+    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws1_kernel<1>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws_kernel<2>),
+    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws1_kernel<2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
     attr_done = true;
   }
   const dim3 grid(a.B * k.G), block(512);
-  const char* v = getenv("DIFFSEP_CONV_WS");
-  if (v && atoi(v) == 4) {
-    static bool attr3 = false;
-    if (!attr3) {
-      DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws3_kernel<1>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-      DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws3_kernel<2>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-      attr3 = true;
-    }
-    if (mode == 1) hipLaunchKernelGGL(conv3x3_ws3_kernel<1>, grid, block, LDS_TOTAL, st, k);
-    else hipLaunchKernelGGL(conv3x3_ws3_kernel<2>, grid, block, LDS_TOTAL, st, k);
-    DS_LAUNCH_CHECK();
-    return 0;
-  }
-  if (v && atoi(v) == 3 && a.H % TH2 == 0) {
-    static bool attr2 = false;
-    if (!attr2) {
-      DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws2_kernel<1>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2));
-      DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws2_kernel<2>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL2));
-      attr2 = true;
-    }
-    k.tiles_per_img = (a.H / TH2) * (a.W / TW);
-    if (k.G > k.tiles_per_img) k.G = k.tiles_per_img;
-    const dim3 grid2(a.B * k.G);
-    if (mode == 1) hipLaunchKernelGGL(conv3x3_ws2_kernel<1>, grid2, block, LDS_TOTAL2, st, k);
-    else hipLaunchKernelGGL(conv3x3_ws2_kernel<2>, grid2, block, LDS_TOTAL2, st, k);
-    DS_LAUNCH_CHECK();
-    return 0;
-  }
-  if (!v || atoi(v) >= 2) {
-    static bool attr1 = false;
-    if (!attr1) {
-      DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws1_kernel<1>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-      DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws1_kernel<2>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-      attr1 = true;
-    }
-    if (mode == 1) hipLaunchKernelGGL(conv3x3_ws1_kernel<1>, grid, block, LDS_TOTAL, st, k);
-    else hipLaunchKernelGGL(conv3x3_ws1_kernel<2>, grid, block, LDS_TOTAL, st, k);
-    DS_LAUNCH_CHECK();
-    return 0;
-  }
-  if (mode == 1) hipLaunchKernelGGL(conv3x3_ws_kernel<1>, grid, block, LDS_TOTAL, st, k);
-  else hipLaunchKernelGGL(conv3x3_ws_kernel<2>, grid, block, LDS_TOTAL, st, k);
+  if (mode == 1) hipLaunchKernelGGL(conv3x3_ws1_kernel<1>, grid, block, LDS_TOTAL, st, k);
+  else hipLaunchKernelGGL(conv3x3_ws1_kernel<2>, grid, block, LDS_TOTAL, st, k);
   DS_LAUNCH_CHECK();
   return 0;
 }

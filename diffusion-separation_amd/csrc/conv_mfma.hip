@@ -816,35 +816,17 @@ static int launch_typed(const ConvArgs& a, hipStream_t st) {
   constexpr int KC9 = (sizeof(T) == 4) ? 16 : 32;
   constexpr int KC1 = (sizeof(T) == 4) ? 32 : 64;
   switch (ds_conv_config_id(a)) {
-    case 0: {
-      static int alt = -1;
-      if (alt < 0) { const char* v = getenv("DIFFSEP_CONV_ALT"); alt = v ? atoi(v) : 0; }
-      if (alt == 2) return launch_cfg<T, 9, 8, 32, 64, 2, 2, KC9, 2, 2>(a, st);      // 2-pass epilogue only
-      return launch_cfg<T, 9, 8, 32, 64, 2, 2, KC9>(a, st);
-    }
+    case 0: return launch_cfg<T, 9, 8, 32, 64, 2, 2, KC9>(a, st);
     case 1: return launch_cfg<T, 9, 8, 32, 32, 2, 1, KC9>(a, st);
-    case 2: {  // small images: a chain of dependent chunk round trips (1.7 us each) -> chunks twice as deep
-      static int alt2 = -1;  // (+1 % end to end; DIFFSEP_CONV_ALT2=0 restores the single-depth chunks)
-      if (alt2 < 0) { const char* v = getenv("DIFFSEP_CONV_ALT2"); alt2 = v ? atoi(v) : 1; }
-      const bool deep = alt2 == 1 && a.Cin % (2 * KC9) == 0 && (!a.x2 || a.C1 % (2 * KC9) == 0) &&
+    case 2: {  // small images: a chain of dependent chunk round trips (1.7 us each) -> chunks twice as deep (+1 %)
+      const bool deep = a.Cin % (2 * KC9) == 0 && (!a.x2 || a.C1 % (2 * KC9) == 0) &&
                         (!a.sx || (a.sCin % (2 * KC9) == 0 && (!a.sx2 || a.sC1 % (2 * KC9) == 0)));
-      // experiment (DIFFSEP_CONV_SMALL_NARROW=1): a 32-cout tile halves the weight slab one CU has to stream and
-      // doubles the CUs that share it — measured +0.3 % end to end, i.e. noise; off by default
-      static int narrow = -1;
-      if (narrow < 0) { const char* v = getenv("DIFFSEP_CONV_SMALL_NARROW"); narrow = v ? atoi(v) : 0; }
-      if (deep && narrow) return launch_cfg<T, 9, 8, 16, 32, 1, 1, KC9 * 2>(a, st);
       if (deep) return launch_cfg<T, 9, 8, 8, 64, 1, 1, KC9 * 2>(a, st);
       return launch_cfg<T, 9, 8, 8, 64, 1, 1, KC9>(a, st);
     }
     case 3: return launch_cfg<T, 1, 8, 32, 64, 2, 2, KC1>(a, st);
     case 4: return launch_cfg<T, 1, 8, 32, 32, 2, 1, KC1>(a, st);
-    default: {
-      static int alt5 = -1;
-      if (alt5 < 0) { const char* v = getenv("DIFFSEP_CONV_ALT5"); alt5 = v ? atoi(v) : 0; }
-      if (alt5 == 1 && a.Cin % (2 * KC1) == 0 && (!a.x2 || a.C1 % (2 * KC1) == 0))
-        return launch_cfg<T, 1, 8, 8, 64, 1, 1, KC1 * 2>(a, st);
-      return launch_cfg<T, 1, 8, 8, 64, 1, 1, KC1>(a, st);
-    }
+    default: return launch_cfg<T, 1, 8, 8, 64, 1, 1, KC1>(a, st);
   }
 }
 

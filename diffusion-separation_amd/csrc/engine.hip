@@ -339,11 +339,6 @@ struct diffsep_engine {
   // mapped to this private stream, ordered against the null stream with events on both sides.
   hipStream_t own = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
-  // independent branches of the network (1x1 skip convolutions, the output pyramid) run on two side
-  // streams, forked / joined with events (captured into the graph as parallel branches)
-  hipStream_t sideA = nullptr, sideB = nullptr;
-  std::vector<hipEvent_t> fj_events;
-  size_t fj_i = 0;
   float* ts_pin = nullptr;    // pinned staging buffer of the time-step upload (+ the event of its last use)
   size_t ts_pin_cap = 0;
   hipEvent_t ts_ev = nullptr;
@@ -352,7 +347,6 @@ struct diffsep_engine {
   int ts_B = 0;
   bool had_arena = false;
   bool dbg_alloc = false;  // DIFFSEP_DBG_ALLOC=1: log every arena allocation (offset, bytes) to stderr
-  int use_side = 0;  // measured on MI355X: parallel graph branches cost ~5 % here (DIFFSEP_SIDE=1|2|3 enables them)
   // optional per-launch timing of the MFMA kernels (HIP events on the launch stream)
   bool prof = false;
   struct ProfRec { hipEvent_t a, b; double flops, bytes; int cls; };
@@ -360,21 +354,6 @@ struct diffsep_engine {
   std::vector<hipEvent_t> ev_pool;
 };
 #define DS_NCLS 7
-static hipEvent_t fj_event(diffsep_engine* e) {
-  if (e->fj_i == e->fj_events.size()) {
-    hipEvent_t v = nullptr;
-    hipEventCreateWithFlags(&v, hipEventDisableTiming);
-    e->fj_events.push_back(v);
-  }
-  return e->fj_events[e->fj_i++];
-}
-// make `to` wait for everything issued so far on `from`
-static int stream_dep(diffsep_engine* e, hipStream_t from, hipStream_t to) {
-  hipEvent_t ev = fj_event(e);
-  DS_HIP(hipEventRecord(ev, from));
-  DS_HIP(hipStreamWaitEvent(to, ev, 0));
-  return 0;
-}
 static hipEvent_t prof_event(diffsep_engine* e) {
   if (!e->ev_pool.empty()) { hipEvent_t v = e->ev_pool.back(); e->ev_pool.pop_back(); return v; }
   hipEvent_t v = nullptr;
@@ -441,10 +420,8 @@ static int stats_begin(diffsep_engine* e, hipStream_t st) {  // call right after
   if (e->dry) { e->stats_need = 0; return 0; }
   e->stats_ptr = (char*)e_alloc(e, e->stats_need);
   // zeroed by a kernel, not hipMemsetAsync: as a captured memset NODE it made every engine but the first return
-  // different samples when the graph was replayed on another stream (B >= 4; DIFFSEP_STATS_MEMSET=1 reproduces it)
-  static const bool use_memset = getenv("DIFFSEP_STATS_MEMSET") != nullptr;
-  if (e->stats_need && use_memset) DS_HIP(hipMemsetAsync(e->stats_ptr, 0, e->stats_need, st));
-  else if (e->stats_need && ds_launch_fill((float*)e->stats_ptr, 0.f, (long)(e->stats_need / 4), st)) return 1;
+  // different samples when the graph was replayed on another stream (B >= 4; profiles/experiments/README.md)
+  if (e->stats_need && ds_launch_fill((float*)e->stats_ptr, 0.f, (long)(e->stats_need / 4), st)) return 1;
   return 0;
 }
 static Tn e_tensor(diffsep_engine* e, int B, int H, int W, int C) {
@@ -509,8 +486,7 @@ static int gn_stats(diffsep_engine* e, const Tn& x, const float* gamma, const fl
   const int groups = (x.C / 4 < 32) ? x.C / 4 : 32;
   aff = GnAff();
   const bool have_acc = x.sa && (!x.p2 || x.sa2);
-  static const bool lazy_ok = !(getenv("DIFFSEP_GN_LAZY") && atoi(getenv("DIFFSEP_GN_LAZY")) == 0);  // A/B switch
-  if (have_acc && lazy && lazy_ok && x.C <= 512) {  // the consuming conv computes scale / shift in its prologue
+  if (have_acc && lazy && x.C <= 512) {  // the consuming conv computes scale / shift in its prologue
     // (its LDS table holds 512 channels; wider inputs take the materialised arrays below)
     aff.acc1 = x.sa; aff.acc2 = x.sa2; aff.gamma = gamma; aff.beta = beta; aff.groups = groups;
     aff.inv_count = (float)(1.0 / ((double)x.H * x.W * (x.C / groups)));
@@ -729,10 +705,7 @@ static int net_forward(diffsep_engine* e, const Tn& x0, const float* t, const Tn
     const Module& g = A.mods[mi++];
     const Module& cv = A.mods[mi++];
     DS_CHECK(g.kind == MK_GN && cv.kind == MK_CONV3, "internal: expected pyramid GN + conv");
-    // the pyramid chain only depends on h of each level: it runs on its own stream beside the up path
-    const bool sideb = !e->dry && (e->use_side & 2);
-    hipStream_t sp = sideb ? e->sideB : st;
-    if (sideb && stream_dep(e, st, sp)) return 1;
+    hipStream_t sp = st;  // (the pyramid chain on a side stream was measured 6 % slower: profiles/experiments)
     GnAff ga;
     if (gn_stats(e, h, P(e, g.w0), P(e, g.b0), B, ga, sp, true)) return 1;
     Tn pnew = e_tensor(e, B, h.H, h.W, A.cpad_in);
@@ -755,7 +728,6 @@ static int net_forward(diffsep_engine* e, const Tn& x0, const float* t, const Tn
   }
   DS_CHECK(hs.empty() && mi == A.mods.size(), "internal: module walk did not consume all modules");
   // h = pyramid / t ; out = output_layer(h)   (ncsnpp.py:472-477)
-  if (!e->dry && (e->use_side & 2) && stream_dep(e, e->sideB, st)) return 1;
   Tn yy = y;
   return conv(e, pyramid, PK(e, A.pk_out), P(e, A.out_b), nullptr, 0, nullptr, 1.f, yy, A.chan_out, 1, B, t, st);
 }
@@ -766,7 +738,6 @@ static int score_forward_impl(diffsep_engine* e, const float* xt, const float* t
   const diffsep_model_config& c = e->cfg;
   const int W = diffsep_padded_frames(&c, T), H = c.n_fft / 2 + 1, S = c.num_sources;
   e->top = e->fwd_base;
-  e->fj_i = 0;
   if (stats_begin(e, st)) return 1;
   Tn x0 = e_tensor(e, B, H, W, e->arch.cpad_in);
   Tn y = e_tensor(e, B, H, W, e->arch.cpad_out);
@@ -841,10 +812,55 @@ static int ensure_plan(diffsep_engine* e, int B, long T, hipStream_t st) {
   e->planT = T;
   e->ts_dev.clear();
   // a new plan is captured at its first score evaluation (hipFuncSetAttribute inside the launchers is not a stream
-  // operation and is legal during capture); DIFFSEP_EAGER_FIRST=1 restores one eager evaluation before the capture
-  static const bool eager_first = getenv("DIFFSEP_EAGER_FIRST") != nullptr;
-  e->warmed = !eager_first;
+  // operation and is legal during capture)
+  e->warmed = true;
   return 0;
+}
+
+// ------------------------------------------------------------------ weight repack (fp32 blob -> engine dtype, kernel layout)
+static int repack_weight(diffsep_engine* e, const PRef& src, long pk, int O, int I, int taps, long so, long si, long stp,
+                         bool allow_chunk = true, int kc_taps = 0, int c1 = 0) {
+  const int dtype = e->cfg.dtype;
+  const int Ipad = rup8(I);
+  // kc_taps: the kernel that will READ these weights (the fused skip conv is read by the 3x3 kernel)
+  const int kc = allow_chunk ? weight_chunk(kc_taps ? kc_taps : taps, I, c1, dtype) : 0;
+  const long total = (long)O * taps * Ipad;
+  long nb = (total + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  if (dtype == DS_F32)
+    hipLaunchKernelGGL(repack_kernel<float>, dim3(nb), dim3(256), 0, 0, e->d_blob + src.off, (float*)(e->d_pack) + pk, O,
+                       I, Ipad, taps, so, si, stp, kc);
+  else
+    hipLaunchKernelGGL(repack_kernel<bf16_t>, dim3(nb), dim3(256), 0, 0, e->d_blob + src.off, (bf16_t*)(e->d_pack) + pk,
+                       O, I, Ipad, taps, so, si, stp, kc);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+static int repack_module(diffsep_engine* e, const Module& m) {
+  int rc = 0;
+  const int nf4 = 4 * e->cfg.nf;
+  switch (m.kind) {
+    case MK_CONV3: rc |= repack_weight(e, m.w0, m.pk0, m.out_ch, m.in_ch, 9, (long)m.in_ch * 9, 9, 1); break;
+    case MK_COMBINE: rc |= repack_weight(e, m.w0, m.pk0, m.out_ch, m.in_ch, 1, m.in_ch, 1, 0); break;
+    case MK_RES:
+      rc |= repack_weight(e, m.conv0_w, m.pk0, m.out_ch, m.in_ch, 9, (long)m.in_ch * 9, 9, 1, true, 0, m.in_c1);
+      rc |= repack_weight(e, m.conv1_w, m.pk1, m.out_ch, m.out_ch, 9, (long)m.out_ch * 9, 9, 1);
+      if (m.has_conv2)
+        rc |= repack_weight(e, m.conv2_w, m.pk2, m.out_ch, m.in_ch, 1, m.in_ch, 1, 0, true, fuse_skip(m) ? 9 : 0, m.in_c1);
+      // Dense_0 rows -> concatenated projection [dense_total][temb dim]
+      DS_HIP(hipMemcpy(e->d_dense_w + (size_t)m.temb_off * nf4, e->d_blob + m.dense_w.off, (size_t)m.dense_w.numel * 4,
+                       hipMemcpyDeviceToDevice));
+      DS_HIP(hipMemcpy(e->d_dense_b + m.temb_off, e->d_blob + m.dense_b.off, (size_t)m.dense_b.numel * 4,
+                       hipMemcpyDeviceToDevice));
+      break;
+    case MK_ATTN:  // NIN.W is [in][out] (layers.py:678-689): packed as [out][in]
+      // (the V projection is the A operand of its GEMM: it stays row-major)
+      for (int i = 0; i < 4; ++i)
+        rc |= repack_weight(e, m.nin_w[i], m.pk_nin[i], m.in_ch, m.in_ch, 1, 1, m.in_ch, 0, i != 2);
+      break;
+    default: break;
+  }
+  return rc;
 }
 
 extern "C" int32_t diffsep_engine_create(const diffsep_model_config* cfg, const float* weights_host, int64_t n_floats,
@@ -870,56 +886,12 @@ extern "C" int32_t diffsep_engine_create(const diffsep_model_config* cfg, const 
   DS_HIP(hipMalloc((void**)&e->d_dense_b, (size_t)A.dense_total * 4));
   e->weight_bytes = (int64_t)A.total * 4 + (int64_t)A.pack_total * e->esz + (int64_t)A.dense_total * (4 * cfg->nf + 1) * 4;
   if (ds_build_stft_table(cfg->n_fft, &e->d_tab)) { delete e; return 1; }
-  if (const char* sv = getenv("DIFFSEP_SIDE")) e->use_side = atoi(sv);
   if (const char* sv = getenv("DIFFSEP_DBG_ALLOC")) e->dbg_alloc = atoi(sv) != 0;
-  if (e->use_side) {
-    DS_HIP(hipStreamCreateWithFlags(&e->sideA, hipStreamNonBlocking));
-    DS_HIP(hipStreamCreateWithFlags(&e->sideB, hipStreamNonBlocking));
-  }
   DS_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
   DS_HIP(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
 
-  auto repack = [&](const PRef& src, long pk, int O, int I, int taps, long so, long si, long stp,
-                    bool allow_chunk = true, int kc_taps = 0, int c1 = 0) -> int {
-    const int Ipad = rup8(I);
-    // kc_taps: the kernel that will READ these weights (the fused skip conv is read by the 3x3 kernel)
-    const int kc = allow_chunk ? weight_chunk(kc_taps ? kc_taps : taps, I, c1, cfg->dtype) : 0;
-    const long total = (long)O * taps * Ipad;
-    long nb = (total + 255) / 256;
-    if (nb > 4096) nb = 4096;
-    if (cfg->dtype == DS_F32)
-      hipLaunchKernelGGL(repack_kernel<float>, dim3(nb), dim3(256), 0, 0, e->d_blob + src.off,
-                         (float*)(e->d_pack) + pk, O, I, Ipad, taps, so, si, stp, kc);
-    else
-      hipLaunchKernelGGL(repack_kernel<bf16_t>, dim3(nb), dim3(256), 0, 0, e->d_blob + src.off,
-                         (bf16_t*)(e->d_pack) + pk, O, I, Ipad, taps, so, si, stp, kc);
-    DS_LAUNCH_CHECK();
-    return 0;
-  };
-  int rc = 0;
-  rc |= repack(A.out_w, A.pk_out, A.chan_out, A.chan_in, 1, A.chan_in, 1, 0);
-  for (const Module& m : A.mods) {
-    switch (m.kind) {
-      case MK_CONV3: rc |= repack(m.w0, m.pk0, m.out_ch, m.in_ch, 9, (long)m.in_ch * 9, 9, 1); break;
-      case MK_COMBINE: rc |= repack(m.w0, m.pk0, m.out_ch, m.in_ch, 1, m.in_ch, 1, 0); break;
-      case MK_RES:
-        rc |= repack(m.conv0_w, m.pk0, m.out_ch, m.in_ch, 9, (long)m.in_ch * 9, 9, 1, true, 0, m.in_c1);
-        rc |= repack(m.conv1_w, m.pk1, m.out_ch, m.out_ch, 9, (long)m.out_ch * 9, 9, 1);
-        if (m.has_conv2)
-          rc |= repack(m.conv2_w, m.pk2, m.out_ch, m.in_ch, 1, m.in_ch, 1, 0, true, fuse_skip(m) ? 9 : 0, m.in_c1);
-        // Dense_0 rows -> concatenated projection [dense_total][4 nf]
-        DS_HIP(hipMemcpy(e->d_dense_w + (size_t)m.temb_off * 4 * cfg->nf, e->d_blob + m.dense_w.off,
-                         (size_t)m.dense_w.numel * 4, hipMemcpyDeviceToDevice));
-        DS_HIP(hipMemcpy(e->d_dense_b + m.temb_off, e->d_blob + m.dense_b.off, (size_t)m.dense_b.numel * 4,
-                         hipMemcpyDeviceToDevice));
-        break;
-      case MK_ATTN:  // NIN.W is [in][out] (layers.py:678-689): packed as [out][in]
-        // (the V projection is the A operand of its GEMM: it stays row-major)
-        for (int i = 0; i < 4; ++i) rc |= repack(m.nin_w[i], m.pk_nin[i], m.in_ch, m.in_ch, 1, 1, m.in_ch, 0, i != 2);
-        break;
-      default: break;
-    }
-  }
+  int rc = repack_weight(e, A.out_w, A.pk_out, A.chan_out, A.chan_in, 1, A.chan_in, 1, 0);
+  for (const Module& m : A.mods) rc |= repack_module(e, m);
   if (rc) { delete e; return 1; }
   DS_HIP(hipDeviceSynchronize());
   *out = e;
@@ -932,9 +904,6 @@ extern "C" void diffsep_engine_destroy(diffsep_engine* e) {
   hipFree(e->d_blob); hipFree(e->d_pack); hipFree(e->d_dense_w); hipFree(e->d_dense_b); hipFree(e->d_tab);
   if (e->arena) hipFree(e->arena);
   if (e->own) hipStreamDestroy(e->own);
-  if (e->sideA) hipStreamDestroy(e->sideA);
-  if (e->sideB) hipStreamDestroy(e->sideB);
-  for (auto v : e->fj_events) hipEventDestroy(v);
   if (e->ts_ev) hipEventDestroy(e->ts_ev);
   if (e->ts_pin) hipHostFree(e->ts_pin);
   if (e->ext_ev) hipEventDestroy(e->ext_ev);
@@ -1017,7 +986,6 @@ extern "C" int32_t diffsep_backbone_forward(diffsep_engine* e, const void* x, co
   if (ensure_plan(e, B, T, st)) return 1;
   const int H = e->cfg.n_fft / 2 + 1;
   e->top = e->fwd_base;
-  e->fj_i = 0;
   if (stats_begin(e, st)) return 1;
   Tn xin; xin.p = (void*)x; xin.C = xin.ld = e->arch.cpad_in; xin.H = H; xin.W = W;
   Tn x0 = e_tensor(e, B, H, W, e->arch.cpad_in);
@@ -1355,6 +1323,118 @@ extern "C" int32_t diffsep_attention(const void* q, const void* k, const void* v
   const long one = (((long)B * L * Lp * esz) + 255) & ~255L;
   DS_CHECK(workspace_bytes >= 2 * one, "attention: workspace too small");
   return attention_core(q, k, vt, o, B, L, C, ld, ld, workspace, (char*)workspace + one, dtype, (hipStream_t)stream);
+}
+
+// ---- one ResnetBlockBigGANpp / AttnBlockpp through the ENGINE's block code (res_block / attn_block above: folded
+// Conv_2, GroupNorm from the producer's accumulators, fused FIR resampling, MFMA attention), on caller-supplied
+// parameters: the parity tests check the composition against the reference blocks in isolation (layerspp.py:291-323,
+// 76-92).  A throw-away one-module engine is built per call (test path, not a hot path).
+struct MiniEngine {
+  diffsep_engine* e = nullptr;
+  ~MiniEngine() { if (e) diffsep_engine_destroy(e); }
+};
+static int mini_engine_init(MiniEngine& me, int dtype, int temb_dim, const float* params_host, int64_t n_floats) {
+  diffsep_engine* e = me.e;
+  const Arch& A = e->arch;
+  if (n_floats != A.total) {
+    ds_set_error("block_forward: parameter blob has " + std::to_string(n_floats) + " floats, expected " +
+                 std::to_string(A.total));
+    return 1;
+  }
+  e->esz = dtype == DS_F32 ? 4 : 2;
+  DS_HIP(hipMalloc((void**)&e->d_blob, (size_t)A.total * 4));
+  DS_HIP(hipMemcpy(e->d_blob, params_host, (size_t)A.total * 4, hipMemcpyHostToDevice));
+  DS_HIP(hipMalloc((void**)&e->d_pack, (size_t)A.pack_total * e->esz + 256));
+  DS_HIP(hipMemset(e->d_pack, 0, (size_t)A.pack_total * e->esz + 256));
+  DS_HIP(hipMalloc((void**)&e->d_dense_w, (size_t)(A.dense_total + 1) * (temb_dim + 1) * 4));
+  DS_HIP(hipMalloc((void**)&e->d_dense_b, (size_t)(A.dense_total + 1) * 4));
+  for (const Module& m : A.mods)
+    if (repack_module(e, m)) return 1;
+  DS_HIP(hipDeviceSynchronize());
+  return 0;
+}
+template <typename F>
+static int mini_engine_run(diffsep_engine* e, hipStream_t st, F&& body) {
+  e->fwd_base = 0;
+  e->dry = true;
+  e->top = 0;
+  if (stats_begin(e, st)) return 1;
+  if (body()) { e->dry = false; return 1; }
+  e->dry = false;
+  const size_t need = e->top + e->stats_need + 8192;
+  DS_HIP(hipMalloc((void**)&e->arena, need));
+  e->cap = need;
+  DS_HIP(hipMemsetAsync(e->arena, 0, need, st));
+  e->top = 0;
+  if (stats_begin(e, st)) return 1;
+  if (body()) return 1;
+  DS_HIP(hipStreamSynchronize(st));  // the arena is freed with the engine when the caller returns
+  return 0;
+}
+
+extern "C" int32_t diffsep_resblock_forward(int32_t in_ch, int32_t out_ch, int32_t up, int32_t down, int32_t temb_dim,
+                                            int32_t dtype, const float* params_host, int64_t n_floats, const void* x,
+                                            const float* temb, void* y, int32_t B, int32_t H, int32_t W, void* stream) {
+  DS_CHECK(params_host && x && temb && y, "resblock_forward: null pointer");
+  DS_CHECK(dtype == DS_F32 || dtype == DS_BF16, "resblock_forward: bad dtype");
+  DS_CHECK(in_ch % 8 == 0 && out_ch % 8 == 0 && in_ch >= 8 && out_ch >= 8, "resblock_forward: channels must be multiples of 8");
+  DS_CHECK(temb_dim >= 4 && temb_dim % 4 == 0, "resblock_forward: temb_dim must be a multiple of 4");
+  DS_CHECK(!(up && down) && B >= 1 && H >= 1 && W >= 1 && (!down || (H % 2 == 0 && W % 2 == 0)), "resblock_forward: bad shape");
+  MiniEngine me;
+  me.e = new diffsep_engine();
+  diffsep_engine* e = me.e;
+  memset(&e->cfg, 0, sizeof(e->cfg));
+  e->cfg.dtype = dtype;
+  e->cfg.nf = temb_dim / 4;
+  {
+    ArchBuilder b(e->arch);
+    b.res(in_ch, out_ch, up != 0, down != 0, temb_dim);
+  }
+  if (mini_engine_init(me, dtype, temb_dim, params_host, n_floats)) return 1;
+  const Module& m = e->arch.mods[0];
+  hipStream_t st = (hipStream_t)stream;
+  const int Ho = up ? 2 * H : (down ? H / 2 : H), Wo = up ? 2 * W : (down ? W / 2 : W);
+  return mini_engine_run(e, st, [&]() -> int {
+    float* proj = e_f32(e, (size_t)B * e->arch.dense_total);
+    // Dense_0(act(temb))  layerspp.py:311-312
+    if (!e->dry && ds_launch_linear(temb, e->d_dense_w, e->d_dense_b, proj, B, temb_dim, e->arch.dense_total, 1, st)) return 1;
+    Tn xin;
+    xin.p = const_cast<void*>(x); xin.C = xin.ld = in_ch; xin.H = H; xin.W = W;
+    Tn out;
+    if (res_block(e, m, xin, proj, B, out, st)) return 1;
+    if (!e->dry)
+      DS_HIP(hipMemcpyAsync(y, out.p, (size_t)B * Ho * Wo * out_ch * e->esz, hipMemcpyDeviceToDevice, st));
+    return 0;
+  });
+}
+
+extern "C" int32_t diffsep_attnblock_forward(int32_t channels, int32_t dtype, const float* params_host, int64_t n_floats,
+                                             const void* x, void* y, int32_t B, int32_t H, int32_t W, void* stream) {
+  DS_CHECK(params_host && x && y, "attnblock_forward: null pointer");
+  DS_CHECK(dtype == DS_F32 || dtype == DS_BF16, "attnblock_forward: bad dtype");
+  DS_CHECK(channels % 8 == 0 && channels >= 8 && B >= 1 && H >= 1 && W >= 1, "attnblock_forward: bad shape");
+  MiniEngine me;
+  me.e = new diffsep_engine();
+  diffsep_engine* e = me.e;
+  memset(&e->cfg, 0, sizeof(e->cfg));
+  e->cfg.dtype = dtype;
+  e->cfg.nf = 8;
+  {
+    ArchBuilder b(e->arch);
+    b.attn(channels);
+  }
+  if (mini_engine_init(me, dtype, 4, params_host, n_floats)) return 1;
+  const Module& m = e->arch.mods[0];
+  hipStream_t st = (hipStream_t)stream;
+  return mini_engine_run(e, st, [&]() -> int {
+    Tn xin;
+    xin.p = const_cast<void*>(x); xin.C = xin.ld = channels; xin.H = H; xin.W = W;
+    Tn out;
+    if (attn_block(e, m, xin, B, out, st)) return 1;
+    if (!e->dry)
+      DS_HIP(hipMemcpyAsync(y, out.p, (size_t)B * H * W * channels * e->esz, hipMemcpyDeviceToDevice, st));
+    return 0;
+  });
 }
 
 static float* g_tab = nullptr;

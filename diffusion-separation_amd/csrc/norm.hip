@@ -360,8 +360,7 @@ static int gn_apply_typed(const void* x, int ldx, const float* scale, const floa
   if (nb > 16384) nb = 16384;
   if (nb < 1) nb = 1;
   const bool aff = scale != nullptr;
-  static const bool blk = !(getenv("DIFFSEP_RESAMPLE_BLOCK") && atoi(getenv("DIFFSEP_RESAMPLE_BLOCK")) == 0);
-  if (blk && aff && (mode == 1 || (mode == 2 && H % 4 == 0 && W % 4 == 0))) {  // 2 x 2 output blocks per thread
+  if (aff && (mode == 1 || (mode == 2 && H % 4 == 0 && W % 4 == 0))) {  // 2 x 2 output blocks per thread
     const long tot2 = (mode == 1 ? (long)B * H * W : (long)B * (H / 4) * (W / 4)) * (C >> 3);
     long nb2 = (tot2 + 255) / 256;
     if (nb2 > 16384) nb2 = 16384;

@@ -90,12 +90,14 @@ def NoisyDataset(audio_path, audio_len=None, fs=16000, augmentation=False, split
     return voicebank_demand(audio_path, fs=fs, split=split)
 
 
-def pad_batch(items, side="center"):
+def pad_batch(items, side="center", to=None):
     """[(mix [1,T_i], tgt [S,T_i])] -> (mix [B,1,Tmax], tgt [B,S,Tmax], lengths [B]).  side="center" spreads the padding
     on both ends (left half rounded down) like the reference's max_collator (datasets/wsj0_mix.py:95-111); side="right"
-    appends it (what the engine's mixed-length batches take: Engine.pc_sample(lengths=...))."""
+    appends it (what the engine's mixed-length batches take: Engine.pc_sample(lengths=...)).  to: pad to this length
+    instead of the longest item (Engine.bucket_length: one workspace plan per padded width)."""
     lengths = [int(m.shape[-1]) for m, _ in items]
-    Tmax = max(lengths)
+    Tmax = max(lengths) if to is None else int(to)
+    assert Tmax >= max(lengths)
     out_m, out_t = [], []
     for (m, t), n in zip(items, lengths):
         left = (Tmax - n) // 2 if side == "center" else 0

@@ -105,6 +105,12 @@ class Engine:
     def padded_frames(self, T):
         return int(lib().diffsep_padded_frames(C.byref(self.cfg), T))
 
+    def bucket_length(self, W):
+        """The longest signal whose padded frame count is W = 64 k: F = 1 + (T + n_fft - hop) // hop <= W.  Mixed-length
+        batches padded to this length share ONE workspace plan / captured graph per (B, W), whatever their members'
+        lengths (the results do not depend on the padding: diffsep_sampler_ext.lengths_host)."""
+        return int(self.cfg.hop) * int(W) - (int(self.cfg.n_fft) - int(self.cfg.hop)) - 1
+
     def _f32(self, t):
         assert t.is_cuda and t.dtype == torch.float32, "device float32 tensor expected"
         return t.contiguous()

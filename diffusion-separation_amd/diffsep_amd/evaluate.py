@@ -162,7 +162,7 @@ def main(argv=None):
     batches = plan_batches(mine, lengths, eng0.padded_frames, max(1, args.batch))
     if batches:  # workspace for the largest call now: growing it later would stall every stream
         bmax = max(len(g) for g in batches)
-        tmax = max(lengths[i] for i in mine)
+        tmax = eng0.bucket_length(eng0.padded_frames(max(lengths[i] for i in mine)))
         for m in models:
             m.score_model.engine().reserve(bmax, tmax)
             if m.tail_engine() is not None:
@@ -177,7 +177,9 @@ def main(argv=None):
     def stage(group, w):
         """load, pad, upload and normalise one batch on worker w's stream -> (mix, mix_n, tgt_n, lens)"""
         items = [get(i) for i in group]
-        mix, tgt, lens = datasets.pad_batch(items, side="right")
+        # padded to the longest length of the batch's width bucket: one workspace plan / captured graph per (B, W)
+        mix, tgt, lens = datasets.pad_batch(items, side="right",
+                                            to=eng0.bucket_length(eng0.padded_frames(max(lengths[i] for i in group))))
         # pinned staging + asynchronous copies: a pageable host->device copy serialises the whole device
         mix = mix.contiguous().pin_memory().to("cuda", non_blocking=True)
         tgt = tgt.contiguous().pin_memory().to("cuda", non_blocking=True)

@@ -136,6 +136,29 @@ def attention(q, k, vt):
     return o
 
 
+def resblock_forward(params, x, temb, out_ch, up=False, down=False):
+    """ResnetBlockBigGANpp through the engine's block code.  params: list of float32 arrays in reference state_dict
+    order; x [B,H,W,Cin] NHWC, temb [B,D] f32 -> [B,H',W',out_ch]."""
+    B, H, W, cin = x.shape
+    blob = np.ascontiguousarray(np.concatenate([np.asarray(p, np.float32).reshape(-1) for p in params]))
+    Ho, Wo = (2 * H, 2 * W) if up else ((H // 2, W // 2) if down else (H, W))
+    y = torch.empty((B, Ho, Wo, out_ch), dtype=x.dtype, device=x.device)
+    check(lib().diffsep_resblock_forward(cin, out_ch, int(up), int(down), temb.shape[1], _dt(x),
+                                         blob.ctypes.data_as(C.c_void_p), blob.size, _ptr(x.contiguous()),
+                                         _ptr(temb.contiguous()), _ptr(y), B, H, W, _stream_ptr()))
+    return y
+
+
+def attnblock_forward(params, x):
+    """AttnBlockpp through the engine's block code.  params: GroupNorm_0.{weight,bias}, NIN_0..3.{W,b}."""
+    B, H, W, Cc = x.shape
+    blob = np.ascontiguousarray(np.concatenate([np.asarray(p, np.float32).reshape(-1) for p in params]))
+    y = torch.empty_like(x)
+    check(lib().diffsep_attnblock_forward(Cc, _dt(x), blob.ctypes.data_as(C.c_void_p), blob.size, _ptr(x.contiguous()),
+                                          _ptr(y), B, H, W, _stream_ptr()))
+    return y
+
+
 def stft_pack(xt, mix, W, cpad, n_fft=510, hop=128, exponent=0.5, factor=0.33, shift=False, dtype=torch.float32):
     B, S, T = xt.shape
     y = torch.empty((B, n_fft // 2 + 1, W, cpad), dtype=dtype, device=xt.device)

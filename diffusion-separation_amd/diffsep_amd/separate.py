@@ -124,9 +124,10 @@ def main(argv=None):
     batches = plan_batches(range(len(files)), lengths, eng.padded_frames, max(1, args.batch))
     if batches:  # workspace for the largest call now (growing it later synchronises the whole device)
         for m in models:
-            m.score_model.engine().reserve(max(len(g) for g in batches), max(lengths))
+            tmax = eng.bucket_length(eng.padded_frames(max(lengths)))
+            m.score_model.engine().reserve(max(len(g) for g in batches), tmax)
             if m.tail_engine() is not None:
-                m.tail_engine().reserve(max(len(g) for g in batches), max(lengths))
+                m.tail_engine().reserve(max(len(g) for g in batches), tmax)
     seeds = None
     if args.seed is not None:
         seeds = torch.randint(0, 2 ** 62, (max(len(files), 1),),
@@ -157,7 +158,8 @@ def main(argv=None):
                 print(f"Warning: {files[i].stem}: this model expects {model_sr} Hz, but the file is {sr} Hz.")
             items.append((wav[:1], wav[:1]))
             srs.append(sr)
-        mix, _, lens = datasets.pad_batch(items, side="right")
+        mix, _, lens = datasets.pad_batch(items, side="right",
+                                          to=eng.bucket_length(eng.padded_frames(max(lengths[i] for i in group))))
         with torch.cuda.stream(streams[w]):
             sep = separate_on_device(mix.pin_memory().to(args.device, non_blocking=True), models[w], kw, args.device,
                                      lengths=lens, seeds=[seeds[i] for i in group] if seeds is not None else None)

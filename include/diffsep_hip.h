@@ -235,6 +235,20 @@ int32_t diffsep_conv2d_chunk(int32_t ksize, int32_t dtype);
  * GroupNorm affine parameters gamma / beta [Cin] and the group count; the kernel derives scale / shift itself
  * (eps = 1e-6, statistics over H * W * Cin / groups elements per group). */
 
+/* ResnetBlockBigGANpp.forward (layerspp.py:291-323) through the engine's own block code (GroupNorm + SiLU fused into
+ * the convolutions' input staging, FIR up / down of both branches in one pass, Conv_2 folded into Conv_1, temb
+ * projection Dense_0(act(temb))): x [B,H,W,in_ch] NHWC (dtype), temb [B,temb_dim] f32 -> y [B,H',W',out_ch].
+ * params_host: the block's parameters as one float32 blob in reference state_dict order (GroupNorm_0.{weight,bias},
+ * Conv_0.{weight,bias}, Dense_0.{weight,bias}, GroupNorm_1.{weight,bias}, Conv_1.{weight,bias}[, Conv_2.{weight,
+ * bias} when in_ch != out_ch or up or down]).  Test aid: builds a one-module engine per call and synchronises. */
+int32_t diffsep_resblock_forward(int32_t in_ch, int32_t out_ch, int32_t up, int32_t down, int32_t temb_dim,
+                                 int32_t dtype, const float* params_host, int64_t n_floats, const void* x,
+                                 const float* temb, void* y, int32_t B, int32_t H, int32_t W, void* stream);
+/* AttnBlockpp.forward (layerspp.py:76-92) through the engine's block code: x, y [B,H,W,C] NHWC (dtype);
+ * params_host = GroupNorm_0.{weight,bias}, NIN_0.{W,b} .. NIN_3.{W,b} as one float32 blob.  Test aid. */
+int32_t diffsep_attnblock_forward(int32_t channels, int32_t dtype, const float* params_host, int64_t n_floats,
+                                  const void* x, void* y, int32_t B, int32_t H, int32_t W, void* stream);
+
 /* AttnBlockpp core (layerspp.py:83-87): o = softmax(q k^T * C^-0.5) v over L = H*W tokens.
  * q,k [B,L,C] (ld), vt [B,C,Lp] (V transposed, Lp = L rounded up to 8), o [B,L,C];
  * ws >= B*L*Lp*(2*elt) bytes.  QK^T and PV run on MFMA. */

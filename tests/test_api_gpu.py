@@ -141,15 +141,18 @@ def test_evaluate_cli_writes_reference_style_results(tmp_path):
              str(tmp_path / "sep")])
     rec = json.load(open(tmp_path / "sep" / "test.json"))
     assert [r["batch_idx"] for r in rec] == [0, 1, 2]
-    assert all(r["nfe"] == 4 and r["runtime"] > 0 and abs(r["len_s"] - 0.5) < 1e-9 and np.isfinite(r["si_sdr"]) for r in rec)
+    assert all(r["nfe"] == 4 and r["runtime"] > 0 and abs(r["len_s"] - 0.5) < 1e-9 and np.isfinite(r["si_sdr"]).all()
+               and np.asarray(r["si_sdr"]).shape == (1, 2) for r in rec)   # per-source lists (evaluate.py:394-405)
     summ = json.load(open(tmp_path / "sep" / "test_summary.json"))
     assert summ["number"] == 3 and summ["world_size"] == 1 and summ["nfe"] == 4
-    assert abs(summ["si_sdr"] - np.mean([r["si_sdr"] for r in rec])) < 1e-9
-    # --enhance: PriorMixSDE model (nr.yaml), metrics on the first source only
+    assert abs(summ["si_sdr"] - np.mean([np.mean(r["si_sdr"]) for r in rec])) < 1e-9
+    # --enhance: PriorMixSDE model (nr.yaml); both channels (speech, noise) are scored with the best permutation and
+    # the first n_src = 1 entry is kept (evaluate.py:105-127,268-271)
     ev.main(["--synthetic", "2", "--samples", "4000", "--synthetic-weights", "16", "-N", "2", "--dtype", "f32",
              "--enhance", "-o", str(tmp_path / "enh")])
     rec = json.load(open(tmp_path / "enh" / "test.json"))
-    assert len(rec) == 2 and all(len(r["si_sdr_per_source"]) == 1 for r in rec)
+    assert len(rec) == 2 and all(np.asarray(r["si_sdr"]).shape == (1, 1) and len(r["perm"]) == 2 for r in rec)
+    assert all(abs(r["si_sir"][0][0]) < 99.0 for r in rec)  # a real interference term (one channel alone would clamp)
     assert all({"batch_idx", "si_sdr", "si_sir", "si_sar", "pesq", "stoi", "nfe", "runtime", "len_s"} <= set(r) for r in rec)
 
 

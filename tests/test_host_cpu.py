@@ -209,3 +209,38 @@ def test_bench_multi_rank_sequencing_gloo(tmp_path):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak" and "roofline" in res
     assert res["config"]["sharding"] == "utterances/2" and res["value"] > 0
+
+
+def test_bench_strong_scaling_sequencing_gloo():
+    # bench.py --scaling strong as the driver would launch it on 2 GPUs, with 2 CPU ranks over gloo and the stand-in
+    # engine: a fixed set split by length, width-bucketed batches, ONE gather per pass, one JSON line with the per-rank
+    # busy times and their imbalance
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, DIFFSEP_BENCH_DRYRUN="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                                       "--warmup", "1", "--batch", "4", "--scaling", "strong", "--utterances", "11"],
+                                      env=e, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-800:] for o in outs]
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    res = json.loads(lines[0])
+    assert res["scaling"] == "strong" and res["n_gpus"] == 2 and res["config"]["utterances"] == 11
+    assert len(res["rank_busy_s_per_step"]) == 2 and res["imbalance_max_over_mean"] >= 1.0 and res["value"] > 0
+
+
+def test_plan_batches_buckets_by_padded_width():
+    from diffsep_amd.evaluate import plan_batches
+    width = lambda T: 64 * ((1 + (T + 382) // 128 + 63) // 64)
+    lengths = [32000, 31000, 40000, 8000, 32001, 7000, 39000, 31999]
+    got = plan_batches(range(len(lengths)), lengths, width, 3)
+    assert got == [[5], [3], [4, 0, 7], [1], [2, 6]]          # ascending width, longest first, <= 3 per call
+    assert all(len({width(lengths[i]) for i in g}) == 1 for g in got)
+    assert sorted(i for g in got for i in g) == list(range(len(lengths)))
