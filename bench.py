@@ -27,7 +27,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
                  the host cores for a bounded number of network evaluations and scaled to utt/s.
   fp32_parity_mode — the same step on the fp32 engine (the mode that meets the 1e-3 RMS parity bar), timed after the
                  main region: utt/s and the roofline fraction of its dominant kernel (fp32 MFMA peak).
-  hybrid       — bf16 for the first N - K reverse steps, the fp32 engine for the last K (pl_model.HYBRID_TAIL_STEPS):
+  hybrid       — bf16 for the first N - K reverse steps, the fp32 engine for the last K (pl_model.HYBRID_HEAD_STEPS):
                  utt/s, and SI-SDR of its output against the fp32 engine's output on the same seeds (the quality the
                  throughput mode gives up).
 """
@@ -375,7 +375,7 @@ def main():
     extra = {}
     if world == 1 and not dry and not args.no_extra_modes and args.dtype == "bf16":
         # ---- the other two precision modes of the same step, on the driver's clock (after the main timed region)
-        from diffsep_amd.pl_model import HYBRID_TAIL_STEPS
+        from diffsep_amd.pl_model import HYBRID_HEAD_STEPS
         cfg32 = _lib.model_config(nf=args.nf, num_sources=S, dtype=_lib.F32)
         K2 = min(K, 2)
         e32 = [Engine(cfg32, blob) for _ in range(K2)]
@@ -389,7 +389,7 @@ def main():
                                               denoise=True, seed=2000 + i)
                 else:
                     sep, _ = engs[w].pc_sample(mn, sde, N=args.N, corrector_steps=args.corrector_steps, snr=0.5, eps=0.03,
-                                               denoise=True, seed=2000 + i, tail=e32[w], tail_steps=HYBRID_TAIL_STEPS)
+                                               denoise=True, seed=2000 + i, tail=e32[w], head_steps=HYBRID_HEAD_STEPS)
                 out = ops.scale_output(mix, sep)
             keep[w] = (mn, sep, out)
             return out
@@ -411,7 +411,7 @@ def main():
             return 10 * torch.log10(((a * ref) ** 2).sum(-1) / ((est - a * ref) ** 2).sum(-1))
         kw = dict(N=args.N, corrector_steps=args.corrector_steps, snr=0.5, eps=0.03, denoise=True, seed=4242)
         o32 = e32[0].pc_sample(mix_norm0, sde, **kw)[0]
-        ohy = engs[0].pc_sample(mix_norm0, sde, tail=e32[0], tail_steps=HYBRID_TAIL_STEPS, **kw)[0]
+        ohy = engs[0].pc_sample(mix_norm0, sde, tail=e32[0], head_steps=HYBRID_HEAD_STEPS, **kw)[0]
         o16 = engs[0].pc_sample(mix_norm0, sde, **kw)[0]
         q_hy, q_16 = si_sdr_db(ohy, o32), si_sdr_db(o16, o32)
         e32[0].profile_begin()
@@ -425,7 +425,7 @@ def main():
                                  "frac": round(fl32 / (ms32 * 1e-3) / 1e12 / PEAK_TFLOPS["f32"], 4) if ms32 > 0 else None,
                                  "bound": "mfma", "peak_tflops": PEAK_TFLOPS["f32"],
                                  "note": "the mode that meets the 1e-3 RMS parity bar (tests/test_engine_gpu.py)"},
-            "hybrid": {"K": HYBRID_TAIL_STEPS, "utt_per_s": round(extra["hybrid"], 3), "batches_in_flight": K2,
+            "hybrid": {"K": HYBRID_HEAD_STEPS, "utt_per_s": round(extra["hybrid"], 3), "batches_in_flight": K2,
                        "si_sdr_db": round(float(q_hy.mean()), 2), "si_sdr_db_min": round(float(q_hy.min()), 2),
                        "bf16_only_si_sdr_db": round(float(q_16.mean()), 2),
                        "bf16_only_si_sdr_db_min": round(float(q_16.min()), 2),

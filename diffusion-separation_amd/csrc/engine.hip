@@ -1068,8 +1068,9 @@ extern "C" int32_t diffsep_pc_sample_ex(diffsep_engine* e, const diffsep_sde_con
            "pc_sample: the 'ald' corrector supports MixSDE only (sdes/correctors.py:64-67)");
   const int64_t* lengths = ext ? ext->lengths_host : nullptr;
   const uint64_t* seeds = ext ? ext->seeds_host : nullptr;
-  diffsep_engine* tail = (ext && ext->tail_steps > 0) ? ext->tail_engine : nullptr;
+  diffsep_engine* tail = (ext && (ext->tail_steps > 0 || ext->head_steps > 0)) ? ext->tail_engine : nullptr;
   const int tail_steps = tail ? ext->tail_steps : 0;
+  const int head_steps = tail ? ext->head_steps : 0;
   if (tail) {
     DS_CHECK(tail != e, "pc_sample: the tail engine must be a different engine");
     diffsep_model_config a = e->cfg, b2 = tail->cfg;
@@ -1181,7 +1182,7 @@ extern "C" int32_t diffsep_pc_sample_ex(diffsep_engine* e, const diffsep_sde_con
   bool tail_ready = false;
   const float* score = e->st_score;
   auto eval_score = [&](int i) -> int {
-    if (tail && i >= N - tail_steps) {
+    if (tail && (i >= N - tail_steps || i < head_steps)) {
       if (!tail_ready) {
         DS_HIP(hipMemcpyAsync(tail->st_mix, e->st_mix, (size_t)B * T * 4, hipMemcpyDeviceToDevice, st));
         tail_ready = true;

@@ -31,7 +31,7 @@ class SamplerConfig(C.Structure):
 
 class SamplerExt(C.Structure):
     _fields_ = [("lengths_host", C.POINTER(C.c_int64)), ("seeds_host", C.POINTER(C.c_uint64)),
-                ("tail_engine", C.c_void_p), ("tail_steps", C.c_int32)]
+                ("tail_engine", C.c_void_p), ("tail_steps", C.c_int32), ("head_steps", C.c_int32)]
 
 
 class DiffsepError(RuntimeError):

@@ -154,7 +154,7 @@ class Engine:
 
     def pc_sample(self, mix_norm, sde, N=30, corrector_steps=1, snr=0.5, eps=0.03, denoise=True,
                   predictor="reverse_diffusion", corrector="ald2", noise=None, seed=0, timesteps=None, lengths=None,
-                  seeds=None, tail=None, tail_steps=0):
+                  seeds=None, tail=None, tail_steps=0, head_steps=0):
         """The whole sampler (sdes.get_pc_sampler(...)()).  sde: dict(kind, ndim, d_lambda, sigma_min, sigma_max).
         Extensions (diffsep_sampler_ext): lengths [B] = a zero-padded batch of utterances of different lengths that share
         one padded frame count; seeds [B] = per-utterance device-RNG seeds; tail / tail_steps = evaluate the score of the
@@ -181,7 +181,7 @@ class Engine:
             assert ts.size >= N
         nfe = C.c_int32()
         ext, keep = None, []
-        if lengths is not None or seeds is not None or (tail is not None and tail_steps > 0):
+        if lengths is not None or seeds is not None or (tail is not None and (tail_steps > 0 or head_steps > 0)):
             ext = _lib.SamplerExt()
             if lengths is not None:
                 la = np.ascontiguousarray(lengths, dtype=np.int64)
@@ -193,8 +193,8 @@ class Engine:
                 assert sa.shape == (B,), "seeds must be [B]"
                 ext.seeds_host = sa.ctypes.data_as(C.POINTER(C.c_uint64))
                 keep.append(sa)
-            if tail is not None and tail_steps > 0:
-                ext.tail_engine, ext.tail_steps = tail._h, int(tail_steps)
+            if tail is not None and (tail_steps > 0 or head_steps > 0):
+                ext.tail_engine, ext.tail_steps, ext.head_steps = tail._h, int(tail_steps), int(head_steps)
         with torch.cuda.device(self.device):
             check(lib().diffsep_pc_sample_ex(self._h, C.byref(sc), C.byref(sm), C.byref(ext) if ext is not None else None,
                                              _ptr(mix_norm), _ptr(out), B, T, _ptr(noise), seed,

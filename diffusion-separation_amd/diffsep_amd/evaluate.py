@@ -63,11 +63,13 @@ def load_dataset(args, fs):
         return len(ds), (lambda i: tuple(t[..., : ds.num_samples(i)] for t in ds[i])), \
             [ds.num_samples(i) for i in range(len(ds))]
     n = args.synthetic
+    hi = args.samples if args.samples_max is None else max(args.samples, args.samples_max)
+    lens = [args.samples + (i * 7919) % (hi - args.samples + 1) for i in range(n)]  # (--samples-max: varied lengths)
 
     def get(i):
-        mix, tgt = synth.synth_mixture(i, T=args.samples, fs=fs, n_src=args.n_speakers)
+        mix, tgt = synth.synth_mixture(i, T=lens[i], fs=fs, n_src=args.n_speakers)
         return torch.from_numpy(mix), torch.from_numpy(tgt)
-    return n, get, [args.samples] * n
+    return n, get, lens
 
 
 def plan_batches(indices, lengths, width_of, batch):
@@ -90,6 +92,8 @@ def main(argv=None):
     ap.add_argument("--dataset-dir", type=str, default=None)
     ap.add_argument("--synthetic", type=int, default=0, help="number of synthetic mixtures")
     ap.add_argument("--samples", type=int, default=32000)
+    ap.add_argument("--samples-max", type=int, default=None,
+                    help="--synthetic: utterance lengths spread over [--samples, --samples-max] instead of one length")
     ap.add_argument("--n-speakers", type=int, default=2)
     ap.add_argument("-l", "--limit", type=int, default=None)
     ap.add_argument("-s", "--split", default="test", choices=["train", "val", "test", "libri2mix_test"])
@@ -109,11 +113,11 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=16,
                     help="utterances per engine call: those with the same padded spectrogram width share a call "
                          "(zero-padded to the longest; --batch 1 = the reference's one-utterance loop)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=4,
                     help="engine calls (batches) in flight per GPU: K engines on K HIP streams; the records do not "
                          "depend on K.  'runtime' of an utterance is its batch's latency / batch size.")
-    ap.add_argument("--tail-steps", type=int, default=None,
-                    help="with --dtype hybrid: reverse steps evaluated by the fp32 engine (default: pl_model.HYBRID_TAIL_STEPS)")
+    ap.add_argument("--fp32-steps", type=int, default=None,
+                    help="with --dtype hybrid: the first K reverse steps run on the fp32 engine (default: pl_model.HYBRID_HEAD_STEPS)")
     ap.add_argument("--enhance", action="store_true",
                     help="speech enhancement (evaluate.py:173-176,268-271): PriorMixSDE model, metrics on the first "
                          "source (clean speech) only")
@@ -137,8 +141,8 @@ def main(argv=None):
         if args.synthetic_weights or args.ckpt is None:
             cfg = (enhancement_config(nf=args.synthetic_weights or 128) if args.enhance
                    else default_config(nf=args.synthetic_weights or 64, n_speakers=args.n_speakers))
-            return DiffSepModel(cfg, dtype=args.dtype, tail_steps=args.tail_steps)
-        return DiffSepModel.load_from_checkpoint(args.ckpt, dtype=args.dtype, tail_steps=args.tail_steps)
+            return DiffSepModel(cfg, dtype=args.dtype, head_steps=args.fp32_steps)
+        return DiffSepModel.load_from_checkpoint(args.ckpt, dtype=args.dtype, head_steps=args.fp32_steps)
 
     K = max(1, args.streams)
     models = [make_model() for _ in range(K)]  # one engine (weights copy + workspace) per stream

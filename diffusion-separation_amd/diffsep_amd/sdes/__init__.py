@@ -65,7 +65,7 @@ def _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, d
                 x, _ = eng.pc_sample(y, sde.engine_config(), N=sde.N, corrector_steps=corrector.n_steps, snr=snr,
                                      eps=eps, denoise=denoise, predictor=predictor_name, corrector=corrector_name,
                                      seed=s_, timesteps=ts, lengths=lengths, seeds=seeds, tail=tail,
-                                     tail_steps=getattr(score_fn, "tail_steps", 0) if tail is not None else 0)
+                                     head_steps=getattr(score_fn, "head_steps", 0) if tail is not None else 0)
                 return x, ns
             im = []
             xt = sde.prior_sampling((true_mean if true_mean is not None else y).shape,

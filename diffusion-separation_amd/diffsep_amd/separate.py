@@ -28,14 +28,14 @@ DEFAULT_MODEL = "fakufaku/diffsep"
 def get_model(args):
     if args.synthetic_weights:
         model = DiffSepModel(default_config(nf=args.synthetic_weights), dtype=args.dtype, device=args.device,
-                             tail_steps=getattr(args, "tail_steps", None))
+                             head_steps=getattr(args, "fp32_steps", None))
     else:
         path = Path(args.model)
         if not path.exists():
             raise FileNotFoundError(f"checkpoint '{args.model}' not found (Hugging Face download needs network access; "
                                     "pass a local Lightning checkpoint or --synthetic-weights NF)")
         model = DiffSepModel.load_from_checkpoint(str(path), dtype=args.dtype, device=args.device,
-                                                  tail_steps=getattr(args, "tail_steps", None))
+                                                  head_steps=getattr(args, "fp32_steps", None))
     model.to(args.device)
     model.eval()
     N = cfg_get(model.config, "model.sampler.N", 30) if args.N is None else args.N
@@ -95,7 +95,7 @@ def main(argv=None):
     ap.add_argument("-s", "--schedule", type=str, default=None)
     ap.add_argument("--synthetic-weights", type=int, default=0, metavar="NF")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "hybrid"])
-    ap.add_argument("--tail-steps", type=int, default=None, help="--dtype hybrid: reverse steps on the fp32 engine")
+    ap.add_argument("--fp32-steps", type=int, default=None, help="--dtype hybrid: the first K reverse steps run on the fp32 engine")
     ap.add_argument("--batch", type=int, default=1, help="files per engine call (equal padded width)")
     ap.add_argument("--streams", type=int, default=1, help="engine calls in flight: K engines on K HIP streams")
     ap.add_argument("--seed", type=int, default=None,

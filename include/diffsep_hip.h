@@ -156,15 +156,17 @@ int32_t diffsep_pc_sample(diffsep_engine* e, const diffsep_sde_config* sde, cons
  *   seeds_host [B]    : per-utterance Philox seeds (with noise == NULL): utterance b draws exactly what a B = 1 call
  *                       with seed = seeds_host[b] draws, whatever batch it rides in.  Without it `seed` keys the
  *                       whole batch as in diffsep_pc_sample (with lengths: utterance b uses seed + b * 0x9E3779B97F4A7C15).
- *   tail_engine/steps : evaluate the score of the LAST tail_steps reverse steps (their corrector and predictor
- *                       evaluations) with another engine of the same architecture and weights — the fp32 engine
- *                       behind a bf16 one: rounding noise of the bf16 network only matters once the injected noise
- *                       G z has become small, i.e. in the last steps. */
+ *   tail_engine       : a second engine of the same architecture and weights (the fp32 engine behind a bf16 one) that
+ *                       evaluates the score of the FIRST head_steps and / or the LAST tail_steps reverse steps (their
+ *                       corrector and predictor evaluations).  A score error enters the state scaled by the step size
+ *                       G(t)^2, ~100x larger at t = 1 than at t = eps: it is the early steps whose precision decides
+ *                       how closely the bf16 sampler follows the fp32 one (tools/hybrid_probe.py). */
 typedef struct {
   const int64_t* lengths_host;
   const uint64_t* seeds_host;
   diffsep_engine* tail_engine;
   int32_t tail_steps;
+  int32_t head_steps;
 } diffsep_sampler_ext;
 int32_t diffsep_pc_sample_ex(diffsep_engine* e, const diffsep_sde_config* sde, const diffsep_sampler_config* smp,
                              const diffsep_sampler_ext* ext, const float* mix_norm, float* out, int32_t B, int64_t T,
