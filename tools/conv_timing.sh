@@ -7,7 +7,7 @@ mkdir -p ../abl
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DCONV_TIMING -c conv_mfma.hip -o /tmp/conv_timing.o
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../abl/lib_timing.so /tmp/conv_timing.o build/conv3x3_ws.o build/norm.o build/stft.o build/sde.o build/engine.o
 cd ../..
-DIFFSEP_CONV_WS=0 DIFFSEP_LIB=$PWD/diffusion-separation_amd/abl/lib_timing.so python - <<'PY'
+DIFFSEP_LIB=$PWD/diffusion-separation_amd/abl/lib_timing.so python - <<'PY'
 import ctypes, sys, os, torch
 sys.path.insert(0, "diffusion-separation_amd")
 from diffsep_amd import ops, _lib

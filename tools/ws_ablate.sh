@@ -9,7 +9,7 @@ for v in NOLOAD NOACT NOLDSW NOMFMA NOEPI; do
     hipcc --offload-arch=gfx950 -shared -fPIC -o diffusion-separation_amd/abl/lib_wsa_$v.so /tmp/wsa_$v.o $C/build/conv_mfma.o $C/build/norm.o $C/build/stft.o $C/build/sde.o $C/build/engine.o ) &
 done
 wait
-echo "== BASE"; DIFFSEP_CONV_WS=2 timeout 60 python tools/bench_conv.py bf16 20 0 2>&1 | grep "^k"
+echo "== BASE"; timeout 60 python tools/bench_conv.py bf16 20 0 2>&1 | grep "^k"
 for v in NOLOAD NOACT NOLDSW NOMFMA NOEPI; do
-  echo "== $v"; DIFFSEP_CONV_WS=2 DIFFSEP_LIB=$PWD/diffusion-separation_amd/abl/lib_wsa_$v.so timeout 60 python tools/bench_conv.py bf16 20 0 2>&1 | grep "^k"
+  echo "== $v"; DIFFSEP_LIB=$PWD/diffusion-separation_amd/abl/lib_wsa_$v.so timeout 60 python tools/bench_conv.py bf16 20 0 2>&1 | grep "^k"
 done

@@ -6,7 +6,7 @@ mkdir -p ../abl
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DWS_TIMING -c conv3x3_ws.hip -o /tmp/ws_timing.o
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../abl/lib_wstiming.so /tmp/ws_timing.o build/conv_mfma.o build/norm.o build/stft.o build/sde.o build/engine.o
 cd ../..
-DIFFSEP_CONV_WS=${WSV:-2} DIFFSEP_LIB=$PWD/diffusion-separation_amd/abl/lib_wstiming.so python - <<'PY'
+DIFFSEP_LIB=$PWD/diffusion-separation_amd/abl/lib_wstiming.so python - <<'PY'
 import ctypes, sys, os, torch
 sys.path.insert(0, "diffusion-separation_amd")
 from diffsep_amd import ops
