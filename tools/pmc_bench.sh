@@ -1,17 +1,20 @@
 #!/bin/bash
-# HBM traffic of the dominant kernel inside the real bench: FETCH_SIZE and WRITE_SIZE in separate passes
+# HBM traffic of the dominant kernels inside the real bench: FETCH_SIZE and WRITE_SIZE in separate passes
 # (TCC has 4 slots: FETCH_SIZE costs 3, WRITE_SIZE 2), kernel-trace only, as MI355X_MICROARCH.md prescribes.
+# Usage (GPU box, repo root): COMMIT=<git hash> bash tools/pmc_bench.sh [outdir]; writes <outdir>/pmc_conv3x3.json,
+# which is copied to profiles/pmc_conv3x3.json (bench.py reads roofline.traffic from there and names the commit).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=${1:-gpurun_out/pmc_bench}
 mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d $OUT/$c -o pmc --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-graph > $OUT/$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d $OUT/$c -o pmc --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-graph --no-extra-modes > $OUT/$c.log 2>&1
 done
-python - <<'PY'
+OUT=$OUT python - <<'PY'
 import csv, glob, json, os
+out = os.environ["OUT"]
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(os.path.join("gpurun_out/pmc_bench", c, "*counter_collection.csv"))
+    f = glob.glob(os.path.join(out, c, "**", "*counter_collection.csv"), recursive=True)
     for r in csv.DictReader(open(f[0])):
         k = r["Kernel_Name"]
         key = ("conv_mfma_9_8_32_64" if "conv_mfma_kernel<unsigned short, 9, 8, 32, 64" in k else
@@ -19,6 +22,23 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if key and r["Counter_Name"] == c:
             d = res.setdefault(key, {}).setdefault(c, [0.0, 0])
             d[0] += float(r["Counter_Value"]); d[1] += 1
-print(json.dumps(res))
-json.dump(res, open("gpurun_out/pmc_bench/summary.json", "w"))
+kern = {}
+for k, v in res.items():
+    n = v["FETCH_SIZE"][1]
+    f, w = v["FETCH_SIZE"][0] / n, v["WRITE_SIZE"][0] / max(v["WRITE_SIZE"][1], 1)
+    kern[k] = {"launches": n, "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
+               "hbm_bytes_per_launch_guide_formula": (2 * f + w) * 1024, "hbm_bytes_per_launch_lower_bound": (f + w) * 1024}
+doc = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 1 "
+                 "--warmup 0 --no-graph` (tools/pmc_bench.sh)",
+       "commit": os.environ.get("COMMIT", "unrecorded"),
+       "correction": "MI355X_MICROARCH.md (HBM): FETCH_SIZE tallies 128-byte requests at 64 B -> doubled for wide coalesced reads; "
+                     "WRITE_SIZE uncorrected; unit KB = 1024 B.  Calibration on this kernel family's own pattern (DESIGN.md section 5): "
+                     "the 64-byte halo pieces are counted 1:1, full-line rows at 1/2, so 2*FETCH+WRITE is an upper bound and "
+                     "FETCH+WRITE a lower bound of the true traffic.",
+       "kernels": kern,
+       "hbm_bytes_per_launch_bf16_B16": kern.get("conv_mfma_9_8_32_64", {}).get("hbm_bytes_per_launch_guide_formula"),
+       "hbm_bytes_per_launch_ws_bf16_B16": kern.get("conv3x3_ws1", {}).get("hbm_bytes_per_launch_guide_formula")}
+json.dump(doc, open(os.path.join(out, "pmc_conv3x3.json"), "w"), indent=1)
+print(json.dumps(doc["kernels"]))
 PY
+rm -rf $OUT/FETCH_SIZE $OUT/WRITE_SIZE
