@@ -124,7 +124,7 @@ def run_strong(args, engs, ops, on_stream, sync, fence, dist, world, rank, dev, 
                 for b, L in enumerate(lens):
                     mixn[b, :, :L] = ops.normalize_batch(mix[b:b + 1, :, :L])[0][0]
                 sep, nfe = engs[w].pc_sample(mixn, sde, N=args.N, corrector_steps=args.corrector_steps, snr=0.5, eps=0.03,
-                                             denoise=True, lengths=lens, seeds=[10_000 * p + i for i in g])
+                                             denoise=True, lengths=lens, seeds=[10_000 * (p + 1000) + i for i in g])
                 for b, L in enumerate(lens):
                     block[row + b, :, :L] = ops.scale_output(mix[b:b + 1, :, :L], sep[b:b + 1, :, :L])[0]
             keep[w] = (mixn, sep)

@@ -104,6 +104,15 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise DiffsepError(f"{LIB_PATH} not found: build it with __graft_entry__.build() or "
                                "`make -C diffusion-separation_amd/csrc` (hipcc, gfx950). There is no CPU fallback.")
+        # On a GPU box torch must have brought the HIP runtime up BEFORE this library is loaded: loaded first (e.g.
+        # __graft_entry__.build() followed by smoke() in one process), its device calls then failed with "no
+        # ROCm-capable device is detected" (measured; the library and torch share one libamdhip64).  No-op without a GPU.
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
