@@ -84,3 +84,27 @@ def test_engine_refuses_to_run_without_gpu():
     cfg = _lib.model_config(nf=16)
     with pytest.raises(_lib.DiffsepError):
         Engine(cfg, np.zeros(10, np.float32))
+
+
+def test_ctypes_structs_mirror_the_header():
+    # field order and C types of every struct of the boundary: a silent mismatch would shift every argument after it
+    hdr = open(os.path.join(ROOT, "include", "diffsep_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    ctype = {"int32_t": C.c_int32, "float": C.c_float, "const int64_t*": C.POINTER(C.c_int64),
+             "const uint64_t*": C.POINTER(C.c_uint64), "diffsep_engine*": C.c_void_p}
+    want = {"diffsep_model_config": _lib.ModelConfig, "diffsep_sde_config": _lib.SdeConfig,
+            "diffsep_sampler_config": _lib.SamplerConfig, "diffsep_sampler_ext": _lib.SamplerExt}
+    for body, name in re.findall(r"typedef struct \{(.*?)\}\s*(\w+);", hdr, flags=re.S):
+        if name not in want:
+            continue
+        fields = []
+        for decl in [d.strip() for d in body.split(";") if d.strip()]:
+            m = re.match(r"(.+?[\s*])([\w\[\], ]+)$", decl)
+            typ, names = m.group(1).strip().replace(" *", "*"), m.group(2)
+            for nm in [n.strip() for n in names.split(",")]:
+                arr = re.match(r"(\w+)\[(\d+)\]", nm)
+                fields.append((arr.group(1), ctype[typ] * int(arr.group(2))) if arr else (nm, ctype[typ]))
+        mine = [(n, t) for n, t in want.pop(name)._fields_]
+        assert [n for n, _ in mine] == [n for n, _ in fields], name
+        assert all(C.sizeof(a) == C.sizeof(b) for (_, a), (_, b) in zip(mine, fields)), name
+    assert not want, f"structs not found in the header: {list(want)}"
