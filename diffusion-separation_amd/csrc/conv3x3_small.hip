@@ -1,0 +1,488 @@
+// conv3x3_small.hip — 3x3 convolution for the small-image levels of NCSN++ (16^2, 8^2, 4^2; bf16, gfx950).
+//
+// At these levels (ddpm_conv3x3 inside ResnetBlockBigGANpp, reference layers.py:141-156, layerspp.py:291-323) a launch
+// is a few MFLOP per sample: with the 64-cout tile of conv_mfma.hip the grid is 32 - 128 blocks, each of which pulls
+// 64 couts x 9 taps of weights through one CU in a chain of dependent stages (19 us per launch, 1 % MFMA use).
+// The decomposition here is the opposite one — many thin blocks, few stages, everything in flight at once:
+//
+//   * a block owns 16 couts of a 4-row x GW-column pixel tile (GW = 16, 8 or 4 by image width) of one sample:
+//     grid = tiles x Cout / 16 x B (512 blocks for 128 couts at 16^2 and B = 16), 2 blocks per CU;
+//   * K is walked in phases of PC = 128 (or 64) input channels of ONE source (x, then x2 of a concat view, then the raw
+//     block input of the folded 1x1 skip convolution through the centre tap).  A phase stages the whole halo tile
+//     (6 x (GW + 2) pixels) and the block's [9][16][PC] weight slab through registers into LDS; TWO phases are in
+//     flight in two register sets, so the first two phases (= the whole K of most launches) cost one memory round
+//     trip; GroupNorm affine + SiLU is applied in registers on the way to LDS;
+//   * v_mfma_f32_16x16x32_bf16 with A = weights (16 couts x 32 channels), B = 16 pixels of the tile: a lane ends up
+//     with 4 consecutive couts of one pixel = one 8-byte store; wave w owns pixels 16 w .. 16 w + 15 of the tile;
+//   * epilogue in registers: bias (+ per-sample bias), residual, scale, bf16 rounding, GroupNorm statistics of the
+//     output (16-lane shuffles, 4 waves through LDS, integer atomics like every other conv epilogue).
+//
+// Same ConvArgs contract as ds_launch_conv (common.h); ds_conv_small_eligible says which launches come here.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+#ifdef SM_TIMING  // profiling build only (tools/small_timing.sh): per-phase cycle totals of wave 0 of every block
+__device__ unsigned long long g_sm_dbg[16];
+#define ST_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define ST_MARK(i) { unsigned long long st_now = __builtin_readcyclecounter(); st_acc[i] += st_now - st_prev; st_prev = st_now; }
+#define ST_WAIT asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define ST_FLUSH if (threadIdx.x == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_sm_dbg[i_], st_acc[i_]); atomicAdd(&g_sm_dbg[15], 1ull); }
+extern "C" int diffsep_small_debug_read(unsigned long long* out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sm_dbg), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sm_dbg), z, sizeof(z)); }
+  return 0;
+}
+#else
+#define ST_DECL
+#define ST_MARK(i)
+#define ST_WAIT
+#define ST_FLUSH
+#endif
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ inline __amdgpu_buffer_rsrc_t rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ inline uint4 ld16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ inline uint2 ld8(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+  return make_uint2(v.x, v.y);
+}
+__device__ inline void st8(__amdgpu_buffer_rsrc_t r, unsigned voff, uint2 d) {
+  const u32x2_t v = {d.x, d.y};
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, 0, 0);
+}
+
+constexpr int NS = 16;              // couts per block
+constexpr int GN_MAX = 512;         // channels of the lazy GroupNorm table
+
+struct SmK {
+  const bf16_t* x; long x_bs; int ldx;
+  const bf16_t* x2; long x2_bs; int ldx2;
+  int C1, Cin;
+  const bf16_t* w; int w_chunked, w_shift;
+  const bf16_t* sx; long sx_bs; int ldsx;
+  const bf16_t* sx2; long sx2_bs; int ldsx2;
+  int sC1, sCin;
+  const bf16_t* sw; int sw_chunked, sw_shift;
+  const float* gn_scale; const float* gn_shift;
+  const long long* gn_acc1; const long long* gn_acc2; const float* gn_gamma; const float* gn_beta;
+  int gn_cpg; float gn_inv_count; float gn_eps;
+  const float* bias; const float* bias_b; int bias_b_ld;
+  const bf16_t* res; long res_bs; int ldr;
+  float out_scale;
+  bf16_t* y; long y_bs; int ldy;
+  long long* stats;
+  int H, W, Cout, tiles_x;
+};
+
+// GN affine (+ SiLU) on 8 bf16 channels
+template <bool ACT>
+__device__ inline uint4 gn8(const uint4& u, const float* sc, const float* sh) {
+  float f[8];
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = f[j] * sc[j] + sh[j];
+    f[j] = ACT ? silu_t<bf16_t>(v) : v;
+  }
+  uint4 o;
+  o.x = pack_bf16x2(f[0], f[1]);
+  o.y = pack_bf16x2(f[2], f[3]);
+  o.z = pack_bf16x2(f[4], f[5]);
+  o.w = pack_bf16x2(f[6], f[7]);
+  return o;
+}
+
+// tile shapes by image width: 16 columns x 8 rows on 8 waves, 8 x 8 on 4 waves, 4 x 4 (one MFMA group) on 4 waves
+template <int GW> struct SmTile;
+template <> struct SmTile<16> { static constexpr int THT = 8, NT = 512; };
+template <> struct SmTile<8> { static constexpr int THT = 8, NT = 256; };
+template <> struct SmTile<4> { static constexpr int THT = 4, NT = 256; };
+
+template <int GW, int PC>
+struct SmGeom {
+  static constexpr int THT = SmTile<GW>::THT, NT = SmTile<GW>::NT;
+  static constexpr int HWS = GW + 2, HP = (THT + 2) * HWS;  // halo columns / pixels
+  static constexpr int NVEC = PC / 8;                        // 16-byte vectors per pixel / weight row
+  static constexpr int RPS = NT / NVEC;                      // rows staged by one pass of the block
+  static constexpr int PSTR = PC * 2 + 16;                   // LDS pitch of a halo pixel / of a (tap, cout) weight row
+  static constexpr int NA = (HP + RPS - 1) / RPS;            // input vectors per thread and phase
+  static constexpr int NWV = (9 * NS + RPS - 1) / RPS;       // weight vectors per thread and phase
+  static constexpr int NGRP = THT * GW / 16;                 // 16-pixel groups of the tile (one per wave)
+  static_assert(NGRP <= NT / 64 && NS <= RPS, "one MFMA group per wave; the skip weights are staged in one pass");
+  static constexpr int LDS_IN = HP * PSTR, LDS_W = 9 * NS * PSTR;
+  static constexpr int LDS = LDS_IN + LDS_W + 2 * GN_MAX * 4;
+  static_assert(LDS_IN + LDS_W >= 2 * GN_MAX * 8, "the GroupNorm table is built in the staging area");
+};
+
+// GW: tile columns (16, 8, 4).  PC: channels per phase (64, 128).  MODE: 0 raw input, 1 GroupNorm affine, 2 affine + SiLU.
+template <int GW, int PC, int MODE>
+__global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p) {
+  using G = SmGeom<GW, PC>;
+  constexpr int THT = G::THT, NT = G::NT, NWAVES = NT / 64;
+  constexpr int HWS = G::HWS, HP = G::HP, NVEC = G::NVEC, RPS = G::RPS, PSTR = G::PSTR, NA = G::NA, NWV = G::NWV,
+                NGRP = G::NGRP;
+  ST_DECL
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sIn = smem;
+  char* sW = smem + G::LDS_IN;
+  float* sGN = reinterpret_cast<float*>(smem + G::LDS_IN + G::LDS_W);  // [2][Cin] (lazy GroupNorm)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, q = lane >> 4;
+  const int b = blockIdx.z;
+  const int co0 = blockIdx.y * NS;
+  const int y0 = (blockIdx.x / p.tiles_x) * THT, x0 = (blockIdx.x % p.tiles_x) * GW;
+  const int M = p.H * p.W;
+
+  // ---- staging geometry: vector i = tid + NT k is 16 bytes (8 channels, slot tid % NVEC) of halo pixel i / NVEC
+  const int cv = tid % NVEC, row0 = tid / NVEC;
+  int pixi[NA];    // linear pixel index in the image, or -1 (outside the image or past the halo)
+  bool inner[NA];  // the pixel belongs to the tile proper (all the folded 1x1 convolution needs)
+#pragma unroll
+  for (int k = 0; k < NA; ++k) {
+    const int pix = row0 + RPS * k;
+    const int hy = pix / HWS, hx = pix - hy * HWS;
+    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+    const bool ok = pix < HP && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    pixi[k] = ok ? gy * p.W + gx : -1;
+    inner[k] = ok && hy >= 1 && hy <= THT && hx >= 1 && hx <= GW;
+  }
+  const int lds0 = row0 * PSTR + cv * 16;  // + RPS k PSTR
+
+  const int C1 = p.x2 ? p.C1 : p.Cin, C2 = p.Cin - C1;
+  const int sC1 = p.sx2 ? p.sC1 : p.sCin, sC2 = p.sCin - sC1;
+  const int nph1 = C1 / PC, nphc = nph1 + C2 / PC;                                    // conv phases
+  const int nphs1 = p.sx ? sC1 / PC : 0, nph = nphc + nphs1 + (p.sx ? sC2 / PC : 0);  // + folded skip phases
+
+  const __amdgpu_buffer_rsrc_t rw = rsrc(p.w, (unsigned)p.Cout * 9u * p.Cin * 2u);
+  const __amdgpu_buffer_rsrc_t rsw = rsrc(p.sw ? p.sw : p.w, p.sw ? (unsigned)p.Cout * p.sCin * 2u : 0u);
+
+  struct Stage {
+    uint4 pa[NA], pw[NWV];
+    float gsc[8], gsh[8];
+    bool raw;  // a folded-skip phase: no activation, centre tap only
+  };
+  Stage s0, s1;
+
+  auto issue = [&](int ph, Stage& S) __attribute__((always_inline)) {
+    if (ph >= nphc) {  // folded 1x1 skip convolution: raw input, [Cout][sCin] weights into the centre tap's rows
+      const int s = ph - nphc;
+      const bool second = s >= nphs1;
+      const int cb = (second ? s - nphs1 : s) * PC;
+      const int wb = (second ? sC1 : 0) + cb + cv * 8;  // channel in the skip weights
+      const bf16_t* base = second ? p.sx2 + (long)b * p.sx2_bs : p.sx + (long)b * p.sx_bs;
+      const int ld = second ? p.ldsx2 : p.ldsx;
+      const __amdgpu_buffer_rsrc_t rs = rsrc(base, (unsigned)M * ld * 2u);
+#pragma unroll
+      for (int k = 0; k < NA; ++k)
+        S.pa[k] = ld16(rs, inner[k] ? (unsigned)((pixi[k] * ld + cb + cv * 8) * 2) : OOB, 0);
+      const int co = row0;  // RPS >= NS: one pass
+      const unsigned vo = p.sw_chunked
+                              ? (unsigned)((((wb >> p.sw_shift) * p.Cout + co0 + co) * p.sw_chunked + (wb & (p.sw_chunked - 1))) * 2)
+                              : (unsigned)(((co0 + co) * p.sCin + wb) * 2);
+      S.pw[0] = ld16(rsw, co < NS ? vo : OOB, 0);
+      S.raw = true;
+      return;
+    }
+    const bool second = ph >= nph1;
+    const int cb = (second ? ph - nph1 : ph) * PC;
+    const int wb = (second ? C1 : 0) + cb + cv * 8;  // channel in the weights / GroupNorm tables
+    const bf16_t* base = second ? p.x2 + (long)b * p.x2_bs : p.x + (long)b * p.x_bs;
+    const int ld = second ? p.ldx2 : p.ldx;
+    const __amdgpu_buffer_rsrc_t rx = rsrc(base, (unsigned)M * ld * 2u);
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+      S.pa[k] = ld16(rx, pixi[k] >= 0 ? (unsigned)((pixi[k] * ld + cb + cv * 8) * 2) : OOB, 0);
+#pragma unroll
+    for (int k = 0; k < NWV; ++k) {
+      const int row = row0 + RPS * k, tap = row >> 4, co = row & 15;
+      const unsigned vo =
+          p.w_chunked ? (unsigned)(((((wb >> p.w_shift) * 9 + tap) * p.Cout + co0 + co) * p.w_chunked + (wb & (p.w_chunked - 1))) * 2)
+                      : (unsigned)((((co0 + co) * 9 + tap) * p.Cin + wb) * 2);
+      S.pw[k] = ld16(rw, row < 9 * NS ? vo : OOB, 0);
+    }
+    S.raw = false;
+  };
+  // GroupNorm scale / shift of the thread's 8 channels of conv phase ph (from the LDS table or the materialised arrays)
+  auto fetch_gn = [&](int ph, Stage& S) __attribute__((always_inline)) {
+    if (MODE == 0 || ph >= nphc) return;
+    const bool second = ph >= nph1;
+    const int wb = (second ? C1 + (ph - nph1) * PC : ph * PC) + cv * 8;
+    const float4* ps = p.gn_acc1 ? reinterpret_cast<const float4*>(sGN + wb)
+                                 : reinterpret_cast<const float4*>(p.gn_scale + (long)b * p.Cin + wb);
+    const float4* ph_ = p.gn_acc1 ? reinterpret_cast<const float4*>(sGN + p.Cin + wb)
+                                  : reinterpret_cast<const float4*>(p.gn_shift + (long)b * p.Cin + wb);
+    const float4 a0 = ps[0], a1 = ps[1], h0 = ph_[0], h1 = ph_[1];
+    S.gsc[0] = a0.x; S.gsc[1] = a0.y; S.gsc[2] = a0.z; S.gsc[3] = a0.w; S.gsc[4] = a1.x; S.gsc[5] = a1.y; S.gsc[6] = a1.z; S.gsc[7] = a1.w;
+    S.gsh[0] = h0.x; S.gsh[1] = h0.y; S.gsh[2] = h0.z; S.gsh[3] = h0.w; S.gsh[4] = h1.x; S.gsh[5] = h1.y; S.gsh[6] = h1.z; S.gsh[7] = h1.w;
+  };
+  auto activate = [&](Stage& S) __attribute__((always_inline)) {  // zero padding keeps its loaded zeros
+    if (MODE == 0 || S.raw) return;
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      const uint4 r = gn8<MODE == 2>(S.pa[k], S.gsc, S.gsh);
+      const bool ok = pixi[k] >= 0;
+      S.pa[k].x = ok ? r.x : S.pa[k].x;
+      S.pa[k].y = ok ? r.y : S.pa[k].y;
+      S.pa[k].z = ok ? r.z : S.pa[k].z;
+      S.pa[k].w = ok ? r.w : S.pa[k].w;
+    }
+  };
+  auto write = [&](Stage& S) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NA; ++k)
+      if (row0 + RPS * k < HP) *reinterpret_cast<uint4*>(sIn + lds0 + RPS * k * PSTR) = S.pa[k];
+    if (S.raw) {
+      if (row0 < NS) *reinterpret_cast<uint4*>(sW + (4 * NS) * PSTR + lds0) = S.pw[0];
+      return;
+    }
+#pragma unroll
+    for (int k = 0; k < NWV; ++k)
+      if (row0 + RPS * k < 9 * NS) *reinterpret_cast<uint4*>(sW + lds0 + RPS * k * PSTR) = S.pw[k];
+  };
+
+  // this lane's pixel of the tile: 16 w + l16 in raster order, couts co0 + 4 q .. + 3
+  const int pl = wave * 16 + l16, ty = pl / GW, tx = pl % GW;
+  const bool mma_wave = wave < NGRP;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int woff = l16 * PSTR + q * 16;
+  const int aoff = (ty * HWS + tx) * PSTR + q * 16;
+  auto mma = [&](bool raw) __attribute__((always_inline)) {
+    if (!mma_wave) return;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (raw && tap != 4) continue;
+#pragma unroll
+      for (int kb = 0; kb < PC / 32; ++kb) {
+        const bf16x8 wf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sW + tap * NS * PSTR + woff + kb * 64));
+        const bf16x8 xf = __builtin_bit_cast(
+            bf16x8, *reinterpret_cast<const uint4*>(sIn + ((tap / 3) * HWS + tap % 3) * PSTR + aoff + kb * 64));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc, 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- prologue: the first two phases in flight while the GroupNorm table is built
+  ST_MARK(0)
+  issue(0, s0);
+  if (nph > 1) issue(1, s1);
+  ST_MARK(1)
+  if (MODE != 0 && p.gn_acc1) {
+    long long* tmp = reinterpret_cast<long long*>(smem);  // [Cin][2]: the staging area is still unused
+    for (int c = tid; c < p.Cin; c += NT) {
+      const long long* src = c < C1 ? p.gn_acc1 + ((long)b * C1 + c) * 2 : p.gn_acc2 + ((long)b * C2 + (c - C1)) * 2;
+      const longlong2 v = *reinterpret_cast<const longlong2*>(src);
+      tmp[2 * c] = v.x;
+      tmp[2 * c + 1] = v.y;
+    }
+    __syncthreads();
+    const int cpg = p.gn_cpg;
+    constexpr int NIT = GN_MAX / NT;
+    float sc_[NIT], sh_[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = tid + NT * it;
+      sc_[it] = 0.f; sh_[it] = 0.f;
+      if (c < p.Cin) {
+        const int g0 = (int)(((float)c + 0.5f) / (float)cpg) * cpg;  // floor(c / cpg) * cpg, exact for c < 512
+        long long ssum = 0, ssq = 0;
+        for (int j = 0; j < cpg; ++j) {
+          ssum += tmp[2 * (g0 + j)];
+          ssq += tmp[2 * (g0 + j) + 1];
+        }
+        const double mean = (double)ssum * (1.0 / DS_STAT_SUM_SCALE) * (double)p.gn_inv_count;
+        double var = (double)ssq * (1.0 / DS_STAT_SQ_SCALE) * (double)p.gn_inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+        sc_[it] = rstd * (p.gn_gamma ? p.gn_gamma[c] : 1.f);
+        sh_[it] = (p.gn_beta ? p.gn_beta[c] : 0.f) - (float)mean * sc_[it];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int c = tid + NT * it;
+      if (c < p.Cin) { sGN[c] = sc_[it]; sGN[p.Cin + c] = sh_[it]; }
+    }
+    __syncthreads();
+  }
+  fetch_gn(0, s0);
+  if (nph > 1) fetch_gn(1, s1);
+  ST_MARK(2)
+
+  // residual of this lane's output quad: in flight during the K loop
+  const __amdgpu_buffer_rsrc_t rr = rsrc(p.res ? p.res + (long)b * p.res_bs : p.y, p.res ? (unsigned)M * p.ldr * 2u : 0u);
+  const __amdgpu_buffer_rsrc_t ry = rsrc(p.y + (long)b * p.y_bs, (unsigned)M * p.ldy * 2u);
+  const int gy = y0 + ty, gx = x0 + tx;
+  const int mo = (mma_wave && gy < p.H && gx < p.W) ? gy * p.W + gx : -1;
+  const uint2 rres = ld8(rr, mo >= 0 ? (unsigned)((mo * p.ldr + co0 + 4 * q) * 2) : OOB);
+
+  auto step = [&](int ph, Stage& S) __attribute__((always_inline)) {
+    ST_WAIT
+    ST_MARK(3)
+    activate(S);
+    ST_MARK(4)
+    if (ph) __syncthreads();  // the previous phase's fragment reads are done
+    write(S);
+    const bool raw = S.raw;
+    if (ph + 2 < nph) { issue(ph + 2, S); fetch_gn(ph + 2, S); }
+    __syncthreads();
+    ST_MARK(5)
+    mma(raw);
+    ST_MARK(6)
+  };
+  for (int ph = 0; ph < nph; ph += 2) {
+    step(ph, s0);
+    if (ph + 1 < nph) step(ph + 1, s1);
+  }
+
+  // ---- epilogue
+  const float osc = p.out_scale;
+  float v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = co0 + 4 * q + i;
+    const float bs = ((p.bias ? p.bias[c] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + c] : 0.f)) * osc;
+    v[i] = fmaf(acc[i], osc, bs);
+  }
+  v[0] = fmaf(__uint_as_float(rres.x << 16), osc, v[0]);
+  v[1] = fmaf(__uint_as_float(rres.x & 0xffff0000u), osc, v[1]);
+  v[2] = fmaf(__uint_as_float(rres.y << 16), osc, v[2]);
+  v[3] = fmaf(__uint_as_float(rres.y & 0xffff0000u), osc, v[3]);
+  st8(ry, mo >= 0 ? (unsigned)((mo * p.ldy + co0 + 4 * q) * 2) : OOB, make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])));
+  ST_MARK(7)
+  if (p.stats) {
+    const float keep = mo >= 0 ? 1.f : 0.f;
+    float ssum[4], ssq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ssum[i] = keep * v[i];
+      ssq[i] = keep * v[i] * v[i];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        ssum[i] += __shfl_xor(ssum[i], o, 64);
+        ssq[i] += __shfl_xor(ssq[i], o, 64);
+      }
+    }
+    __syncthreads();  // the last phase's fragment reads are done: reuse the staging area
+    float* sr = reinterpret_cast<float*>(smem);  // [waves][16 couts][2]
+    if (l16 == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        sr[((wave * NS) + 4 * q + i) * 2] = ssum[i];
+        sr[((wave * NS) + 4 * q + i) * 2 + 1] = ssq[i];
+      }
+    }
+    __syncthreads();
+    if (tid < NS) {
+      double a = 0.0, s2 = 0.0;
+      for (int w = 0; w < NWAVES; ++w) {
+        a += (double)sr[(w * NS + tid) * 2];
+        s2 += (double)sr[(w * NS + tid) * 2 + 1];
+      }
+      long long* o = p.stats + ((long)b * p.Cout + co0 + tid) * 2;
+      ds_stat_add(o, (long long)llrint(a * DS_STAT_SUM_SCALE));
+      ds_stat_add(o + 1, (long long)llrint(s2 * DS_STAT_SQ_SCALE));
+    }
+  }
+  ST_MARK(8)
+  ST_FLUSH
+}
+
+template <int GW, int PC, int MODE>
+int launch_small(const SmK& k, const ConvArgs& a, hipStream_t st) {
+  constexpr int LDS = SmGeom<GW, PC>::LDS;
+  static bool attr_done = false;
+  if (!attr_done) {
+    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_small_kernel<GW, PC, MODE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_done = true;
+  }
+  dim3 grid(k.tiles_x * cdiv(a.H, SmTile<GW>::THT), a.Cout / NS, a.B);
+  hipLaunchKernelGGL((conv3x3_small_kernel<GW, PC, MODE>), grid, dim3(SmTile<GW>::NT), LDS, st, k);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+template <int GW, int PC>
+int launch_small_mode(const SmK& k, const ConvArgs& a, int mode, hipStream_t st) {
+  if (mode == 2) return launch_small<GW, PC, 2>(k, a, st);
+  if (mode == 1) return launch_small<GW, PC, 1>(k, a, st);
+  return launch_small<GW, PC, 0>(k, a, st);
+}
+
+}  // namespace
+
+// Small images (the launches ds_launch_conv would give to its 8 x 8 tile: W < 32 or H < 8; at most 16 rows), bf16,
+// whole 64-channel phases per source, 16-cout slabs.
+static bool small_sources_multiple_of(const ConvArgs& a, int pc) {
+  const int C1 = a.x2 ? a.C1 : a.Cin;
+  if (C1 % pc != 0 || (a.Cin - C1) % pc != 0) return false;
+  if (a.sx) {
+    const int sC1 = a.sx2 ? a.sC1 : a.sCin;
+    if (sC1 % pc != 0 || (a.sCin - sC1) % pc != 0) return false;
+  }
+  return true;
+}
+bool ds_conv_small_eligible(const ConvArgs& a) {
+  static const bool off = getenv("DIFFSEP_NO_SMALL") != nullptr;  // TEMPORARY A/B switch
+  if (off) return false;
+  if (a.dtype != DS_BF16 || a.taps != 9 || a.w_bs != 0 || a.bias_mode != 0 || a.div_b) return false;
+  if (!(a.W < 32 || a.H < 8) || a.H > 16) return false;
+  if (a.Cout % NS != 0 || !small_sources_multiple_of(a, 64)) return false;
+  if (a.ldx % 8 != 0 || (a.x2 && a.ldx2 % 8 != 0)) return false;
+  if ((a.w_chunked & (a.w_chunked - 1)) || (a.w_chunked && a.w_chunked < 8)) return false;
+  if (a.sx && (!a.sw || (a.sw_chunked & (a.sw_chunked - 1)) || (a.sw_chunked && a.sw_chunked < 8) || a.ldsx % 8 != 0 ||
+               (a.sx2 && a.ldsx2 % 8 != 0)))
+    return false;
+  if (a.gn_acc1 && (a.Cin > GN_MAX || a.gn_groups <= 0 || a.Cin % a.gn_groups != 0 || (a.x2 && !a.gn_acc2))) return false;
+  if (a.ldy % 4 != 0 || (a.res && a.ldr % 4 != 0)) return false;
+  return true;
+}
+
+int ds_launch_conv_small(const ConvArgs& a, hipStream_t st) {
+  SmK k;
+  k.x = reinterpret_cast<const bf16_t*>(a.x); k.x_bs = a.x_bs; k.ldx = a.ldx;
+  k.x2 = reinterpret_cast<const bf16_t*>(a.x2); k.x2_bs = a.x2_bs; k.ldx2 = a.ldx2;
+  k.C1 = a.C1; k.Cin = a.Cin;
+  k.w = reinterpret_cast<const bf16_t*>(a.w); k.w_chunked = a.w_chunked; k.w_shift = a.w_chunked ? __builtin_ctz(a.w_chunked) : 0;
+  k.sx = reinterpret_cast<const bf16_t*>(a.sx); k.sx_bs = a.sx_bs; k.ldsx = a.ldsx;
+  k.sx2 = reinterpret_cast<const bf16_t*>(a.sx2); k.sx2_bs = a.sx2_bs; k.ldsx2 = a.ldsx2;
+  k.sC1 = a.sC1; k.sCin = a.sCin;
+  k.sw = reinterpret_cast<const bf16_t*>(a.sw); k.sw_chunked = a.sw_chunked; k.sw_shift = a.sw_chunked ? __builtin_ctz(a.sw_chunked) : 0;
+  k.gn_scale = a.gn_scale; k.gn_shift = a.gn_shift;
+  k.gn_acc1 = a.gn_acc1; k.gn_acc2 = a.gn_acc2; k.gn_gamma = a.gn_gamma; k.gn_beta = a.gn_beta;
+  k.gn_cpg = a.gn_acc1 ? a.Cin / a.gn_groups : 1; k.gn_inv_count = a.gn_inv_count; k.gn_eps = a.gn_eps;
+  k.bias = a.bias; k.bias_b = a.bias_b; k.bias_b_ld = a.bias_b_ld;
+  k.res = reinterpret_cast<const bf16_t*>(a.res); k.res_bs = a.res_bs; k.ldr = a.ldr;
+  k.out_scale = a.out_scale;
+  k.y = reinterpret_cast<bf16_t*>(a.y); k.y_bs = a.y_bs; k.ldy = a.ldy;
+  k.stats = a.stats_acc;
+  const int gw = a.W <= 4 ? 4 : (a.W <= 8 ? 8 : 16);
+  k.H = a.H; k.W = a.W; k.Cout = a.Cout; k.tiles_x = cdiv(a.W, gw);
+  const int mode = (a.gn_scale || a.gn_acc1) ? (a.gn_act ? 2 : 1) : 0;
+  if (small_sources_multiple_of(a, 128)) {
+    if (gw == 4) return launch_small_mode<4, 128>(k, a, mode, st);
+    if (gw == 8) return launch_small_mode<8, 128>(k, a, mode, st);
+    return launch_small_mode<16, 128>(k, a, mode, st);
+  }
+  if (gw == 4) return launch_small_mode<4, 64>(k, a, mode, st);
+  if (gw == 8) return launch_small_mode<8, 64>(k, a, mode, st);
+  return launch_small_mode<16, 64>(k, a, mode, st);
+}

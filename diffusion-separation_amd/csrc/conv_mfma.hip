@@ -132,10 +132,10 @@ template <> __device__ inline void pack8<bf16_t>(const float* f, uint4* u) {
 struct ConvK {  // kernel-side copy of ConvArgs (typed by the template)
   const void* x; long x_bs; int ldx; int C1;
   const void* x2; long x2_bs; int ldx2;
-  const void* w; long w_bs; int w_chunked;
+  const void* w; long w_bs; int w_chunked; int w_shift;   // w_shift = log2(w_chunked): no integer division in the kernel
   // fused 1x1 skip convolution (ResnetBlockBigGANpp Conv_2): extra K chunks with one tap, raw input
   const void* sx; long sx_bs; int ldsx; const void* sx2; long sx2_bs; int ldsx2; int sC1; int sCin;
-  const void* sw; int sw_chunked;
+  const void* sw; int sw_chunked; int sw_shift;
   const float* gn_scale; const float* gn_shift; int gn_act;
   // GroupNorm from channel-sum accumulators of the producer(s) (fixed point, common.h): the block turns them
   // into its per-channel scale / shift table while its first loads are in flight
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     // weights: [Cout][tap][Cin] or, chunk-major, [Cin / KC][tap][Cout][KC] (a stage's rows are then contiguous:
     // full 128-byte lines per request instead of 64-byte pieces)
     vob[k] = !ok ? DS_OOB
-                 : p.w_chunked ? (unsigned)((((vch / p.w_chunked) * TAPS + tap) * p.Cout + n0 + col) * p.w_chunked +
-                                            vch % p.w_chunked) * ESZ
+                 : p.w_chunked ? (unsigned)((((vch >> p.w_shift) * TAPS + tap) * p.Cout + n0 + col) * p.w_chunked +
+                                            (vch & (p.w_chunked - 1))) * ESZ
                                : (unsigned)(((n0 + col) * TAPS + tap) * p.Cin + vch) * ESZ;
   }
 
@@ -355,8 +355,8 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
       for (int q = 0; q < QS; ++q) {
         const int col = row0 + q * RPS;  // (RPS == BN: row0 < BN)
         const bool okw = ch_ok && col < BN && n0 + col < p.Cout;
-        const unsigned vo = p.sw_chunked ? (unsigned)((((wb + vch) / p.sw_chunked) * p.Cout + n0 + col) * p.sw_chunked +
-                                                      (wb + vch) % p.sw_chunked) * ESZ
+        const unsigned vo = p.sw_chunked ? (unsigned)((((wb + vch) >> p.sw_shift) * p.Cout + n0 + col) * p.sw_chunked +
+                                                      ((wb + vch) & (p.sw_chunked - 1))) * ESZ
                                          : (unsigned)((n0 + col) * p.sCin + wb + vch) * ESZ;
         pb[KSKIP + q] = buf_load16(rsw, okw ? vo : DS_OOB, 0);
       }
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     const int wb = second ? C1 + cb : cb;                // channel offset inside the weights / GN tables
     ch_ok = vch < width;
     const unsigned so = (unsigned)cb * ESZ;
-    const unsigned sw = p.w_chunked ? (unsigned)(wb / p.w_chunked) * (unsigned)(TAPS * p.Cout * p.w_chunked * ESZ)
+    const unsigned sw = p.w_chunked ? (unsigned)(wb >> p.w_shift) * (unsigned)(TAPS * p.Cout * p.w_chunked * ESZ)
                                     : (unsigned)wb * ESZ;
 #ifdef ABL_NOLOAD
     return;
@@ -780,13 +780,14 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   // chunk-major weights [Cin/kc][taps][Cout][kc]: a K stage of KC channels is KC / kc consecutive layout chunks
   DS_CHECK(a.w_chunked == 0 || (a.w_chunked >= 8 && KC % a.w_chunked == 0 && a.Cin % KC == 0 && (!a.x2 || a.C1 % KC == 0)),
            "conv: chunk-major weights need kc | the kernel's chunk width and whole chunks per source");
-  k.w_chunked = a.w_chunked;
+  k.w_chunked = a.w_chunked; k.w_shift = a.w_chunked ? __builtin_ctz(a.w_chunked) : 0;
+  DS_CHECK((a.w_chunked & (a.w_chunked - 1)) == 0 && (a.sw_chunked & (a.sw_chunked - 1)) == 0, "conv: weight chunks are powers of two");
   DS_CHECK(!a.sx || (G::SKIP_OK && a.sw && a.sCin % 8 == 0 && a.ldsx % 8 == 0 &&
                      (a.sw_chunked == 0 || (a.sw_chunked >= 8 && KC % a.sw_chunked == 0 && a.sCin % KC == 0 &&
                                             (!a.sx2 || a.sC1 % KC == 0)))),
            "conv: bad fused skip convolution arguments");
   k.sx = a.sx; k.sx_bs = a.sx_bs; k.ldsx = a.ldsx; k.sx2 = a.sx2; k.sx2_bs = a.sx2_bs; k.ldsx2 = a.ldsx2;
-  k.sC1 = a.sx2 ? a.sC1 : a.sCin; k.sCin = a.sCin; k.sw = a.sw; k.sw_chunked = a.sw_chunked;
+  k.sC1 = a.sx2 ? a.sC1 : a.sCin; k.sCin = a.sCin; k.sw = a.sw; k.sw_chunked = a.sw_chunked; k.sw_shift = a.sw_chunked ? __builtin_ctz(a.sw_chunked) : 0;
   k.gn_scale = a.gn_scale; k.gn_shift = a.gn_shift; k.gn_act = a.gn_act;
   k.bias = a.bias; k.bias_b = a.bias_b; k.bias_b_ld = a.bias_b_ld; k.bias_mode = a.bias_mode; k.div_b = a.div_b;
   k.res = a.res; k.res_bs = a.res_bs; k.ldr = a.ldr; k.out_scale = a.out_scale;
@@ -836,7 +837,7 @@ bool ds_conv_skip_supported(int H, int W, int Cout, int dtype) {
   memset(&a, 0, sizeof(a));
   a.H = H; a.W = W; a.Cout = Cout; a.taps = 9; a.dtype = dtype; a.sx = &a;
   const int id = ds_conv_config_id(a);
-  return id == 0 || id == 2;
+  return id == 0 || id == 2;  // (bf16 small images go to conv3x3_small.hip, which takes the skip too: checked there)
 }
 
 // chunk width (channels per K stage) of the kernel that would run this problem: the kc of chunk-major weights
@@ -846,9 +847,11 @@ int ds_conv_chunk(int taps, int dtype) {
 }
 
 // Which instantiation ds_launch_conv picks (profiling label): 0/1/2 = 3x3 {8x32xBN64, 8x32xBN32, 8x8xBN64},
-// 3/4/5 = the same tiles for 1x1 / GEMM, 6 = the weight-stationary 64 -> 64 kernel (conv3x3_ws.hip).
+// 3/4/5 = the same tiles for 1x1 / GEMM, 6 = the weight-stationary 64 -> 64 kernel (conv3x3_ws.hip), 7 = the
+// small-image kernel (conv3x3_small.hip).
 int ds_conv_config_id(const ConvArgs& a) {
   if (ds_conv_ws_eligible(a)) return 6;
+  if (ds_conv_small_eligible(a)) return 7;
   if (a.taps == 9) {
     if (a.W >= 32 && a.H >= 8) return a.Cout <= 32 ? 1 : 0;
     return 2;
@@ -874,6 +877,7 @@ int ds_launch_conv(const ConvArgs& a, hipStream_t st) {
     DS_CHECK((long)a.Cout * a.taps * a.Cin * esz < 2147483647L, "conv: weight tensor too large");
   }
   if (ds_conv_ws_eligible(a)) return ds_launch_conv_ws(a, st);
+  if (ds_conv_small_eligible(a)) return ds_launch_conv_small(a, st);
   if (a.dtype == DS_F32) return launch_typed<float>(a, st);
   if (a.dtype == DS_BF16) return launch_typed<bf16_t>(a, st);
   DS_CHECK(false, "conv: unknown dtype");

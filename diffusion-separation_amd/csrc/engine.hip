@@ -353,7 +353,7 @@ struct diffsep_engine {
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
 };
-#define DS_NCLS 7
+#define DS_NCLS 8
 static hipEvent_t prof_event(diffsep_engine* e) {
   if (!e->ev_pool.empty()) { hipEvent_t v = e->ev_pool.back(); e->ev_pool.pop_back(); return v; }
   hipEvent_t v = nullptr;
@@ -937,8 +937,8 @@ extern "C" int32_t diffsep_engine_set_graph(diffsep_engine* e, int32_t enable) {
 
 // Per-launch timing of the MFMA contraction kernels inside the real launch sequence: between
 // profile_begin and profile_end every conv/GEMM launch is bracketed by HIP events on its stream
-// (graph replay is bypassed meanwhile).  Arrays have 7 entries: 3x3 {8x32xBN64, 8x32xBN32, 8x8xBN64},
-// then the same three tiles for 1x1/GEMM, then the weight-stationary 64 -> 64 3x3 kernel.  flops = algorithmic 2*taps*Cin*Cout*H*W*B (unpadded).
+// (graph replay is bypassed meanwhile).  Arrays have 8 entries: 3x3 {8x32xBN64, 8x32xBN32, 8x8xBN64},
+// then the same three tiles for 1x1/GEMM, the weight-stationary 64 -> 64 3x3 kernel, the small-image 3x3 kernel.  flops = algorithmic 2*taps*Cin*Cout*H*W*B (unpadded).
 extern "C" int32_t diffsep_engine_profile_begin(diffsep_engine* e) {
   DS_CHECK(e, "null engine");
   e->prof = true;

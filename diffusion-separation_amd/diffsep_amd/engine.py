@@ -90,7 +90,7 @@ class Engine:
         check(lib().diffsep_engine_set_graph(self._h, int(bool(enable))))
 
     CONV_CLASSES = ("conv3x3_8x32xN64", "conv3x3_8x32xN32", "conv3x3_8x8xN64", "gemm1x1_256xN64", "gemm1x1_256xN32",
-                    "gemm1x1_64xN64", "conv3x3_ws_64to64")
+                    "gemm1x1_64xN64", "conv3x3_ws_64to64", "conv3x3_small_16couts")
 
     def profile_begin(self):
         check(lib().diffsep_engine_profile_begin(self._h))
@@ -98,7 +98,7 @@ class Engine:
     def profile_end(self):
         """{class: (algorithmic flops, milliseconds, launches, algorithmic bytes)} of the MFMA kernels since
         profile_begin."""
-        fl, ms, n, by = (C.c_double * 7)(), (C.c_double * 7)(), (C.c_int64 * 7)(), (C.c_double * 7)()
+        fl, ms, n, by = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int64 * 8)(), (C.c_double * 8)()
         check(lib().diffsep_engine_profile_end(self._h, fl, ms, n, by))
         return {k: (fl[i], ms[i], int(n[i]), by[i]) for i, k in enumerate(self.CONV_CLASSES)}
 

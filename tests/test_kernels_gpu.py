@@ -434,3 +434,55 @@ def test_conv_groupnorm_from_producer_accumulators(dtype, tol, C1, C2, Cout, H, 
         hn = hn.to(dtype).float()
     ref = F.conv2d(hn, w.to(DEV), bias, padding=k // 2).permute(0, 2, 3, 1)
     assert rel_rms(y.float(), ref) < tol
+
+
+@pytest.mark.parametrize("C1,C2,Cout,H,W", [(128, 0, 128, 16, 16), (128, 0, 128, 8, 8), (128, 0, 128, 4, 4),
+                                            (128, 128, 128, 8, 8), (64, 192, 48, 16, 12), (256, 256, 256, 4, 1),
+                                            (64, 0, 16, 16, 4), (128, 64, 64, 8, 6), (128, 128, 128, 16, 24)])
+@pytest.mark.parametrize("act,lazy", [(1, False), (1, True), (0, False), (None, False)])
+def test_small_image_conv3x3(C1, C2, Cout, H, W, act, lazy):
+    # the 16-cout-slab kernel of the <= 16-row levels (conv3x3_small.hip): whole and ragged tiles, concat views,
+    # GroupNorm (+SiLU) from materialised tables or from the producers' accumulators, bias + per-sample bias, residual,
+    # scale, statistics of the output; chunk-major and row-major weights.  Reference: torch fp32 on the CPU
+    dt = torch.bfloat16
+    B, C = 3, C1 + C2
+    tag = f"{C1}.{C2}.{H}.{W}"
+    xa = (rnd("sm.a" + tag, (B, H, W, C1), 1.2) + 0.1).to(DEV).to(dt)
+    xb = (rnd("sm.b" + tag, (B, H, W, C2), 0.8) - 0.2).to(DEV).to(dt) if C2 else None
+    w = rnd(f"sm.w{C}.{Cout}", (Cout, C, 3, 3), (9 * C) ** -0.5)
+    bias, bb = rnd(f"sm.bias{Cout}", (Cout,), 0.1).to(DEV), rnd(f"sm.bb{Cout}", (B, Cout), 0.1).to(DEV)
+    res = rnd(f"sm.r{Cout}" + tag, (B, H, W, Cout)).to(DEV).to(dt)
+    groups = min(C // 4, 32)
+    g, be = (1.0 + rnd(f"sm.g{C}", (C,), 0.2)).to(DEV), rnd(f"sm.be{C}", (C,), 0.1).to(DEV)
+    xcat = torch.cat([xa, xb], -1).float().cpu() if C2 else xa.float().cpu()
+    kw = {}
+    if act is None:
+        hn = xcat
+    elif lazy:
+        # accumulators as a producing conv would leave them: fixed-point sums of the stored tensors
+        def acc(x):
+            xd = x.double()
+            return torch.stack([(xd.sum((1, 2)) * ops.STAT_SUM_SCALE).round(), ((xd * xd).sum((1, 2)) * ops.STAT_SQ_SCALE).round()],
+                               -1).to(torch.int64).contiguous()
+        kw = dict(gn_acc=(acc(xa), acc(xb) if C2 else None, g, be, groups), gn_act=act)
+        hn = F.group_norm(xcat.permute(0, 3, 1, 2), groups, g.cpu(), be.cpu(), eps=1e-6).permute(0, 2, 3, 1)
+    else:
+        sc, sh = (1.0 + rnd(f"sm.sc{C}", (B, C), 0.2)).to(DEV), rnd(f"sm.sh{C}", (B, C), 0.2).to(DEV)
+        kw = dict(gn=(sc, sh), gn_act=act)
+        hn = xcat * sc.cpu()[:, None, None, :] + sh.cpu()[:, None, None, :]
+    if act:
+        hn = F.silu(hn)
+    hn = hn.to(dt).float()  # the kernel rounds the activated input to bf16 before the MFMA
+    ref = F.conv2d(hn.permute(0, 3, 1, 2), w.to(dt).float(), bias.cpu(), padding=1).permute(0, 2, 3, 1)
+    ref = (ref + bb.cpu()[:, None, None, :] + res.float().cpu()) * 0.70710678
+    for chunk in (0, 32):
+        wp = ops.pack_conv_weight(w, dt, chunk=chunk).to(DEV)
+        y, st = ops.conv2d_fused(xa, wp, bias, Cout, 3, x2=xb, bias_b=bb, res=res, out_scale=0.70710678, stats=True,
+                                 w_chunk=chunk, **kw)
+        assert rel_rms(y.float().cpu(), ref) < 4e-3
+        s = ops.stats_to_float(st).cpu()
+        assert torch.allclose(s[..., 0], ref.double().sum((1, 2)), rtol=2e-3, atol=2e-3 * H * W)
+        assert torch.allclose(s[..., 1], (ref.double() ** 2).sum((1, 2)), rtol=2e-3, atol=2e-3 * H * W)
+    y2 = ops.conv2d_fused(xa, ops.pack_conv_weight(w, dt).to(DEV), None, Cout, 3, x2=xb)  # bare convolution
+    ref2 = F.conv2d(xcat.permute(0, 3, 1, 2), w.to(dt).float(), None, padding=1).permute(0, 2, 3, 1)
+    assert rel_rms(y2.float().cpu(), ref2) < 4e-3

@@ -465,3 +465,25 @@ def test_evaluate_batched_equals_one_utterance_at_a_time(tmp_path):
     assert [strip(r) for r in recs["one"]] == [strip(r) for r in recs["bat"]]
     r0 = recs["bat"][0]
     assert np.asarray(r0["si_sdr"]).shape == (1, 2) and len(r0["perm"]) == 2  # per-source lists like evaluate.py:394-405
+
+
+@pytest.mark.parametrize("cin,c1,cout,H,W,up,down", [(256, 128, 128, 8, 8, False, False), (128, 0, 128, 16, 16, False, False),
+                                                     (128, 0, 128, 8, 8, True, False), (128, 0, 128, 16, 16, False, True),
+                                                     (128, 0, 128, 4, 4, False, False), (384, 128, 256, 8, 4, False, False)])
+def test_resblock_on_small_images_vs_oracle(cin, c1, cout, H, W, up, down):
+    # the blocks of the <= 16-row levels at the widths the engine runs them (bf16: conv3x3_small.hip, Conv_2 folded in
+    # as extra K phases; fp32: the generic tile), against the oracle's block
+    tbl = [("GroupNorm_0.weight", (cin,)), ("GroupNorm_0.bias", (cin,)), ("Conv_0.weight", (cout, cin, 3, 3)),
+           ("Conv_0.bias", (cout,)), ("Dense_0.weight", (cout, 64)), ("Dense_0.bias", (cout,)),
+           ("GroupNorm_1.weight", (cout,)), ("GroupNorm_1.bias", (cout,)), ("Conv_1.weight", (cout, cout, 3, 3)),
+           ("Conv_1.bias", (cout,))]
+    if cin != cout or up or down:
+        tbl += [("Conv_2.weight", (cout, cin, 1, 1)), ("Conv_2.bias", (cout,))]
+    sd = synth.synth_state_dict(tbl, 21)
+    x, temb = rnd(f"rbs.x{cin}{H}{W}", (2, cin, H, W)), rnd("rbs.t", (2, 64))
+    ref = O._res_block(O.to_torch(sd), "", x, temb, up=up, down=down)
+    y = ops.resblock_forward([sd[n] for n, _ in tbl], ops.to_nhwc(x).to(DEV), temb.to(DEV), cout, up=up, down=down)
+    assert rel_rms(ops.to_nchw(y), ref) < 2e-5
+    yb = ops.resblock_forward([sd[n] for n, _ in tbl], ops.to_nhwc(x).to(torch.bfloat16).to(DEV), temb.to(DEV), cout,
+                              up=up, down=down)
+    assert rel_rms(ops.to_nchw(yb).float(), ref) < 3e-2

@@ -13,7 +13,7 @@ sys.path.insert(0, "diffusion-separation_amd")
 from diffsep_amd import ops, _lib
 l = ctypes.CDLL(os.environ["DIFFSEP_LIB"])
 names = ["setup (offsets, descriptors)", "issue first loads", "wait first loads", "activation of chunk 0", "barrier+LDS store+barrier", "issue next loads", "MFMA loop (+activation of next)", "acc dump+barriers+residual loads", "epilogue LDS read+math", "epilogue global stores", "statistics reduce", "-"]
-for (k, ci, co, H, W) in [(3, 128, 64, 256, 256), (3, 128, 128, 64, 64)]:
+for (k, ci, co, H, W) in [(3, 128, 128, 16, 16), (3, 128, 128, 8, 8), (3, 128, 128, 4, 4), (3, 256, 128, 8, 8)]:
     B = 16
     x = torch.randn(B, H, W, ci, device="cuda").to(torch.bfloat16)
     w = (torch.randn(co, k * k, ci, device="cuda") / (k * k * ci) ** 0.5).to(torch.bfloat16)
