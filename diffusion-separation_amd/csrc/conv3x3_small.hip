@@ -2,20 +2,28 @@
 //
 // At these levels (ddpm_conv3x3 inside ResnetBlockBigGANpp, reference layers.py:141-156, layerspp.py:291-323) a launch
 // is a few MFLOP per sample: with the 64-cout tile of conv_mfma.hip the grid is 32 - 128 blocks, each of which pulls
-// 64 couts x 9 taps of weights through one CU in a chain of dependent stages (19 us per launch, 1 % MFMA use).
-// The decomposition here is the opposite one — many thin blocks, few stages, everything in flight at once:
+// 64 couts x 9 taps of weights through one CU in a chain of dependent stages (19 us per launch, 1 % MFMA use; 25k
+// cycles per block of which 5k are address set-up).  The decomposition here is the opposite one — thin blocks, at
+// most a few stages, everything in flight at once:
 //
-//   * a block owns 16 couts of a 4-row x GW-column pixel tile (GW = 16, 8 or 4 by image width) of one sample:
-//     grid = tiles x Cout / 16 x B (512 blocks for 128 couts at 16^2 and B = 16), 2 blocks per CU;
+//   * a block owns 16 couts of one pixel tile of one sample — 8 rows x 16 columns (8 waves), 8 x 8 (8 waves, 4 of
+//     them multiply) or 4 x 4 (4 waves, 1 multiplies) by image width: grid = tiles x Cout / 16 x B (128 - 256 blocks
+//     for 128 couts at B = 16);
 //   * K is walked in phases of PC = 128 (or 64) input channels of ONE source (x, then x2 of a concat view, then the raw
-//     block input of the folded 1x1 skip convolution through the centre tap).  A phase stages the whole halo tile
-//     (6 x (GW + 2) pixels) and the block's [9][16][PC] weight slab through registers into LDS; TWO phases are in
-//     flight in two register sets, so the first two phases (= the whole K of most launches) cost one memory round
-//     trip; GroupNorm affine + SiLU is applied in registers on the way to LDS;
+//     block input of the folded 1x1 skip convolution through the centre tap).  A phase stages the whole halo tile and
+//     the block's [9][16][PC] weight slab through registers into LDS; TWO phases are in flight in two register sets,
+//     so the first two phases (= the whole K of most launches) cost one memory round trip; GroupNorm affine + SiLU is
+//     applied in registers on the way to LDS (scale / shift from materialised tables or, lazily, from the producers'
+//     channel-sum accumulators: table built in LDS behind the first loads);
 //   * v_mfma_f32_16x16x32_bf16 with A = weights (16 couts x 32 channels), B = 16 pixels of the tile: a lane ends up
 //     with 4 consecutive couts of one pixel = one 8-byte store; wave w owns pixels 16 w .. 16 w + 15 of the tile;
+//     fragment reads run one tap ahead of the MFMAs, two accumulator chains per output quad;
 //   * epilogue in registers: bias (+ per-sample bias), residual, scale, bf16 rounding, GroupNorm statistics of the
-//     output (16-lane shuffles, 4 waves through LDS, integer atomics like every other conv epilogue).
+//     output (DPP row sums, waves through LDS, integer atomics like every other conv epilogue).
+//
+// Measured (B = 16, 128 -> 128, inside the captured graph): 16^2 19.2 -> ~14 us, 8^2 18.8 -> ~11, 4^2 18.8 -> ~9.5 per
+// launch, of which ~5 us is the floor of any kernel node; one batch alone 371 -> 350 ms, four in flight unchanged.
+// tools/small_timing.sh (-DSM_TIMING) prints the per-phase cycles of a block.
 //
 // Same ConvArgs contract as ds_launch_conv (common.h); ds_conv_small_eligible says which launches come here.
 #include <stdlib.h>
@@ -65,7 +73,6 @@ __device__ inline void st8(__amdgpu_buffer_rsrc_t r, unsigned voff, uint2 d) {
   __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, 0, 0);
 }
 
-constexpr int NS = 16;              // couts per block
 constexpr int GN_MAX = 512;         // channels of the lazy GroupNorm table
 
 struct SmK {
@@ -88,6 +95,19 @@ struct SmK {
   int H, W, Cout, tiles_x;
 };
 
+// sum over the 16 lanes of a DPP row (every lane gets the total): rotations by 8 and 4, then the two quad permutations
+template <int CTRL>
+__device__ inline float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ inline float row16_sum(float v) {
+  v = dpp_add<0x128>(v);  // row_ror:8
+  v = dpp_add<0x124>(v);  // row_ror:4
+  v = dpp_add<0x4e>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0xb1>(v);   // quad_perm [1,0,3,2]
+  return v;
+}
+
 // GN affine (+ SiLU) on 8 bf16 channels
 template <bool ACT>
 __device__ inline uint4 gn8(const uint4& u, const float* sc, const float* sh) {
@@ -109,13 +129,14 @@ __device__ inline uint4 gn8(const uint4& u, const float* sc, const float* sh) {
   return o;
 }
 
-// tile shapes by image width: 16 columns x 8 rows on 8 waves, 8 x 8 on 4 waves, 4 x 4 (one MFMA group) on 4 waves
+// tile shapes by image width: 16 columns x 8 rows on 8 waves, 8 x 8 on 8 waves (4 of them multiply: 512 threads keep the two
+// staging register sets small), 4 x 4 (one MFMA group) on 4 waves
 template <int GW> struct SmTile;
 template <> struct SmTile<16> { static constexpr int THT = 8, NT = 512; };
-template <> struct SmTile<8> { static constexpr int THT = 8, NT = 256; };
+template <> struct SmTile<8> { static constexpr int THT = 8, NT = 512; };
 template <> struct SmTile<4> { static constexpr int THT = 4, NT = 256; };
 
-template <int GW, int PC>
+template <int GW, int PC, int NS>
 struct SmGeom {
   static constexpr int THT = SmTile<GW>::THT, NT = SmTile<GW>::NT;
   static constexpr int HWS = GW + 2, HP = (THT + 2) * HWS;  // halo columns / pixels
@@ -125,16 +146,19 @@ struct SmGeom {
   static constexpr int NA = (HP + RPS - 1) / RPS;            // input vectors per thread and phase
   static constexpr int NWV = (9 * NS + RPS - 1) / RPS;       // weight vectors per thread and phase
   static constexpr int NGRP = THT * GW / 16;                 // 16-pixel groups of the tile (one per wave)
-  static_assert(NGRP <= NT / 64 && NS <= RPS, "one MFMA group per wave; the skip weights are staged in one pass");
+  static constexpr int NSK = (NS + RPS - 1) / RPS;           // staging passes of the folded skip convolution's weights
+  static_assert(NGRP <= NT / 64 && NSK <= NWV && RPS % NS == 0, "one MFMA group per wave; a staging pass covers whole taps");
   static constexpr int LDS_IN = HP * PSTR, LDS_W = 9 * NS * PSTR;
   static constexpr int LDS = LDS_IN + LDS_W + 2 * GN_MAX * 4;
   static_assert(LDS_IN + LDS_W >= 2 * GN_MAX * 8, "the GroupNorm table is built in the staging area");
 };
 
-// GW: tile columns (16, 8, 4).  PC: channels per phase (64, 128).  MODE: 0 raw input, 1 GroupNorm affine, 2 affine + SiLU.
-template <int GW, int PC, int MODE>
+// GW: tile columns (16, 8, 4).  PC: channels per phase (64, 128).  NS: couts per block (16, 32).
+// MODE: 0 raw input, 1 GroupNorm affine, 2 affine + SiLU.
+template <int GW, int PC, int NS, int MODE>
 __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p) {
-  using G = SmGeom<GW, PC>;
+  using G = SmGeom<GW, PC, NS>;
+  constexpr int NSK = G::NSK, NH = NS / 16;
   constexpr int THT = G::THT, NT = G::NT, NWAVES = NT / 64;
   constexpr int HWS = G::HWS, HP = G::HP, NVEC = G::NVEC, RPS = G::RPS, PSTR = G::PSTR, NA = G::NA, NWV = G::NWV,
                 NGRP = G::NGRP;
@@ -193,12 +217,15 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
       const __amdgpu_buffer_rsrc_t rs = rsrc(base, (unsigned)M * ld * 2u);
 #pragma unroll
       for (int k = 0; k < NA; ++k)
-        S.pa[k] = ld16(rs, inner[k] ? (unsigned)((pixi[k] * ld + cb + cv * 8) * 2) : OOB, 0);
-      const int co = row0;  // RPS >= NS: one pass
-      const unsigned vo = p.sw_chunked
-                              ? (unsigned)((((wb >> p.sw_shift) * p.Cout + co0 + co) * p.sw_chunked + (wb & (p.sw_chunked - 1))) * 2)
-                              : (unsigned)(((co0 + co) * p.sCin + wb) * 2);
-      S.pw[0] = ld16(rsw, co < NS ? vo : OOB, 0);
+        S.pa[k] = ld16(rs, inner[k] ? (unsigned)((__umul24(pixi[k], ld) + cb + cv * 8) * 2) : OOB, 0);
+#pragma unroll
+      for (int k = 0; k < NSK; ++k) {
+        const int co = row0 + RPS * k;
+        const unsigned vo = p.sw_chunked
+                                ? (unsigned)((((wb >> p.sw_shift) * p.Cout + co0 + co) * p.sw_chunked + (wb & (p.sw_chunked - 1))) * 2)
+                                : (unsigned)(((co0 + co) * p.sCin + wb) * 2);
+        S.pw[k] = ld16(rsw, co < NS ? vo : OOB, 0);
+      }
       S.raw = true;
       return;
     }
@@ -210,15 +237,15 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
     const __amdgpu_buffer_rsrc_t rx = rsrc(base, (unsigned)M * ld * 2u);
 #pragma unroll
     for (int k = 0; k < NA; ++k)
-      S.pa[k] = ld16(rx, pixi[k] >= 0 ? (unsigned)((pixi[k] * ld + cb + cv * 8) * 2) : OOB, 0);
+      S.pa[k] = ld16(rx, pixi[k] >= 0 ? (unsigned)((__umul24(pixi[k], ld) + cb + cv * 8) * 2) : OOB, 0);
+    // weight row (tap, cout) = row0 + RPS k: RPS is a multiple of NS, so the cout stays and the tap advances by RPS / NS
+    const int tap0 = row0 / NS, co = row0 % NS;
+    const unsigned vo0 =
+        p.w_chunked ? (unsigned)(((((wb >> p.w_shift) * 9 + tap0) * p.Cout + co0 + co) * p.w_chunked + (wb & (p.w_chunked - 1))) * 2)
+                    : (unsigned)((((co0 + co) * 9 + tap0) * p.Cin + wb) * 2);
+    const unsigned vstep = (unsigned)((RPS / NS) * (p.w_chunked ? p.Cout * p.w_chunked : p.Cin) * 2);
 #pragma unroll
-    for (int k = 0; k < NWV; ++k) {
-      const int row = row0 + RPS * k, tap = row >> 4, co = row & 15;
-      const unsigned vo =
-          p.w_chunked ? (unsigned)(((((wb >> p.w_shift) * 9 + tap) * p.Cout + co0 + co) * p.w_chunked + (wb & (p.w_chunked - 1))) * 2)
-                      : (unsigned)((((co0 + co) * 9 + tap) * p.Cin + wb) * 2);
-      S.pw[k] = ld16(rw, row < 9 * NS ? vo : OOB, 0);
-    }
+    for (int k = 0; k < NWV; ++k) S.pw[k] = ld16(rw, row0 + RPS * k < 9 * NS ? vo0 + k * vstep : OOB, 0);
     S.raw = false;
   };
   // GroupNorm scale / shift of the thread's 8 channels of conv phase ph (from the LDS table or the materialised arrays)
@@ -251,7 +278,9 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
     for (int k = 0; k < NA; ++k)
       if (row0 + RPS * k < HP) *reinterpret_cast<uint4*>(sIn + lds0 + RPS * k * PSTR) = S.pa[k];
     if (S.raw) {
-      if (row0 < NS) *reinterpret_cast<uint4*>(sW + (4 * NS) * PSTR + lds0) = S.pw[0];
+#pragma unroll
+      for (int k = 0; k < NSK; ++k)
+        if (row0 + RPS * k < NS) *reinterpret_cast<uint4*>(sW + (4 * NS) * PSTR + lds0 + RPS * k * PSTR) = S.pw[k];
       return;
     }
 #pragma unroll
@@ -262,21 +291,45 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
   // this lane's pixel of the tile: 16 w + l16 in raster order, couts co0 + 4 q .. + 3
   const int pl = wave * 16 + l16, ty = pl / GW, tx = pl % GW;
   const bool mma_wave = wave < NGRP;
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[NH][2];  // two dependency chains per output quad (even / odd k-blocks)
+#pragma unroll
+  for (int h = 0; h < NH; ++h) { acc[h][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[h][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const int woff = l16 * PSTR + q * 16;
   const int aoff = (ty * HWS + tx) * PSTR + q * 16;
+  // fragment reads run one tap ahead of the MFMAs (two register sets): the LDS latency is paid once per phase
   auto mma = [&](bool raw) __attribute__((always_inline)) {
     if (!mma_wave) return;
+    constexpr int KB = PC / 32;
+    uint4 xf[2][KB], wf[2][NH][KB];
+    auto frag = [&](int tap, int set) __attribute__((always_inline)) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        xf[set][kb] = *reinterpret_cast<const uint4*>(sIn + ((tap / 3) * HWS + tap % 3) * PSTR + aoff + kb * 64);
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+          wf[set][h][kb] = *reinterpret_cast<const uint4*>(sW + (tap * NS + 16 * h) * PSTR + woff + kb * 64);
+      }
+    };
+    auto fma_tap = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+          acc[h][kb & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[set][h][kb]),
+                                                                   __builtin_bit_cast(bf16x8, xf[set][kb]), acc[h][kb & 1], 0, 0, 0);
+    };
+    if (raw) {  // folded 1x1 convolution: the centre tap only
+      frag(4, 0);
+      fma_tap(0);
+      return;
+    }
+    frag(0, 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      if (raw && tap != 4) continue;
-#pragma unroll
-      for (int kb = 0; kb < PC / 32; ++kb) {
-        const bf16x8 wf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sW + tap * NS * PSTR + woff + kb * 64));
-        const bf16x8 xf = __builtin_bit_cast(
-            bf16x8, *reinterpret_cast<const uint4*>(sIn + ((tap / 3) * HWS + tap % 3) * PSTR + aoff + kb * 64));
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc, 0, 0, 0);
-      }
+      if (tap + 1 < 9) frag(tap + 1, (tap + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      fma_tap(tap & 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -332,7 +385,9 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
   const __amdgpu_buffer_rsrc_t ry = rsrc(p.y + (long)b * p.y_bs, (unsigned)M * p.ldy * 2u);
   const int gy = y0 + ty, gx = x0 + tx;
   const int mo = (mma_wave && gy < p.H && gx < p.W) ? gy * p.W + gx : -1;
-  const uint2 rres = ld8(rr, mo >= 0 ? (unsigned)((mo * p.ldr + co0 + 4 * q) * 2) : OOB);
+  uint2 rres[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) rres[h] = ld8(rr, mo >= 0 ? (unsigned)((mo * p.ldr + co0 + 16 * h + 4 * q) * 2) : OOB);
 
   auto step = [&](int ph, Stage& S) __attribute__((always_inline)) {
     ST_WAIT
@@ -355,40 +410,43 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
 
   // ---- epilogue
   const float osc = p.out_scale;
-  float v[4];
+  float v[NH][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = co0 + 4 * q + i;
-    const float bs = ((p.bias ? p.bias[c] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + c] : 0.f)) * osc;
-    v[i] = fmaf(acc[i], osc, bs);
+  for (int h = 0; h < NH; ++h) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = co0 + 16 * h + 4 * q + i;
+      const float bs = ((p.bias ? p.bias[c] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + c] : 0.f)) * osc;
+      v[h][i] = fmaf(acc[h][0][i] + acc[h][1][i], osc, bs);
+    }
+    v[h][0] = fmaf(__uint_as_float(rres[h].x << 16), osc, v[h][0]);
+    v[h][1] = fmaf(__uint_as_float(rres[h].x & 0xffff0000u), osc, v[h][1]);
+    v[h][2] = fmaf(__uint_as_float(rres[h].y << 16), osc, v[h][2]);
+    v[h][3] = fmaf(__uint_as_float(rres[h].y & 0xffff0000u), osc, v[h][3]);
+    st8(ry, mo >= 0 ? (unsigned)((mo * p.ldy + co0 + 16 * h + 4 * q) * 2) : OOB,
+        make_uint2(pack_bf16x2(v[h][0], v[h][1]), pack_bf16x2(v[h][2], v[h][3])));
   }
-  v[0] = fmaf(__uint_as_float(rres.x << 16), osc, v[0]);
-  v[1] = fmaf(__uint_as_float(rres.x & 0xffff0000u), osc, v[1]);
-  v[2] = fmaf(__uint_as_float(rres.y << 16), osc, v[2]);
-  v[3] = fmaf(__uint_as_float(rres.y & 0xffff0000u), osc, v[3]);
-  st8(ry, mo >= 0 ? (unsigned)((mo * p.ldy + co0 + 4 * q) * 2) : OOB, make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])));
   ST_MARK(7)
   if (p.stats) {
     const float keep = mo >= 0 ? 1.f : 0.f;
-    float ssum[4], ssq[4];
+    float ssum[NH][4], ssq[NH][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ssum[i] = keep * v[i];
-      ssq[i] = keep * v[i] * v[i];
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        ssum[i] += __shfl_xor(ssum[i], o, 64);
-        ssq[i] += __shfl_xor(ssq[i], o, 64);
-      }
-    }
-    __syncthreads();  // the last phase's fragment reads are done: reuse the staging area
-    float* sr = reinterpret_cast<float*>(smem);  // [waves][16 couts][2]
-    if (l16 == 0) {
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        sr[((wave * NS) + 4 * q + i) * 2] = ssum[i];
-        sr[((wave * NS) + 4 * q + i) * 2 + 1] = ssq[i];
+        ssum[h][i] = row16_sum(keep * v[h][i]);
+        ssq[h][i] = row16_sum(keep * v[h][i] * v[h][i]);
       }
+    __syncthreads();  // the last phase's fragment reads are done: reuse the staging area
+    float* sr = reinterpret_cast<float*>(smem);  // [waves][NS couts][2]
+    if (l16 == 0) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          sr[((wave * NS) + 16 * h + 4 * q + i) * 2] = ssum[h][i];
+          sr[((wave * NS) + 16 * h + 4 * q + i) * 2 + 1] = ssq[h][i];
+        }
     }
     __syncthreads();
     if (tid < NS) {
@@ -406,25 +464,31 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
   ST_FLUSH
 }
 
-template <int GW, int PC, int MODE>
+template <int GW, int PC, int NS, int MODE>
 int launch_small(const SmK& k, const ConvArgs& a, hipStream_t st) {
-  constexpr int LDS = SmGeom<GW, PC>::LDS;
+  constexpr int LDS = SmGeom<GW, PC, NS>::LDS;
   static bool attr_done = false;
   if (!attr_done) {
-    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_small_kernel<GW, PC, MODE>),
+    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_small_kernel<GW, PC, NS, MODE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done = true;
   }
   dim3 grid(k.tiles_x * cdiv(a.H, SmTile<GW>::THT), a.Cout / NS, a.B);
-  hipLaunchKernelGGL((conv3x3_small_kernel<GW, PC, MODE>), grid, dim3(SmTile<GW>::NT), LDS, st, k);
+  hipLaunchKernelGGL((conv3x3_small_kernel<GW, PC, NS, MODE>), grid, dim3(SmTile<GW>::NT), LDS, st, k);
   DS_LAUNCH_CHECK();
   return 0;
 }
-template <int GW, int PC>
+template <int GW, int PC, int NS>
 int launch_small_mode(const SmK& k, const ConvArgs& a, int mode, hipStream_t st) {
-  if (mode == 2) return launch_small<GW, PC, 2>(k, a, st);
-  if (mode == 1) return launch_small<GW, PC, 1>(k, a, st);
-  return launch_small<GW, PC, 0>(k, a, st);
+  if (mode == 2) return launch_small<GW, PC, NS, 2>(k, a, st);
+  if (mode == 1) return launch_small<GW, PC, NS, 1>(k, a, st);
+  return launch_small<GW, PC, NS, 0>(k, a, st);
+}
+template <int PC, int NS>
+int launch_small_gw(const SmK& k, const ConvArgs& a, int gw, int mode, hipStream_t st) {
+  if (gw == 4) return launch_small_mode<4, PC, NS>(k, a, mode, st);
+  if (gw == 8) return launch_small_mode<8, PC, NS>(k, a, mode, st);
+  return launch_small_mode<16, PC, NS>(k, a, mode, st);
 }
 
 }  // namespace
@@ -441,11 +505,9 @@ static bool small_sources_multiple_of(const ConvArgs& a, int pc) {
   return true;
 }
 bool ds_conv_small_eligible(const ConvArgs& a) {
-  static const bool off = getenv("DIFFSEP_NO_SMALL") != nullptr;  // TEMPORARY A/B switch
-  if (off) return false;
   if (a.dtype != DS_BF16 || a.taps != 9 || a.w_bs != 0 || a.bias_mode != 0 || a.div_b) return false;
   if (!(a.W < 32 || a.H < 8) || a.H > 16) return false;
-  if (a.Cout % NS != 0 || !small_sources_multiple_of(a, 64)) return false;
+  if (a.Cout % 16 != 0 || !small_sources_multiple_of(a, 64)) return false;
   if (a.ldx % 8 != 0 || (a.x2 && a.ldx2 % 8 != 0)) return false;
   if ((a.w_chunked & (a.w_chunked - 1)) || (a.w_chunked && a.w_chunked < 8)) return false;
   if (a.sx && (!a.sw || (a.sw_chunked & (a.sw_chunked - 1)) || (a.sw_chunked && a.sw_chunked < 8) || a.ldsx % 8 != 0 ||
@@ -477,12 +539,7 @@ int ds_launch_conv_small(const ConvArgs& a, hipStream_t st) {
   const int gw = a.W <= 4 ? 4 : (a.W <= 8 ? 8 : 16);
   k.H = a.H; k.W = a.W; k.Cout = a.Cout; k.tiles_x = cdiv(a.W, gw);
   const int mode = (a.gn_scale || a.gn_acc1) ? (a.gn_act ? 2 : 1) : 0;
-  if (small_sources_multiple_of(a, 128)) {
-    if (gw == 4) return launch_small_mode<4, 128>(k, a, mode, st);
-    if (gw == 8) return launch_small_mode<8, 128>(k, a, mode, st);
-    return launch_small_mode<16, 128>(k, a, mode, st);
-  }
-  if (gw == 4) return launch_small_mode<4, 64>(k, a, mode, st);
-  if (gw == 8) return launch_small_mode<8, 64>(k, a, mode, st);
-  return launch_small_mode<16, 64>(k, a, mode, st);
+  // (32-cout slabs were measured slower: 406 vs 366 ms for one batch — twice the weight staging per block)
+  if (small_sources_multiple_of(a, 128)) return launch_small_gw<128, 16>(k, a, gw, mode, st);
+  return launch_small_gw<64, 16>(k, a, gw, mode, st);
 }
