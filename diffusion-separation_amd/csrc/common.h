@@ -233,4 +233,8 @@ int ds_launch_fill(float* p, float v, long n, hipStream_t st);
 // time embedding: y[b][o] = sum_k act_in(x[b][k]) * W[o][k] + bias[o]   (fp32)
 int ds_launch_linear(const float* x, const float* W, const float* bias, float* y, int B, int K, int O, int silu_in,
                      hipStream_t st);
+// wide outputs, weights transposed [K][O] (ds_launch_dense_transpose builds that layout block by block)
+int ds_launch_linear_t(const float* x, const float* Wt, const float* bias, float* y, int B, int K, int O, int silu_in,
+                       hipStream_t st);
+int ds_launch_dense_transpose(const float* src, float* dst, int O, int K, int ldo, int off, hipStream_t st);
 int ds_launch_fourier(const float* t, const float* Wf, float* emb, int B, int nf, hipStream_t st);

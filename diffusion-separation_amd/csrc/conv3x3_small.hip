@@ -34,10 +34,10 @@
 
 #ifdef SM_TIMING  // profiling build only (tools/small_timing.sh): per-phase cycle totals of wave 0 of every block
 __device__ unsigned long long g_sm_dbg[16];
-#define ST_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define ST_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime();
 #define ST_MARK(i) { unsigned long long st_now = __builtin_readcyclecounter(); st_acc[i] += st_now - st_prev; st_prev = st_now; }
 #define ST_WAIT asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#define ST_FLUSH if (threadIdx.x == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_sm_dbg[i_], st_acc[i_]); atomicAdd(&g_sm_dbg[15], 1ull); }
+#define ST_FLUSH if (threadIdx.x == 0) { st_acc[11] = __builtin_amdgcn_s_memrealtime() - st_rt0; /* 100 MHz ticks */ for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_sm_dbg[i_], st_acc[i_]); atomicAdd(&g_sm_dbg[15], 1ull); }
 extern "C" int diffsep_small_debug_read(unsigned long long* out, int reset) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sm_dbg), sizeof(unsigned long long) * 16);
   if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sm_dbg), z, sizeof(z)); }

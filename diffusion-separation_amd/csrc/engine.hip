@@ -638,7 +638,7 @@ static int net_forward(diffsep_engine* e, const Tn& x0, const float* t, const Tn
     if (ds_launch_fourier(t, P(e, mf.w0), emb, B, nf, st)) return 1;
     if (ds_launch_linear(emb, P(e, l1.w0), P(e, l1.b0), t1, B, 2 * nf, 4 * nf, 0, st)) return 1;
     if (ds_launch_linear(t1, P(e, l2.w0), P(e, l2.b0), temb, B, 4 * nf, 4 * nf, 1, st)) return 1;
-    if (ds_launch_linear(temb, e->d_dense_w, e->d_dense_b, proj, B, 4 * nf, A.dense_total, 1, st)) return 1;
+    if (ds_launch_linear_t(temb, e->d_dense_w, e->d_dense_b, proj, B, 4 * nf, A.dense_total, 1, st)) return 1;
   }
   // ---- input conv
   const Module& cin = A.mods[mi++];
@@ -838,7 +838,6 @@ static int repack_weight(diffsep_engine* e, const PRef& src, long pk, int O, int
 }
 static int repack_module(diffsep_engine* e, const Module& m) {
   int rc = 0;
-  const int nf4 = 4 * e->cfg.nf;
   switch (m.kind) {
     case MK_CONV3: rc |= repack_weight(e, m.w0, m.pk0, m.out_ch, m.in_ch, 9, (long)m.in_ch * 9, 9, 1); break;
     case MK_COMBINE: rc |= repack_weight(e, m.w0, m.pk0, m.out_ch, m.in_ch, 1, m.in_ch, 1, 0); break;
@@ -847,9 +846,10 @@ static int repack_module(diffsep_engine* e, const Module& m) {
       rc |= repack_weight(e, m.conv1_w, m.pk1, m.out_ch, m.out_ch, 9, (long)m.out_ch * 9, 9, 1);
       if (m.has_conv2)
         rc |= repack_weight(e, m.conv2_w, m.pk2, m.out_ch, m.in_ch, 1, m.in_ch, 1, 0, true, fuse_skip(m) ? 9 : 0, m.in_c1);
-      // Dense_0 rows -> concatenated projection [dense_total][temb dim]
-      DS_HIP(hipMemcpy(e->d_dense_w + (size_t)m.temb_off * nf4, e->d_blob + m.dense_w.off, (size_t)m.dense_w.numel * 4,
-                       hipMemcpyDeviceToDevice));
+      // Dense_0.weight [out][temb dim] -> columns [temb_off, temb_off + out) of the transposed concatenation
+      // [temb dim][dense_total] (ds_launch_linear_t)
+      rc |= ds_launch_dense_transpose(e->d_blob + m.dense_w.off, e->d_dense_w, m.out_ch, (int)(m.dense_w.numel / m.out_ch),
+                                      e->arch.dense_total, m.temb_off, 0);
       DS_HIP(hipMemcpy(e->d_dense_b + m.temb_off, e->d_blob + m.dense_b.off, (size_t)m.dense_b.numel * 4,
                        hipMemcpyDeviceToDevice));
       break;
@@ -1398,7 +1398,7 @@ extern "C" int32_t diffsep_resblock_forward(int32_t in_ch, int32_t out_ch, int32
   return mini_engine_run(e, st, [&]() -> int {
     float* proj = e_f32(e, (size_t)B * e->arch.dense_total);
     // Dense_0(act(temb))  layerspp.py:311-312
-    if (!e->dry && ds_launch_linear(temb, e->d_dense_w, e->d_dense_b, proj, B, temb_dim, e->arch.dense_total, 1, st)) return 1;
+    if (!e->dry && ds_launch_linear_t(temb, e->d_dense_w, e->d_dense_b, proj, B, temb_dim, e->arch.dense_total, 1, st)) return 1;
     Tn xin;
     xin.p = const_cast<void*>(x); xin.C = xin.ld = in_ch; xin.H = H; xin.W = W;
     Tn out;

@@ -360,8 +360,11 @@ static int gn_apply_typed(const void* x, int ldx, const float* scale, const floa
   if (nb > 16384) nb = 16384;
   if (nb < 1) nb = 1;
   const bool aff = scale != nullptr;
-  if (aff && (mode == 1 || (mode == 2 && H % 4 == 0 && W % 4 == 0))) {  // 2 x 2 output blocks per thread
-    const long tot2 = (mode == 1 ? (long)B * H * W : (long)B * (H / 4) * (W / 4)) * (C >> 3);
+  const long tot2 = (mode == 1 ? (long)B * H * W : (long)B * (H / 4) * (W / 4)) * (C >> 3);
+  // 2 x 2 output blocks per thread: fewer SiLU evaluations and loads per output, but a thread of the down mode walks
+  // 36 input vectors — on the small levels (a few blocks' worth of threads) that is a 20 us latency chain, and the
+  // one-output-per-thread kernel with 4x the threads takes 6 - 11 us
+  if (aff && (mode == 1 || (mode == 2 && H % 4 == 0 && W % 4 == 0 && tot2 >= 262144))) {
     long nb2 = (tot2 + 255) / 256;
     if (nb2 > 16384) nb2 = 16384;
     if (nb2 < 1) nb2 = 1;

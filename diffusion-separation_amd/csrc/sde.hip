@@ -655,6 +655,65 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
   acc = wave_sum(acc);
   if (lane == 0) y[(long)b * O + o] = acc + (bias ? bias[o] : 0.f);
 }
+// The same product for a WIDE output (every block's Dense_0 at once, O ~ 5k) with the weights stored transposed
+// [K][O]: a thread owns one output and 4 batch entries, walks K with coalesced weight loads and LDS-broadcast
+// activations (one wave per (output, batch entry) with lane-strided K took 29 us per forward: 22k blocks re-activating
+// the embedding; this takes ~6).
+__global__ __launch_bounds__(256) void linear_t_kernel(const float* __restrict__ x, const float* __restrict__ Wt,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                       int K, int O, int silu_in) {
+  extern __shared__ float xs[];  // [16][K]: act(x) of this block's batch entries
+  const int b00 = blockIdx.y * 16;
+  for (int i = threadIdx.x; i < 16 * K; i += 256) {
+    const int bb = b00 + i / K;
+    float v = bb < B ? x[(long)bb * K + i % K] : 0.f;
+    if (silu_in) v = silu_t<float>(v);
+    xs[i] = v;
+  }
+  __syncthreads();
+  const int o = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  if (o >= O) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* xg = xs + 4 * g * K;
+  for (int k = 0; k < K; k += 4) {
+    float w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = Wt[(long)(k + i) * O + o];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(xg + j * K + k);
+      acc[j] = fmaf(v.x, w[0], acc[j]);
+      acc[j] = fmaf(v.y, w[1], acc[j]);
+      acc[j] = fmaf(v.z, w[2], acc[j]);
+      acc[j] = fmaf(v.w, w[3], acc[j]);
+    }
+  }
+  const float bo = bias ? bias[o] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int bb = b00 + 4 * g + j;
+    if (bb < B) y[(long)bb * O + o] = acc[j] + bo;
+  }
+}
+int ds_launch_linear_t(const float* x, const float* Wt, const float* bias, float* y, int B, int K, int O, int silu_in,
+                       hipStream_t st) {
+  DS_CHECK(K % 4 == 0 && K <= 2048, "linear_t: K must be a multiple of 4 (at most 2048)");
+  hipLaunchKernelGGL(linear_t_kernel, dim3(cdiv(O, 64), cdiv(B, 16)), dim3(256), (size_t)16 * K * 4, st, x, Wt, bias, y, B, K,
+                     O, silu_in);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+// dst[k][off + o] = src[o][k]: one block's Dense_0.weight into the transposed concatenation [K][ldo]
+__global__ __launch_bounds__(256) void dense_transpose_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                              int O, int K, int ldo, int off) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < O * K) dst[(long)(i % K) * ldo + off + i / K] = src[i];
+}
+int ds_launch_dense_transpose(const float* src, float* dst, int O, int K, int ldo, int off, hipStream_t st) {
+  hipLaunchKernelGGL(dense_transpose_kernel, dim3(cdiv((long)O * K, 256)), dim3(256), 0, st, src, dst, O, K, ldo, off);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
 int ds_launch_linear(const float* x, const float* W, const float* bias, float* y, int B, int K, int O, int silu_in,
                      hipStream_t st) {
   hipLaunchKernelGGL(linear_kernel, dim3(cdiv(O, 4), B), dim3(256), 0, st, x, W, bias, y, K, O, silu_in);

@@ -32,8 +32,8 @@ for (ci, co, H, W, act) in [(128, 128, 16, 16, 1), (128, 128, 16, 16, None), (12
     torch.cuda.synchronize()
     l.diffsep_small_debug_read(out, 1)
     nb = out[15]
-    tot = sum(out[i] for i in range(12))
-    print(f"{ci}->{co} {H}x{W} act={act}: {nb//5} blocks, {tot/nb:.0f} cycles/block")
+    tot = sum(out[i] for i in range(11))
+    print(f"{ci}->{co} {H}x{W} act={act}: {nb//5} blocks, {tot/nb:.0f} cycles/block in {out[11]/nb*10:.0f} ns = {tot/(out[11]*10):.2f} GHz shader clock")
     for i in range(9):
         print(f"    {names[i]:40s} {out[i]/nb:9.0f}  {100*out[i]/tot:5.1f} %")
 PY
