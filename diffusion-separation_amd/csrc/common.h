@@ -12,6 +12,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 #define DS_F32 0
 #define DS_BF16 1
+#define DS_F32_SPLIT 2  // boundary value only: fp32 tensors, MFMA products as 3 bf16 MFMAs (ConvArgs.split); kernels see DS_F32
 #define DS_MAX_SRC 4
 // fixed-point scales of the GroupNorm channel-sum accumulators (int64): sums 2^-24, sums of squares 2^-16
 #define DS_STAT_SUM_SCALE 16777216.0
@@ -160,6 +161,7 @@ struct ConvArgs {
   int B, H, W;                           // taps==9: image H x W; taps==1: M = H*W rows
   int Cin, Cout, taps;
   int dtype;
+  int split;                             // fp32 only: 3 bf16 MFMAs per k-block on hi / lo halves (2^-17 products) instead of fp32 MFMAs
 };
 int ds_launch_conv(const ConvArgs& a, hipStream_t st);
 int ds_conv_config_id(const ConvArgs& a);
@@ -192,9 +194,9 @@ long ds_stft_workspace_bytes(int B, int S, long T, int n_fft, int hop);
 long ds_istft_workspace_bytes(int B, int S, long T, int n_fft, int hop);
 int ds_launch_stft_pack(const float* xt, const float* mix, void* y, int B, int S, long T, int n_fft, int hop,
                         float exponent, float factor, int W, int Cpad, int shift, int dtype, const float* tab,
-                        float* ws, hipStream_t st);
+                        float* ws, hipStream_t st, int split = 0);  // split: the DFT GEMM in split mode (ConvArgs.split)
 int ds_launch_istft(const void* x, float* out, int B, int S, long T, int n_fft, int hop, float exponent, float factor,
-                    int W, int Cpad, int dtype, const float* tab, float* ws, hipStream_t st);
+                    int W, int Cpad, int dtype, const float* tab, float* ws, hipStream_t st, int split = 0);
 // tab: device floats: cos | sin | hann (n_fft each), then the [512][512] forward and inverse(+window) DFT matrices
 int ds_build_stft_table(int n_fft, float** dev_tab);
 

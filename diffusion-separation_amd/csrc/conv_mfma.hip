@@ -70,6 +70,16 @@ template <> struct Mma<bf16_t> {
   }
 };
 
+// fp32 value = hi + lo with hi, lo bf16 (|error| <= 2^-17 |v|): the operands of the "split" mode, in which an fp32 conv
+// runs as three bf16 MFMAs per k-block (hi*hi + hi*lo + lo*hi, fp32 accumulation) instead of eight fp32 MFMAs
+__device__ inline void split4(const uint4& v, uint2& hi, uint2& lo) {
+  const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
+  hi.x = pack_bf16x2(f0, f1);
+  hi.y = pack_bf16x2(f2, f3);
+  lo.x = pack_bf16x2(f0 - __uint_as_float(hi.x << 16), f1 - __uint_as_float(hi.x & 0xffff0000u));
+  lo.y = pack_bf16x2(f2 - __uint_as_float(hi.y << 16), f3 - __uint_as_float(hi.y & 0xffff0000u));
+}
+
 // GN-apply (+SiLU) on one 16-byte vector of KV channels
 template <typename T> struct GnVec;
 template <> struct GnVec<float> {
@@ -196,12 +206,15 @@ __device__ inline void buf_store16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsi
   __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0);
 }
 
-template <typename T, int TAPS, int TH, int TW, int BN, int WM, int WN, int KC, int EP = 1, int OCC = 2>
+// SP (fp32 only): split mode.  The staged chunk is written to LDS as two bf16 planes per row ([KC hi][KC lo], the same
+// KC * 4 bytes as fp32) and every k-block of 16 channels is three bf16 MFMAs.
+template <typename T, int TAPS, int TH, int TW, int BN, int WM, int WN, int KC, int EP = 1, int OCC = 2, int SP = 0>
 __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
   using G = ConvGeom<T, TAPS, TH, TW, BN, KC, EP>;
   static_assert(EP == 1 || (WM % EP == 0), "epilogue passes split the wave's M blocks");
+  static_assert(SP == 0 || (sizeof(T) == 4 && KC % 16 == 0), "split mode: fp32 storage, whole 16-channel k-blocks");
   constexpr int KV = G::KV, R = G::R, HW_ = G::HW_, HP = G::HP, BM = G::BM, ROWB = G::ROWB, NVEC = G::NVEC,
-                NKB = G::NKB, NA = G::NA, NB = G::NB, OROW = G::OROW;
+                NKB = SP ? KC / 16 : G::NKB, NA = G::NA, NB = G::NB, OROW = G::OROW;
   constexpr int ESZ = (int)sizeof(T);
   constexpr int WAVES_N = BN / (32 * WN);
   constexpr int WAVES_M = BM / (32 * WM);
@@ -446,21 +459,32 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
   // The chunk in flight is activated IN REGISTERS (GN affine + SiLU) while the matrix pipe works on the chunk
   // that is resident in LDS: the activation's VALU is spread over the MFMA loop of the same wave, so between
   // the two barriers of a chunk only the LDS writes remain.
+  auto put = [&](char* dst, const uint4& v) __attribute__((always_inline)) {
+    if constexpr (SP) {  // row = [KC bf16 hi][KC bf16 lo]; this thread's 4 channels: 8 bytes in each plane
+      uint2 hi, lo;
+      split4(v, hi, lo);
+      *reinterpret_cast<uint2*>(dst) = hi;
+      *reinterpret_cast<uint2*>(dst + KC * 2) = lo;
+    } else {
+      *reinterpret_cast<uint4*>(dst) = v;
+    }
+  };
+  const int ldsw0 = SP ? row0 * ROWB + (tid % NVEC) * 8 : lds0;
   auto write_chunk = [&](bool skip) __attribute__((always_inline)) {
 #ifdef ABL_NOLDSW
     return;
 #endif
 #pragma unroll
     for (int k = 0; k < NA; ++k)
-      if (a_in(k)) *reinterpret_cast<uint4*>(sA + lds0 + k * RPS * ROWB) = pa[k];
+      if (a_in(k)) put(sA + ldsw0 + k * RPS * ROWB, pa[k]);
     if (skip) {  // only the centre tap's weight rows exist (and only they are read)
 #pragma unroll
-      for (int q = 0; q < QS; ++q) *reinterpret_cast<uint4*>(sB + lds0 + (KSKIP + q) * RPS * ROWB) = pb[KSKIP + q];
+      for (int q = 0; q < QS; ++q) put(sB + ldsw0 + (KSKIP + q) * RPS * ROWB, pb[KSKIP + q]);
       return;
     }
 #pragma unroll
     for (int k = 0; k < NB; ++k)
-      if (b_in(k)) *reinterpret_cast<uint4*>(sB + lds0 + k * RPS * ROWB) = pb[k];
+      if (b_in(k)) put(sB + ldsw0 + k * RPS * ROWB, pb[k]);
   };
   constexpr int SLOTS = TAPS * NKB;                 // k-blocks of one chunk
   constexpr int S0 = SLOTS / 3;                     // the loads of the next chunk get this long to land
@@ -495,10 +519,27 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
           for (int j = 0; j < WN; ++j)
             bfr[j] = *reinterpret_cast<const uint4*>(sB + boff[j] + tap * BN * ROWB + kb * 32);
+          if constexpr (SP) {
+            uint4 afl[WM], bfl[WN];
 #pragma unroll
-          for (int i = 0; i < WM; ++i)
+            for (int i = 0; i < WM; ++i) afl[i] = *reinterpret_cast<const uint4*>(sA + aoff[i] + toff + kb * 32 + KC * 2);
 #pragma unroll
-            for (int j = 0; j < WN; ++j) Mma<T>::run(bfr[j], af[i], acc[i][j]);  // D[cout][pixel]
+            for (int j = 0; j < WN; ++j)
+              bfl[j] = *reinterpret_cast<const uint4*>(sB + boff[j] + tap * BN * ROWB + kb * 32 + KC * 2);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+              for (int j = 0; j < WN; ++j) {  // small terms first
+                Mma<bf16_t>::run(bfl[j], af[i], acc[i][j]);
+                Mma<bf16_t>::run(bfr[j], afl[i], acc[i][j]);
+                Mma<bf16_t>::run(bfr[j], af[i], acc[i][j]);
+              }
+          } else {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+              for (int j = 0; j < WN; ++j) Mma<T>::run(bfr[j], af[i], acc[i][j]);  // D[cout][pixel]
+          }
           if constexpr (NEXT) {
             const int s = tap * NKB + kb;
             if (s >= S0) {
@@ -763,11 +804,11 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
   CT_FLUSH
 }
 
-template <typename T, int TAPS, int TH, int TW, int BN, int WM, int WN, int KC, int EP = 1, int OCC = 2>
+template <typename T, int TAPS, int TH, int TW, int BN, int WM, int WN, int KC, int EP = 1, int OCC = 2, int SP = 0>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   using G = ConvGeom<T, TAPS, TH, TW, BN, KC, EP>;
   constexpr int LDS = G::LDS + 4096;  // + the [2][Cin <= 512] GroupNorm table of the accumulator mode
-  auto kern = conv_mfma_kernel<T, TAPS, TH, TW, BN, WM, WN, KC, EP, OCC>;
+  auto kern = conv_mfma_kernel<T, TAPS, TH, TW, BN, WM, WN, KC, EP, OCC, SP>;
   static bool attr_done = false;
   if (!attr_done) {
     DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -812,22 +853,22 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
-template <typename T>
+template <typename T, int SP = 0>
 static int launch_typed(const ConvArgs& a, hipStream_t st) {
   constexpr int KC9 = (sizeof(T) == 4) ? 16 : 32;
   constexpr int KC1 = (sizeof(T) == 4) ? 32 : 64;
   switch (ds_conv_config_id(a)) {
-    case 0: return launch_cfg<T, 9, 8, 32, 64, 2, 2, KC9>(a, st);
-    case 1: return launch_cfg<T, 9, 8, 32, 32, 2, 1, KC9>(a, st);
+    case 0: return launch_cfg<T, 9, 8, 32, 64, 2, 2, KC9, 1, 2, SP>(a, st);
+    case 1: return launch_cfg<T, 9, 8, 32, 32, 2, 1, KC9, 1, 2, SP>(a, st);
     case 2: {  // small images: a chain of dependent chunk round trips (1.7 us each) -> chunks twice as deep (+1 %)
       const bool deep = a.Cin % (2 * KC9) == 0 && (!a.x2 || a.C1 % (2 * KC9) == 0) &&
                         (!a.sx || (a.sCin % (2 * KC9) == 0 && (!a.sx2 || a.sC1 % (2 * KC9) == 0)));
-      if (deep) return launch_cfg<T, 9, 8, 8, 64, 1, 1, KC9 * 2>(a, st);
-      return launch_cfg<T, 9, 8, 8, 64, 1, 1, KC9>(a, st);
+      if (deep) return launch_cfg<T, 9, 8, 8, 64, 1, 1, KC9 * 2, 1, 2, SP>(a, st);
+      return launch_cfg<T, 9, 8, 8, 64, 1, 1, KC9, 1, 2, SP>(a, st);
     }
-    case 3: return launch_cfg<T, 1, 8, 32, 64, 2, 2, KC1>(a, st);
-    case 4: return launch_cfg<T, 1, 8, 32, 32, 2, 1, KC1>(a, st);
-    default: return launch_cfg<T, 1, 8, 8, 64, 1, 1, KC1>(a, st);
+    case 3: return launch_cfg<T, 1, 8, 32, 64, 2, 2, KC1, 1, 2, SP>(a, st);
+    case 4: return launch_cfg<T, 1, 8, 32, 32, 2, 1, KC1, 1, 2, SP>(a, st);
+    default: return launch_cfg<T, 1, 8, 8, 64, 1, 1, KC1, 1, 2, SP>(a, st);
   }
 }
 
@@ -878,7 +919,7 @@ int ds_launch_conv(const ConvArgs& a, hipStream_t st) {
   }
   if (ds_conv_ws_eligible(a)) return ds_launch_conv_ws(a, st);
   if (ds_conv_small_eligible(a)) return ds_launch_conv_small(a, st);
-  if (a.dtype == DS_F32) return launch_typed<float>(a, st);
+  if (a.dtype == DS_F32) return a.split ? launch_typed<float, 1>(a, st) : launch_typed<float, 0>(a, st);
   if (a.dtype == DS_BF16) return launch_typed<bf16_t>(a, st);
   DS_CHECK(false, "conv: unknown dtype");
 }

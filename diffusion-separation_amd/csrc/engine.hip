@@ -347,6 +347,8 @@ struct diffsep_engine {
   int ts_B = 0;
   bool had_arena = false;
   bool dbg_alloc = false;  // DIFFSEP_DBG_ALLOC=1: log every arena allocation (offset, bytes) to stderr
+  // DIFFSEP_F32_SPLIT: fp32 tensors, every MFMA product as 3 bf16 MFMAs on hi / lo halves (cfg.dtype stays DS_F32)
+  int split = 0;
   // optional per-launch timing of the MFMA kernels (HIP events on the launch stream)
   bool prof = false;
   struct ProfRec { hipEvent_t a, b; double flops, bytes; int cls; };
@@ -449,7 +451,7 @@ static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias
                 const SkipConv* skip = nullptr) {
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.B = B; a.H = x.H; a.W = x.W; a.Cin = x.C; a.Cout = Cout; a.taps = taps; a.dtype = e->cfg.dtype;
+  a.B = B; a.H = x.H; a.W = x.W; a.Cin = x.C; a.Cout = Cout; a.taps = taps; a.dtype = e->cfg.dtype; a.split = e->split;
   a.x = x.p; a.x_bs = (long)x.H * x.W * x.ld; a.ldx = x.ld;
   a.x2 = x.p2; a.x2_bs = (long)x.H * x.W * x.ld2; a.ldx2 = x.ld2; a.C1 = x.C1;
   a.gn_scale = gn ? gn->scale : nullptr; a.gn_shift = gn ? gn->shift : nullptr; a.gn_act = gn_act;
@@ -564,11 +566,11 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
 
 // attention core shared with the unit entry point: o = softmax(q k^T C^-1/2) v
 static int attention_core(const void* q, const void* k, const void* vt, void* o, int B, int L, int C, int ldq, int ldo,
-                          void* scores, void* probs, int dtype, hipStream_t st) {
+                          void* scores, void* probs, int dtype, hipStream_t st, int split = 0) {
   const int Lp = rup8(L);
   ConvArgs a;
   memset(&a, 0, sizeof(a));
-  a.dtype = dtype; a.B = B; a.taps = 1; a.bias_mode = 0; a.out_scale = 1.f;
+  a.dtype = dtype; a.split = split; a.B = B; a.taps = 1; a.bias_mode = 0; a.out_scale = 1.f;
   // scores[b, i, j] = sum_c q[b,i,c] k[b,j,c] * C^-0.5
   a.x = q; a.x_bs = (long)L * ldq; a.ldx = ldq;
   a.w = k; a.w_bs = (long)L * C;
@@ -606,14 +608,14 @@ static int attn_block(diffsep_engine* e, const Module& m, const Tn& x, int B, Tn
   if (!e->dry) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.dtype = e->cfg.dtype; a.B = B; a.taps = 1; a.out_scale = 1.f;
+    a.dtype = e->cfg.dtype; a.split = e->split; a.B = B; a.taps = 1; a.out_scale = 1.f;
     a.x = PK(e, m.pk_nin[2]); a.x_bs = 0; a.ldx = C;
     a.w = h.p; a.w_bs = (long)L * C;
     a.bias = P(e, m.nin_b[2]); a.bias_mode = 1;
     a.y = vt; a.y_bs = (long)C * Lp; a.ldy = Lp;
     a.H = 1; a.W = C; a.Cin = C; a.Cout = L;
     if (ds_launch_conv(a, st)) return 1;
-    if (attention_core(q.p, k.p, vt, o.p, B, L, C, C, C, scores, probs, e->cfg.dtype, st)) return 1;
+    if (attention_core(q.p, k.p, vt, o.p, B, L, C, C, C, scores, probs, e->cfg.dtype, st, e->split)) return 1;
   }
   // (the dry run must see this call too: it sizes the accumulator region)
   return conv(e, o, PK(e, m.pk_nin[3]), P(e, m.nin_b[3]), nullptr, 0, &x, kInvSqrt2, out, C, 1, B, nullptr, st, nullptr,
@@ -745,12 +747,12 @@ static int score_forward_impl(diffsep_engine* e, const float* xt, const float* t
   float* frames = (float*)e_alloc(e, (size_t)ds_istft_workspace_bytes(B, S, T, c.n_fft, c.hop));
   if (!e->dry)
     if (ds_launch_stft_pack(xt, mix, x0.p, B, S, T, c.n_fft, c.hop, c.spec_abs_exponent, c.spec_factor, W,
-                            e->arch.cpad_in, 1, c.dtype, e->d_tab, ws_f, st))
+                            e->arch.cpad_in, 1, c.dtype, e->d_tab, ws_f, st, e->split))
       return 1;
   if (net_forward(e, x0, t, y, B, st)) return 1;
   if (!e->dry)
     if (ds_launch_istft(y.p, out, B, S, T, c.n_fft, c.hop, c.spec_abs_exponent, c.spec_factor, W, e->arch.cpad_out,
-                        c.dtype, e->d_tab, frames, st))
+                        c.dtype, e->d_tab, frames, st, e->split))
       return 1;
   return 0;
 }
@@ -866,10 +868,12 @@ static int repack_module(diffsep_engine* e, const Module& m) {
 extern "C" int32_t diffsep_engine_create(const diffsep_model_config* cfg, const float* weights_host, int64_t n_floats,
                                          diffsep_engine** out) {
   DS_CHECK(cfg && weights_host && out, "engine_create: null argument");
-  DS_CHECK(cfg->dtype == DS_F32 || cfg->dtype == DS_BF16, "engine_create: dtype must be DIFFSEP_F32 or DIFFSEP_BF16");
+  DS_CHECK(cfg->dtype == DS_F32 || cfg->dtype == DS_BF16 || cfg->dtype == DS_F32_SPLIT,
+           "engine_create: dtype must be DIFFSEP_F32, DIFFSEP_BF16 or DIFFSEP_F32_SPLIT");
   diffsep_engine* e = new diffsep_engine();
   e->cfg = *cfg;
-  if (build_arch(*cfg, e->arch)) { delete e; return 1; }
+  if (cfg->dtype == DS_F32_SPLIT) { e->cfg.dtype = DS_F32; e->split = 1; }  // storage and every non-MFMA kernel: plain fp32
+  if (build_arch(e->cfg, e->arch)) { delete e; return 1; }
   const Arch& A = e->arch;
   if (n_floats != A.total) {
     ds_set_error("engine_create: weight blob has " + std::to_string(n_floats) + " floats, expected " +
@@ -877,7 +881,7 @@ extern "C" int32_t diffsep_engine_create(const diffsep_model_config* cfg, const 
     delete e;
     return 1;
   }
-  e->esz = cfg->dtype == DS_F32 ? 4 : 2;
+  e->esz = e->cfg.dtype == DS_F32 ? 4 : 2;
   DS_HIP(hipMalloc((void**)&e->d_blob, (size_t)A.total * 4));
   DS_HIP(hipMemcpy(e->d_blob, weights_host, (size_t)A.total * 4, hipMemcpyHostToDevice));
   DS_HIP(hipMalloc((void**)&e->d_pack, (size_t)A.pack_total * e->esz + 256));
@@ -1269,7 +1273,8 @@ extern "C" int32_t diffsep_conv2d(const void* x, const void* w, const float* bia
   a.res = res; a.res_bs = (long)H * W * ldr; a.ldr = ldr;
   a.out_scale = out_scale;
   a.y = y; a.y_bs = (long)H * W * ldy; a.ldy = ldy;
-  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.taps = ksize == 3 ? 9 : 1; a.dtype = dtype;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.taps = ksize == 3 ? 9 : 1;
+  a.dtype = dtype == DS_F32_SPLIT ? DS_F32 : dtype; a.split = dtype == DS_F32_SPLIT;
   return ds_launch_conv(a, (hipStream_t)stream);
 }
 
@@ -1309,7 +1314,8 @@ extern "C" int32_t diffsep_conv2d_fused(const void* x, const void* x2, int32_t C
   a.res = res; a.res_bs = (long)H * W * ldr; a.ldr = ldr;
   a.out_scale = out_scale;
   a.y = y; a.y_bs = (long)H * W * ldy; a.ldy = ldy;
-  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.taps = ksize == 3 ? 9 : 1; a.dtype = dtype;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.taps = ksize == 3 ? 9 : 1;
+  a.dtype = dtype == DS_F32_SPLIT ? DS_F32 : dtype; a.split = dtype == DS_F32_SPLIT;
   return ds_launch_conv(a, (hipStream_t)stream);
 }
 
@@ -1320,10 +1326,12 @@ extern "C" int32_t diffsep_attention(const void* q, const void* k, const void* v
                                      void* stream) {
   DS_CHECK(q && k && vt && o && workspace, "attention: null pointer");
   DS_CHECK(ld == C, "attention: q/k must be dense [B,L,C] (ld == C)");
+  const int split = dtype == DS_F32_SPLIT;
+  if (split) dtype = DS_F32;
   const int Lp = rup8(L), esz = dtype == DS_F32 ? 4 : 2;
   const long one = (((long)B * L * Lp * esz) + 255) & ~255L;
   DS_CHECK(workspace_bytes >= 2 * one, "attention: workspace too small");
-  return attention_core(q, k, vt, o, B, L, C, ld, ld, workspace, (char*)workspace + one, dtype, (hipStream_t)stream);
+  return attention_core(q, k, vt, o, B, L, C, ld, ld, workspace, (char*)workspace + one, dtype, (hipStream_t)stream, split);
 }
 
 // ---- one ResnetBlockBigGANpp / AttnBlockpp through the ENGINE's block code (res_block / attn_block above: folded

@@ -137,7 +137,7 @@ long ds_stft_workspace_bytes(int B, int S, long T, int n_fft, int hop) {
 
 int ds_launch_stft_pack(const float* xt, const float* mix, void* y, int B, int S, long T, int n_fft, int hop,
                         float exponent, float factor, int W, int Cpad, int shift, int dtype, const float* tab,
-                        float* ws, hipStream_t st) {
+                        float* ws, hipStream_t st, int split) {
   DS_CHECK(S >= 1 && S + 1 <= DS_MAXC, "stft: num_sources must be in [1,3]");
   DS_CHECK(Cpad % 8 == 0 && Cpad >= 2 * (S + 1) && Cpad <= 16, "stft: bad channel padding");
   DS_CHECK(n_fft % 2 == 0 && n_fft >= 2 && n_fft <= 510 && hop >= 1, "stft: n_fft must be even and <= 510");
@@ -157,7 +157,7 @@ int ds_launch_stft_pack(const float* xt, const float* mix, void* y, int B, int S
   a.x = tab + ds_stft_fwd_offset(n_fft); a.ldx = 512; a.x_bs = 0;
   a.w = frames; a.w_bs = 0;
   a.y = specT; a.ldy = (int)rows_p; a.y_bs = 0;
-  a.B = 1; a.H = 1; a.W = 512; a.Cin = 512; a.Cout = (int)rows; a.taps = 1; a.dtype = DS_F32; a.out_scale = 1.f;
+  a.B = 1; a.H = 1; a.W = 512; a.Cin = 512; a.Cout = (int)rows; a.taps = 1; a.dtype = DS_F32; a.split = split; a.out_scale = 1.f;
   if (ds_launch_conv(a, st)) return 1;
   const long total = (long)B * bins * W;
   if (dtype == DS_F32)
@@ -236,7 +236,7 @@ long ds_istft_workspace_bytes(int B, int S, long T, int n_fft, int hop) {
 }
 
 int ds_launch_istft(const void* x, float* out, int B, int S, long T, int n_fft, int hop, float exponent, float factor,
-                    int W, int Cpad, int dtype, const float* tab, float* ws, hipStream_t st) {
+                    int W, int Cpad, int dtype, const float* tab, float* ws, hipStream_t st, int split) {
   DS_CHECK(n_fft % 2 == 0 && n_fft <= 510, "istft: n_fft must be even and <= 510");
   DS_CHECK(S >= 1 && S <= DS_MAXC - 1 && Cpad >= 2 * S && Cpad % 8 == 0 && 2 * S <= 8, "istft: bad source / channel count");
   const int F = 1 + (int)((T + n_fft - hop) / hop);
@@ -259,7 +259,7 @@ int ds_launch_istft(const void* x, float* out, int B, int S, long T, int n_fft, 
   a.x = U; a.ldx = 512; a.x_bs = 0;
   a.w = tab + ds_stft_inv_offset(n_fft); a.w_bs = 0;
   a.y = frames; a.ldy = DS_FRAME_PITCH; a.y_bs = 0;
-  a.B = 1; a.H = 1; a.W = (int)rows; a.Cin = 512; a.Cout = 512; a.taps = 1; a.dtype = DS_F32; a.out_scale = 1.f;
+  a.B = 1; a.H = 1; a.W = (int)rows; a.Cin = 512; a.Cout = 512; a.taps = 1; a.dtype = DS_F32; a.split = split; a.out_scale = 1.f;
   if (ds_launch_conv(a, st)) return 1;
   dim3 g2((unsigned)cdiv(T, 256), (unsigned)(B * S));
   hipLaunchKernelGGL(istft_ola_kernel, g2, dim3(256), 0, st, frames, out, T, n_fft, hop, F, tab);

@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DIFFSEP_LIB", os.path.join(os.path.dirname(_HERE), "libdiffsep_hip.so"))
 
 F32, BF16 = 0, 1
+F32_SPLIT = 2  # fp32 tensors; matrix products as 3 bf16 MFMAs on hi / lo halves (include/diffsep_hip.h)
 SDE_MIX, SDE_PRIORMIX = 0, 1
 PRED_REVERSE_DIFFUSION, PRED_EULER_MARUYAMA, PRED_NONE = 0, 1, 2
 CORR_ALD2, CORR_NONE, CORR_ALD, CORR_LANGEVIN = 0, 1, 2, 3

@@ -102,7 +102,7 @@ def main(argv=None):
     ap.add_argument("--snr", type=float, default=None)
     ap.add_argument("--corrector-steps", type=int, default=None)
     ap.add_argument("--schedule", type=str, default=None)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "hybrid"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "split", "hybrid"])
     ap.add_argument("-o", "--output-dir", type=Path, default=Path("results"))
     ap.add_argument("--save-wav", action="store_true")
     ap.add_argument("--seed", type=int, default=0, help="torch.manual_seed before the first utterance: the i-th "

@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ._lib import F32, BF16, SdeConfig, SDE_MIX, check, lib
+from ._lib import F32_SPLIT, F32, BF16, SdeConfig, SDE_MIX, check, lib
 from .engine import _ptr, _stream_ptr
 
 
@@ -15,6 +15,13 @@ def _dt(t):
     if t.dtype == torch.bfloat16:
         return BF16
     raise TypeError("float32 or bfloat16 expected")
+
+
+def _dts(t, split):
+    """dtype code of a matrix-product launch: split=True asks for bf16x3 products on fp32 tensors."""
+    if split and t.dtype != torch.float32:
+        raise TypeError("split products are a mode of fp32 tensors")
+    return F32_SPLIT if split else _dt(t)
 
 
 def to_nhwc(x, cpad=None):
@@ -94,7 +101,7 @@ STAT_SUM_SCALE, STAT_SQ_SCALE = 2.0 ** 24, 2.0 ** 16  # fixed-point scales of th
 
 
 def conv2d_fused(x, wpacked, bias, cout, ksize, x2=None, gn=None, gn_act=1, bias_b=None, res=None, out_scale=1.0,
-                 cout_pad=None, out=None, stats=False, w_chunk=0, gn_acc=None):
+                 cout_pad=None, out=None, stats=False, w_chunk=0, gn_acc=None, split=False):
     """stats=True additionally returns the int64 channel-sum accumulators [B,cout,2] of the output (sum * 2^24,
     sum of squares * 2^16); stats=<tensor> adds into it.  gn_acc=(acc1, acc2|None, gamma, beta, groups): GroupNorm of
     the input from such accumulators instead of gn=(scale, shift)."""
@@ -112,7 +119,7 @@ def conv2d_fused(x, wpacked, bias, cout, ksize, x2=None, gn=None, gn_act=1, bias
     check(lib().diffsep_conv2d_fused(_ptr(x), _ptr(x2), C1, _ptr(sc), _ptr(sh), gn_act, _ptr(wpacked), _ptr(bias),
                                      _ptr(bias_b), _ptr(res), _ptr(y), B, H, W, Cin, cout, ksize, C1,
                                      x2.shape[-1] if x2 is not None else 0, res.shape[-1] if res is not None else 0, cp,
-                                     out_scale, _dt(x), _ptr(st), w_chunk, _ptr(a1), _ptr(a2), _ptr(gam), _ptr(bet), grp,
+                                     out_scale, _dts(x, split), _ptr(st), w_chunk, _ptr(a1), _ptr(a2), _ptr(gam), _ptr(bet), grp,
                                      _stream_ptr()))
     return (y, st) if stats is not False else y
 
@@ -125,13 +132,14 @@ def stats_to_float(st):
     return out
 
 
-def attention(q, k, vt):
+def attention(q, k, vt, split=False):
+    """split=True (fp32 tensors only): both GEMMs with bf16x3 products (DIFFSEP_F32_SPLIT)."""
     B, L, Cc = q.shape
     Lp = (L + 7) // 8 * 8
     assert vt.shape == (B, Cc, Lp)
     o = torch.empty_like(q)
     ws = torch.empty(2 * (B * L * Lp * q.element_size() + 256), dtype=torch.uint8, device=q.device)
-    check(lib().diffsep_attention(_ptr(q), _ptr(k), _ptr(vt), _ptr(o), B, L, Cc, Cc, _dt(q), _ptr(ws), ws.numel(),
+    check(lib().diffsep_attention(_ptr(q), _ptr(k), _ptr(vt), _ptr(o), B, L, Cc, Cc, _dts(q, split), _ptr(ws), ws.numel(),
                                   _stream_ptr()))
     return o
 

@@ -64,8 +64,11 @@ def default_config(nf=64, n_speakers=2, fs=8000, spec_factor=0.33):
         "sampler": {"N": 30, "snr": 0.5, "corrector_steps": 1}}}
 
 
-# dtype="hybrid": the fp32 engine evaluates the score of the FIRST HYBRID_HEAD_STEPS reverse steps, the bf16 engine the
-# rest.  Measured (tools/hybrid_probe.py): a score error enters the state scaled by the step size
+# dtype="split": fp32 tensors, every matrix product as three bf16 MFMAs on the hi / lo bf16 halves of both operands
+# (DIFFSEP_F32_SPLIT): 4e-5 relative RMS / >= 79 dB from the exact fp32 engine after 60 NFE at 1.9x its speed
+# (tools/probes/split_probe.py) — the fast mode that meets the parity bar.
+# dtype="hybrid": such a split-fp32 engine evaluates the score of the FIRST HYBRID_HEAD_STEPS reverse steps, the bf16
+# engine the rest.  Measured (tools/hybrid_probe.py): a score error enters the state scaled by the step size
 # G(t)^2, which is ~100x larger at t = 1 than at t = 0.03, so the bf16 rounding of the EARLY steps is what separates the
 # bf16 trajectory from the fp32 one (fp32 for the last 5 / 15 / 25 steps: 31.1 / 31.2 / 31.8 dB agreement, i.e. nothing;
 # fp32 for the first 5 / 10 / 15: 42 / 46 / 49 dB).  10 steps = >= 42 dB on every utterance measured.
@@ -74,8 +77,9 @@ HYBRID_HEAD_STEPS = 10
 
 class DiffSepModel:
     def __init__(self, config, dtype="bf16", device=None, init_seed=0, head_steps=None):
-        """dtype: "bf16" (throughput), "f32" (parity with the reference to 1e-3 RMS) or "hybrid": the fp32 engine for
-        the first head_steps reverse steps, bf16 for the rest (an extension: the reference has one precision)."""
+        """dtype: "bf16" (throughput), "f32" (exact fp32 MFMAs: parity with the reference to 1e-7), "split" (fp32 tensors,
+        bf16x3 matrix products: parity to 4e-5 at twice the speed of "f32") or "hybrid": a "split" engine for the first
+        head_steps reverse steps, bf16 for the rest (extensions: the reference has one precision)."""
         self.config = config
         sm = dict(cfg_get(config, "model.score_model"))
         sm.pop("_target_", None)
@@ -86,7 +90,7 @@ class DiffSepModel:
                                             init_seed=init_seed, **sm)
         self.tail_model, self.head_steps = None, 0
         if dtype == "hybrid":
-            self.tail_model = ScoreModelNCSNpp(dtype="f32", device=device, init_seed=init_seed, **sm)
+            self.tail_model = ScoreModelNCSNpp(dtype="split", device=device, init_seed=init_seed, **sm)
             self.head_steps = HYBRID_HEAD_STEPS if head_steps is None else int(head_steps)
         sd = dict(cfg_get(config, "model.sde"))
         target = str(sd.pop("_target_", "sdes.sdes.MixSDE"))
@@ -134,7 +138,7 @@ class DiffSepModel:
         return self
 
     def tail_engine(self):
-        """the fp32 engine of dtype="hybrid" (None otherwise)"""
+        """the (split-)fp32 engine of dtype="hybrid" (None otherwise)"""
         return self.tail_model.engine() if self.tail_model is not None and self.head_steps > 0 else None
 
     def eval(self, no_ema=False):

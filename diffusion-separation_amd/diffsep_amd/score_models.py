@@ -49,7 +49,7 @@ class ScoreModelNCSNpp:
             nf=ba.get("nf", 128), num_sources=num_sources, ch_mult=tuple(ba.get("ch_mult", (1, 1, 2, 2, 2, 2, 2))),
             num_res_blocks=ba.get("num_res_blocks", 2), attn_resolution=tuple(ba.get("attn_resolutions", (16,)))[0],
             n_fft=stft_args["n_fft"], hop=stft_args["hop_length"], spec_abs_exponent=abs(spec_abs_exponent),
-            spec_factor=spec_factor, dtype={"bf16": _lib.BF16, "f32": _lib.F32, "fp32": _lib.F32}[dtype])
+            spec_factor=spec_factor, dtype={"bf16": _lib.BF16, "f32": _lib.F32, "fp32": _lib.F32, "split": _lib.F32_SPLIT}[dtype])
         self.device = device
         self._engine = None
         # random init like the reference constructor (no checkpoint yet): synthetic variance-scaling weights

@@ -94,7 +94,7 @@ def main(argv=None):
     ap.add_argument("--denoise", type=bool, default=True)
     ap.add_argument("-s", "--schedule", type=str, default=None)
     ap.add_argument("--synthetic-weights", type=int, default=0, metavar="NF")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "hybrid"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "split", "hybrid"])
     ap.add_argument("--fp32-steps", type=int, default=None, help="--dtype hybrid: the first K reverse steps run on the fp32 engine")
     ap.add_argument("--batch", type=int, default=1, help="files per engine call (equal padded width)")
     ap.add_argument("--streams", type=int, default=1, help="engine calls in flight: K engines on K HIP streams")

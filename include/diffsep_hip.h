@@ -35,6 +35,11 @@ extern "C" {
 
 #define DIFFSEP_F32 0
 #define DIFFSEP_BF16 1
+/* fp32 tensors and fp32 everywhere except the matrix products: every MFMA k-block runs as three bf16 MFMAs on the
+ * hi / lo bf16 halves of both operands (hi*hi + hi*lo + lo*hi, fp32 accumulation: products good to ~2^-17 instead of
+ * 2^-24), ~2x the speed of DIFFSEP_F32.  Accepted by diffsep_engine_create and by the unit convolution / attention
+ * entry points; tensors are fp32 exactly as for DIFFSEP_F32. */
+#define DIFFSEP_F32_SPLIT 2
 
 #define DIFFSEP_SDE_MIX 0      /* sdes/sdes.py:180-349  MixSDE      */
 #define DIFFSEP_SDE_PRIORMIX 1 /* sdes/sdes.py:352-590  PriorMixSDE */
