@@ -743,16 +743,19 @@ static int score_forward_impl(diffsep_engine* e, const float* xt, const float* t
   if (stats_begin(e, st)) return 1;
   Tn x0 = e_tensor(e, B, H, W, e->arch.cpad_in);
   Tn y = e_tensor(e, B, H, W, e->arch.cpad_out);
+  // the DFT GEMMs work on fp32 frames in every mode: exact fp32 MFMAs for the fp32 engine, bf16x3 products (4e-5, far
+  // below the bf16 rounding of the packed spectrogram) for the split and the bf16 engine
+  const int dft_split = e->split || c.dtype == DS_BF16;
   float* ws_f = (float*)e_alloc(e, (size_t)ds_stft_workspace_bytes(B, S, T, c.n_fft, c.hop));
   float* frames = (float*)e_alloc(e, (size_t)ds_istft_workspace_bytes(B, S, T, c.n_fft, c.hop));
   if (!e->dry)
     if (ds_launch_stft_pack(xt, mix, x0.p, B, S, T, c.n_fft, c.hop, c.spec_abs_exponent, c.spec_factor, W,
-                            e->arch.cpad_in, 1, c.dtype, e->d_tab, ws_f, st, e->split))
+                            e->arch.cpad_in, 1, c.dtype, e->d_tab, ws_f, st, dft_split))
       return 1;
   if (net_forward(e, x0, t, y, B, st)) return 1;
   if (!e->dry)
     if (ds_launch_istft(y.p, out, B, S, T, c.n_fft, c.hop, c.spec_abs_exponent, c.spec_factor, W, e->arch.cpad_out,
-                        c.dtype, e->d_tab, frames, st, e->split))
+                        c.dtype, e->d_tab, frames, st, dft_split))
       return 1;
   return 0;
 }

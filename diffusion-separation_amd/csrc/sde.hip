@@ -675,17 +675,21 @@ __global__ __launch_bounds__(256) void linear_t_kernel(const float* __restrict__
   if (o >= O) return;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   const float* xg = xs + 4 * g * K;
-  for (int k = 0; k < K; k += 4) {
-    float w[4];
+  for (int k = 0; k < K; k += 16) {  // 16 independent weight loads in flight (K % 16 != 0: the tail reads zeros)
+    float w[16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = Wt[(long)(k + i) * O + o];
+    for (int i = 0; i < 16; ++i) w[i] = (k + i < K) ? Wt[(long)(k + i) * O + o] : 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 v = *reinterpret_cast<const float4*>(xg + j * K + k);
-      acc[j] = fmaf(v.x, w[0], acc[j]);
-      acc[j] = fmaf(v.y, w[1], acc[j]);
-      acc[j] = fmaf(v.z, w[2], acc[j]);
-      acc[j] = fmaf(v.w, w[3], acc[j]);
+    for (int q = 0; q < 4; ++q) {
+      if (k + 4 * q >= K) break;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(xg + j * K + k + 4 * q);
+        acc[j] = fmaf(v.x, w[4 * q], acc[j]);
+        acc[j] = fmaf(v.y, w[4 * q + 1], acc[j]);
+        acc[j] = fmaf(v.z, w[4 * q + 2], acc[j]);
+        acc[j] = fmaf(v.w, w[4 * q + 3], acc[j]);
+      }
     }
   }
   const float bo = bias ? bias[o] : 0.f;

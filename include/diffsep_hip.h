@@ -69,7 +69,7 @@ typedef struct {
   int32_t hop;              /* 128 */
   float spec_abs_exponent;  /* 0.5 */
   float spec_factor;        /* 0.33 (0.15 published) */
-  int32_t dtype;            /* DIFFSEP_F32 (parity) or DIFFSEP_BF16 (throughput) activations/weights */
+  int32_t dtype;            /* DIFFSEP_F32 (exact), DIFFSEP_F32_SPLIT (parity-grade, 2x faster) or DIFFSEP_BF16 (throughput) */
 } diffsep_model_config;
 
 /* sdes/sdes.py:217-240 (MixSDE ctor), :397-450 (PriorMixSDE ctor). */
