@@ -108,3 +108,11 @@ def test_ctypes_structs_mirror_the_header():
         assert [n for n, _ in mine] == [n for n, _ in fields], name
         assert all(C.sizeof(a) == C.sizeof(b) for (_, a), (_, b) in zip(mine, fields)), name
     assert not want, f"structs not found in the header: {list(want)}"
+
+
+def test_dtype_codes_match_the_header():
+    hdr = open(os.path.join(ROOT, "include", "diffsep_hip.h")).read()
+    codes = {n: int(v) for n, v in re.findall(r"#define (DIFFSEP_(?:F32|BF16|F32_SPLIT))\s+(\d+)", hdr)}
+    assert codes == {"DIFFSEP_F32": _lib.F32, "DIFFSEP_BF16": _lib.BF16, "DIFFSEP_F32_SPLIT": _lib.F32_SPLIT}
+    cfg = _lib.model_config(nf=16, dtype=_lib.F32_SPLIT)  # the parameter table does not depend on the precision mode
+    assert [n for n, _, _ in param_table(cfg)] == [n for n, _, _ in param_table(_lib.model_config(nf=16))]

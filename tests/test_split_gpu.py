@@ -104,3 +104,44 @@ def test_split_graph_replay_and_determinism():
     b, _ = eng.pc_sample(mn, SDE, N=3, corrector_steps=1, seed=11)
     eng.set_graph(True)
     assert torch.equal(a, b)
+
+
+def test_split_engine_other_configurations_match_reference_golden(golden, golden2):
+    # the remaining BASELINE configurations on the split engine: PriorMixSDE enhancement sampler, the other predictor /
+    # corrector pairs, three sources, the published width nf = 128 (Cin = 512 concat inputs, 512-channel GroupNorm table)
+    g, _ = golden
+    eng, _ = engine(16, 2, _lib.F32_SPLIT)
+    mix, draws, N, cs = _g9_inputs()
+    mix_norm, _, _ = ops.normalize_batch(mix.to(DEV))
+    psde = dict(kind=_lib.SDE_PRIORMIX, ndim=2, d_lambda=2.0, sigma_min=0.05, sigma_max=0.5, avg_len=510)
+    sep, nfe = eng.pc_sample(mix_norm, psde, N=N, corrector_steps=cs, snr=0.5, eps=0.03, denoise=True, noise=draws.to(DEV))
+    assert nfe == 6 and rel_rms(sep, g["g11_sep"]) < 3e-4 and diff_rms(sep, g["g11_sep"]) < 1e-3
+    ts = O.scheduled_timesteps(N, 0.03, "log").numpy()
+    a, _ = eng.pc_sample(mix_norm, SDE, N=N, corrector_steps=cs, snr=0.5, eps=0.03, predictor="euler_maruyama",
+                         corrector="ald", noise=draws.to(DEV), timesteps=ts)
+    assert rel_rms(a, g["g12_sep_em_ald_log"]) < 3e-4
+    eng3, _ = engine(16, 3, _lib.F32_SPLIT)
+    T = 4000
+    xt3, mix3 = rnd("g7.xt3", (1, 3, T), 0.5), rnd("g7.mix3", (1, 1, T), 0.5)
+    out3 = eng3.score(xt3.to(DEV), torch.tensor([0.3], device=DEV), mix3.to(DEV))
+    assert rel_rms(out3, g["g7_score_S3"]) < 2e-4
+    eng128, _ = engine(128, 2, _lib.F32_SPLIT, spec_factor=0.15)
+    xt, mx = rnd("g7.xt", (1, 2, T), 0.5), rnd("g7.mix", (1, 1, T), 0.5)
+    out = eng128.score(xt.to(DEV), torch.tensor([0.6], device=DEV), mx.to(DEV))
+    assert rel_rms(out, golden2["g14_score_nf128"]) < 2e-4
+
+
+def test_split_mixed_length_batch_equals_single_utterances():
+    # per-utterance lengths and seeds (diffsep_pc_sample_ex) on the split engine: bit-for-bit like the fp32 engine
+    eng, _ = engine(16, 2, _lib.F32_SPLIT)
+    lens = [6000, 5200, 5999, 5100]
+    assert len({eng.padded_frames(L) for L in lens}) == 1
+    T = max(lens)
+    mixn = torch.zeros(4, 1, T, device=DEV)
+    for b, L in enumerate(lens):
+        mixn[b, :, :L] = ops.normalize_batch(torch.from_numpy(synth.synth_mixture(b, T=L)[0])[None].to(DEV))[0][0]
+    seeds = [5, 6, 7, 8]
+    batch, _ = eng.pc_sample(mixn, SDE, N=2, corrector_steps=1, lengths=lens, seeds=seeds)
+    for b, L in enumerate(lens):
+        one, _ = eng.pc_sample(mixn[b:b + 1, :, :L].contiguous(), SDE, N=2, corrector_steps=1, seed=seeds[b])
+        assert torch.equal(batch[b, :, :L], one[0]) and not bool(batch[b, :, L:].any())
