@@ -526,14 +526,19 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
             for (int j = 0; j < WN; ++j)
               bfl[j] = *reinterpret_cast<const uint4*>(sB + boff[j] + tap * BN * ROWB + kb * 32 + KC * 2);
+            // term-major: consecutive MFMAs go to different accumulators (small terms first)
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-              for (int j = 0; j < WN; ++j) {  // small terms first
-                Mma<bf16_t>::run(bfl[j], af[i], acc[i][j]);
-                Mma<bf16_t>::run(bfr[j], afl[i], acc[i][j]);
-                Mma<bf16_t>::run(bfr[j], af[i], acc[i][j]);
-              }
+              for (int j = 0; j < WN; ++j) Mma<bf16_t>::run(bfl[j], af[i], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+              for (int j = 0; j < WN; ++j) Mma<bf16_t>::run(bfr[j], afl[i], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+              for (int j = 0; j < WN; ++j) Mma<bf16_t>::run(bfr[j], af[i], acc[i][j]);
           } else {
 #pragma unroll
             for (int i = 0; i < WM; ++i)
