@@ -7,20 +7,21 @@
 //
 //   * one block of 8 waves per CU; the [9][64][64] weights are copied into LDS ONCE per block (83 KB, rows padded
 //     to 144 B) and stay there for all of the block's tiles (a contiguous raster range of one image);
-//   * the 8 waves form two groups of 4 that work on alternating tiles in PING-PONG: while one group multiplies
-//     (MFMA + LDS fragment reads only), the other group does everything else for its own tile — GroupNorm affine +
-//     SiLU on the chunk it has in flight in registers, the LDS write of that chunk into the group's staging slot,
-//     the global loads of the following chunk, and the epilogue.  The groups swap roles at every block barrier
-//     (group 1 is started one phase late), so the matrix pipe / LDS read port and the VALU / memory path are
-//     busy at the same time without any intra-wave instruction interleaving;
-//   * a wave owns 2 pixel rows x 64 couts of its group's 8 x 32 tile (2 x 2 MFMA tiles: one LDS fragment read per
-//     MFMA).  MFMA operands are swapped (A = weights, B = pixels), so a lane ends up holding 4 consecutive output
-//     channels of ONE pixel per accumulator quad = one 16-byte LDS write.  The epilogue turns the wave's result
-//     into pixel rows through a private 2.3 KB LDS scratch, 8 pixels at a time (no block barrier: LDS operations
-//     of one wave execute in order); a lane then owns 8 consecutive couts of a pixel: bias / residual / scale /
-//     statistics / bf16 packing and full 128-byte-line stores;
+//   * all 8 waves run the same phase: a tile is two chunks of 32 input channels that go through a 2-slot LDS ring with
+//     ONE LDS-only barrier per chunk; two register sets keep every global load in flight for a whole chunk phase (the
+//     loads are issued one per k-step inside the MFMA loop), GroupNorm affine + SiLU is applied in registers between
+//     the MFMAs of the same wave, and the next tile's first chunk is loading while this tile's epilogue runs;
+//   * a wave owns 1 pixel row (32 pixels) x 64 couts of the 8 x 32 tile (2 MFMA tiles: 36 MFMAs per chunk).  MFMA
+//     operands are swapped (A = weights, B = pixels), so a lane ends up holding 4 consecutive output channels of ONE
+//     pixel per accumulator quad = one 16-byte LDS write.  The epilogue turns the wave's result into pixel rows
+//     through a private 2.3 KB LDS scratch, 8 pixels at a time (no block barrier: LDS operations of one wave execute
+//     in order); a lane then owns 8 consecutive couts of a pixel: bias / residual / scale / statistics / bf16 packing
+//     and full 128-byte-line stores;
 //   * GroupNorm statistics of the output are accumulated in 16 registers per lane over all tiles of the block
 //     and added once at the end to the [B][64][2] fixed-point accumulators of the tensor.
+//
+// (Measured alternatives — ping-pong wave groups, 16 x 32 tiles, role-specialised waves, register-resident weights with
+// LDS-DMA — are kept as text under profiles/experiments/ with their numbers.)
 //
 // K order (chunk, tap, 16-channel block) is the same as in conv_mfma.hip.
 #include <stdlib.h>
