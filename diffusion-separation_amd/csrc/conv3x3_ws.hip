@@ -98,6 +98,11 @@ struct WsK {
   float out_scale;
   bf16_t* y; long y_bs; int ldy;
   long long* stats;
+  // folded 1x1 skip convolution on the raw block input (SKB > 0): y += sw * cat([sx, sx2])
+  const bf16_t* sx; long sx_bs; int ldsx;
+  const bf16_t* sx2; long sx2_bs; int ldsx2;
+  int sC1, sCin;
+  const bf16_t* sw; int sw_chunked, sw_shift;
   int H, W, G, tiles_x, tiles_per_img;
 };
 
@@ -127,7 +132,14 @@ __device__ inline uint4 gn8(const uint4& u, const float* sc, const float* sh) {
 // is activated in registers between the MFMAs of the same wave; the next tile's first chunk is loading while
 // this tile's epilogue runs.
 constexpr int NA1 = (HP * (KC / 8) + 511) / 512;  // 16-byte vectors per thread per chunk: 3
-template <int MODE>
+// SKB: 16-channel k-blocks of the folded 1x1 skip convolution (0 = none, 4 = 64 raw channels, 8 = 128 = two sources of
+// 64).  Conv_2 of a residual block is linear in the RAW block input, so its product can be added to the conv
+// accumulators at any time.  A 1x1 convolution has no halo and no reuse between waves, so it stays private to the wave:
+// the wave keeps its 64 couts x 16 SKB channels of Conv_2.weight in registers for the whole launch (8 SKB VGPRs), reads
+// the raw input of ITS 32 pixels with full-line loads (8 pixels x 128 bytes per instruction) behind chunk c's MFMA loop
+// (source c), turns them into MFMA fragments through its private epilogue scratch (16 pixels at a time, wave-local LDS
+// order, no barrier) and issues the 8 extra MFMAs at the end of the chunk.  These instantiations take no residual.
+template <int MODE, int SKB = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sW = smem;
@@ -273,10 +285,50 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
   const int woff = l32 * WROW + h * 16;
   char* sE = smem + LDS_MAIN + wave * LDS_E;
   const int epx = lane >> 3, ecg = lane & 7;
-  const bool has_res = p.res != nullptr, has_stats = p.stats != nullptr;
+  const bool has_res = SKB == 0 && p.res != nullptr, has_stats = p.stats != nullptr;
   const float osc = p.out_scale;
   unsigned res_o = 0;
   uint4 rres[4];
+  // folded skip: this lane's weight fragments (cout 32 j + l32, channels 16 kb + 8 h ..) and pixel fragments
+  constexpr int NSRC = SKB / 4;  // 64-channel sources of the skip input
+  uint4 wsk[2][SKB > 0 ? SKB : 1], xsk[4], xg[2];
+  __amdgpu_buffer_rsrc_t rs1 = rx, rs2 = rx;
+  unsigned skip_o1 = 0, skip_o2 = 0;
+  if constexpr (SKB > 0) {
+    const __amdgpu_buffer_rsrc_t rsw = rsrc(p.sw, (unsigned)C * p.sCin * 2u);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kb = 0; kb < SKB; ++kb) {
+        const int co = 32 * j + l32, c0 = 16 * kb + 8 * h;
+        const unsigned vo = p.sw_chunked ? (unsigned)((((c0 >> p.sw_shift) * C + co) * p.sw_chunked + (c0 & (p.sw_chunked - 1))) * 2)
+                                         : (unsigned)((co * p.sCin + c0) * 2);
+        wsk[j][kb] = ld16(rsw, vo, 0);
+      }
+    rs1 = rsrc(p.sx + (long)b * p.sx_bs, (unsigned)(p.H * p.W) * p.ldsx * 2u);
+    rs2 = p.sx2 ? rsrc(p.sx2 + (long)b * p.sx2_bs, (unsigned)(p.H * p.W) * p.ldsx2 * 2u) : rs1;
+  }
+  // lane i of a staging load: pixel 8 m + (i >> 3) of the wave's row, 16-byte piece i & 7 of its 64 channels
+  auto skip_load = [&](int c, int half) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const unsigned pixo = (unsigned)(16 * half + 8 * m + (lane >> 3));
+      xg[m] = c == 0 ? ld16(rs1, skip_o1 + pixo * (unsigned)(p.ldsx * 2) + (unsigned)((lane & 7) * 16), 0)
+                     : ld16(rs2, skip_o2 + pixo * (unsigned)(p.ldsx2 * 2) + (unsigned)((lane & 7) * 16), 0);
+    }
+  };
+  auto skip_stage = [&](int half) {  // 16 pixels through the wave's private scratch: rows of 128 + 16 bytes
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+      *reinterpret_cast<uint4*>(sE + (8 * m + (lane >> 3)) * 144 + (lane & 7) * 16) = xg[m];
+    __builtin_amdgcn_wave_barrier();
+    if ((l32 >> 4) == half) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) xsk[kb] = *reinterpret_cast<const uint4*>(sE + (l32 & 15) * 144 + (2 * kb + h) * 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
   auto mma = [&](int c, int sl, auto NEXT_, bool loads, bool resl) {
     constexpr bool NEXT = decltype(NEXT_)::value;
     if constexpr (NEXT) act_tab(c ^ 1);
@@ -302,6 +354,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
         if (s < NA1 && loads) issue_one(c, s);                    // chunk q + 2 -> the set chunk q came from
         if (s >= NA1 && s < NA1 + 4 && resl)                      // the tile's residual rows
           rres[s - NA1] = ld16(rr, res_o + (unsigned)((s - NA1) * 8 * p.ldr * 2), 0);
+        if constexpr (SKB > 0) {  // raw block input of source c for the folded 1x1 convolution
+          if (c < NSRC) {
+            if (s == NA1) skip_load(c, 0);
+            if (s == 9) { skip_stage(0); skip_load(c, 1); }
+            if (s == 15) skip_stage(1);
+          }
+        }
         if constexpr (NEXT) {
           if (s == 8) act_one(c ^ 1, 0);
           if (s == 11) act_one(c ^ 1, 1);
@@ -309,10 +368,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
         }
       }
     }
+    if constexpr (SKB > 0) {
+      if (c < NSRC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bf16x8 xf = __builtin_bit_cast(bf16x8, xsk[i]);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wsk[0][(SKB > 4 ? 4 : 0) * c + i]), xf, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wsk[1][(SKB > 4 ? 4 : 0) * c + i]), xf, acc[1], 0, 0, 0);
+        }
+      }
+    }
   };
   auto prep_res = [&](int t) {
     const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
     res_o = (unsigned)((((ty * TH + wave) * p.W + tx * TW + epx) * p.ldr + ecg * 8) * 2);
+  };
+  auto prep_skip = [&](int t) {
+    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+    const int pix = (ty * TH + wave) * p.W + tx * TW;  // first pixel of the wave's row
+    skip_o1 = (unsigned)(pix * p.ldsx * 2);
+    skip_o2 = (unsigned)(pix * p.ldsx2 * 2) + (p.sx2 ? 0u : 128u);  // one 128-channel source: its second half
   };
   auto epilogue = [&](int t) {
     const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
@@ -389,6 +464,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
     WT_MARK(0)
     if (more) prep(q + 2);
     if (has_res) prep_res(t);        // (the residual is consumed by the epilogue at the end of the next phase)
+    if constexpr (SKB > 0) prep_skip(t);
     WT_MARK(1)
     mma(0, 0, std::true_type{}, more, has_res);   // activates set 1, fetches set 0 + the residual meanwhile
     WT_MARK(2)
@@ -452,10 +528,17 @@ int ws_blocks_per_image(const ConvArgs& a) {
 
 // The layers this kernel takes over from conv_mfma.hip.
 bool ds_conv_ws_eligible(const ConvArgs& a) {
-  return a.dtype == DS_BF16 && a.taps == 9 && a.Cin == C && a.Cout == C && !a.x2 && a.w_bs == 0 &&
-         (a.w_chunked == 0 || a.w_chunked == KC) && !a.sx &&
-         a.bias_mode == 0 && !a.div_b && a.H % TH == 0 && a.W % TW == 0 && a.ldx >= C && a.ldy >= C &&
-         (!a.res || a.ldr >= C);
+  if (!(a.dtype == DS_BF16 && a.taps == 9 && a.Cin == C && a.Cout == C && !a.x2 && a.w_bs == 0 &&
+        (a.w_chunked == 0 || a.w_chunked == KC) && a.bias_mode == 0 && !a.div_b && a.H % TH == 0 && a.W % TW == 0 &&
+        a.ldx >= C && a.ldy >= C && (!a.res || a.ldr >= C)))
+    return false;
+  if (a.sx) {  // folded 1x1 skip convolution: 64 or 128 raw channels, whole 16-channel k-blocks per source, no residual
+    const int sC1 = a.sx2 ? a.sC1 : a.sCin;
+    if (!(a.sw && !a.res && (a.sCin == 64 || a.sCin == 128) && (!a.sx2 || sC1 == 64) && a.ldsx % 8 == 0 && (!a.sx2 || a.ldsx2 % 8 == 0) &&
+          (a.sw_chunked == 0 || ((a.sw_chunked & (a.sw_chunked - 1)) == 0 && a.sw_chunked >= 8))))
+      return false;
+  }
+  return true;
 }
 
 int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st) {
@@ -473,17 +556,26 @@ int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st) {
   k.H = a.H; k.W = a.W; k.G = ws_blocks_per_image(a);
   k.tiles_x = a.W / TW; k.tiles_per_img = (a.H / TH) * (a.W / TW);
   const int mode = ((a.gn_scale || a.gn_acc1) && a.gn_act) ? 2 : 1;  // raw input = affine with scale 1, shift 0 (exact in bf16)
-  static bool attr_done = false;
-  if (!attr_done) {
-    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws1_kernel<1>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws1_kernel<2>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    attr_done = true;
-  }
+  k.sx = reinterpret_cast<const bf16_t*>(a.sx); k.sx_bs = a.sx_bs; k.ldsx = a.ldsx;
+  k.sx2 = reinterpret_cast<const bf16_t*>(a.sx2); k.sx2_bs = a.sx2_bs; k.ldsx2 = a.sx2 ? a.ldsx2 : a.ldsx;
+  k.sC1 = a.sx2 ? a.sC1 : a.sCin; k.sCin = a.sCin;
+  k.sw = reinterpret_cast<const bf16_t*>(a.sw); k.sw_chunked = a.sw_chunked; k.sw_shift = a.sw_chunked ? __builtin_ctz(a.sw_chunked) : 0;
+  const int skb = a.sx ? a.sCin / 16 : 0;
   const dim3 grid(a.B * k.G), block(512);
-  if (mode == 1) hipLaunchKernelGGL(conv3x3_ws1_kernel<1>, grid, block, LDS_TOTAL, st, k);
-  else hipLaunchKernelGGL(conv3x3_ws1_kernel<2>, grid, block, LDS_TOTAL, st, k);
+#define DS_WS_LAUNCH(M_, S_)                                                                                       \
+  do {                                                                                                             \
+    static bool attr_done = false;                                                                                 \
+    if (!attr_done) {                                                                                              \
+      DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws1_kernel<M_, S_>),                        \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));                          \
+      attr_done = true;                                                                                            \
+    }                                                                                                              \
+    hipLaunchKernelGGL((conv3x3_ws1_kernel<M_, S_>), grid, block, LDS_TOTAL, st, k);                               \
+  } while (0)
+  if (skb == 8) { if (mode == 1) DS_WS_LAUNCH(1, 8); else DS_WS_LAUNCH(2, 8); }
+  else if (skb == 4) { if (mode == 1) DS_WS_LAUNCH(1, 4); else DS_WS_LAUNCH(2, 4); }
+  else { if (mode == 1) DS_WS_LAUNCH(1, 0); else DS_WS_LAUNCH(2, 0); }
+#undef DS_WS_LAUNCH
   DS_LAUNCH_CHECK();
   return 0;
 }

@@ -257,16 +257,21 @@ def test_full_size_sampler_nf64_N30_parity_with_oracle():
     d, r = diff_rms(out, ref), rel_rms(out, ref)
     print(f"\n[parity nf64 N30] out rms {rms(ref):.4f}  diff rms {d:.3e}  rel {r:.3e}")
     assert d < 1e-3, f"waveform RMS difference {d:.3e} exceeds the 1e-3 bar"
-    # bf16 engine on the same inputs: gated on SI-SDR agreement with the fp32 reference output
+    # bf16 engine: gated on SI-SDR agreement with the fp32 result.  Which way 60 NFE of bf16 rounding push ONE utterance
+    # depends on the summation order of every kernel (the same utterance measured 26.5 - 32.7 dB across kernel revisions),
+    # so the gate is on 8 utterances against the fp32 ENGINE's output (itself 6e-8 from the oracle, asserted above):
+    # measured 31.6 - 32.0 dB mean, 24.7 - 25.2 dB min over 16 utterances (bench.py `hybrid.bf16_only_si_sdr_db`)
+    B8 = 8
+    mix8 = torch.from_numpy(synth.synth_batch(B8, T=T)[0]).to(DEV)
+    mn8, _, _ = ops.normalize_batch(mix8)
+    kw = dict(N=N, corrector_steps=1, snr=0.5, eps=0.03, denoise=True, seed=99)
+    ref8, _ = eng.pc_sample(mn8, SDE, **kw)
     eng16, _ = engine(64, 2, _lib.BF16)
-    sep16, _ = eng16.pc_sample(mix_norm, SDE, N=N, corrector_steps=1, snr=0.5, eps=0.03, denoise=True,
-                               noise=torch.stack(draws).to(DEV))
-    out16 = ops.scale_output(mix.to(DEV), sep16)
-    s = si_sdr(out16, ref)
-    print(f"[bf16 vs fp32 reference] rel rms {rel_rms(out16, ref):.3e}  SI-SDR(out16, ref) {s.flatten().tolist()}")
-    assert torch.isfinite(out16).all()
-    # throughput mode after 60 NFE with identical noise: measured 2.4e-2 relative RMS, 30.8 / 32.7 dB per source
-    assert rel_rms(out16, ref) < 4e-2 and float(s.min()) > 27.0
+    sep16, _ = eng16.pc_sample(mn8, SDE, **kw)
+    s = si_sdr(sep16, ref8)
+    print(f"[bf16 vs fp32 engine, {B8} utterances] rel rms {rel_rms(sep16, ref8):.3e}  SI-SDR mean {float(s.mean()):.2f} min {float(s.min()):.2f} dB")
+    assert torch.isfinite(sep16).all()
+    assert rel_rms(sep16, ref8) < 4e-2 and float(s.mean()) > 29.5 and float(s.min()) > 22.0
 
 
 def test_priormix_sampler_matches_reference_golden(golden):

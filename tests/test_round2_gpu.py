@@ -487,3 +487,24 @@ def test_resblock_on_small_images_vs_oracle(cin, c1, cout, H, W, up, down):
     yb = ops.resblock_forward([sd[n] for n, _ in tbl], ops.to_nhwc(x).to(torch.bfloat16).to(DEV), temb.to(DEV), cout,
                               up=up, down=down)
     assert rel_rms(ops.to_nchw(yb).float(), ref) < 3e-2
+
+
+@pytest.mark.parametrize("cin,cout,H,W,up,down", [(128, 64, 32, 64, False, False), (128, 64, 8, 32, False, False),
+                                                  (64, 64, 16, 32, True, False), (64, 64, 32, 128, False, True)])
+def test_resblock_weight_stationary_folded_skip_vs_oracle(cin, cout, H, W, up, down):
+    # 64-cout blocks whose Conv_1 runs on the weight-stationary kernel WITH Conv_2 folded in (conv3x3_ws.hip, SKB = 8 / 4:
+    # the wave-private 1x1 product on the raw block input), one and several tiles per block; fp32 = the generic tile
+    tbl = [("GroupNorm_0.weight", (cin,)), ("GroupNorm_0.bias", (cin,)), ("Conv_0.weight", (cout, cin, 3, 3)),
+           ("Conv_0.bias", (cout,)), ("Dense_0.weight", (cout, 64)), ("Dense_0.bias", (cout,)),
+           ("GroupNorm_1.weight", (cout,)), ("GroupNorm_1.bias", (cout,)), ("Conv_1.weight", (cout, cout, 3, 3)),
+           ("Conv_1.bias", (cout,)), ("Conv_2.weight", (cout, cin, 1, 1)), ("Conv_2.bias", (cout,))]
+    sd = synth.synth_state_dict(tbl, 23)
+    # a large Conv_2 so that a wrong or missing skip product cannot hide inside the bf16 tolerance
+    sd["Conv_2.weight"] = (sd["Conv_2.weight"] * 3.0).astype(np.float32)
+    x, temb = rnd(f"rbw2.x{cin}{H}{W}", (3, cin, H, W)), rnd("rbw2.t", (3, 64))
+    ref = O._res_block(O.to_torch(sd), "", x, temb, up=up, down=down)
+    y = ops.resblock_forward([sd[n] for n, _ in tbl], ops.to_nhwc(x).to(DEV), temb.to(DEV), cout, up=up, down=down)
+    assert rel_rms(ops.to_nchw(y), ref) < 2e-5
+    yb = ops.resblock_forward([sd[n] for n, _ in tbl], ops.to_nhwc(x).to(torch.bfloat16).to(DEV), temb.to(DEV), cout,
+                              up=up, down=down)
+    assert rel_rms(ops.to_nchw(yb).float(), ref) < 1.5e-2
