@@ -3,8 +3,8 @@
 set -e
 cd $(dirname $0)/../diffusion-separation_amd/csrc
 mkdir -p ../abl
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DWS_TIMING -c conv3x3_ws.hip -o /tmp/ws_timing.o
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../abl/lib_wstiming.so /tmp/ws_timing.o build/conv_mfma.o build/norm.o build/stft.o build/sde.o build/engine.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC -DWS_TIMING -c conv3x3_ws.hip -o /tmp/ws_timing.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../abl/lib_wstiming.so /tmp/ws_timing.o build/conv_mfma.o build/conv3x3_small.o build/norm.o build/stft.o build/sde.o build/engine.o
 cd ../..
 DIFFSEP_LIB=$PWD/diffusion-separation_amd/abl/lib_wstiming.so python - <<'PY'
 import ctypes, sys, os, torch
