@@ -350,6 +350,125 @@ __global__ __launch_bounds__(256) void gn_resample2x2_kernel(const T* __restrict
   }
 }
 
+// Tiled FIR x2 UP for the large levels: the 2 x 2-block kernel above evaluates SiLU(GN(.)) 9 times per input element in
+// its up mode, which makes it VALU-bound (91 us at 256^2 output against 60 us of HBM time).  Here a block stages one input
+// tile — 8 channel groups x (4 + 2) x (8 + 2) pixels — in LDS ONCE: the activated value as fp32 and the raw value in the
+// storage type; then one thread per (input pixel, channel group) builds its 2 x 2 outputs from the 3 x 3 neighbourhood in
+// LDS.  Same arithmetic as the kernels above (horizontal taps first, then vertical, fp32 FMAs; zeros outside the image).
+// 91 -> 57 us at 256^2, 46 -> 27 us at 128^2.  (The FIR-down mode of this design measured slower than the 2 x 2-block
+// kernel: profiles/experiments/gn_resample_tiled_down_r02.hip.txt.)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_resample_up_tiled_kernel(const T* __restrict__ x, int ldx,
+                                                                   const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, int C,
+                                                                   T* __restrict__ y, int ldy, T* __restrict__ xr,
+                                                                   int ldxr, int B, int H, int W, int act, int tiles_x,
+                                                                   int tiles_y) {
+  constexpr int TH_ = 4, TW_ = 8, CG = 8;                         // tile of input pixels, channel groups per block
+  constexpr int IH = TH_ + 2, IW = TW_ + 2;                       // staged input tile (1 pixel of halo)
+  constexpr int RAWB = 8 * (int)sizeof(T);                        // raw vector bytes
+  constexpr int PITCH = 32 + RAWB;                                // per (pixel, group): 8 fp32 activated + raw
+  extern __shared__ __attribute__((aligned(16))) char sm[];       // IH * IW * CG * PITCH bytes
+  const int tid = threadIdx.x;
+  const int ncgb = (C >> 3) / CG;                                 // channel-group blocks (C % 64 == 0)
+  int bid = blockIdx.x;
+  const int cgb = bid % ncgb; bid /= ncgb;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int cg = tid & 7;                                         // this thread's channel group in both phases
+  const int ch0 = (cgb * CG + cg) * 8;
+  float sc[8], sf[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = scale[(long)b * C + ch0 + j];
+    sf[j] = shift[(long)b * C + ch0 + j];
+  }
+  // ---- stage: input pixel (iy0 + r, ix0 + c), r < IH, c < IW
+  const int iy0 = ty * TH_ - 1, ix0 = tx * TW_ - 1;
+  const T* xb = x + (long)b * H * W * ldx + ch0;
+  for (int i = tid; i < IH * IW * CG; i += 256) {
+    const int pix = i >> 3;
+    const int r = pix / IW, c = pix - r * IW;
+    const int iy = iy0 + r, ix = ix0 + c;
+    char* dst = sm + (pix * CG + cg) * PITCH;
+    float v[8];
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+      const T* src = xb + ((long)iy * W + ix) * ldx;
+      float f[8];
+      load8<T>(src, f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float u = f[j] * sc[j] + sf[j];
+        v[j] = act ? silu_t<T>(u) : u;
+      }
+      *reinterpret_cast<uint4*>(dst + 32) = reinterpret_cast<const uint4*>(src)[0];
+      if (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst + 48) = reinterpret_cast<const uint4*>(src)[1];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      *reinterpret_cast<uint4*>(dst + 32) = make_uint4(0, 0, 0, 0);
+      if (sizeof(T) == 4) *reinterpret_cast<uint4*>(dst + 48) = make_uint4(0, 0, 0, 0);
+    }
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(dst + 16) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+  __syncthreads();
+  // ---- FIR: thread = (input pixel p of the 4 x 8 tile, channel group cg) -> outputs (2 iy + a, 2 ix + c)
+  const int p = tid >> 3, py = p / TW_, px = p - py * TW_;
+  const int iy = ty * TH_ + py, ix = tx * TW_ + px;
+  if (iy >= H || ix >= W) return;
+  float oh[2][2][8], ox[2][2][8];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { oh[a][c][j] = 0.f; ox[a][c][j] = 0.f; }
+#pragma unroll
+  for (int ri = 0; ri < 3; ++ri) {
+    float hh[2][8], hx[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { hh[c][j] = 0.f; hx[c][j] = 0.f; }
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci) {
+      const float w0 = ci == 0 ? 0.25f : (ci == 1 ? 0.75f : 0.f), w1 = ci == 1 ? 0.75f : (ci == 2 ? 0.25f : 0.f);
+      const char* src = sm + (((py + ri) * IW + px + ci) * CG + cg) * PITCH;
+      const float4 a0 = *reinterpret_cast<const float4*>(src), a1 = *reinterpret_cast<const float4*>(src + 16);
+      const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      float f[8];
+      load8<T>(reinterpret_cast<const T*>(src + 32), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (w0 != 0.f) { hh[0][j] = fmaf(w0, a[j], hh[0][j]); hx[0][j] = fmaf(w0, f[j], hx[0][j]); }
+        if (w1 != 0.f) { hh[1][j] = fmaf(w1, a[j], hh[1][j]); hx[1][j] = fmaf(w1, f[j], hx[1][j]); }
+      }
+    }
+    const float v0 = ri == 0 ? 0.25f : (ri == 1 ? 0.75f : 0.f), v1 = ri == 1 ? 0.75f : (ri == 2 ? 0.25f : 0.f);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (v0 != 0.f) { oh[0][c][j] = fmaf(v0, hh[c][j], oh[0][c][j]); ox[0][c][j] = fmaf(v0, hx[c][j], ox[0][c][j]); }
+        if (v1 != 0.f) { oh[1][c][j] = fmaf(v1, hh[c][j], oh[1][c][j]); ox[1][c][j] = fmaf(v1, hx[c][j], ox[1][c][j]); }
+      }
+  }
+  const int Ho = 2 * H, Wo = 2 * W;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const long opix = ((long)b * Ho + 2 * iy + a) * Wo + 2 * ix + c;
+      store8<T>(y + opix * ldy + ch0, oh[a][c]);
+      if (xr) store8<T>(xr + opix * ldxr + ch0, ox[a][c]);
+    }
+}
+
+template <typename T>
+static constexpr int gn_resample_up_tiled_lds() { return 6 * 10 * 8 * (32 + 8 * (int)sizeof(T)); }
+
 template <typename T>
 static int gn_apply_typed(const void* x, int ldx, const float* scale, const float* shift, int C, void* y, int ldy,
                           void* xr, int ldxr, int B, int H, int W, int act, int mode, hipStream_t st) {
@@ -364,6 +483,21 @@ static int gn_apply_typed(const void* x, int ldx, const float* scale, const floa
   // 2 x 2 output blocks per thread: fewer SiLU evaluations and loads per output, but a thread of the down mode walks
   // 36 input vectors — on the small levels (a few blocks' worth of threads) that is a 20 us latency chain, and the
   // one-output-per-thread kernel with 4x the threads takes 6 - 11 us
+  // large levels, FIR up: one activation per input element (LDS-staged tiles of 8 channel groups)
+  if (aff && mode == 1 && C % 64 == 0 && tot2 >= 262144) {
+    const int th = cdiv(H, 4), tw = cdiv(W, 8);
+    const long nblk = (long)B * th * tw * (C / 64);
+    static bool attr_done = false;
+    if (!attr_done) {
+      DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_resample_up_tiled_kernel<T>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, gn_resample_up_tiled_lds<T>()));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL((gn_resample_up_tiled_kernel<T>), dim3((unsigned)nblk), dim3(256), gn_resample_up_tiled_lds<T>(), st,
+                       (const T*)x, ldx, scale, shift, C, (T*)y, ldy, (T*)xr, ldxr, B, H, W, act, tw, th);
+    DS_LAUNCH_CHECK();
+    return 0;
+  }
   if (aff && (mode == 1 || (mode == 2 && H % 4 == 0 && W % 4 == 0 && tot2 >= 262144))) {
     long nb2 = (tot2 + 255) / 256;
     if (nb2 > 16384) nb2 = 16384;
