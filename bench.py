@@ -370,6 +370,12 @@ def main():
                 "hbm_floor_us": round(hbm_floor_us, 2), "mfma_floor_us": round(mfma_floor_us, 2),
                 "achieved_tflops": round(ach, 2),
                 "per_kernel_ms": {k: round(v[1], 2) for k, v in prof.items() if v[2]},
+                # every MFMA kernel class of the step against both roofs (algorithmic flops / bytes over its summed time)
+                "per_kernel_roofline": {k: {"launches": v[2], "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1),
+                                            "gb_per_s": round(v[3] / (v[1] * 1e-3) / 1e9, 1),
+                                            "frac_mfma": round(v[0] / (v[1] * 1e-3) / 1e12 / peak, 4),
+                                            "frac_hbm": round(v[3] / (v[1] * 1e-3) / HBM_PEAK_BPS, 4)}
+                                        for k, v in prof.items() if v[2] and v[1] > 0},
                 "all_mfma_kernels_ms": round(tot_ms, 2),
                 "all_mfma_kernels_tflops": round(sum(v[0] for v in prof.values()) / (tot_ms * 1e-3) / 1e12, 2)})
 

@@ -169,6 +169,8 @@ int ds_conv_chunk(int taps, int dtype);
 bool ds_conv_skip_supported(int H, int W, int Cout, int dtype);
 bool ds_conv_ws_eligible(const ConvArgs& a);   // conv3x3_ws.hip: weight-stationary 64 -> 64 bf16 kernel
 int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st);
+bool ds_conv_thin_eligible(const ConvArgs& a);   // conv3x3_ws.hip: the 8 -> 64 first layer
+int ds_launch_conv_thin(const ConvArgs& a, hipStream_t st);
 bool ds_conv_small_eligible(const ConvArgs& a);  // conv3x3_small.hip: <= 16-row images, 16-cout slabs, bf16
 int ds_launch_conv_small(const ConvArgs& a, hipStream_t st);
 

@@ -508,6 +508,132 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
   WT_FLUSH
 }
 
+// ---- the network's first layer: conv3x3 8 -> 64 (ncsnpp.py:352-357; 6 real input channels padded to 8) on the same
+// 8 x 32 tiles and persistent blocks.  K = 9 taps x 8 channels = 72: a 16-wide k-block is a PAIR of taps, so the B
+// fragment of lane (pixel l32, half h) for k-block kb is the 16-byte pixel vector of tap 2 kb + h — read straight from a
+// [340 halo pixels][16 B] LDS tile (5.4 KB, double-buffered: one barrier per tile) — and the 64 x 72 weights live in 40
+// registers per lane.  10 MFMAs per wave and tile; the launch is bound by writing its 64-channel output (and its
+// statistics), which the generic tile did at 1.5 TB/s (102 us at 256^2, B = 16).
+struct ThinK {
+  const bf16_t* x; long x_bs; int ldx;
+  const bf16_t* w;              // [64][9][8]
+  const float* bias;
+  bf16_t* y; long y_bs; int ldy;
+  long long* stats;
+  int H, W, G, tiles_x, tiles_per_img;
+};
+constexpr int THIN_LDS = 512 * RED_ROW * 4;  // input tiles 2 x 5.4 KB + 8 epilogue scratches 18 KB; the final statistics reduce needs 40 KB
+static_assert(2 * HP * 16 + 8 * LDS_E <= THIN_LDS, "LDS of the thin-input kernel");
+__global__ __launch_bounds__(512, 2) void conv3x3_thin_in_kernel(ThinK p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sX = smem;                       // [2][HP][16 B]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l32 = lane & 31, h = lane >> 5;
+  char* sE = smem + 2 * HP * 16 + wave * LDS_E;
+  const int b = blockIdx.x / p.G, part = blockIdx.x % p.G;
+  const int t0 = (int)((long)part * p.tiles_per_img / p.G);
+  const int nt = (int)((long)(part + 1) * p.tiles_per_img / p.G) - t0;
+  const __amdgpu_buffer_rsrc_t rx = rsrc(p.x + (long)b * p.x_bs, (unsigned)(p.H * p.W) * p.ldx * 2u);
+  const __amdgpu_buffer_rsrc_t ry = rsrc(p.y + (long)b * p.y_bs, (unsigned)(p.H * p.W) * p.ldy * 2u);
+  // weight fragments: cout 32 j + l32, tap 2 kb + h (tap 9 does not exist: zero)
+  uint4 wf[2][5];
+  {
+    const __amdgpu_buffer_rsrc_t rw = rsrc(p.w, 64u * 9u * 8u * 2u);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kb = 0; kb < 5; ++kb) {
+        const int tap = 2 * kb + h;
+        wf[j][kb] = ld16(rw, tap < 9 ? (unsigned)(((32 * j + l32) * 9 + tap) * 16) : OOB, 0);
+      }
+  }
+  float bz[8];
+  const int epx = lane >> 3, ecg = lane & 7;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bz[j] = p.bias ? p.bias[ecg * 8 + j] : 0.f;
+  // staging: thread i < HP owns halo pixel i of the tile
+  const int hy = tid / HW_, hx = tid - hy * HW_;
+  uint4 px = make_uint4(0, 0, 0, 0);
+  auto issue = [&](int t) {
+    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+    const int gy = ty * TH + hy - 1, gx = tx * TW + hx - 1;
+    const bool ok = tid < HP && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    px = ld16(rx, ok ? (unsigned)((gy * p.W + gx) * p.ldx * 2) : OOB, 0);
+  };
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+  const bool has_stats = p.stats != nullptr;
+  issue(t0);
+  for (int i = 0; i < nt; ++i) {
+    const int t = t0 + i;
+    char* sx = sX + (i & 1) * HP * 16;
+    if (tid < HP) *reinterpret_cast<uint4*>(sx + tid * 16) = px;
+    if (i + 1 < nt) issue(t + 1);
+    sync_lds();  // tile i visible; the slot written next iteration was last read two barriers ago
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 5; ++kb) {
+      const int tap = 2 * kb + h < 9 ? 2 * kb + h : 8;  // (the missing tenth tap multiplies zero weights)
+      const bf16x8 pf = __builtin_bit_cast(
+          bf16x8, *reinterpret_cast<const uint4*>(sx + ((wave + tap / 3) * HW_ + l32 + tap % 3) * 16));
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[0][kb]), pf, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[1][kb]), pf, acc[1], 0, 0, 0);
+    }
+    // epilogue: the wave's 32 pixels x 64 couts through its private scratch, 8 pixels at a time, as full 128-byte lines
+    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+    const unsigned o = (unsigned)((((ty * TH + wave) * p.W + tx * TW + epx) * p.ldy + ecg * 8) * 2);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      if ((l32 >> 3) == s4) {
+        char* dst = sE + (l32 & 7) * EROW + h * 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(dst + (j * 32 + g * 8) * 4) =
+                make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      const float4 a0 = *reinterpret_cast<const float4*>(sE + epx * EROW + ecg * 32);
+      const float4 a1 = *reinterpret_cast<const float4*>(sE + epx * EROW + ecg * 32 + 16);
+      __builtin_amdgcn_wave_barrier();
+      float v[8] = {a0.x + bz[0], a0.y + bz[1], a0.z + bz[2], a0.w + bz[3], a1.x + bz[4], a1.y + bz[5], a1.z + bz[6], a1.w + bz[7]};
+      if (has_stats) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          ssum[j] += v[j];
+          ssq[j] = fmaf(v[j], v[j], ssq[j]);
+        }
+      }
+      u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+      WS_STORE(ov, ry, o + (unsigned)(s4 * 8 * p.ldy * 2), 0, 0);
+    }
+  }
+  if (has_stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    *reinterpret_cast<float4*>(red + tid * RED_ROW) = make_float4(ssum[0], ssum[1], ssum[2], ssum[3]);
+    *reinterpret_cast<float4*>(red + tid * RED_ROW + 4) = make_float4(ssum[4], ssum[5], ssum[6], ssum[7]);
+    *reinterpret_cast<float4*>(red + tid * RED_ROW + 8) = make_float4(ssq[0], ssq[1], ssq[2], ssq[3]);
+    *reinterpret_cast<float4*>(red + tid * RED_ROW + 12) = make_float4(ssq[4], ssq[5], ssq[6], ssq[7]);
+    __syncthreads();
+    if (tid < 128) {
+      const int co = tid >> 1, st = tid & 1;
+      const float* src = red + (co >> 3) * RED_ROW + st * 8 + (co & 7);
+      double a = 0.0;
+#pragma unroll 8
+      for (int i = 0; i < 64; ++i) a += (double)src[i * 8 * RED_ROW];
+      ds_stat_add(p.stats + ((long)b * C + co) * 2 + st, (long long)llrint(a * (st ? DS_STAT_SQ_SCALE : DS_STAT_SUM_SCALE)));
+    }
+  }
+}
+
 int ws_blocks_per_image(const ConvArgs& a) {
   static int cus = 0;
   if (!cus) {
@@ -576,6 +702,29 @@ int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st) {
   else if (skb == 4) { if (mode == 1) DS_WS_LAUNCH(1, 4); else DS_WS_LAUNCH(2, 4); }
   else { if (mode == 1) DS_WS_LAUNCH(1, 0); else DS_WS_LAUNCH(2, 0); }
 #undef DS_WS_LAUNCH
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+
+// The first layer of the network: 8 (padded) input channels, no GroupNorm, no residual.
+bool ds_conv_thin_eligible(const ConvArgs& a) {
+  return a.dtype == DS_BF16 && a.taps == 9 && a.Cin == 8 && a.Cout == C && !a.x2 && !a.sx && a.w_bs == 0 &&
+         a.w_chunked == 0 && !a.gn_scale && !a.gn_acc1 && !a.res && !a.bias_b && a.bias_mode == 0 && !a.div_b &&
+         a.out_scale == 1.f && a.H % TH == 0 && a.W % TW == 0 && a.ldx % 8 == 0 && a.ldy >= C;
+}
+
+int ds_launch_conv_thin(const ConvArgs& a, hipStream_t st) {
+  ThinK k;
+  k.x = reinterpret_cast<const bf16_t*>(a.x); k.x_bs = a.x_bs; k.ldx = a.ldx;
+  k.w = reinterpret_cast<const bf16_t*>(a.w);
+  k.bias = a.bias;
+  k.y = reinterpret_cast<bf16_t*>(a.y); k.y_bs = a.y_bs; k.ldy = a.ldy;
+  k.stats = a.stats_acc;
+  k.H = a.H; k.W = a.W; k.G = ws_blocks_per_image(a) * 2;  // two blocks per CU
+  const int tiles = (a.H / TH) * (a.W / TW);
+  if (k.G > tiles) k.G = tiles;
+  k.tiles_x = a.W / TW; k.tiles_per_img = tiles;
+  hipLaunchKernelGGL(conv3x3_thin_in_kernel, dim3(a.B * k.G), dim3(512), THIN_LDS, st, k);
   DS_LAUNCH_CHECK();
   return 0;
 }

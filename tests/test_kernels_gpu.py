@@ -489,3 +489,22 @@ def test_small_image_conv3x3(C1, C2, Cout, H, W, act, lazy):
     y2 = ops.conv2d_fused(xa, ops.pack_conv_weight(w, dt).to(DEV), None, Cout, 3, x2=xb)  # bare convolution
     ref2 = F.conv2d(xcat.permute(0, 3, 1, 2), w.to(dt).float(), None, padding=1).permute(0, 2, 3, 1)
     assert rel_rms(y2.float().cpu(), ref2) < 4e-3
+
+
+@pytest.mark.parametrize("B,H,W,cin", [(2, 16, 32, 6), (16, 64, 64, 6), (3, 8, 96, 8), (64, 24, 32, 4)])
+def test_first_layer_conv3x3_8_to_64(B, H, W, cin):
+    # the network's first layer (<= 8 input channels, padded to 8) on its own persistent kernel in bf16
+    # (conv3x3_thin_in_kernel): image borders, one and several tiles per block, bias, statistics of the output
+    dt = torch.bfloat16
+    x = torch.zeros(B, H, W, 8)
+    x[..., :cin] = rnd(f"fl.x{B}{H}{W}", (B, H, W, cin), 1.3)
+    x = x.to(DEV).to(dt)
+    w = torch.zeros(64, 8, 3, 3)
+    w[:, :cin] = rnd(f"fl.w{cin}", (64, cin, 3, 3), (9 * cin) ** -0.5)
+    bias = rnd("fl.b", (64,), 0.2).to(DEV)
+    y, st = ops.conv2d_fused(x, ops.pack_conv_weight(w, dt).to(DEV), bias, 64, 3, stats=True)
+    ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.to(dt).float(), bias.cpu(), padding=1).permute(0, 2, 3, 1)
+    assert rel_rms(y.float().cpu(), ref) < 4e-3
+    s = ops.stats_to_float(st).cpu()
+    assert torch.allclose(s[..., 0], ref.double().sum((1, 2)), rtol=2e-3, atol=2e-3 * H * W)
+    assert torch.allclose(s[..., 1], (ref.double() ** 2).sum((1, 2)), rtol=2e-3, atol=2e-3 * H * W)

@@ -48,7 +48,7 @@ def main():
         sd_ = si_sdr(outs[k], outs["f32"])
         print(f"sampler N={N}: {k:5s} vs fp32: rel RMS {rel(outs[k], outs['f32']):.3e}, SI-SDR mean {float(sd_.mean()):.1f} min {float(sd_.min()):.1f} dB")
     print("one batch of 16 alone: " + ", ".join(f"{k} {times[k]*1e3:.0f} ms = {B/times[k]:.1f} utt/s" for k in engs))
-    for head, K in (("f32", 10), ("split", 10), ("split", 15), ("split", 30)):
+    for head, K in (("f32", 10), ("split", 10), ("split", 5), ("split", 6), ("split", 7), ("split", 8), ("split", 9), ("split", 15), ("split", 30)):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         o, _ = engs["bf16"].pc_sample(mixn, SDE, N=N, corrector_steps=1, seed=7, tail=engs[head], head_steps=K)
