@@ -171,6 +171,8 @@ bool ds_conv_ws_eligible(const ConvArgs& a);   // conv3x3_ws.hip: weight-station
 int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st);
 bool ds_conv_thin_eligible(const ConvArgs& a);   // conv3x3_ws.hip: the 8 -> 64 first layer
 int ds_launch_conv_thin(const ConvArgs& a, hipStream_t st);
+bool ds_conv_thin_out_eligible(const ConvArgs& a);   // conv3x3_ws.hip: the <= 8-cout pyramid heads
+int ds_launch_conv_thin_out(const ConvArgs& a, hipStream_t st);
 bool ds_conv_small_eligible(const ConvArgs& a);  // conv3x3_small.hip: <= 16-row images, 16-cout slabs, bf16
 int ds_launch_conv_small(const ConvArgs& a, hipStream_t st);
 

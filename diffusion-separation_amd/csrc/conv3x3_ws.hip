@@ -64,6 +64,16 @@ __device__ inline uint4 ld16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned s
   const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
   return make_uint4(v.x, v.y, v.z, v.w);
 }
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+__device__ inline uint2 ld8(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+  return make_uint2(v.x, v.y);
+}
+__device__ inline void st8(__amdgpu_buffer_rsrc_t r, unsigned voff, uint2 d) {
+  const u32x2_t v = {d.x, d.y};
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, 0, 0);
+}
 
 // Block barrier that only orders LDS traffic.  __syncthreads() is a workgroup-scope fence: it drains vmcnt, i.e. it
 // would wait for the global prefetch loads issued just before it and serialize them with the barrier.
@@ -634,6 +644,172 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin_in_kernel(ThinK p) {
   }
 }
 
+// ---- the output-pyramid heads: conv3x3 (64 | 128 | 256) -> <= 8 channels on act(GN(h)) (+ the FIR-upsampled previous
+// pyramid as residual), ncsnpp.py:419-440.  With 8 couts the layer is all input handling: a block stages the activated
+// 8 x 32 (+halo) tile of 64 input channels in LDS, a wave multiplies its pixel row as two 16-pixel groups with
+// v_mfma_f32_16x16x32_bf16 (A = the 8 real couts padded to 16, kept in LDS: 18 KB per 64 channels), and lanes 0 - 31 of
+// each group write 8 bytes of output.  Wider inputs run as consecutive 64-channel passes into the same accumulators.
+// The generic tile (32 couts of MFMA work for 8, 256 VGPRs, 2 waves per SIMD) took 109 us at 256^2, B = 16.
+struct ThinOutK {
+  const bf16_t* x; long x_bs; int ldx; int Cin;
+  const bf16_t* w; int w_chunked, w_shift;  // [Cout][9][Cin] or chunk-major [Cin/kc][9][Cout][kc]
+  const float* gn_scale; const float* gn_shift;
+  const long long* gn_acc; const float* gn_gamma; const float* gn_beta; int gn_cpg; float gn_inv_count; float gn_eps;
+  int act;
+  const float* bias;
+  const bf16_t* res; long res_bs; int ldr;
+  bf16_t* y; long y_bs; int ldy;
+  int Cout;
+  int H, W, G, tiles_x, tiles_per_img;
+};
+constexpr int TO_PROW = 64 * 2 + 16;              // LDS pitch of a halo pixel (64 channels) / of a (tap, cout) weight row
+constexpr int TO_LDS_X = HP * TO_PROW;            // 48,960
+constexpr int TO_LDS_W = 9 * 16 * TO_PROW;        // 20,736
+constexpr int TO_LDS = TO_LDS_X + TO_LDS_W + 2 * 64 * 4;
+__global__ __launch_bounds__(512, 2) void conv3x3_thin_out_kernel(ThinOutK p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sX = smem;
+  char* sWt = smem + TO_LDS_X;
+  float* sTab = reinterpret_cast<float*>(smem + TO_LDS_X + TO_LDS_W);  // scale[64], shift[64] of the current pass
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x / p.G, part = blockIdx.x % p.G;
+  const int t0 = (int)((long)part * p.tiles_per_img / p.G);
+  const int nt = (int)((long)(part + 1) * p.tiles_per_img / p.G) - t0;
+  const int M = p.H * p.W;
+  const __amdgpu_buffer_rsrc_t rx = rsrc(p.x + (long)b * p.x_bs, (unsigned)M * p.ldx * 2u);
+  const __amdgpu_buffer_rsrc_t ry = rsrc(p.y + (long)b * p.y_bs, (unsigned)M * p.ldy * 2u);
+  const __amdgpu_buffer_rsrc_t rr = rsrc(p.res ? p.res + (long)b * p.res_bs : p.y, p.res ? (unsigned)M * p.ldr * 2u : 0u);
+  const __amdgpu_buffer_rsrc_t rw = rsrc(p.w, (unsigned)p.Cout * 9u * p.Cin * 2u);
+  const int npass = p.Cin / 64;
+  const int slot = tid & 7;  // this thread's 8 channels of a pixel in the staging pass
+  constexpr int NV = (HP * 8 + 511) / 512;  // 6 vectors per thread and tile
+  float bz[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bz[i] = (p.bias && 4 * q + i < p.Cout) ? p.bias[4 * q + i] : 0.f;
+  const int foff = l16 * TO_PROW + q * 16;
+  // the (tile, 64-channel pass) steps of the block as one sequence: the loads of step s + 1 are issued right after step
+  // s's tile is in LDS, so they are in flight during its MFMAs and epilogue
+  uint4 pv[NV];
+  bool ok[NV];
+  auto issue = [&](int s_) {
+    const int t = t0 + s_ / npass, cb = (s_ % npass) * 64;
+    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int v = tid + 512 * k, pix = v >> 3;
+      const int hy = pix / HW_, hx = pix - hy * HW_;
+      const int gy = ty * TH + hy - 1, gx = tx * TW + hx - 1;
+      ok[k] = pix < HP && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      pv[k] = ld16(rx, ok[k] ? (unsigned)(((gy * p.W + gx) * p.ldx + cb + slot * 8) * 2) : OOB, 0);
+    }
+  };
+  const int nsteps = nt * npass;
+  if (nsteps > 0) issue(0);
+  f32x4 acc[2];
+  for (int s_ = 0; s_ < nsteps; ++s_) {
+    const int i = s_ / npass, ps = s_ - i * npass;
+    const int t = t0 + i;
+    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+    if (ps == 0) {
+      acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    {
+      const int cb = ps * 64;
+      const bool new_tab = s_ == 0 || npass > 1;  // weights / GroupNorm table of this pass (resident when Cin == 64)
+      uint4 wv[3];
+      if (new_tab) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {  // 9 x 16 rows x 8 vectors = 1152 vectors
+          const int v = tid + 512 * k, row = v >> 3, tap = row >> 4, co = row & 15;
+          const int ch = cb + slot * 8;
+          const unsigned vo = p.w_chunked ? (unsigned)(((((ch >> p.w_shift) * 9 + tap) * p.Cout + co) * p.w_chunked + (ch & (p.w_chunked - 1))) * 2)
+                                          : (unsigned)(((co * 9 + tap) * p.Cin + ch) * 2);
+          wv[k] = ld16(rw, (v < 9 * 16 * 8 && co < p.Cout) ? vo : OOB, 0);
+        }
+      }
+      __syncthreads();  // the previous step's fragment reads are done
+      if (new_tab) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int v = tid + 512 * k;
+          if (v < 9 * 16 * 8) *reinterpret_cast<uint4*>(sWt + (v >> 3) * TO_PROW + slot * 16) = wv[k];
+        }
+        if (tid < 64) {
+          const int c = cb + tid;
+          float sc = 1.f, sh = 0.f;
+          if (p.gn_acc) {
+            const int g0 = (int)(((float)c + 0.5f) / (float)p.gn_cpg) * p.gn_cpg;
+            long long ssum = 0, ssq = 0;
+            for (int j = 0; j < p.gn_cpg; ++j) {
+              ssum += p.gn_acc[((long)b * p.Cin + g0 + j) * 2];
+              ssq += p.gn_acc[((long)b * p.Cin + g0 + j) * 2 + 1];
+            }
+            const double mean = (double)ssum * (1.0 / DS_STAT_SUM_SCALE) * (double)p.gn_inv_count;
+            double var = (double)ssq * (1.0 / DS_STAT_SQ_SCALE) * (double)p.gn_inv_count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            sc = (float)(1.0 / sqrt(var + (double)p.gn_eps)) * (p.gn_gamma ? p.gn_gamma[c] : 1.f);
+            sh = (p.gn_beta ? p.gn_beta[c] : 0.f) - (float)mean * sc;
+          } else if (p.gn_scale) {
+            sc = p.gn_scale[(long)b * p.Cin + c];
+            sh = p.gn_shift[(long)b * p.Cin + c];
+          }
+          sTab[tid] = sc;
+          sTab[64 + tid] = sh;
+        }
+        __syncthreads();
+      }
+      float gsc[8], gsh[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { gsc[j] = sTab[slot * 8 + j]; gsh[j] = sTab[64 + slot * 8 + j]; }
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const int v = tid + 512 * k;
+        if (v < HP * 8) {
+          uint4 r = pv[k];
+          if (ok[k]) r = p.act ? gn8<true>(pv[k], gsc, gsh) : gn8<false>(pv[k], gsc, gsh);
+          *reinterpret_cast<uint4*>(sX + (v >> 3) * TO_PROW + slot * 16) = r;
+        }
+      }
+      __syncthreads();
+      if (s_ + 1 < nsteps) issue(s_ + 1);
+      // ---- wave = pixel row `wave` of the tile: two 16-pixel groups x 16 (8 real) couts
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const bf16x8 wf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sWt + tap * 16 * TO_PROW + foff + kb * 64));
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const bf16x8 xf = __builtin_bit_cast(
+                bf16x8, *reinterpret_cast<const uint4*>(sX + ((wave + tap / 3) * HW_ + 16 * g + tap % 3) * TO_PROW + foff + kb * 64));
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[g], 0, 0, 0);
+          }
+        }
+    }
+    if (ps != npass - 1) continue;
+    // ---- epilogue: lane (pixel 16 g + l16, couts 4 q .. 4 q + 3); couts >= 8 do not exist
+    if (q < 2) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int m = (ty * TH + wave) * p.W + tx * TW + 16 * g + l16;
+        const uint2 rv = ld8(rr, (unsigned)((m * p.ldr + 4 * q) * 2));
+        float v[4];
+        v[0] = acc[g][0] + bz[0] + __uint_as_float(rv.x << 16);
+        v[1] = acc[g][1] + bz[1] + __uint_as_float(rv.x & 0xffff0000u);
+        v[2] = acc[g][2] + bz[2] + __uint_as_float(rv.y << 16);
+        v[3] = acc[g][3] + bz[3] + __uint_as_float(rv.y & 0xffff0000u);
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2)
+          if (4 * q + i2 >= p.Cout) v[i2] = 0.f;
+        st8(ry, (unsigned)((m * p.ldy + 4 * q) * 2), make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])));
+      }
+    }
+  }
+}
+
 int ws_blocks_per_image(const ConvArgs& a) {
   static int cus = 0;
   if (!cus) {
@@ -725,6 +901,42 @@ int ds_launch_conv_thin(const ConvArgs& a, hipStream_t st) {
   if (k.G > tiles) k.G = tiles;
   k.tiles_x = a.W / TW; k.tiles_per_img = tiles;
   hipLaunchKernelGGL(conv3x3_thin_in_kernel, dim3(a.B * k.G), dim3(512), THIN_LDS, st, k);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
+
+// The output-pyramid heads: <= 8 couts, 64-channel multiples in, GroupNorm (+ SiLU) on the input, optional residual.
+bool ds_conv_thin_out_eligible(const ConvArgs& a) {
+  return a.dtype == DS_BF16 && a.taps == 9 && a.Cout <= 8 && a.Cin % 64 == 0 && a.Cin <= 512 && !a.x2 && !a.sx && a.w_bs == 0 &&
+         ((a.w_chunked & (a.w_chunked - 1)) == 0) && (a.w_chunked == 0 || a.w_chunked >= 8) && !a.bias_b && a.bias_mode == 0 &&
+         !a.div_b && a.out_scale == 1.f && !a.stats_acc && a.H % TH == 0 && a.W % TW == 0 && a.ldx % 8 == 0 && a.ldy >= 8 &&
+         a.ldy % 4 == 0 && (!a.res || (a.ldr >= 8 && a.ldr % 4 == 0)) &&
+         (!a.gn_acc1 || (a.gn_groups > 0 && a.Cin % a.gn_groups == 0));
+}
+
+int ds_launch_conv_thin_out(const ConvArgs& a, hipStream_t st) {
+  ThinOutK k;
+  k.x = reinterpret_cast<const bf16_t*>(a.x); k.x_bs = a.x_bs; k.ldx = a.ldx; k.Cin = a.Cin;
+  k.w = reinterpret_cast<const bf16_t*>(a.w); k.w_chunked = a.w_chunked; k.w_shift = a.w_chunked ? __builtin_ctz(a.w_chunked) : 0;
+  k.gn_scale = a.gn_scale; k.gn_shift = a.gn_shift;
+  k.gn_acc = a.gn_acc1; k.gn_gamma = a.gn_gamma; k.gn_beta = a.gn_beta;
+  k.gn_cpg = a.gn_acc1 ? a.Cin / a.gn_groups : 1; k.gn_inv_count = a.gn_inv_count; k.gn_eps = a.gn_eps;
+  k.act = a.gn_act;
+  k.bias = a.bias;
+  k.res = reinterpret_cast<const bf16_t*>(a.res); k.res_bs = a.res_bs; k.ldr = a.ldr;
+  k.y = reinterpret_cast<bf16_t*>(a.y); k.y_bs = a.y_bs; k.ldy = a.ldy;
+  k.Cout = a.Cout;
+  const int tiles = (a.H / TH) * (a.W / TW);
+  k.H = a.H; k.W = a.W; k.G = ws_blocks_per_image(a) * 2;  // two blocks per CU
+  if (k.G > tiles) k.G = tiles;
+  k.tiles_x = a.W / TW; k.tiles_per_img = tiles;
+  static bool attr_done = false;
+  if (!attr_done) {
+    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_thin_out_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               TO_LDS));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(conv3x3_thin_out_kernel, dim3(a.B * k.G), dim3(512), TO_LDS, st, k);
   DS_LAUNCH_CHECK();
   return 0;
 }

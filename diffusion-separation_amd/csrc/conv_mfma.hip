@@ -896,7 +896,7 @@ int ds_conv_chunk(int taps, int dtype) {
 // 3/4/5 = the same tiles for 1x1 / GEMM, 6 = the weight-stationary 64 -> 64 kernel (conv3x3_ws.hip), 7 = the
 // small-image kernel (conv3x3_small.hip).
 int ds_conv_config_id(const ConvArgs& a) {
-  if (ds_conv_ws_eligible(a) || ds_conv_thin_eligible(a)) return 6;
+  if (ds_conv_ws_eligible(a) || ds_conv_thin_eligible(a) || ds_conv_thin_out_eligible(a)) return 6;
   if (ds_conv_small_eligible(a)) return 7;
   if (a.taps == 9) {
     if (a.W >= 32 && a.H >= 8) return a.Cout <= 32 ? 1 : 0;
@@ -924,6 +924,7 @@ int ds_launch_conv(const ConvArgs& a, hipStream_t st) {
   }
   if (ds_conv_ws_eligible(a)) return ds_launch_conv_ws(a, st);
   if (ds_conv_thin_eligible(a)) return ds_launch_conv_thin(a, st);
+  if (ds_conv_thin_out_eligible(a)) return ds_launch_conv_thin_out(a, st);
   if (ds_conv_small_eligible(a)) return ds_launch_conv_small(a, st);
   if (a.dtype == DS_F32) return a.split ? launch_typed<float, 1>(a, st) : launch_typed<float, 0>(a, st);
   if (a.dtype == DS_BF16) return launch_typed<bf16_t>(a, st);

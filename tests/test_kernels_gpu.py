@@ -508,3 +508,44 @@ def test_first_layer_conv3x3_8_to_64(B, H, W, cin):
     s = ops.stats_to_float(st).cpu()
     assert torch.allclose(s[..., 0], ref.double().sum((1, 2)), rtol=2e-3, atol=2e-3 * H * W)
     assert torch.allclose(s[..., 1], (ref.double() ** 2).sum((1, 2)), rtol=2e-3, atol=2e-3 * H * W)
+
+
+@pytest.mark.parametrize("Cin,Cout,B,H,W", [(64, 6, 2, 16, 32), (64, 6, 16, 64, 64), (128, 6, 3, 8, 64), (256, 4, 2, 8, 32),
+                                           (64, 8, 2, 24, 96)])
+@pytest.mark.parametrize("act,lazy,with_res", [(1, True, True), (1, False, False), (0, False, True)])
+def test_pyramid_head_conv3x3_to_8_channels(Cin, Cout, B, H, W, act, lazy, with_res):
+    # the output-pyramid heads (<= 8 couts) on their own kernel in bf16 (conv3x3_thin_out_kernel): GroupNorm (+ SiLU) from
+    # tables or from the producer's accumulators, one or several 64-channel passes, residual, zero channel padding
+    dt = torch.bfloat16
+    tag = f"{Cin}.{Cout}.{H}.{W}"
+    x = (rnd("ph.x" + tag, (B, H, W, Cin), 1.2) + 0.1).to(DEV).to(dt)
+    w = rnd("ph.w" + tag, (Cout, Cin, 3, 3), (9 * Cin) ** -0.5)
+    bias = rnd("ph.b" + tag, (Cout,), 0.1).to(DEV)
+    res = torch.zeros(B, H, W, 8)
+    res[..., :Cout] = rnd("ph.r" + tag, (B, H, W, Cout))
+    res = res.to(DEV).to(dt)
+    groups = min(Cin // 4, 32)
+    g, be = (1.0 + rnd(f"ph.g{Cin}", (Cin,), 0.2)).to(DEV), rnd(f"ph.be{Cin}", (Cin,), 0.1).to(DEV)
+    xf = x.float().cpu()
+    if lazy:
+        xd = x.double()
+        acc = torch.stack([(xd.sum((1, 2)) * ops.STAT_SUM_SCALE).round(), ((xd * xd).sum((1, 2)) * ops.STAT_SQ_SCALE).round()],
+                          -1).to(torch.int64).contiguous()
+        kw = dict(gn_acc=(acc, None, g, be, groups), gn_act=act)
+        hn = F.group_norm(xf.permute(0, 3, 1, 2), groups, g.cpu(), be.cpu(), eps=1e-6).permute(0, 2, 3, 1)
+    else:
+        sc, sh = (1.0 + rnd(f"ph.sc{Cin}", (B, Cin), 0.2)).to(DEV), rnd(f"ph.sh{Cin}", (B, Cin), 0.2).to(DEV)
+        kw = dict(gn=(sc, sh), gn_act=act)
+        hn = xf * sc.cpu()[:, None, None, :] + sh.cpu()[:, None, None, :]
+    if act:
+        hn = F.silu(hn)
+    hn = hn.to(dt).float()
+    ref = F.conv2d(hn.permute(0, 3, 1, 2), w.to(dt).float(), bias.cpu(), padding=1).permute(0, 2, 3, 1)
+    if with_res:
+        ref = ref + res.float().cpu()[..., :Cout]
+    for chunk in (0, 32):
+        y = ops.conv2d_fused(x, ops.pack_conv_weight(w, dt, chunk=chunk).to(DEV), bias, Cout, 3, res=res if with_res else None,
+                             cout_pad=8, w_chunk=chunk, **kw)
+        assert rel_rms(y.float().cpu()[..., :Cout], ref) < 4e-3
+        if Cout < 8:
+            assert not bool(y[..., Cout:].any())
