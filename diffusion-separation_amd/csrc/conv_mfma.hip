@@ -863,7 +863,13 @@ static int launch_typed(const ConvArgs& a, hipStream_t st) {
   constexpr int KC9 = (sizeof(T) == 4) ? 16 : 32;
   constexpr int KC1 = (sizeof(T) == 4) ? 32 : 64;
   switch (ds_conv_config_id(a)) {
-    case 0: return launch_cfg<T, 9, 8, 32, 64, 2, 2, KC9, 1, 2, SP>(a, st);
+    case 0: {
+      // few tiles (the 32^2 level: 128 blocks of 8 x 32 pixels on 256 CUs): half-width tiles fill the chip
+      // (one batch alone 325.6 -> 320.6 ms, four in flight unchanged)
+      const long blocks = (long)cdiv(a.W, 32) * cdiv(a.H, 8) * cdiv(a.Cout, 64) * a.B;
+      if (sizeof(T) == 2 && blocks <= 128) return launch_cfg<T, 9, 8, 16, 64, 1, 2, KC9, 1, 2, SP>(a, st);
+      return launch_cfg<T, 9, 8, 32, 64, 2, 2, KC9, 1, 2, SP>(a, st);
+    }
     case 1: return launch_cfg<T, 9, 8, 32, 32, 2, 1, KC9, 1, 2, SP>(a, st);
     case 2: {  // small images: a chain of dependent chunk round trips (1.7 us each) -> chunks twice as deep (+1 %)
       const bool deep = a.Cin % (2 * KC9) == 0 && (!a.x2 || a.C1 % (2 * KC9) == 0) &&
