@@ -200,7 +200,9 @@ int ds_launch_stft_pack(const float* xt, const float* mix, void* y, int B, int S
                         float exponent, float factor, int W, int Cpad, int shift, int dtype, const float* tab,
                         float* ws, hipStream_t st, int split = 0);  // split: the DFT GEMM in split mode (ConvArgs.split)
 int ds_launch_istft(const void* x, float* out, int B, int S, long T, int n_fft, int hop, float exponent, float factor,
-                    int W, int Cpad, int dtype, const float* tab, float* ws, hipStream_t st, int split = 0);
+                    int W, int Cpad, int dtype, const float* tab, float* ws, hipStream_t st, int split = 0,
+                    const float* ow = nullptr, const float* ob = nullptr, const float* tdiv = nullptr, int ow_cin = 0);
+// (ow [2S][ow_cin], ob [2S], tdiv [B]: the network's output layer fused into the unpack pass; x is then the last pyramid)
 // tab: device floats: cos | sin | hann (n_fft each), then the [512][512] forward and inverse(+window) DFT matrices
 int ds_build_stft_table(int n_fft, float** dev_tab);
 

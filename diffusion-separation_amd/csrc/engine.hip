@@ -623,7 +623,10 @@ static int attn_block(diffsep_engine* e, const Module& m, const Tn& x, int B, Tn
 }
 
 // NCSNpp.forward  ncsnpp.py:319-478.  x0: packed input AFTER 2x-1, [B,H,W,cpad_in]; y: [B,H,W,cpad_out]
-static int net_forward(diffsep_engine* e, const Tn& x0, const float* t, const Tn& y, int B, hipStream_t st) {
+// pyr_out != null: stop before the output layer and hand back the last pyramid tensor (the caller's iSTFT applies
+// `output_layer(pyramid / t)` while unpacking)
+static int net_forward(diffsep_engine* e, const Tn& x0, const float* t, const Tn& y, int B, hipStream_t st,
+                       Tn* pyr_out = nullptr) {
   const Arch& A = e->arch;
   const diffsep_model_config& c = e->cfg;
   const int nf = c.nf;
@@ -730,6 +733,7 @@ static int net_forward(diffsep_engine* e, const Tn& x0, const float* t, const Tn
   }
   DS_CHECK(hs.empty() && mi == A.mods.size(), "internal: module walk did not consume all modules");
   // h = pyramid / t ; out = output_layer(h)   (ncsnpp.py:472-477)
+  if (pyr_out) { *pyr_out = pyramid; return 0; }
   Tn yy = y;
   return conv(e, pyramid, PK(e, A.pk_out), P(e, A.out_b), nullptr, 0, nullptr, 1.f, yy, A.chan_out, 1, B, t, st);
 }
@@ -752,10 +756,11 @@ static int score_forward_impl(diffsep_engine* e, const float* xt, const float* t
     if (ds_launch_stft_pack(xt, mix, x0.p, B, S, T, c.n_fft, c.hop, c.spec_abs_exponent, c.spec_factor, W,
                             e->arch.cpad_in, 1, c.dtype, e->d_tab, ws_f, st, dft_split))
       return 1;
-  if (net_forward(e, x0, t, y, B, st)) return 1;
+  Tn pyr;
+  if (net_forward(e, x0, t, y, B, st, &pyr)) return 1;
   if (!e->dry)
-    if (ds_launch_istft(y.p, out, B, S, T, c.n_fft, c.hop, c.spec_abs_exponent, c.spec_factor, W, e->arch.cpad_out,
-                        c.dtype, e->d_tab, frames, st, dft_split))
+    if (ds_launch_istft(pyr.p, out, B, S, T, c.n_fft, c.hop, c.spec_abs_exponent, c.spec_factor, W, pyr.ld, c.dtype,
+                        e->d_tab, frames, st, dft_split, P(e, e->arch.out_w), P(e, e->arch.out_b), t, e->arch.chan_in))
       return 1;
   return 0;
 }

@@ -173,10 +173,15 @@ int ds_launch_stft_pack(const float* xt, const float* mix, void* y, int B, int S
 // rows = (b, s, f): U[row][j] = Re z_j, U[row][256 + j] = Im z_j with z = decompress(channels / |factor|):
 // |z|^(1/e) e^{j angle} == z * |z|^(1/e - 1)                         score_models.py:59-64, 78-81
 #define DS_FRAME_PITCH 512
+// ow != null: x is the network's last pyramid tensor and the output layer — NCSNpp's `h = pyramid / t; output_layer(h)`,
+// a 1x1 convolution on <= 8 channels (ncsnpp.py:472-477) — is applied on the fly: v[c] = (sum_k ow[c][k] x[k]) / t[b] + ob[c]
+// (no separate launch, no packed output tensor in HBM)
 template <typename T>
 __global__ __launch_bounds__(256) void istft_unpack_kernel(const T* __restrict__ x, float* __restrict__ U, int S,
                                                            int bins, int F, int W, int Cpad, float expo, float factor,
-                                                           long total) {
+                                                           long total, const float* __restrict__ ow,
+                                                           const float* __restrict__ ob, const float* __restrict__ tdiv,
+                                                           int ow_cin) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;  // (b, f, j), j fastest: coalesced writes of U rows
   if (i >= total) return;
   const int j = (int)(i & 255);
@@ -185,6 +190,23 @@ __global__ __launch_bounds__(256) void istft_unpack_kernel(const T* __restrict__
   const float inv_fac = 1.0f / fabsf(factor);
   float v[8];
   if (j < bins) load8<T>(x + ((b * bins + j) * W + f) * Cpad, v);
+  if (ow && j < bins) {
+    float h[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) h[k] = v[k];
+    const float td = tdiv[b];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float a = 0.f;
+      if (c < 2 * S) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k < ow_cin) a = fmaf(ow[c * ow_cin + k], h[k], a);
+        a = a / td + ob[c];
+      }
+      v[c] = a;
+    }
+  }
 #pragma unroll
   for (int s = 0; s < DS_MAXC - 1; ++s) {
     if (s < S) {
@@ -236,8 +258,10 @@ long ds_istft_workspace_bytes(int B, int S, long T, int n_fft, int hop) {
 }
 
 int ds_launch_istft(const void* x, float* out, int B, int S, long T, int n_fft, int hop, float exponent, float factor,
-                    int W, int Cpad, int dtype, const float* tab, float* ws, hipStream_t st, int split) {
+                    int W, int Cpad, int dtype, const float* tab, float* ws, hipStream_t st, int split, const float* ow,
+                    const float* ob, const float* tdiv, int ow_cin) {
   DS_CHECK(n_fft % 2 == 0 && n_fft <= 510, "istft: n_fft must be even and <= 510");
+  DS_CHECK(!ow || (ob && tdiv && ow_cin >= 1 && ow_cin <= 8), "istft: bad fused output layer");
   DS_CHECK(S >= 1 && S <= DS_MAXC - 1 && Cpad >= 2 * S && Cpad % 8 == 0 && 2 * S <= 8, "istft: bad source / channel count");
   const int F = 1 + (int)((T + n_fft - hop) / hop);
   DS_CHECK(W >= F, "istft: padded width smaller than the frame count");
@@ -248,10 +272,10 @@ int ds_launch_istft(const void* x, float* out, int B, int S, long T, int n_fft, 
   const long total = (long)B * F * 256;
   if (dtype == DS_F32)
     hipLaunchKernelGGL(istft_unpack_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)x, U, S, bins,
-                       F, W, Cpad, exponent, factor, total);
+                       F, W, Cpad, exponent, factor, total, ow, ob, tdiv, ow_cin);
   else
     hipLaunchKernelGGL(istft_unpack_kernel<bf16_t>, dim3(cdiv(total, 256)), dim3(256), 0, st, (const bf16_t*)x, U, S,
-                       bins, F, W, Cpad, exponent, factor, total);
+                       bins, F, W, Cpad, exponent, factor, total, ow, ob, tdiv, ow_cin);
   DS_LAUNCH_CHECK();
   // frames[row][n] = sum_K U[row][K] * dft_inv[n][K]   (NT GEMM, fp32 MFMA; window and 1/n_fft folded in)
   ConvArgs a;
