@@ -482,7 +482,7 @@ static int gn_apply_typed(const void* x, int ldx, const float* scale, const floa
   const long tot2 = (mode == 1 ? (long)B * H * W : (long)B * (H / 4) * (W / 4)) * (C >> 3);
   // 2 x 2 output blocks per thread: fewer SiLU evaluations and loads per output, but a thread of the down mode walks
   // 36 input vectors — on the small levels (a few blocks' worth of threads) that is a 20 us latency chain, and the
-  // one-output-per-thread kernel with 4x the threads takes 6 - 11 us
+  // one-output-per-thread kernel with 4x the threads takes 6 - 11 us (at 131072 block-threads: 26 vs 30 us, the blocks win)
   // large levels, FIR up: one activation per input element (LDS-staged tiles of 8 channel groups)
   if (aff && mode == 1 && C % 64 == 0 && tot2 >= 262144) {
     const int th = cdiv(H, 4), tw = cdiv(W, 8);
@@ -498,7 +498,7 @@ static int gn_apply_typed(const void* x, int ldx, const float* scale, const floa
     DS_LAUNCH_CHECK();
     return 0;
   }
-  if (aff && (mode == 1 || (mode == 2 && H % 4 == 0 && W % 4 == 0 && tot2 >= 262144))) {
+  if (aff && (mode == 1 || (mode == 2 && H % 4 == 0 && W % 4 == 0 && tot2 >= 131072))) {
     long nb2 = (tot2 + 255) / 256;
     if (nb2 > 16384) nb2 = 16384;
     if (nb2 < 1) nb2 = 1;
