@@ -25,6 +25,10 @@
 // launch, of which ~5 us is the floor of any kernel node; one batch alone 371 -> 350 ms, four in flight unchanged.
 // tools/small_timing.sh (-DSM_TIMING) prints the per-phase cycles of a block.
 //
+// ESZ = 4 instantiates the same kernel for fp32 tensors in split mode (DIFFSEP_F32_SPLIT): 64-channel phases (the bytes of
+// 128 bf16 channels), values split into hi / lo bf16 planes on the way to LDS, three MFMAs per k-block, fp32 epilogue
+// (the split engine's <= 16-row levels: 31 -> ~14 us per launch, one batch alone 759 -> 702 ms).
+//
 // Same ConvArgs contract as ds_launch_conv (common.h); ds_conv_small_eligible says which launches come here.
 #include <stdlib.h>
 
@@ -76,21 +80,21 @@ __device__ inline void st8(__amdgpu_buffer_rsrc_t r, unsigned voff, uint2 d) {
 constexpr int GN_MAX = 512;         // channels of the lazy GroupNorm table
 
 struct SmK {
-  const bf16_t* x; long x_bs; int ldx;
-  const bf16_t* x2; long x2_bs; int ldx2;
+  const void* x; long x_bs; int ldx;
+  const void* x2; long x2_bs; int ldx2;
   int C1, Cin;
-  const bf16_t* w; int w_chunked, w_shift;
-  const bf16_t* sx; long sx_bs; int ldsx;
-  const bf16_t* sx2; long sx2_bs; int ldsx2;
+  const void* w; int w_chunked, w_shift;
+  const void* sx; long sx_bs; int ldsx;
+  const void* sx2; long sx2_bs; int ldsx2;
   int sC1, sCin;
-  const bf16_t* sw; int sw_chunked, sw_shift;
+  const void* sw; int sw_chunked, sw_shift;
   const float* gn_scale; const float* gn_shift;
   const long long* gn_acc1; const long long* gn_acc2; const float* gn_gamma; const float* gn_beta;
   int gn_cpg; float gn_inv_count; float gn_eps;
   const float* bias; const float* bias_b; int bias_b_ld;
-  const bf16_t* res; long res_bs; int ldr;
+  const void* res; long res_bs; int ldr;
   float out_scale;
-  bf16_t* y; long y_bs; int ldy;
+  void* y; long y_bs; int ldy;
   long long* stats;
   int H, W, Cout, tiles_x;
 };
@@ -129,6 +133,25 @@ __device__ inline uint4 gn8(const uint4& u, const float* sc, const float* sh) {
   return o;
 }
 
+// fp32 storage (DIFFSEP_F32_SPLIT): GN affine (+ SiLU) on 4 fp32 channels, and the hi / lo bf16 split of conv_mfma.hip
+template <bool ACT>
+__device__ inline uint4 gn4(const uint4& u, const float* sc, const float* sh) {
+  float f[4] = {__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float v = f[j] * sc[j] + sh[j];
+    f[j] = ACT ? silu_t<float>(v) : v;
+  }
+  return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+__device__ inline void split4(const uint4& v, uint2& hi, uint2& lo) {
+  const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
+  hi.x = pack_bf16x2(f0, f1);
+  hi.y = pack_bf16x2(f2, f3);
+  lo.x = pack_bf16x2(f0 - __uint_as_float(hi.x << 16), f1 - __uint_as_float(hi.x & 0xffff0000u));
+  lo.y = pack_bf16x2(f2 - __uint_as_float(hi.y << 16), f3 - __uint_as_float(hi.y & 0xffff0000u));
+}
+
 // tile shapes by image width: 16 columns x 8 rows on 8 waves, 8 x 8 on 8 waves (4 of them multiply: 512 threads keep the two
 // staging register sets small), 4 x 4 (one MFMA group) on 4 waves
 template <int GW> struct SmTile;
@@ -136,13 +159,16 @@ template <> struct SmTile<16> { static constexpr int THT = 8, NT = 512; };
 template <> struct SmTile<8> { static constexpr int THT = 8, NT = 512; };
 template <> struct SmTile<4> { static constexpr int THT = 4, NT = 256; };
 
-template <int GW, int PC, int NS>
+// ESZ: storage bytes per element: 2 = bf16, 4 = fp32 with split (bf16x3) products — an LDS row is then two bf16 planes
+// [PC hi][PC lo]
+template <int GW, int PC, int NS, int ESZ>
 struct SmGeom {
   static constexpr int THT = SmTile<GW>::THT, NT = SmTile<GW>::NT;
   static constexpr int HWS = GW + 2, HP = (THT + 2) * HWS;  // halo columns / pixels
-  static constexpr int NVEC = PC / 8;                        // 16-byte vectors per pixel / weight row
+  static constexpr int KVE = 16 / ESZ;                       // elements per 16-byte vector
+  static constexpr int NVEC = PC / KVE;                      // 16-byte vectors per pixel / weight row
   static constexpr int RPS = NT / NVEC;                      // rows staged by one pass of the block
-  static constexpr int PSTR = PC * 2 + 16;                   // LDS pitch of a halo pixel / of a (tap, cout) weight row
+  static constexpr int PSTR = PC * ESZ + 16;                 // LDS pitch of a halo pixel / of a (tap, cout) weight row
   static constexpr int NA = (HP + RPS - 1) / RPS;            // input vectors per thread and phase
   static constexpr int NWV = (9 * NS + RPS - 1) / RPS;       // weight vectors per thread and phase
   static constexpr int NGRP = THT * GW / 16;                 // 16-pixel groups of the tile (one per wave)
@@ -155,9 +181,11 @@ struct SmGeom {
 
 // GW: tile columns (16, 8, 4).  PC: channels per phase (64, 128).  NS: couts per block (16, 32).
 // MODE: 0 raw input, 1 GroupNorm affine, 2 affine + SiLU.
-template <int GW, int PC, int NS, int MODE>
+template <int GW, int PC, int NS, int MODE, int ESZ = 2>
 __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p) {
-  using G = SmGeom<GW, PC, NS>;
+  using G = SmGeom<GW, PC, NS, ESZ>;
+  constexpr int KVE = G::KVE;
+  constexpr bool SPLIT = ESZ == 4;
   constexpr int NSK = G::NSK, NH = NS / 16;
   constexpr int THT = G::THT, NT = G::NT, NWAVES = NT / 64;
   constexpr int HWS = G::HWS, HP = G::HP, NVEC = G::NVEC, RPS = G::RPS, PSTR = G::PSTR, NA = G::NA, NWV = G::NWV,
@@ -189,15 +217,15 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
     pixi[k] = ok ? gy * p.W + gx : -1;
     inner[k] = ok && hy >= 1 && hy <= THT && hx >= 1 && hx <= GW;
   }
-  const int lds0 = row0 * PSTR + cv * 16;  // + RPS k PSTR
+  const int lds0 = row0 * PSTR + cv * (SPLIT ? 8 : 16);  // + RPS k PSTR (split: 8 bytes in each of the two planes)
 
   const int C1 = p.x2 ? p.C1 : p.Cin, C2 = p.Cin - C1;
   const int sC1 = p.sx2 ? p.sC1 : p.sCin, sC2 = p.sCin - sC1;
   const int nph1 = C1 / PC, nphc = nph1 + C2 / PC;                                    // conv phases
   const int nphs1 = p.sx ? sC1 / PC : 0, nph = nphc + nphs1 + (p.sx ? sC2 / PC : 0);  // + folded skip phases
 
-  const __amdgpu_buffer_rsrc_t rw = rsrc(p.w, (unsigned)p.Cout * 9u * p.Cin * 2u);
-  const __amdgpu_buffer_rsrc_t rsw = rsrc(p.sw ? p.sw : p.w, p.sw ? (unsigned)p.Cout * p.sCin * 2u : 0u);
+  const __amdgpu_buffer_rsrc_t rw = rsrc(p.w, (unsigned)p.Cout * 9u * p.Cin * (unsigned)ESZ);
+  const __amdgpu_buffer_rsrc_t rsw = rsrc(p.sw ? p.sw : p.w, p.sw ? (unsigned)p.Cout * p.sCin * (unsigned)ESZ : 0u);
 
   struct Stage {
     uint4 pa[NA], pw[NWV];
@@ -211,19 +239,19 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
       const int s = ph - nphc;
       const bool second = s >= nphs1;
       const int cb = (second ? s - nphs1 : s) * PC;
-      const int wb = (second ? sC1 : 0) + cb + cv * 8;  // channel in the skip weights
-      const bf16_t* base = second ? p.sx2 + (long)b * p.sx2_bs : p.sx + (long)b * p.sx_bs;
+      const int wb = (second ? sC1 : 0) + cb + cv * KVE;  // channel in the skip weights
+      const char* base = second ? (const char*)p.sx2 + (long)b * p.sx2_bs * ESZ : (const char*)p.sx + (long)b * p.sx_bs * ESZ;
       const int ld = second ? p.ldsx2 : p.ldsx;
-      const __amdgpu_buffer_rsrc_t rs = rsrc(base, (unsigned)M * ld * 2u);
+      const __amdgpu_buffer_rsrc_t rs = rsrc(base, (unsigned)M * ld * (unsigned)ESZ);
 #pragma unroll
       for (int k = 0; k < NA; ++k)
-        S.pa[k] = ld16(rs, inner[k] ? (unsigned)((__umul24(pixi[k], ld) + cb + cv * 8) * 2) : OOB, 0);
+        S.pa[k] = ld16(rs, inner[k] ? (unsigned)((__umul24(pixi[k], ld) + cb + cv * KVE) * ESZ) : OOB, 0);
 #pragma unroll
       for (int k = 0; k < NSK; ++k) {
         const int co = row0 + RPS * k;
         const unsigned vo = p.sw_chunked
-                                ? (unsigned)((((wb >> p.sw_shift) * p.Cout + co0 + co) * p.sw_chunked + (wb & (p.sw_chunked - 1))) * 2)
-                                : (unsigned)(((co0 + co) * p.sCin + wb) * 2);
+                                ? (unsigned)((((wb >> p.sw_shift) * p.Cout + co0 + co) * p.sw_chunked + (wb & (p.sw_chunked - 1))) * ESZ)
+                                : (unsigned)(((co0 + co) * p.sCin + wb) * ESZ);
         S.pw[k] = ld16(rsw, co < NS ? vo : OOB, 0);
       }
       S.raw = true;
@@ -231,19 +259,19 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
     }
     const bool second = ph >= nph1;
     const int cb = (second ? ph - nph1 : ph) * PC;
-    const int wb = (second ? C1 : 0) + cb + cv * 8;  // channel in the weights / GroupNorm tables
-    const bf16_t* base = second ? p.x2 + (long)b * p.x2_bs : p.x + (long)b * p.x_bs;
+    const int wb = (second ? C1 : 0) + cb + cv * KVE;  // channel in the weights / GroupNorm tables
+    const char* base = second ? (const char*)p.x2 + (long)b * p.x2_bs * ESZ : (const char*)p.x + (long)b * p.x_bs * ESZ;
     const int ld = second ? p.ldx2 : p.ldx;
-    const __amdgpu_buffer_rsrc_t rx = rsrc(base, (unsigned)M * ld * 2u);
+    const __amdgpu_buffer_rsrc_t rx = rsrc(base, (unsigned)M * ld * (unsigned)ESZ);
 #pragma unroll
     for (int k = 0; k < NA; ++k)
-      S.pa[k] = ld16(rx, pixi[k] >= 0 ? (unsigned)((__umul24(pixi[k], ld) + cb + cv * 8) * 2) : OOB, 0);
+      S.pa[k] = ld16(rx, pixi[k] >= 0 ? (unsigned)((__umul24(pixi[k], ld) + cb + cv * KVE) * ESZ) : OOB, 0);
     // weight row (tap, cout) = row0 + RPS k: RPS is a multiple of NS, so the cout stays and the tap advances by RPS / NS
     const int tap0 = row0 / NS, co = row0 % NS;
     const unsigned vo0 =
-        p.w_chunked ? (unsigned)(((((wb >> p.w_shift) * 9 + tap0) * p.Cout + co0 + co) * p.w_chunked + (wb & (p.w_chunked - 1))) * 2)
-                    : (unsigned)((((co0 + co) * 9 + tap0) * p.Cin + wb) * 2);
-    const unsigned vstep = (unsigned)((RPS / NS) * (p.w_chunked ? p.Cout * p.w_chunked : p.Cin) * 2);
+        p.w_chunked ? (unsigned)(((((wb >> p.w_shift) * 9 + tap0) * p.Cout + co0 + co) * p.w_chunked + (wb & (p.w_chunked - 1))) * ESZ)
+                    : (unsigned)((((co0 + co) * 9 + tap0) * p.Cin + wb) * ESZ);
+    const unsigned vstep = (unsigned)((RPS / NS) * (p.w_chunked ? p.Cout * p.w_chunked : p.Cin) * ESZ);
 #pragma unroll
     for (int k = 0; k < NWV; ++k) S.pw[k] = ld16(rw, row0 + RPS * k < 9 * NS ? vo0 + k * vstep : OOB, 0);
     S.raw = false;
@@ -252,20 +280,21 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
   auto fetch_gn = [&](int ph, Stage& S) __attribute__((always_inline)) {
     if (MODE == 0 || ph >= nphc) return;
     const bool second = ph >= nph1;
-    const int wb = (second ? C1 + (ph - nph1) * PC : ph * PC) + cv * 8;
-    const float4* ps = p.gn_acc1 ? reinterpret_cast<const float4*>(sGN + wb)
-                                 : reinterpret_cast<const float4*>(p.gn_scale + (long)b * p.Cin + wb);
-    const float4* ph_ = p.gn_acc1 ? reinterpret_cast<const float4*>(sGN + p.Cin + wb)
-                                  : reinterpret_cast<const float4*>(p.gn_shift + (long)b * p.Cin + wb);
-    const float4 a0 = ps[0], a1 = ps[1], h0 = ph_[0], h1 = ph_[1];
-    S.gsc[0] = a0.x; S.gsc[1] = a0.y; S.gsc[2] = a0.z; S.gsc[3] = a0.w; S.gsc[4] = a1.x; S.gsc[5] = a1.y; S.gsc[6] = a1.z; S.gsc[7] = a1.w;
-    S.gsh[0] = h0.x; S.gsh[1] = h0.y; S.gsh[2] = h0.z; S.gsh[3] = h0.w; S.gsh[4] = h1.x; S.gsh[5] = h1.y; S.gsh[6] = h1.z; S.gsh[7] = h1.w;
+    const int wb = (second ? C1 + (ph - nph1) * PC : ph * PC) + cv * KVE;
+    const float* ps = p.gn_acc1 ? sGN + wb : p.gn_scale + (long)b * p.Cin + wb;
+    const float* ph_ = p.gn_acc1 ? sGN + p.Cin + wb : p.gn_shift + (long)b * p.Cin + wb;
+#pragma unroll
+    for (int j = 0; j < KVE; j += 4) {
+      const float4 a0 = *reinterpret_cast<const float4*>(ps + j), h0 = *reinterpret_cast<const float4*>(ph_ + j);
+      S.gsc[j] = a0.x; S.gsc[j + 1] = a0.y; S.gsc[j + 2] = a0.z; S.gsc[j + 3] = a0.w;
+      S.gsh[j] = h0.x; S.gsh[j + 1] = h0.y; S.gsh[j + 2] = h0.z; S.gsh[j + 3] = h0.w;
+    }
   };
   auto activate = [&](Stage& S) __attribute__((always_inline)) {  // zero padding keeps its loaded zeros
     if (MODE == 0 || S.raw) return;
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
-      const uint4 r = gn8<MODE == 2>(S.pa[k], S.gsc, S.gsh);
+      const uint4 r = SPLIT ? gn4<MODE == 2>(S.pa[k], S.gsc, S.gsh) : gn8<MODE == 2>(S.pa[k], S.gsc, S.gsh);
       const bool ok = pixi[k] >= 0;
       S.pa[k].x = ok ? r.x : S.pa[k].x;
       S.pa[k].y = ok ? r.y : S.pa[k].y;
@@ -273,19 +302,29 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
       S.pa[k].w = ok ? r.w : S.pa[k].w;
     }
   };
+  auto put = [&](char* dst, const uint4& v) __attribute__((always_inline)) {
+    if constexpr (SPLIT) {  // row = [PC bf16 hi][PC bf16 lo]: this thread's 4 channels, 8 bytes in each plane
+      uint2 hi, lo;
+      split4(v, hi, lo);
+      *reinterpret_cast<uint2*>(dst) = hi;
+      *reinterpret_cast<uint2*>(dst + PC * 2) = lo;
+    } else {
+      *reinterpret_cast<uint4*>(dst) = v;
+    }
+  };
   auto write = [&](Stage& S) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < NA; ++k)
-      if (row0 + RPS * k < HP) *reinterpret_cast<uint4*>(sIn + lds0 + RPS * k * PSTR) = S.pa[k];
+      if (row0 + RPS * k < HP) put(sIn + lds0 + RPS * k * PSTR, S.pa[k]);
     if (S.raw) {
 #pragma unroll
       for (int k = 0; k < NSK; ++k)
-        if (row0 + RPS * k < NS) *reinterpret_cast<uint4*>(sW + (4 * NS) * PSTR + lds0 + RPS * k * PSTR) = S.pw[k];
+        if (row0 + RPS * k < NS) put(sW + (4 * NS) * PSTR + lds0 + RPS * k * PSTR, S.pw[k]);
       return;
     }
 #pragma unroll
     for (int k = 0; k < NWV; ++k)
-      if (row0 + RPS * k < 9 * NS) *reinterpret_cast<uint4*>(sW + lds0 + RPS * k * PSTR) = S.pw[k];
+      if (row0 + RPS * k < 9 * NS) put(sW + lds0 + RPS * k * PSTR, S.pw[k]);
   };
 
   // this lane's pixel of the tile: 16 w + l16 in raster order, couts co0 + 4 q .. + 3
@@ -300,23 +339,39 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
   auto mma = [&](bool raw) __attribute__((always_inline)) {
     if (!mma_wave) return;
     constexpr int KB = PC / 32;
-    uint4 xf[2][KB], wf[2][NH][KB];
+    constexpr int NP = SPLIT ? 2 : 1;  // bf16 planes of an LDS row (split: hi, lo)
+    uint4 xf[2][NP][KB], wf[2][NP][NH][KB];
     auto frag = [&](int tap, int set) __attribute__((always_inline)) {
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        xf[set][kb] = *reinterpret_cast<const uint4*>(sIn + ((tap / 3) * HWS + tap % 3) * PSTR + aoff + kb * 64);
+      for (int pl_ = 0; pl_ < NP; ++pl_)
 #pragma unroll
-        for (int h = 0; h < NH; ++h)
-          wf[set][h][kb] = *reinterpret_cast<const uint4*>(sW + (tap * NS + 16 * h) * PSTR + woff + kb * 64);
-      }
+        for (int kb = 0; kb < KB; ++kb) {
+          xf[set][pl_][kb] =
+              *reinterpret_cast<const uint4*>(sIn + ((tap / 3) * HWS + tap % 3) * PSTR + aoff + pl_ * PC * 2 + kb * 64);
+#pragma unroll
+          for (int h = 0; h < NH; ++h)
+            wf[set][pl_][h][kb] = *reinterpret_cast<const uint4*>(sW + (tap * NS + 16 * h) * PSTR + woff + pl_ * PC * 2 + kb * 64);
+        }
     };
     auto fma_tap = [&](int set) __attribute__((always_inline)) {
+      if constexpr (SPLIT) {  // lo * hi, hi * lo, hi * hi (small terms first), term-major over the accumulators
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
+        for (int term = 0; term < 3; ++term)
 #pragma unroll
-        for (int h = 0; h < NH; ++h)
-          acc[h][kb & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[set][h][kb]),
-                                                                   __builtin_bit_cast(bf16x8, xf[set][kb]), acc[h][kb & 1], 0, 0, 0);
+          for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+              acc[h][kb & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8, wf[set][term == 0 ? 1 : 0][h][kb]),
+                  __builtin_bit_cast(bf16x8, xf[set][term == 1 ? 1 : 0][kb]), acc[h][kb & 1], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int h = 0; h < NH; ++h)
+            acc[h][kb & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[set][0][h][kb]),
+                                                                     __builtin_bit_cast(bf16x8, xf[set][0][kb]), acc[h][kb & 1], 0, 0, 0);
+      }
     };
     if (raw) {  // folded 1x1 convolution: the centre tap only
       frag(4, 0);
@@ -381,13 +436,22 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
   ST_MARK(2)
 
   // residual of this lane's output quad: in flight during the K loop
-  const __amdgpu_buffer_rsrc_t rr = rsrc(p.res ? p.res + (long)b * p.res_bs : p.y, p.res ? (unsigned)M * p.ldr * 2u : 0u);
-  const __amdgpu_buffer_rsrc_t ry = rsrc(p.y + (long)b * p.y_bs, (unsigned)M * p.ldy * 2u);
+  const __amdgpu_buffer_rsrc_t rr = rsrc(p.res ? (const char*)p.res + (long)b * p.res_bs * ESZ : (const char*)p.y,
+                                         p.res ? (unsigned)M * p.ldr * (unsigned)ESZ : 0u);
+  const __amdgpu_buffer_rsrc_t ry = rsrc((char*)p.y + (long)b * p.y_bs * ESZ, (unsigned)M * p.ldy * (unsigned)ESZ);
   const int gy = y0 + ty, gx = x0 + tx;
   const int mo = (mma_wave && gy < p.H && gx < p.W) ? gy * p.W + gx : -1;
-  uint2 rres[NH];
+  uint4 rres[NH];  // 4 couts: 8 bytes of bf16 or 16 bytes of fp32
 #pragma unroll
-  for (int h = 0; h < NH; ++h) rres[h] = ld8(rr, mo >= 0 ? (unsigned)((mo * p.ldr + co0 + 16 * h + 4 * q) * 2) : OOB);
+  for (int h = 0; h < NH; ++h) {
+    const unsigned ro = mo >= 0 ? (unsigned)((mo * p.ldr + co0 + 16 * h + 4 * q) * ESZ) : OOB;
+    if constexpr (SPLIT) {
+      rres[h] = ld16(rr, ro, 0);
+    } else {
+      const uint2 r2 = ld8(rr, ro);
+      rres[h] = make_uint4(r2.x, r2.y, 0, 0);
+    }
+  }
 
   auto step = [&](int ph, Stage& S) __attribute__((always_inline)) {
     ST_WAIT
@@ -419,12 +483,21 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
       const float bs = ((p.bias ? p.bias[c] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + c] : 0.f)) * osc;
       v[h][i] = fmaf(acc[h][0][i] + acc[h][1][i], osc, bs);
     }
-    v[h][0] = fmaf(__uint_as_float(rres[h].x << 16), osc, v[h][0]);
-    v[h][1] = fmaf(__uint_as_float(rres[h].x & 0xffff0000u), osc, v[h][1]);
-    v[h][2] = fmaf(__uint_as_float(rres[h].y << 16), osc, v[h][2]);
-    v[h][3] = fmaf(__uint_as_float(rres[h].y & 0xffff0000u), osc, v[h][3]);
-    st8(ry, mo >= 0 ? (unsigned)((mo * p.ldy + co0 + 16 * h + 4 * q) * 2) : OOB,
-        make_uint2(pack_bf16x2(v[h][0], v[h][1]), pack_bf16x2(v[h][2], v[h][3])));
+    const unsigned yo = mo >= 0 ? (unsigned)((mo * p.ldy + co0 + 16 * h + 4 * q) * ESZ) : OOB;
+    if constexpr (SPLIT) {
+      v[h][0] = fmaf(__uint_as_float(rres[h].x), osc, v[h][0]);
+      v[h][1] = fmaf(__uint_as_float(rres[h].y), osc, v[h][1]);
+      v[h][2] = fmaf(__uint_as_float(rres[h].z), osc, v[h][2]);
+      v[h][3] = fmaf(__uint_as_float(rres[h].w), osc, v[h][3]);
+      const u32x4_t ov = {__float_as_uint(v[h][0]), __float_as_uint(v[h][1]), __float_as_uint(v[h][2]), __float_as_uint(v[h][3])};
+      __builtin_amdgcn_raw_buffer_store_b128(ov, ry, yo, 0, 0);
+    } else {
+      v[h][0] = fmaf(__uint_as_float(rres[h].x << 16), osc, v[h][0]);
+      v[h][1] = fmaf(__uint_as_float(rres[h].x & 0xffff0000u), osc, v[h][1]);
+      v[h][2] = fmaf(__uint_as_float(rres[h].y << 16), osc, v[h][2]);
+      v[h][3] = fmaf(__uint_as_float(rres[h].y & 0xffff0000u), osc, v[h][3]);
+      st8(ry, yo, make_uint2(pack_bf16x2(v[h][0], v[h][1]), pack_bf16x2(v[h][2], v[h][3])));
+    }
   }
   ST_MARK(7)
   if (p.stats) {
@@ -464,31 +537,31 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
   ST_FLUSH
 }
 
-template <int GW, int PC, int NS, int MODE>
+template <int GW, int PC, int NS, int MODE, int ESZ>
 int launch_small(const SmK& k, const ConvArgs& a, hipStream_t st) {
-  constexpr int LDS = SmGeom<GW, PC, NS>::LDS;
+  constexpr int LDS = SmGeom<GW, PC, NS, ESZ>::LDS;
   static bool attr_done = false;
   if (!attr_done) {
-    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_small_kernel<GW, PC, NS, MODE>),
+    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_small_kernel<GW, PC, NS, MODE, ESZ>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_done = true;
   }
   dim3 grid(k.tiles_x * cdiv(a.H, SmTile<GW>::THT), a.Cout / NS, a.B);
-  hipLaunchKernelGGL((conv3x3_small_kernel<GW, PC, NS, MODE>), grid, dim3(SmTile<GW>::NT), LDS, st, k);
+  hipLaunchKernelGGL((conv3x3_small_kernel<GW, PC, NS, MODE, ESZ>), grid, dim3(SmTile<GW>::NT), LDS, st, k);
   DS_LAUNCH_CHECK();
   return 0;
 }
-template <int GW, int PC, int NS>
+template <int GW, int PC, int NS, int ESZ>
 int launch_small_mode(const SmK& k, const ConvArgs& a, int mode, hipStream_t st) {
-  if (mode == 2) return launch_small<GW, PC, NS, 2>(k, a, st);
-  if (mode == 1) return launch_small<GW, PC, NS, 1>(k, a, st);
-  return launch_small<GW, PC, NS, 0>(k, a, st);
+  if (mode == 2) return launch_small<GW, PC, NS, 2, ESZ>(k, a, st);
+  if (mode == 1) return launch_small<GW, PC, NS, 1, ESZ>(k, a, st);
+  return launch_small<GW, PC, NS, 0, ESZ>(k, a, st);
 }
-template <int PC, int NS>
+template <int PC, int NS, int ESZ>
 int launch_small_gw(const SmK& k, const ConvArgs& a, int gw, int mode, hipStream_t st) {
-  if (gw == 4) return launch_small_mode<4, PC, NS>(k, a, mode, st);
-  if (gw == 8) return launch_small_mode<8, PC, NS>(k, a, mode, st);
-  return launch_small_mode<16, PC, NS>(k, a, mode, st);
+  if (gw == 4) return launch_small_mode<4, PC, NS, ESZ>(k, a, mode, st);
+  if (gw == 8) return launch_small_mode<8, PC, NS, ESZ>(k, a, mode, st);
+  return launch_small_mode<16, PC, NS, ESZ>(k, a, mode, st);
 }
 
 }  // namespace
@@ -505,11 +578,13 @@ static bool small_sources_multiple_of(const ConvArgs& a, int pc) {
   return true;
 }
 bool ds_conv_small_eligible(const ConvArgs& a) {
-  if (a.dtype != DS_BF16 || a.taps != 9 || a.w_bs != 0 || a.bias_mode != 0 || a.div_b) return false;
+  // bf16, or fp32 tensors in split mode (the exact fp32 engine keeps the generic kernel's fp32 MFMAs)
+  if (!(a.dtype == DS_BF16 || (a.dtype == DS_F32 && a.split)) || a.taps != 9 || a.w_bs != 0 || a.bias_mode != 0 || a.div_b) return false;
   if (!(a.W < 32 || a.H < 8) || a.H > 16) return false;
   if (a.Cout % 16 != 0 || !small_sources_multiple_of(a, 64)) return false;
   if (a.ldx % 8 != 0 || (a.x2 && a.ldx2 % 8 != 0)) return false;
   if ((a.w_chunked & (a.w_chunked - 1)) || (a.w_chunked && a.w_chunked < 8)) return false;
+  if (a.dtype == DS_F32 && ((a.w_chunked && a.w_chunked < 4) || (a.sx && a.sw_chunked && a.sw_chunked < 4))) return false;
   if (a.sx && (!a.sw || (a.sw_chunked & (a.sw_chunked - 1)) || (a.sw_chunked && a.sw_chunked < 8) || a.ldsx % 8 != 0 ||
                (a.sx2 && a.ldsx2 % 8 != 0)))
     return false;
@@ -520,26 +595,27 @@ bool ds_conv_small_eligible(const ConvArgs& a) {
 
 int ds_launch_conv_small(const ConvArgs& a, hipStream_t st) {
   SmK k;
-  k.x = reinterpret_cast<const bf16_t*>(a.x); k.x_bs = a.x_bs; k.ldx = a.ldx;
-  k.x2 = reinterpret_cast<const bf16_t*>(a.x2); k.x2_bs = a.x2_bs; k.ldx2 = a.ldx2;
+  k.x = a.x; k.x_bs = a.x_bs; k.ldx = a.ldx;
+  k.x2 = a.x2; k.x2_bs = a.x2_bs; k.ldx2 = a.ldx2;
   k.C1 = a.C1; k.Cin = a.Cin;
-  k.w = reinterpret_cast<const bf16_t*>(a.w); k.w_chunked = a.w_chunked; k.w_shift = a.w_chunked ? __builtin_ctz(a.w_chunked) : 0;
-  k.sx = reinterpret_cast<const bf16_t*>(a.sx); k.sx_bs = a.sx_bs; k.ldsx = a.ldsx;
-  k.sx2 = reinterpret_cast<const bf16_t*>(a.sx2); k.sx2_bs = a.sx2_bs; k.ldsx2 = a.ldsx2;
+  k.w = a.w; k.w_chunked = a.w_chunked; k.w_shift = a.w_chunked ? __builtin_ctz(a.w_chunked) : 0;
+  k.sx = a.sx; k.sx_bs = a.sx_bs; k.ldsx = a.ldsx;
+  k.sx2 = a.sx2; k.sx2_bs = a.sx2_bs; k.ldsx2 = a.ldsx2;
   k.sC1 = a.sC1; k.sCin = a.sCin;
-  k.sw = reinterpret_cast<const bf16_t*>(a.sw); k.sw_chunked = a.sw_chunked; k.sw_shift = a.sw_chunked ? __builtin_ctz(a.sw_chunked) : 0;
+  k.sw = a.sw; k.sw_chunked = a.sw_chunked; k.sw_shift = a.sw_chunked ? __builtin_ctz(a.sw_chunked) : 0;
   k.gn_scale = a.gn_scale; k.gn_shift = a.gn_shift;
   k.gn_acc1 = a.gn_acc1; k.gn_acc2 = a.gn_acc2; k.gn_gamma = a.gn_gamma; k.gn_beta = a.gn_beta;
   k.gn_cpg = a.gn_acc1 ? a.Cin / a.gn_groups : 1; k.gn_inv_count = a.gn_inv_count; k.gn_eps = a.gn_eps;
   k.bias = a.bias; k.bias_b = a.bias_b; k.bias_b_ld = a.bias_b_ld;
-  k.res = reinterpret_cast<const bf16_t*>(a.res); k.res_bs = a.res_bs; k.ldr = a.ldr;
+  k.res = a.res; k.res_bs = a.res_bs; k.ldr = a.ldr;
   k.out_scale = a.out_scale;
-  k.y = reinterpret_cast<bf16_t*>(a.y); k.y_bs = a.y_bs; k.ldy = a.ldy;
+  k.y = a.y; k.y_bs = a.y_bs; k.ldy = a.ldy;
   k.stats = a.stats_acc;
   const int gw = a.W <= 4 ? 4 : (a.W <= 8 ? 8 : 16);
   k.H = a.H; k.W = a.W; k.Cout = a.Cout; k.tiles_x = cdiv(a.W, gw);
   const int mode = (a.gn_scale || a.gn_acc1) ? (a.gn_act ? 2 : 1) : 0;
   // (32-cout slabs were measured slower: 406 vs 366 ms for one batch — twice the weight staging per block)
-  if (small_sources_multiple_of(a, 128)) return launch_small_gw<128, 16>(k, a, gw, mode, st);
-  return launch_small_gw<64, 16>(k, a, gw, mode, st);
+  if (a.dtype == DS_F32) return launch_small_gw<64, 16, 4>(k, a, gw, mode, st);  // 64 fp32 channels = the bytes of 128 bf16
+  if (small_sources_multiple_of(a, 128)) return launch_small_gw<128, 16, 2>(k, a, gw, mode, st);
+  return launch_small_gw<64, 16, 2>(k, a, gw, mode, st);
 }

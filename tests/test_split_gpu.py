@@ -145,3 +145,46 @@ def test_split_mixed_length_batch_equals_single_utterances():
     for b, L in enumerate(lens):
         one, _ = eng.pc_sample(mixn[b:b + 1, :, :L].contiguous(), SDE, N=2, corrector_steps=1, seed=seeds[b])
         assert torch.equal(batch[b, :, :L], one[0]) and not bool(batch[b, :, L:].any())
+
+
+@pytest.mark.parametrize("C1,C2,Cout,H,W", [(128, 0, 128, 16, 16), (128, 128, 128, 8, 8), (64, 192, 48, 16, 12), (256, 256, 256, 4, 1),
+                                            (128, 64, 64, 8, 6), (128, 128, 128, 16, 24)])
+@pytest.mark.parametrize("act,lazy", [(1, False), (1, True), (None, False)])
+def test_split_small_image_conv3x3(C1, C2, Cout, H, W, act, lazy):
+    # the small-image kernel (conv3x3_small.hip) on fp32 tensors with split products: the same cases as its bf16 test
+    # (test_kernels_gpu.py::test_small_image_conv3x3), against torch fp32 on the CPU
+    B, C = 3, C1 + C2
+    tag = f"{C1}.{C2}.{H}.{W}"
+    xa = (rnd("ssm.a" + tag, (B, H, W, C1), 1.2) + 0.1).to(DEV)
+    xb = (rnd("ssm.b" + tag, (B, H, W, C2), 0.8) - 0.2).to(DEV) if C2 else None
+    w = rnd(f"ssm.w{C}.{Cout}", (Cout, C, 3, 3), (9 * C) ** -0.5)
+    bias, bb = rnd(f"ssm.bias{Cout}", (Cout,), 0.1).to(DEV), rnd(f"ssm.bb{Cout}", (B, Cout), 0.1).to(DEV)
+    res = rnd(f"ssm.r{Cout}" + tag, (B, H, W, Cout)).to(DEV)
+    groups = min(C // 4, 32)
+    g, be = (1.0 + rnd(f"ssm.g{C}", (C,), 0.2)).to(DEV), rnd(f"ssm.be{C}", (C,), 0.1).to(DEV)
+    xcat = torch.cat([xa, xb], -1).cpu() if C2 else xa.cpu()
+    kw = {}
+    if act is None:
+        hn = xcat
+    elif lazy:
+        def acc(x):
+            xd = x.double()
+            return torch.stack([(xd.sum((1, 2)) * ops.STAT_SUM_SCALE).round(), ((xd * xd).sum((1, 2)) * ops.STAT_SQ_SCALE).round()],
+                               -1).to(torch.int64).contiguous()
+        kw = dict(gn_acc=(acc(xa), acc(xb) if C2 else None, g, be, groups), gn_act=act)
+        hn = F.silu(F.group_norm(xcat.permute(0, 3, 1, 2), groups, g.cpu(), be.cpu(), eps=1e-6).permute(0, 2, 3, 1))
+    else:
+        sc, sh = (1.0 + rnd(f"ssm.sc{C}", (B, C), 0.2)).to(DEV), rnd(f"ssm.sh{C}", (B, C), 0.2).to(DEV)
+        kw = dict(gn=(sc, sh), gn_act=act)
+        hn = F.silu(xcat * sc.cpu()[:, None, None, :] + sh.cpu()[:, None, None, :])
+    ref = F.conv2d(hn.permute(0, 3, 1, 2).double(), w.double(), bias.cpu().double(), padding=1).permute(0, 2, 3, 1)
+    ref = ((ref + bb.cpu().double()[:, None, None, :] + res.cpu().double()) * 0.70710678).float()
+    kc = ops.conv2d_chunk(3, torch.float32)
+    for chunk in (0, kc):
+        wp = ops.pack_conv_weight(w, torch.float32, chunk=chunk).to(DEV)
+        y, st = ops.conv2d_fused(xa, wp, bias, Cout, 3, x2=xb, bias_b=bb, res=res, out_scale=0.70710678, stats=True,
+                                 w_chunk=chunk, split=True, **kw)
+        assert rel_rms(y.cpu(), ref) < 3e-5
+        s = ops.stats_to_float(st).cpu()
+        assert torch.allclose(s[..., 0], ref.double().sum((1, 2)), rtol=1e-4, atol=1e-4 * H * W)
+        assert torch.allclose(s[..., 1], (ref.double() ** 2).sum((1, 2)), rtol=1e-4, atol=1e-4 * H * W)
