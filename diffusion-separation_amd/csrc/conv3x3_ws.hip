@@ -24,6 +24,10 @@
 // LDS-DMA — are kept as text under profiles/experiments/ with their numbers.)
 //
 // K order (chunk, tap, 16-channel block) is the same as in conv_mfma.hip.
+//
+// The file also holds the two other persistent kernels on the same 8 x 32 tiles: conv3x3_thin_in_kernel (the network's
+// first layer, 8 -> 64) and conv3x3_thin_out_kernel (the output-pyramid heads, 64 k -> <= 8 couts); each is described at
+// its definition.
 #include <stdlib.h>
 
 #include <type_traits>
