@@ -161,7 +161,7 @@ int32_t diffsep_pc_sample(diffsep_engine* e, const diffsep_sde_config* sde, cons
  *   seeds_host [B]    : per-utterance Philox seeds (with noise == NULL): utterance b draws exactly what a B = 1 call
  *                       with seed = seeds_host[b] draws, whatever batch it rides in.  Without it `seed` keys the
  *                       whole batch as in diffsep_pc_sample (with lengths: utterance b uses seed + b * 0x9E3779B97F4A7C15).
- *   tail_engine       : a second engine of the same architecture and weights (the fp32 engine behind a bf16 one) that
+ *   tail_engine       : a second engine of the same architecture and weights (an fp32 or split-fp32 engine behind a bf16 one) that
  *                       evaluates the score of the FIRST head_steps and / or the LAST tail_steps reverse steps (their
  *                       corrector and predictor evaluations).  A score error enters the state scaled by the step size
  *                       G(t)^2, ~100x larger at t = 1 than at t = eps: it is the early steps whose precision decides
