@@ -161,7 +161,7 @@ struct ConvK {  // kernel-side copy of ConvArgs (typed by the template)
   int tiles_x;
 };
 
-template <typename T, int TAPS, int TH, int TW, int BN, int KC, int EP = 1>
+template <typename T, int TAPS, int TH, int TW, int BN, int KC, int EP = 1, int NT = 256>
 struct ConvGeom {
   static constexpr int KV = 16 / (int)sizeof(T);
   static constexpr int R = (TAPS == 9) ? 1 : 0;
@@ -170,14 +170,14 @@ struct ConvGeom {
   static constexpr int ROWB = KC * (int)sizeof(T) + 16;
   static constexpr int NVEC = KC / KV;
   static constexpr int NKB = KC / (2 * KV);
-  static constexpr int NA = (HP * NVEC + 255) / 256;
-  static constexpr int NB = (TAPS * BN * NVEC + 255) / 256;
+  static constexpr int NA = (HP * NVEC + NT - 1) / NT;
+  static constexpr int NB = (TAPS * BN * NVEC + NT - 1) / NT;
   static constexpr int OROW = BN * 4 + 16;  // fp32 output staging row pitch
   static constexpr int LDS_STAGE = HP * ROWB + TAPS * BN * ROWB;
   static constexpr int LDS_OUT = (BM / EP) * OROW;  // the epilogue streams the tile out in EP passes
   static constexpr int LDS = LDS_STAGE > LDS_OUT ? LDS_STAGE : LDS_OUT;
   // fused 1x1 skip convolution: needs one weight staging pass per tap (256 / NVEC rows per pass == BN)
-  static constexpr bool SKIP_OK = TAPS == 9 && (256 / NVEC) <= BN && BN % (256 / NVEC) == 0;
+  static constexpr bool SKIP_OK = TAPS == 9 && (NT / NVEC) <= BN && BN % (NT / NVEC) == 0;
 };
 
 // ---- buffer addressing (SRSRC): a wave-uniform descriptor + a 32-bit per-lane byte offset + a uniform
@@ -208,9 +208,9 @@ __device__ inline void buf_store16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsi
 
 // SP (fp32 only): split mode.  The staged chunk is written to LDS as two bf16 planes per row ([KC hi][KC lo], the same
 // KC * 4 bytes as fp32) and every k-block of 16 channels is three bf16 MFMAs.
-template <typename T, int TAPS, int TH, int TW, int BN, int WM, int WN, int KC, int EP = 1, int OCC = 2, int SP = 0>
-__global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
-  using G = ConvGeom<T, TAPS, TH, TW, BN, KC, EP>;
+template <typename T, int TAPS, int TH, int TW, int BN, int WM, int WN, int KC, int EP = 1, int OCC = 2, int SP = 0, int NT = 256>
+__global__ __launch_bounds__(NT, OCC) void conv_mfma_kernel(ConvK p) {
+  using G = ConvGeom<T, TAPS, TH, TW, BN, KC, EP, NT>;
   static_assert(EP == 1 || (WM % EP == 0), "epilogue passes split the wave's M blocks");
   static_assert(SP == 0 || (sizeof(T) == 4 && KC % 16 == 0), "split mode: fp32 storage, whole 16-channel k-blocks");
   constexpr int KV = G::KV, R = G::R, HW_ = G::HW_, HP = G::HP, BM = G::BM, ROWB = G::ROWB, NVEC = G::NVEC,
@@ -218,9 +218,9 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
   constexpr int ESZ = (int)sizeof(T);
   constexpr int WAVES_N = BN / (32 * WN);
   constexpr int WAVES_M = BM / (32 * WM);
-  static_assert(WAVES_M * WAVES_N == 4, "block is 4 waves");
+  static_assert(WAVES_M * WAVES_N == NT / 64, "the wave tiles cover the block tile");
   static_assert(KC % (2 * KV) == 0, "KC must hold whole k-blocks");
-  static_assert(256 % NVEC == 0, "a thread keeps one channel offset across its vectors");
+  static_assert(NT % NVEC == 0, "a thread keeps one channel offset across its vectors");
 
   CT_DECL
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
   // ---- per-thread staging descriptors.  Vector i = tid + 256 k of a stage: row (pixel / weight row)
   // row0 + k*RPS, 16-byte slot tid % NVEC: LDS offsets are linear in k (immediates), global byte offsets
   // are computed once (pixels: one per source because the pixel strides differ).
-  constexpr int RPS = 256 / NVEC;  // rows covered by one pass of the block
+  constexpr int RPS = NT / NVEC;  // rows covered by one pass of the block
   constexpr bool B_TAPSTEP = (RPS % BN == 0);
   static_assert(B_TAPSTEP || BN % RPS == 0, "a pass of the block covers whole taps or a whole fraction of one");
   const int vch = (tid % NVEC) * KV;  // channel offset of this thread's vectors inside a chunk
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     // one global round trip: every thread fetches the sums of ITS channel into LDS (the staging area is still
     // unused), then the group totals come from LDS
     long long* tmp = reinterpret_cast<long long*>(smem);  // [Cin][2]
-    for (int c = tid; c < p.Cin; c += 256) {
+    for (int c = tid; c < p.Cin; c += NT) {
       const long long* src = c < C1 ? p.gn_acc1 + ((long)b * C1 + c) * 2 : p.gn_acc2 + ((long)b * C2 + (c - C1)) * 2;
       const longlong2 v = *reinterpret_cast<const longlong2*>(src);
       tmp[2 * c] = v.x;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     }
     __syncthreads();
     const int cpg = p.Cin / p.gn_groups;
-    for (int c = tid; c < p.Cin; c += 256) {
+    for (int c = tid; c < p.Cin; c += NT) {
       const int g0 = (c / cpg) * cpg;
       long long ssum = 0, ssq = 0;
       for (int j = 0; j < cpg; ++j) {
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
   const int cout8 = (p.Cout + 7) & ~7;
   const float dvs = p.div_b ? p.div_b[b] : 1.0f;
   constexpr int NCG = BN / 8;
-  static_assert(256 % NCG == 0, "a thread keeps one cout group across the epilogue loop");
+  static_assert(NT % NCG == 0, "a thread keeps one cout group across the epilogue loop");
   constexpr int WME = WM / EP;  // M blocks of a wave per pass
   constexpr int RV = ESZ * 8 / 16;  // 16-byte vectors per 8 channels
   const int cg = tid % NCG;
@@ -671,14 +671,14 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
                           acc[e * WME + i][j][4 * g + 3]);
         }
     // rows of this thread: pixel index (or -1) -> byte offsets of its 8-channel vector in y / res
-    constexpr int NROW = (BM / EP) / (256 / NCG);
-    static_assert((BM / EP) % (256 / NCG) == 0, "whole rows per thread");
+    constexpr int NROW = (BM / EP) / (NT / NCG);
+    static_assert((BM / EP) % (NT / NCG) == 0, "whole rows per thread");
     int mrow[NROW];
     unsigned voy[NROW], vor[NROW];
     uint4 rraw[NROW][RV];
     // EP == 1: local row lp IS the tile pixel, so successive rows of a thread advance linearly
     // ((256/NCG)/TW image rows, or 256/NCG flat pixels): one add per row instead of div/mod/mul
-    constexpr int RSTEP = 256 / NCG;
+    constexpr int RSTEP = NT / NCG;
     const int pp0 = tid / NCG;
     const int gy0 = y0 + pp0 / TW, gx0 = x0 + pp0 % TW;
     const int mlin0 = (TAPS == 9) ? gy0 * p.W + gx0 : m0 + pp0;
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
         const bool ok = col_ok && ((TAPS == 9) ? (gy0 + it * (RSTEP / TW) < p.H) : (mlin0 + it * mstep < M));
         m = ok ? mlin0 + it * mstep : -1;
       } else {
-        const int lp = tid / NCG + it * (256 / NCG);
+        const int lp = tid / NCG + it * (NT / NCG);
         const int pp = ((lp / (32 * WME)) * WM + e * WME + (lp / 32) % WME) * 32 + (lp & 31);
         if (TAPS == 9) {
           const int gy = y0 + pp / TW, gx = x0 + pp % TW;
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
       const bool has_res = p.res != nullptr, has_stats = p.stats != nullptr;
 #pragma unroll
       for (int it = 0; it < NROW; ++it) {
-        const int lp = tid / NCG + it * (256 / NCG);
+        const int lp = tid / NCG + it * (NT / NCG);
         const float4 a0 = *reinterpret_cast<const float4*>(smem + lp * OROW + cg * 32);
         const float4 a1 = *reinterpret_cast<const float4*>(smem + lp * OROW + cg * 32 + 16);
         float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
       for (int it = 0; it < NROW; ++it) {
         const int m = mrow[it];
-        const int lp = tid / NCG + it * (256 / NCG);
+        const int lp = tid / NCG + it * (NT / NCG);
         float v[8];
         const float4 a0 = *reinterpret_cast<const float4*>(smem + lp * OROW + cg * 32);
         const float4 a1 = *reinterpret_cast<const float4*>(smem + lp * OROW + cg * 32 + 16);
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
     __syncthreads();
     if (tid < BN && n0 + tid < p.Cout) {
       double a = 0.0, q = 0.0;
-      for (int rr2 = 0; rr2 < 256 / NCG; ++rr2) {
+      for (int rr2 = 0; rr2 < NT / NCG; ++rr2) {
         a += (double)sr[(rr2 * BN + tid) * 2 + 0];
         q += (double)sr[(rr2 * BN + tid) * 2 + 1];
       }
@@ -809,11 +809,11 @@ __global__ __launch_bounds__(256, OCC) void conv_mfma_kernel(ConvK p) {
   CT_FLUSH
 }
 
-template <typename T, int TAPS, int TH, int TW, int BN, int WM, int WN, int KC, int EP = 1, int OCC = 2, int SP = 0>
+template <typename T, int TAPS, int TH, int TW, int BN, int WM, int WN, int KC, int EP = 1, int OCC = 2, int SP = 0, int NT = 256>
 static int launch_cfg(const ConvArgs& a, hipStream_t st) {
-  using G = ConvGeom<T, TAPS, TH, TW, BN, KC, EP>;
+  using G = ConvGeom<T, TAPS, TH, TW, BN, KC, EP, NT>;
   constexpr int LDS = G::LDS + 4096;  // + the [2][Cin <= 512] GroupNorm table of the accumulator mode
-  auto kern = conv_mfma_kernel<T, TAPS, TH, TW, BN, WM, WN, KC, EP, OCC, SP>;
+  auto kern = conv_mfma_kernel<T, TAPS, TH, TW, BN, WM, WN, KC, EP, OCC, SP, NT>;
   static bool attr_done = false;
   if (!attr_done) {
     DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -853,7 +853,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   }
   grid.y = cdiv(a.Cout, BN);
   grid.z = a.B;
-  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, k);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, st, k);
   DS_LAUNCH_CHECK();
   return 0;
 }
@@ -867,7 +867,13 @@ static int launch_typed(const ConvArgs& a, hipStream_t st) {
       // few tiles (the 32^2 level: 128 blocks of 8 x 32 pixels on 256 CUs): half-width tiles fill the chip
       // (one batch alone 325.6 -> 320.6 ms, four in flight unchanged)
       const long blocks = (long)cdiv(a.W, 32) * cdiv(a.H, 8) * cdiv(a.Cout, 64) * a.B;
-      if (sizeof(T) == 2 && blocks <= 128) return launch_cfg<T, 9, 8, 16, 64, 1, 2, KC9, 1, 2, SP>(a, st);
+      if constexpr (sizeof(T) == 2) {
+      if (blocks <= 128) return launch_cfg<T, 9, 8, 16, 64, 1, 2, KC9, 1, 2, SP>(a, st);
+      // many tiles and >= 128 couts: one 8-wave block computes 128 couts of a tile, so the halo tile is loaded and
+      // activated once per 128 couts instead of once per 64 (nf = 128: 20.3 -> 20.9 utt/s; nf = 64: unchanged)
+      if (a.Cout % 128 == 0 && blocks >= 1024)
+        return launch_cfg<T, 9, 8, 32, 128, 2, 2, KC9, 2, 2, SP, 512>(a, st);
+      }
       return launch_cfg<T, 9, 8, 32, 64, 2, 2, KC9, 1, 2, SP>(a, st);
     }
     case 1: return launch_cfg<T, 9, 8, 32, 32, 2, 1, KC9, 1, 2, SP>(a, st);
