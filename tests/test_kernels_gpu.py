@@ -549,3 +549,25 @@ def test_pyramid_head_conv3x3_to_8_channels(Cin, Cout, B, H, W, act, lazy, with_
         assert rel_rms(y.float().cpu()[..., :Cout], ref) < 4e-3
         if Cout < 8:
             assert not bool(y[..., Cout:].any())
+
+
+@pytest.mark.parametrize("Cin,Cout", [(64, 128), (128, 256)])
+def test_wide_tile_conv3x3_128_couts(Cin, Cout):
+    # launches with >= 1024 blocks and 128 | Cout run on 128-cout tiles (8 waves, two epilogue passes): GroupNorm + SiLU on
+    # the input, bias + per-sample bias, residual, scale, statistics; reference = torch fp32 on the CPU
+    dt = torch.bfloat16
+    B, H, W = 16, 128, 64
+    x = (rnd(f"wt.x{Cin}", (B, H, W, Cin), 1.2) + 0.1).to(DEV).to(dt)
+    w = rnd(f"wt.w{Cin}{Cout}", (Cout, Cin, 3, 3), (9 * Cin) ** -0.5)
+    bias, bb = rnd(f"wt.b{Cout}", (Cout,), 0.1).to(DEV), rnd(f"wt.bb{Cout}", (B, Cout), 0.1).to(DEV)
+    res = rnd(f"wt.r{Cout}", (B, H, W, Cout)).to(DEV).to(dt)
+    sc, sh = (1.0 + rnd(f"wt.sc{Cin}", (B, Cin), 0.2)).to(DEV), rnd(f"wt.sh{Cin}", (B, Cin), 0.2).to(DEV)
+    hn = F.silu(x.float().cpu() * sc.cpu()[:, None, None, :] + sh.cpu()[:, None, None, :]).to(dt).float()
+    ref = F.conv2d(hn.permute(0, 3, 1, 2), w.to(dt).float(), bias.cpu(), padding=1).permute(0, 2, 3, 1)
+    ref = (ref + bb.cpu()[:, None, None, :] + res.float().cpu()) * 0.70710678
+    y, st = ops.conv2d_fused(x, ops.pack_conv_weight(w, dt, chunk=32).to(DEV), bias, Cout, 3, gn=(sc, sh), gn_act=1,
+                             bias_b=bb, res=res, out_scale=0.70710678, stats=True, w_chunk=32)
+    assert rel_rms(y.float().cpu(), ref) < 4e-3
+    s = ops.stats_to_float(st).cpu()
+    assert torch.allclose(s[..., 0], ref.double().sum((1, 2)), rtol=2e-3, atol=2e-3 * H * W)
+    assert torch.allclose(s[..., 1], (ref.double() ** 2).sum((1, 2)), rtol=2e-3, atol=2e-3 * H * W)

@@ -508,3 +508,18 @@ def test_resblock_weight_stationary_folded_skip_vs_oracle(cin, cout, H, W, up, d
     yb = ops.resblock_forward([sd[n] for n, _ in tbl], ops.to_nhwc(x).to(torch.bfloat16).to(DEV), temb.to(DEV), cout,
                               up=up, down=down)
     assert rel_rms(ops.to_nchw(yb).float(), ref) < 1.5e-2
+
+
+def test_resblock_wide_tiles_with_folded_skip_vs_oracle():
+    # 256 -> 128 block at a size whose convolutions run on the 128-cout tiles (>= 1024 blocks), Conv_2 folded into Conv_1
+    cin, cout, B, H, W = 256, 128, 16, 128, 64
+    tbl = [("GroupNorm_0.weight", (cin,)), ("GroupNorm_0.bias", (cin,)), ("Conv_0.weight", (cout, cin, 3, 3)),
+           ("Conv_0.bias", (cout,)), ("Dense_0.weight", (cout, 64)), ("Dense_0.bias", (cout,)),
+           ("GroupNorm_1.weight", (cout,)), ("GroupNorm_1.bias", (cout,)), ("Conv_1.weight", (cout, cout, 3, 3)),
+           ("Conv_1.bias", (cout,)), ("Conv_2.weight", (cout, cin, 1, 1)), ("Conv_2.bias", (cout,))]
+    sd = synth.synth_state_dict(tbl, 29)
+    sd["Conv_2.weight"] = (sd["Conv_2.weight"] * 3.0).astype(np.float32)
+    x, temb = rnd("rbwt.x", (B, cin, H, W)), rnd("rbwt.t", (B, 64))
+    ref = O._res_block(O.to_torch(sd), "", x, temb)
+    yb = ops.resblock_forward([sd[n] for n, _ in tbl], ops.to_nhwc(x).to(torch.bfloat16).to(DEV), temb.to(DEV), cout)
+    assert rel_rms(ops.to_nchw(yb).float(), ref) < 1.5e-2
