@@ -551,12 +551,14 @@ def test_pyramid_head_conv3x3_to_8_channels(Cin, Cout, B, H, W, act, lazy, with_
             assert not bool(y[..., Cout:].any())
 
 
-@pytest.mark.parametrize("Cin,Cout", [(64, 128), (128, 256)])
-def test_wide_tile_conv3x3_128_couts(Cin, Cout):
-    # launches with >= 1024 blocks and 128 | Cout run on 128-cout tiles (8 waves, two epilogue passes): GroupNorm + SiLU on
-    # the input, bias + per-sample bias, residual, scale, statistics; reference = torch fp32 on the CPU
+@pytest.mark.parametrize("Cin,Cout,H,W", [(64, 128, 128, 64), (128, 256, 128, 64), (128, 64, 64, 64), (192, 64, 40, 72)])
+def test_wide_tile_conv3x3_128_couts(Cin, Cout, H, W):
+    # the tile choice of the generic bf16 kernel by launch size: >= 1024 blocks and 128 | Cout run on 128-cout tiles (8 waves,
+    # two epilogue passes), 129 ... 1023 blocks on the standard 8 x 32 x 64-cout tile (the small-batch unit tests above all
+    # land on the half-width tile).  GroupNorm + SiLU on the input, bias + per-sample bias, residual, scale, statistics;
+    # reference = torch fp32 on the CPU
     dt = torch.bfloat16
-    B, H, W = 16, 128, 64
+    B = 16
     x = (rnd(f"wt.x{Cin}", (B, H, W, Cin), 1.2) + 0.1).to(DEV).to(dt)
     w = rnd(f"wt.w{Cin}{Cout}", (Cout, Cin, 3, 3), (9 * Cin) ** -0.5)
     bias, bb = rnd(f"wt.b{Cout}", (Cout,), 0.1).to(DEV), rnd(f"wt.bb{Cout}", (B, Cout), 0.1).to(DEV)
