@@ -871,6 +871,10 @@ static int launch_typed(const ConvArgs& a, hipStream_t st) {
       if (blocks <= 128) return launch_cfg<T, 9, 8, 16, 64, 1, 2, KC9, 1, 2, SP>(a, st);
       // many tiles and >= 128 couts: one 8-wave block computes 128 couts of a tile, so the halo tile is loaded and
       // activated once per 128 couts instead of once per 64 (nf = 128: 20.3 -> 20.9 utt/s; nf = 64: unchanged)
+      // weight-heavy 64-cout launches without a folded skip (Conv_0 of the 256^2 / 128^2 up path): 16 x 32 pixels on 8 waves,
+      // one weight stage per 512 pixels (+1 % end to end)
+      if (!a.sx && a.Cin >= 128 && a.Cout == 64 && a.H % 16 == 0 && blocks >= 1024)
+        return launch_cfg<T, 9, 16, 32, 64, 2, 2, KC9, 2, 2, SP, 512>(a, st);
       if (a.Cout % 128 == 0 && blocks >= 1024)
         return launch_cfg<T, 9, 8, 32, 128, 2, 2, KC9, 2, 2, SP, 512>(a, st);
       }

@@ -551,11 +551,12 @@ def test_pyramid_head_conv3x3_to_8_channels(Cin, Cout, B, H, W, act, lazy, with_
             assert not bool(y[..., Cout:].any())
 
 
-@pytest.mark.parametrize("Cin,Cout,H,W", [(64, 128, 128, 64), (128, 256, 128, 64), (128, 64, 64, 64), (192, 64, 40, 72)])
+@pytest.mark.parametrize("Cin,Cout,H,W", [(64, 128, 128, 64), (128, 256, 128, 64), (128, 64, 64, 64), (192, 64, 40, 72),
+                                          (128, 64, 128, 128)])
 def test_wide_tile_conv3x3_128_couts(Cin, Cout, H, W):
     # the tile choice of the generic bf16 kernel by launch size: >= 1024 blocks and 128 | Cout run on 128-cout tiles (8 waves,
     # two epilogue passes), 129 ... 1023 blocks on the standard 8 x 32 x 64-cout tile (the small-batch unit tests above all
-    # land on the half-width tile).  GroupNorm + SiLU on the input, bias + per-sample bias, residual, scale, statistics;
+    # land on the half-width tile), weight-heavy 64-cout launches of >= 1024 blocks on 16 x 32-pixel tiles.  GroupNorm + SiLU on the input, bias + per-sample bias, residual, scale, statistics;
     # reference = torch fp32 on the CPU
     dt = torch.bfloat16
     B = 16
