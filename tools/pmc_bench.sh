@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=${1:-gpurun_out/pmc_bench}
 mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d $OUT/$c -o pmc --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-graph --no-extra-modes > $OUT/$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d $OUT/$c -o pmc --output-format csv -- python bench.py --steps 1 --warmup 0 -N 4 --in-flight 1 --no-cpu-baseline --no-roofline --no-graph --no-extra-modes > $OUT/$c.log 2>&1
 done
 OUT=$OUT python - <<'PY'
 import csv, glob, json, os
@@ -17,7 +17,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(os.path.join(out, c, "**", "*counter_collection.csv"), recursive=True)
     for r in csv.DictReader(open(f[0])):
         k = r["Kernel_Name"]
-        key = ("conv_mfma_9_8_32_64" if "conv_mfma_kernel<unsigned short, 9, 8, 32, 64" in k else
+        # every bf16 instantiation the launcher picks for its 64-cout class (standard, half-width, 16 x 32, 128-cout tiles)
+        gen = any(t in k for t in ("<unsigned short, 9, 8, 32, 64, 2, 2", "<unsigned short, 9, 8, 16, 64, 1, 2",
+                                   "<unsigned short, 9, 16, 32, 64, 2, 2", "<unsigned short, 9, 8, 32, 128, 2, 2"))
+        key = ("conv_mfma_9_8_32_64" if gen else
                "conv3x3_ws1" if "conv3x3_ws1_kernel" in k else None)
         if key and r["Counter_Name"] == c:
             d = res.setdefault(key, {}).setdefault(c, [0.0, 0])
@@ -29,7 +32,7 @@ for k, v in res.items():
     kern[k] = {"launches": n, "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": w,
                "hbm_bytes_per_launch_guide_formula": (2 * f + w) * 1024, "hbm_bytes_per_launch_lower_bound": (f + w) * 1024}
 doc = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 1 "
-                 "--warmup 0 --no-graph` (tools/pmc_bench.sh)",
+                 "--warmup 0 -N 4 --in-flight 1 --no-graph` (tools/pmc_bench.sh; with N = 30 rocprofv3 --pmc crashes in one of its own threads)",
        "commit": os.environ.get("COMMIT", "unrecorded"),
        "correction": "MI355X_MICROARCH.md (HBM): FETCH_SIZE tallies 128-byte requests at 64 B -> doubled for wide coalesced reads; "
                      "WRITE_SIZE uncorrected; unit KB = 1024 B.  Calibration on this kernel family's own pattern (DESIGN.md section 5): "
