@@ -153,6 +153,7 @@ def run_strong(args, engs, ops, on_stream, sync, fence, dist, world, rank, dev, 
         dist.all_gather(parts, tt)
         elapsed = max(float(q[0]) for q in parts)
         busy_all = [float(q[1]) for q in parts]
+    ranks_seen = seen_ranks(dist, world, rank, int(os.environ.get("LOCAL_RANK", "0")), dev) if world > 1 else [[0, 0]]
     if rank == 0:
         value = n * args.steps / elapsed
         secs = sum(lengths) / 8000.0
@@ -170,7 +171,32 @@ def run_strong(args, engs, ops, on_stream, sync, fence, dist, world, rank, dev, 
             "realtime_factor": round(secs * args.steps / elapsed, 2),
             "rank_busy_s_per_step": [round(b / args.steps, 4) for b in busy_all],
             "imbalance_max_over_mean": round(max(busy_all) / (sum(busy_all) / len(busy_all)), 4),
-            "engine_calls_rank0_per_step": len(staged), "nfe_per_call": int(nfe), "finite": finite}), flush=True)
+            "engine_calls_rank0_per_step": len(staged), "nfe_per_call": int(nfe), "finite": finite,
+            "ranks_seen": ranks_seen}), flush=True)
+
+
+def seen_ranks(dist, world, rank, local_rank, dev):
+    """[rank, local device index] of every participating rank, collected with one all-gather."""
+    me = torch.tensor([rank, local_rank], dtype=torch.int64, device=dev)
+    parts = [torch.zeros_like(me) for _ in range(world)]
+    dist.all_gather(parts, me)
+    return [[int(q[0]), int(q[1])] for q in parts]
+
+
+def self_launch(n):
+    """Re-run this command line as n ranks (evaluate_mp.py:495-518: one worker per GPU)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -203,9 +229,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU under
+        # torch.distributed.run, rendezvous on 127.0.0.1 and a free port) and pass their output through; rank 0
+        # of the children prints the one JSON line
+        sys.exit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit("bench.py: --gpus %d does not match WORLD_SIZE=%d" % (args.gpus, world))
     import torch.distributed as dist
     # DIFFSEP_BENCH_DRYRUN=1: the same control flow (collectives, barriers, who prints) on CPU tensors over gloo with a
     # stand-in for the engine — only for the world_size-2 test of the multi-rank sequencing, never a measurement
@@ -298,6 +328,12 @@ def main():
                     gstream.wait_event(ev)
                     with torch.cuda.stream(gstream):
                         dist.gather(out, gathered[w], dst=0)  # RCCL over xGMI: the only collective on the path
+                    # `out` was allocated on worker stream w and is read by the collective on gstream: tell the caching
+                    # allocator, so the block is not handed back to stream w before the gather has finished with it
+                    out.record_stream(gstream)
+                    if gathered[w] is not None:
+                        for g_ in gathered[w]:
+                            g_.record_stream(gstream)
         keep[w] = (mix_norm, sep, out)
         return out, nfe
 
@@ -461,10 +497,12 @@ def main():
     else:
         extra_json = {}
 
+    ranks_seen = [0]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        ranks_seen = seen_ranks(dist, world, rank, local_rank, dev)
 
     if rank == 0:
         utt = B * world * args.steps
@@ -488,6 +526,7 @@ def main():
             "model_tflops": round(value * nfe * GFLOP_PER_NFE.get(args.nf, float("nan")) * (T / 32000.0) / 1e3, 2),
             "finite": finite,
             "device_bytes": sum(e.device_bytes() for e in engs),
+            "ranks_seen": ranks_seen,  # [rank, local device] of every rank that took part (all-gather)
         }
         if roof is not None:
             res["roofline"] = roof

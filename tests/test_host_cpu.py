@@ -209,6 +209,27 @@ def test_bench_multi_rank_sequencing_gloo(tmp_path):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak" and "roofline" in res
     assert res["config"]["sharding"] == "utterances/2" and res["value"] > 0
+    assert res["ranks_seen"] == [[0, 0], [1, 1]]
+
+
+def test_bench_self_launches_its_ranks_gloo():
+    # `python bench.py --gpus 2` with NO torch.distributed.run around it (how the round-2 driver invoked it): bench.py
+    # must start the two ranks itself, and the single JSON line must say n_gpus = 2 with both ranks seen
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["DIFFSEP_BENCH_DRYRUN"] = "1"
+    for extra in ([], ["--scaling", "strong", "--utterances", "7"]):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                              "--batch", "2", "--samples", "800"] + extra, env=env, cwd=root, capture_output=True,
+                             text=True, timeout=240)
+        assert out.returncode == 0, out.stderr[-800:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout[-500:]
+        res = json.loads(lines[0])
+        assert res["n_gpus"] == 2 and res["value"] > 0 and res["ranks_seen"] == [[0, 0], [1, 1]]
 
 
 def test_bench_strong_scaling_sequencing_gloo():
@@ -234,6 +255,7 @@ def test_bench_strong_scaling_sequencing_gloo():
     res = json.loads(lines[0])
     assert res["scaling"] == "strong" and res["n_gpus"] == 2 and res["config"]["utterances"] == 11
     assert len(res["rank_busy_s_per_step"]) == 2 and res["imbalance_max_over_mean"] >= 1.0 and res["value"] > 0
+    assert res["ranks_seen"] == [[0, 0], [1, 1]]
 
 
 def test_plan_batches_buckets_by_padded_width():
