@@ -164,9 +164,14 @@ struct ConvArgs {
   int split;                             // fp32 only: 3 bf16 MFMAs per k-block on hi / lo halves (2^-17 products) instead of fp32 MFMAs
 };
 int ds_launch_conv(const ConvArgs& a, hipStream_t st);
+// name (with its template arguments) of the kernel instantiation the calling thread's last ds_launch_conv ran
+const char* ds_last_conv_kernel();
+void ds_set_last_conv_kernel(const char* name);
 int ds_conv_config_id(const ConvArgs& a);
 int ds_conv_chunk(int taps, int dtype);
 bool ds_conv_skip_supported(int H, int W, int Cout, int dtype);
+bool ds_conv_rw_eligible(const ConvArgs& a);   // conv3x3_rw.hip: register-resident weights, 64 / 128 -> 64 bf16, >= 32-row images
+int ds_launch_conv_rw(const ConvArgs& a, hipStream_t st);
 bool ds_conv_ws_eligible(const ConvArgs& a);   // conv3x3_ws.hip: weight-stationary 64 -> 64 bf16 kernel
 int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st);
 bool ds_conv_thin_eligible(const ConvArgs& a);   // conv3x3_ws.hip: the 8 -> 64 first layer

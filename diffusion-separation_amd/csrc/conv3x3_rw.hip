@@ -1,0 +1,635 @@
+// conv3x3_rw.hip — 3x3 convolution with REGISTER-resident weights for the 64-cout layers of the large levels
+// (64 -> 64, cat(64, 64) -> 64, each optionally with the folded 1x1 skip of ResnetBlockBigGANpp; bf16, gfx950).
+// Reference: layers.py:141-156 (ddpm_conv3x3), layerspp.py:291-323 (ResnetBlockBigGANpp), ncsnpp.py:411 (the concat).
+//
+// Why another kernel: the generic tile (conv_mfma.hip) re-streams the weights for every 256-pixel tile and runs
+// 2 waves per SIMD in lock step (load -> activate -> LDS write -> barrier -> MFMA -> epilogue add up: 0.21-0.24 of the
+// MFMA peak); the weight-stationary kernel (conv3x3_ws.hip) keeps the weights in LDS and spends its MFMA phase on LDS
+// fragment traffic (1.5 reads per MFMA).  Here:
+//
+//   * one block of 4 waves per CU, ONE wave per SIMD with the whole 512-entry register file: a wave owns 32 couts
+//     (cg = wave & 1) and keeps ALL of their weight fragments in registers for the whole launch (144 registers per 64
+//     input channels; hipcc places part of them in the accumulator half of the file and feeds them to the MFMAs from
+//     there) — no weight traffic at all after the prologue, through HBM, L2, L1 or LDS;
+//   * a wave's pixel group (pg = wave >> 1) is RPW rows x 32 pixels of a (2 RPW) x 32 tile: every weight fragment is
+//     used by RPW consecutive MFMAs on independent accumulators, the only LDS traffic of the MFMA stream is ONE
+//     ds_read_b128 (the pixel fragment) per MFMA;
+//   * persistent blocks walk a contiguous raster range of tiles; the input goes chunk by chunk (32 channels) through a
+//     2-slot halo ring: while the MFMAs of chunk q run, the same wave activates chunk q + 1 in registers (GroupNorm
+//     affine + SiLU), writes it to the other slot and re-issues the freed registers as the loads of chunk q + 2 — a
+//     global load has a whole chunk phase to land, and one LDS-only barrier per chunk is the only synchronisation;
+//   * the K loop is fully unrolled (every MFMA names its own weight registers); a scheduling barrier per k-step keeps
+//     the compiler's interleave local (RPW MFMAs + RPW fragment reads + one staging operation);
+//   * the folded 1x1 skip (Conv_2 on the raw block input) is NSK extra chunks that use only the centre tap;
+//   * epilogue per pixel row through a wave-private LDS scratch into pixel-major order: bias + temb bias, residual,
+//     1/sqrt(2), statistics for the next GroupNorm, bf16 packing, 64-byte row segments.
+//
+// K order (chunk, tap, 16-channel block) is the same as in conv_mfma.hip / conv3x3_ws.hip.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+#ifdef RW_TIMING  // profiling build only: per-phase cycle totals of wave 0
+__device__ unsigned long long g_rw_dbg[16];
+#define RT_DECL unsigned rt_prev = (unsigned)__builtin_readcyclecounter(), rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RT_MARK(i) { unsigned rt_now = (unsigned)__builtin_readcyclecounter(); rt_acc[i] += rt_now - rt_prev; rt_prev = rt_now; }
+#define RT_FLUSH if (threadIdx.x == 0) { for (int q = 0; q < 8; ++q) atomicAdd(&g_rw_dbg[q], (unsigned long long)rt_acc[q]); atomicAdd(&g_rw_dbg[15], 1ull); }
+extern "C" int diffsep_rw_debug_read(unsigned long long* out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rw_dbg), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rw_dbg), z, sizeof(z)); }
+  return 0;
+}
+#else
+#define RT_DECL
+#define RT_MARK(i)
+#define RT_FLUSH
+#endif
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ inline __amdgpu_buffer_rsrc_t rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ inline u32x4_t ld16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+// block barrier that orders LDS traffic only (a __syncthreads() would also drain the global prefetch)
+__device__ inline void sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int CO = 64;                // output channels of the layer
+constexpr int TW = 32, HW_ = TW + 2;  // tile width, halo row
+constexpr int KC = 32;                // channels per chunk
+constexpr int AROW = KC * 2 + 16;     // 80 B: LDS pitch of a halo pixel (16 consecutive rows = 16 distinct bank slots)
+constexpr int NT = 256;
+
+struct RwK {
+  const bf16_t* x; long x_bs; int ldx; int C1;     // channels [0, C1) from x, [C1, Cin) from x2
+  const bf16_t* x2; long x2_bs; int ldx2;
+  const bf16_t* w; int w_chunked;                  // [64][9][Cin] or chunk-major [Cin/32][9][64][32]
+  const float* gn_scale; const float* gn_shift;    // [B][Cin] or null
+  const long long* gn_acc1; const long long* gn_acc2; const float* gn_gamma; const float* gn_beta;
+  int gn_groups; float gn_inv_count; float gn_eps;
+  const float* bias; const float* bias_b; int bias_b_ld;
+  const bf16_t* res; long res_bs; int ldr;
+  float out_scale;
+  bf16_t* y; long y_bs; int ldy;
+  long long* stats;
+  const bf16_t* sx; long sx_bs; int ldsx; int sC1;  // folded skip: raw channels [0, sC1) from sx, the rest from sx2
+  const bf16_t* sx2; long sx2_bs; int ldsx2;
+  const bf16_t* sw; int sw_chunked; int sw_shift; int sCin;
+  int H, W, G, tiles_x, tiles_per_img;
+};
+
+// k-steps whose weight fragments live in LDS instead of registers (the LAST ones in K order): the fourth chunk of the
+// 128-channel layers and the 128-channel skip — what the 512-entry register file does not hold beside the accumulators
+constexpr int rw_lds_ksteps(int nch, int rpw, int nsk) { return nch == 4 ? 18 : (rpw == 8 && nsk == 4 ? 8 : 0); }
+
+template <int NCH, int RPW, int NSK>
+struct RwGeom {
+  static constexpr int TH = 2 * RPW, HH_ = TH + 2, HP = HH_ * HW_;
+  static constexpr int NL = (HP * 4 + NT - 1) / NT;       // 16-byte pieces per thread and chunk
+  static constexpr int LDS_A = NL * (NT / 4) * AROW;      // one ring slot (whole passes of the block: no predicated writes)
+  static constexpr int CIN = NCH * KC, SCIN = NSK * KC;
+  static constexpr int LDS_TAB = (2 * CIN + CO) * 4;      // GN scale, GN shift, (bias + temb bias) * out_scale
+  static constexpr int LDS_DESC = NL * NT * 4;
+  static constexpr int NPH = NCH + NSK;                   // phases (chunks) per tile
+  static constexpr int NKS = NCH * 18 + NSK * 2;          // k-steps = weight fragments per wave
+  static constexpr int NWL = rw_lds_ksteps(NCH, RPW, NSK), NWR = NKS - NWL;  // fragments in LDS / in registers
+  static constexpr int LDS_WL = NWL * 2 * 64 * 16;        // [k-step][cout group][lane] x 16 B
+  static constexpr int OFF_TAB = 2 * LDS_A, OFF_WL = OFF_TAB + ((LDS_TAB + 15) & ~15), OFF_DESC = OFF_WL + LDS_WL;
+  static constexpr int LDS_TOTAL = OFF_DESC + LDS_DESC;
+  // chunk of phase P: [0, NCH) = 3x3 chunk, NCH + s = skip chunk s.  The skip chunks sit between the first and the last
+  // 3x3 chunk: a tile's first and last phase are long ones (they carry the epilogue of the other half-tile)
+  static constexpr int chunk_of(int P) { return NSK == 0 ? P : (P == 0 ? 0 : (P <= NSK ? NCH + P - 1 : P - NSK)); }
+  static_assert(NPH % 2 == 0, "the ring slot of a chunk must not depend on the tile");
+  static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget of one CU");
+  static_assert(NT * 36 * 4 <= LDS_TOTAL, "the statistics reduce reuses the block's LDS");
+};
+
+// GN affine + SiLU on 8 bf16 channels.  sc / sh: the affine; sm / hm: the same affine times -log2(e) (the argument of
+// the sigmoid's exp2), so that z and the exponent come from two independent FMAs
+template <int MODE>
+__device__ inline u32x4_t act8(const u32x4_t& u, const float* sc, const float* sh, const float* sm, const float* hm) {
+  float f[8];
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float z = fmaf(f[j], sc[j], sh[j]);
+    if (MODE == 2) {
+      const float e = __builtin_amdgcn_exp2f(fmaf(f[j], sm[j], hm[j]));
+      f[j] = z * __builtin_amdgcn_rcpf(1.0f + e);
+    } else {
+      f[j] = z;
+    }
+  }
+  u32x4_t o;
+  o.x = pack_bf16x2(f[0], f[1]);
+  o.y = pack_bf16x2(f[2], f[3]);
+  o.z = pack_bf16x2(f[4], f[5]);
+  o.w = pack_bf16x2(f[6], f[7]);
+  return o;
+}
+
+// NCH: 32-channel chunks of the 3x3 input (2: 64 channels, 4: 128 = one or two sources); RPW: pixel rows per wave
+// (tile = 2 RPW x 32); NSK: 32-channel chunks of the folded 1x1 skip (0, 2, 4); MODE: 0 raw input, 2 GroupNorm + SiLU
+template <int NCH, int RPW, int NSK, int MODE>
+__global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
+  using G = RwGeom<NCH, RPW, NSK>;
+  constexpr int TH = G::TH, HP = G::HP, LDS_A = G::LDS_A, NL = G::NL, NPH = G::NPH, NKS = G::NKS, CIN = G::CIN, NWR = G::NWR;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  float* sTab = reinterpret_cast<float*>(smem + G::OFF_TAB);
+  int* sDesc = reinterpret_cast<int*>(smem + G::OFF_DESC);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, h = lane >> 5;
+  const int cg = wave & 1, pg = wave >> 1;
+  const int b = blockIdx.x / p.G, part = blockIdx.x % p.G;
+  const int t0 = (int)((long)part * p.tiles_per_img / p.G);
+  const int nt = (int)((long)(part + 1) * p.tiles_per_img / p.G) - t0;
+  RT_DECL
+
+  // ---- tables: GroupNorm scale / shift of image b, bias; staging descriptors
+  for (int c = tid; c < CIN; c += NT) {
+    float sc = 1.f, sh = 0.f;
+    if (p.gn_acc1) {  // statistics straight from the producers' channel-sum accumulators
+      const int C1 = p.C1, C2 = CIN - C1;
+      const int cpg = CIN / p.gn_groups, g0 = (c / cpg) * cpg;
+      long long ssum = 0, ssq = 0;
+      for (int j = 0; j < cpg; ++j) {
+        const int cc = g0 + j;
+        const long long* src = cc < C1 ? p.gn_acc1 + ((long)b * C1 + cc) * 2 : p.gn_acc2 + ((long)b * C2 + (cc - C1)) * 2;
+        ssum += src[0];
+        ssq += src[1];
+      }
+      const double mean = (double)ssum * (1.0 / DS_STAT_SUM_SCALE) * (double)p.gn_inv_count;
+      double var = (double)ssq * (1.0 / DS_STAT_SQ_SCALE) * (double)p.gn_inv_count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      sc = (float)(1.0 / sqrt(var + (double)p.gn_eps)) * (p.gn_gamma ? p.gn_gamma[c] : 1.f);
+      sh = (p.gn_beta ? p.gn_beta[c] : 0.f) - (float)mean * sc;
+    } else if (p.gn_scale) {
+      sc = p.gn_scale[(long)b * CIN + c];
+      sh = p.gn_shift[(long)b * CIN + c];
+    }
+    sTab[c] = sc;
+    sTab[CIN + c] = sh;
+  }
+  if (tid < CO)
+    sTab[2 * CIN + tid] =
+        ((p.bias ? p.bias[tid] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + tid] : 0.f)) * p.out_scale;
+  const int slot = tid & 3;
+  // staging pieces of this thread: piece k = halo pixel (tid >> 2) + 64 k, 16-byte slot tid & 3.  Relative pixel index
+  // in LDS (read one k-step ahead of its use), 5 flag bits per piece in two registers: bits 0..3 = the piece lies in the
+  // top / bottom / left / right halo line, bit 4 = beyond the halo tile
+  unsigned fl0 = 0, fl1 = 0;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int v = tid + NT * k;
+    const int pix = v >> 2, hy = pix / HW_, hx = pix - hy * HW_;
+    const unsigned flg = pix < HP ? (hy == 0 ? 1u : 0u) | (hy == G::HH_ - 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == HW_ - 1 ? 8u : 0u) : 16u;
+    sDesc[k * NT + tid] = pix < HP ? (hy - 1) * p.W + (hx - 1) : 0;
+    if (k < 6) fl0 |= flg << (5 * k); else fl1 |= flg << (5 * (k - 6));
+  }
+  const int ldo0 = (tid >> 2) * AROW + slot * 16;  // piece k is NT / 4 = 64 pixels further
+
+  const int M = p.H * p.W;
+  const __amdgpu_buffer_rsrc_t rx1 = rsrc(p.x + (long)b * p.x_bs, (unsigned)M * p.ldx * 2u);
+  const __amdgpu_buffer_rsrc_t rx2 = p.x2 ? rsrc(p.x2 + (long)b * p.x2_bs, (unsigned)M * p.ldx2 * 2u) : rx1;
+  const __amdgpu_buffer_rsrc_t rs1 = NSK ? rsrc(p.sx + (long)b * p.sx_bs, (unsigned)M * p.ldsx * 2u) : rx1;
+  const __amdgpu_buffer_rsrc_t rs2 = (NSK && p.sx2) ? rsrc(p.sx2 + (long)b * p.sx2_bs, (unsigned)M * p.ldsx2 * 2u) : rs1;
+  const __amdgpu_buffer_rsrc_t ry = rsrc(p.y + (long)b * p.y_bs, (unsigned)M * p.ldy * 2u);
+
+  // ---- this wave's weight fragments: cout cg * 32 + l32, k-step (chunk, tap, kb): channels 32 chunk + 16 kb + 8 h ..
+  u32x4_t wf[NWR > 0 ? NWR : 1];
+  char* sWl = smem + G::OFF_WL + (cg * 64 + lane) * 16;  // + (ks - NWR) * 2048
+  auto put_w = [&](int ks, const u32x4_t& v) __attribute__((always_inline)) {
+    if (ks < NWR) wf[ks] = v;
+    else if (pg == 0) *reinterpret_cast<u32x4_t*>(sWl + (ks - NWR) * 2048) = v;
+  };
+  auto load_weights = [&]() __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rw = rsrc(p.w, 9u * CO * CIN * 2u);
+    const __amdgpu_buffer_rsrc_t rsw = (NSK && p.sw) ? rsrc(p.sw, (unsigned)CO * G::SCIN * 2u) : rsrc(p.w, 0u);
+    const int co = cg * 32 + l32;
+    // 3x3: [64][9][Cin]: (co * 9 + tap) * Cin + ch; chunk-major [Cin/32][9][64][32]: ((c * 9 + tap) * 64 + co) * 32 + ch % 32
+    const bool wc = p.w_chunked != 0;  // (uniform: the per-fragment part of the offset is a scalar select)
+    const unsigned vlane = wc ? (unsigned)((co * KC + h * 8) * 2) : (unsigned)((co * 9 * CIN + h * 8) * 2);
+    // skip: [64][sCin]: co * sCin + ch; chunk-major [sCin/kc][64][kc] (kc >= 16: a 16-channel k-block never straddles a
+    // layout chunk): ((ch / kc) * 64 + co) * kc + ch % kc
+    const bool sc_ = NSK && p.sw_chunked != 0;
+    const int kcs = sc_ ? p.sw_chunked : 16;
+    const unsigned vl2 = sc_ ? (unsigned)((co * kcs + h * 8) * 2) : (unsigned)((co * G::SCIN + h * 8) * 2);
+    auto load_one = [&](int ks) __attribute__((always_inline)) {
+      if (ks < NCH * 18) {
+        const int c = ks / 18, tap = (ks % 18) / 2, kb = ks % 2;
+        const unsigned so = wc ? (unsigned)(((c * 9 + tap) * CO * KC + kb * 16) * 2) : (unsigned)((tap * CIN + c * KC + kb * 16) * 2);
+        put_w(ks, ld16(rw, vlane, so));
+      } else {
+        const int k2 = ks - NCH * 18;
+        const unsigned so = sc_ ? (unsigned)(((((k2 * 16) >> p.sw_shift) * CO) * kcs + ((k2 * 16) & (kcs - 1))) * 2) : (unsigned)(k2 * 16 * 2);
+        u32x4_t f = ld16(rsw, vl2, so);
+        if (!p.sw) {  // residual as a skip with identity weights: channel 16 k2 + 8 h + j feeds cout co with weight 1
+          const int d = co - (16 * k2 + 8 * h);  // the lane's 8 channels hold the 1 at position d (if 0 <= d < 8)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[e] = d == 2 * e ? 0x3f80u : (d == 2 * e + 1 ? 0x3f800000u : 0u);
+        }
+        put_w(ks, f);
+      }
+    };
+    // the LDS-resident fragments first: they have to be written before the block's first barrier
+#pragma unroll
+    for (int ks = NWR; ks < NKS; ++ks) load_one(ks);
+#pragma unroll
+    for (int ks = 0; ks < NWR; ++ks) load_one(ks);
+  };
+
+  // ---- staging state: pa[] holds the chunk AFTER the one in LDS (in flight or landed)
+  u32x4_t pa[NL];
+  // geometry of the tile a chunk belongs to (wave-uniform): first pixel, border mask (which halo lines lie outside
+  // the image); tiles past the block's range get a pixel index beyond every tensor (the hardware returns zeros)
+  struct TileG { int pix0; unsigned edge; };
+  auto tile_geom = [&](int i) {
+    TileG g;
+    const int t = t0 + i;
+    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+    g.edge = (y0 == 0 ? 1u : 0u) | (y0 + TH == p.H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + TW == p.W ? 8u : 0u);
+    g.pix0 = i < nt ? y0 * p.W + x0 : 0x3fffff;
+    return g;
+  };
+  // piece k of a chunk of type P is valid (inside the image / an interior pixel for the skip chunks)
+  auto piece_ok = [&](auto P_, const TileG& g, int k) __attribute__((always_inline)) {
+    constexpr int P = decltype(P_)::value;
+    const unsigned em = (P < NCH ? (g.edge | 16u) : 31u) << (5 * (k < 6 ? k : k - 6));  // (scalar)
+    return ((k < 6 ? fl0 : fl1) & em) == 0u;
+  };
+  // source of chunk P (compile time): descriptor, pixel pitch in bytes, byte offset of this thread's 8 channels
+  auto issue_one = [&](auto P_, const TileG& g, int k, int rel) __attribute__((always_inline)) {
+    constexpr int P = decltype(P_)::value;
+    constexpr bool CONV = P < NCH;
+    constexpr int CB = (CONV ? P : P - NCH) * KC;
+    const int c1 = CONV ? p.C1 : p.sC1;
+    const bool second = CB >= c1;  // (wave-uniform)
+    const unsigned ld2 = (unsigned)(CONV ? (second ? p.ldx2 : p.ldx) : (second ? p.ldsx2 : p.ldsx)) * 2u;
+    const unsigned co2 = (unsigned)((second ? CB - c1 : CB) * 2) + (unsigned)slot * 16u;
+    const __amdgpu_buffer_rsrc_t r = CONV ? (second ? rx2 : rx1) : (second ? rs2 : rs1);
+    const unsigned off = __umul24((unsigned)(rel + g.pix0), ld2) + co2;
+    pa[k] = ld16(r, piece_ok(P_, g, k) ? off : OOB, 0);
+  };
+  float gsc[8], gsh[8];
+  auto act_tab = [&](int c) __attribute__((always_inline)) {  // scale / shift of this thread's 8 channels of chunk c
+    if constexpr (MODE != 0) {
+      const float4* ts = reinterpret_cast<const float4*>(sTab + c * KC + slot * 8);
+      const float4* th = reinterpret_cast<const float4*>(sTab + CIN + c * KC + slot * 8);
+      const float4 s0 = ts[0], s1 = ts[1], h0 = th[0], h1 = th[1];
+      gsc[0] = s0.x; gsc[1] = s0.y; gsc[2] = s0.z; gsc[3] = s0.w; gsc[4] = s1.x; gsc[5] = s1.y; gsc[6] = s1.z; gsc[7] = s1.w;
+      gsh[0] = h0.x; gsh[1] = h0.y; gsh[2] = h0.z; gsh[3] = h0.w; gsh[4] = h1.x; gsh[5] = h1.y; gsh[6] = h1.z; gsh[7] = h1.w;
+    }
+  };
+  // Staging runs in UNITS of one dword (two channels) so that its VALU work spreads evenly over the k-steps of a phase:
+  // unit u = dword u & 3 of piece u >> 2.  The piece's last unit writes it to the ring and re-issues its registers as
+  // the load of the chunk after next.
+  u32x4_t so;  // the piece being assembled
+  auto unit = [&](auto P1_, auto P2_, const TileG& g1, const TileG& g2, int sl, int u, int rel) __attribute__((always_inline)) {
+    constexpr int P1 = decltype(P1_)::value;
+    const int k = u >> 2, d = u & 3;
+    const unsigned w = pa[k][d];
+    if constexpr (P1 < NCH && MODE != 0) {
+      const float lo = __uint_as_float(w << 16), hi = __uint_as_float(w & 0xffff0000u);
+      float z0 = fmaf(lo, gsc[2 * d], gsh[2 * d]), z1 = fmaf(hi, gsc[2 * d + 1], gsh[2 * d + 1]);
+      if (MODE == 2) {
+        const float e0 = __builtin_amdgcn_exp2f(z0 * -1.4426950408889634f);
+        const float e1 = __builtin_amdgcn_exp2f(z1 * -1.4426950408889634f);
+        z0 *= __builtin_amdgcn_rcpf(1.0f + e0);
+        z1 *= __builtin_amdgcn_rcpf(1.0f + e1);
+      }
+      so[d] = pack_bf16x2(z0, z1);
+    } else {
+      so[d] = w;
+    }
+    if (d == 3) {
+      if constexpr (P1 < NCH && MODE != 0) {  // zero padding stays zero (silu(GN(0)) != 0)
+        const bool ok = piece_ok(P1_, g1, k);
+        so.x = ok ? so.x : 0u;
+        so.y = ok ? so.y : 0u;
+        so.z = ok ? so.z : 0u;
+        so.w = ok ? so.w : 0u;
+      }
+      *reinterpret_cast<u32x4_t*>(sA + sl * LDS_A + ldo0 + k * (NT / 4) * AROW) = so;
+      issue_one(P2_, g2, k, rel);
+    }
+  };
+
+  f32x16 acc[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+  float ssum[16], ssq[16];  // per lane: its 16 couts (8 q + 4 h + i), summed over its pixels
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+  constexpr int RES_AHEAD = 2;  // residual rows requested ahead of the row being finished
+  const bool has_stats = p.stats != nullptr;
+  const float osc = p.out_scale;
+  // fragment base of this lane: pixel (row pg * RPW, column l32) of the halo tile, k-half h
+  const int fbase = (pg * RPW * HW_ + l32) * AROW + h * 16;
+
+  // ---- epilogue of one tile, in the accumulator layout (no LDS): lane (pixel l32, half h) holds, per row, the cout
+  // quads 8 q + 4 h .. + 3 of the wave's 32 couts.  A 16-byte load / store of a lane covers couts 16 j + 8 h .. + 7 of its
+  // pixel; two v_permlane32_swap per 16 bytes turn that into the two quads (q = 2 j, 2 j + 1) of the lane and back.
+  auto swap_halves = [&](u32x4_t& v) __attribute__((always_inline)) {
+    auto r0 = __builtin_amdgcn_permlane32_swap(v.x, v.z, false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
+    v.x = r0[0]; v.z = r0[1]; v.y = r1[0]; v.w = r1[1];
+  };
+  // ---- epilogue work in UNITS of half a row (8 couts of the lane's pixel): bias, statistics, packing, one 16-byte
+  // store.  (There are no loads in the epilogue: a residual rides through the ring as two raw chunks that meet identity
+  // fragments — see the launcher.  vmcnt retires in order and counts stores: residual rows loaded between the stores
+  // were measured waiting for the acknowledgement of every earlier store, 1350 cycles per row on an idle chip.)
+  auto epi_unit = [&](const TileG& g, int r, int j) __attribute__((always_inline)) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {  // (bias + temb bias) * out_scale of the quad's couts: an LDS broadcast read
+      const float4 t = *reinterpret_cast<const float4*>(sTab + 2 * CIN + cg * 32 + 8 * (2 * j + q) + 4 * h);
+      v[4 * q] = fmaf(acc[r][8 * j + 4 * q], osc, t.x);
+      v[4 * q + 1] = fmaf(acc[r][8 * j + 4 * q + 1], osc, t.y);
+      v[4 * q + 2] = fmaf(acc[r][8 * j + 4 * q + 2], osc, t.z);
+      v[4 * q + 3] = fmaf(acc[r][8 * j + 4 * q + 3], osc, t.w);
+    }
+    // (always taken: a branch here would cut the half-phase's instruction stream into separately scheduled pieces)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ssum[8 * j + e] += v[e];
+      ssq[8 * j + e] = fmaf(v[e], v[e], ssq[8 * j + e]);
+    }
+    u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    swap_halves(ov);
+    const int pix = g.pix0 + (pg * RPW + r) * p.W + l32;
+    __builtin_amdgcn_raw_buffer_store_b128(ov, ry, __umul24((unsigned)pix, (unsigned)p.ldy * 2u) + (unsigned)((cg * 32 + 16 * j + 8 * h) * 2), 0, 0);
+  };
+
+  // ---- one HALF of a phase: the MFMAs of chunk (phase P, ring slot P & 1) for the wave's rows [HF * RH, HF * RH + RH),
+  // interleaved k-step by k-step with (i) its share of the staging of the next phase's chunk and of the loads of the
+  // chunk after that, (ii) EPI: the epilogue of the OTHER half's rows — rows [RH, RPW) of the previous tile during the
+  // first half of phase 0, rows [0, RH) of this tile during the second half of the last phase.  The epilogue of one half
+  // of the accumulators thus always runs under the MFMAs of the other half: no second accumulator set, no phase in
+  // which all waves of the chip store at once.
+  constexpr int RH = RPW / 2;
+  auto half = [&](auto P_, auto HF_, auto EPI_, const TileG& ge, const TileG& g1, const TileG& g2) __attribute__((always_inline)) {
+    constexpr int P = decltype(P_)::value, HF = decltype(HF_)::value;
+    constexpr bool EPI = decltype(EPI_)::value;
+    constexpr int C = G::chunk_of(P);
+    constexpr bool CONV = C < NCH;
+    constexpr int NK = CONV ? 18 : 2;
+    constexpr int W0 = CONV ? C * 18 : NCH * 18 + (C - NCH) * 2;
+    constexpr int C1 = G::chunk_of((P + 1) % NPH), C2 = G::chunk_of((P + 2) % NPH);
+    constexpr int SL = P & 1;
+    constexpr int NU = NL * 4, NE = RH * 2;
+    constexpr int R0 = HF * RH, ER0 = HF ? 0 : RH;
+    const char* fb = sA + SL * LDS_A + fbase + R0 * HW_ * AROW;
+    if constexpr (HF == 0 && C1 < NCH) act_tab(C1);
+    auto ldb = [&](int ks, int r) __attribute__((always_inline)) {
+      const int tap = CONV ? ks / 2 : 4, kb = ks % 2;
+      const int dy = tap / 3, dx = tap % 3;
+      return *reinterpret_cast<const u32x4_t*>(fb + ((r + dy) * HW_ + dx) * AROW + kb * 32);
+    };
+    // pixel fragments: two k-steps in flight (a read is issued 2 RH MFMAs ahead of its use)
+    u32x4_t bf[2][RH];
+#pragma unroll
+    for (int r = 0; r < RH; ++r) bf[0][r] = ldb(0, r);
+#pragma unroll
+    for (int r = 0; r < RH; ++r) bf[1][r] = ldb(1, r);
+    // weight fragment of k-step ks: a register, or (the last NWL k-steps) an LDS read issued one k-step ahead
+    u32x4_t wl = {0, 0, 0, 0}, wln = {0, 0, 0, 0};
+    if constexpr (W0 >= NWR) wl = *reinterpret_cast<const u32x4_t*>(sWl + (W0 - NWR) * 2048);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      const int sl = HF * NK + ks;  // slot of this k-step in the phase's staging schedule
+      const int u0 = sl * NU / (2 * NK), u1 = (sl + 1) * NU / (2 * NK);
+      const int e0 = EPI ? ks * NE / NK : 0, e1 = EPI ? (ks + 1) * NE / NK : 0;
+      // relative pixel indices of the pieces that complete in this k-step (read ahead of the MFMAs, used after them)
+      int rels[NL];
+#pragma unroll
+      for (int u = u0; u < u1; ++u)
+        if ((u & 3) == 3) rels[u >> 2] = sDesc[(u >> 2) * NT + tid];
+      if (W0 + ks + 1 >= NWR && ks + 1 < NK) wln = *reinterpret_cast<const u32x4_t*>(sWl + (W0 + ks + 1 - NWR) * 2048);
+      const u32x4_t wk = W0 + ks < NWR ? wf[W0 + ks < NWR ? W0 + ks : 0] : wl;
+#pragma unroll
+      for (int r = 0; r < RH; ++r) {
+        if (P == 0 && ks == 0) {  // a tile's first MFMA of a row starts from zero (the row's epilogue has run)
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[R0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wk),
+                                                                __builtin_bit_cast(bf16x8, bf[ks & 1][r]), zero, 0, 0, 0);
+        } else {
+          acc[R0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wk),
+                                                                __builtin_bit_cast(bf16x8, bf[ks & 1][r]), acc[R0 + r], 0, 0, 0);
+        }
+        if (ks + 2 < NK) bf[ks & 1][r] = ldb(ks + 2, r);
+      }
+      wl = wln;
+#pragma unroll
+      for (int u = u0; u < u1; ++u)
+        unit(std::integral_constant<int, C1>{}, std::integral_constant<int, C2>{}, g1, g2, SL ^ 1, u, (u & 3) == 3 ? rels[u >> 2] : 0);
+#pragma unroll
+      for (int e = e0; e < e1; ++e) epi_unit(ge, ER0 + (e >> 1), e & 1);
+      // the k-step's instruction mix, spread evenly: every MFMA (32 cycles on the matrix pipe) is followed by its share
+      // of the VALU work and one fragment read, so that neither pipe waits for the other
+      {
+        constexpr int VPU = (C1 < NCH && MODE == 2) ? 17 : 1;   // VALU per staging unit
+        constexpr int NV = (NU * VPU + NL * 10 + 2 * NK - 1) / (2 * NK) + 4 + (EPI ? (NE * 36 + NK - 1) / NK : 0);  // VALU of an average k-step
+#pragma unroll
+        for (int r = 0; r < RH; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, (NV + RH - 1) / RH, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- prologue: the first phase's chunk into slot 0, the second phase's chunk in flight
+  TileG gc = tile_geom(0);
+  constexpr int CH0 = G::chunk_of(0), CH1 = G::chunk_of(1);
+  {
+    // the first chunk's loads go out ahead of the weights (loads return in order: the tile can be staged while the
+    // weight fragments are still streaming in; the MFMAs then wait for them fragment by fragment)
+#pragma unroll
+    for (int k = 0; k < NL; ++k) issue_one(std::integral_constant<int, CH0>{}, gc, k, sDesc[k * NT + tid]);
+    load_weights();
+    sync_lds();  // tables (and the LDS-resident weight fragments) visible
+    act_tab(CH0);
+    // (staging the first chunk re-issues every piece as the second one)
+#pragma unroll
+    for (int u = 0; u < NL * 4; ++u)
+      unit(std::integral_constant<int, CH0>{}, std::integral_constant<int, CH1>{}, gc, gc, 0, u, sDesc[(u >> 2) * NT + tid]);
+  }
+  RT_MARK(0)
+  TileG gp = tile_geom(nt);  // "previous tile" of the first one: no tile (its stores fall outside every tensor)
+  for (int i = 0; i < nt; ++i) {
+    const TileG gn = tile_geom(i + 1);
+    // phase P stages the chunk of phase P + 1 and issues that of phase P + 2: both belong to the next tile once they wrap
+    auto run = [&](auto self, auto P_) __attribute__((always_inline)) {
+      constexpr int P = decltype(P_)::value;
+      sync_lds();
+      RT_MARK(1)
+      half(P_, std::integral_constant<int, 0>{}, std::integral_constant<bool, P == 0>{}, gp, (P + 1 < NPH ? gc : gn), (P + 2 < NPH ? gc : gn));
+      if constexpr (P == 0) {
+        if (i == 0) {  // (the first tile has no predecessor: what that epilogue summed up was not an output)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+        }
+      }
+      half(P_, std::integral_constant<int, 1>{}, std::integral_constant<bool, P == NPH - 1>{}, gc, (P + 1 < NPH ? gc : gn), (P + 2 < NPH ? gc : gn));
+      RT_MARK(G::chunk_of(P) < NCH ? 2 : 3)
+      if constexpr (P + 1 < NPH) self(self, std::integral_constant<int, P + 1>{});
+    };
+    run(run, std::integral_constant<int, 0>{});
+    gp = gc;
+    gc = gn;
+  }
+  // the second half of the last tile's rows
+#pragma unroll
+  for (int e = 0; e < RH * 2; ++e) epi_unit(gp, RH + (e >> 1), e & 1);
+  RT_MARK(4)
+  if (has_stats) {
+    __syncthreads();
+    // per lane 16 couts (cg * 32 + 8 q + 4 h + i) of pixel column l32 of its rows: sum over the 32 columns and the two
+    // pixel groups
+    float* red = reinterpret_cast<float*>(smem);  // [256 threads][32 (+4 pad)]
+    constexpr int RED_ROW = 36;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<float4*>(red + tid * RED_ROW + 4 * q) = make_float4(ssum[4 * q], ssum[4 * q + 1], ssum[4 * q + 2], ssum[4 * q + 3]);
+      *reinterpret_cast<float4*>(red + tid * RED_ROW + 16 + 4 * q) = make_float4(ssq[4 * q], ssq[4 * q + 1], ssq[4 * q + 2], ssq[4 * q + 3]);
+    }
+    __syncthreads();
+    if (tid < 2 * CO) {
+      const int co = tid >> 1, st = tid & 1;
+      const int wcg = co >> 5, c32 = co & 31, q = c32 >> 3, hh = (c32 >> 2) & 1, i = c32 & 3;
+      double a = 0.0;
+      for (int wpg = 0; wpg < 2; ++wpg)
+        for (int l = 0; l < 32; ++l) {
+          const int t = (wpg * 2 + wcg) * 64 + hh * 32 + l;
+          a += (double)red[t * RED_ROW + st * 16 + 4 * q + i];
+        }
+      ds_stat_add(p.stats + ((long)b * CO + co) * 2 + st, (long long)llrint(a * (st ? DS_STAT_SQ_SCALE : DS_STAT_SUM_SCALE)));
+    }
+  }
+  RT_MARK(5)
+  RT_FLUSH
+}
+
+int rw_blocks_per_image(const ConvArgs& a, int tiles) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  int g = cus / a.B;
+#ifdef RW_TIMING  // (experiments: fewer, fatter blocks)
+  if (getenv("DIFFSEP_RW_G")) g = atoi(getenv("DIFFSEP_RW_G"));
+#endif
+  if (g < 1) g = 1;
+  if (g > tiles) g = tiles;
+  return g;
+}
+
+template <int NCH, int RPW, int NSK, int MODE>
+int rw_launch(const RwK& k0, const ConvArgs& a, hipStream_t st) {
+  using G = RwGeom<NCH, RPW, NSK>;
+  RwK k = k0;
+  const int tiles = (a.H / G::TH) * (a.W / TW);
+  k.G = rw_blocks_per_image(a, tiles);
+  k.tiles_x = a.W / TW;
+  k.tiles_per_img = tiles;
+  auto kern = conv3x3_rw_kernel<NCH, RPW, NSK, MODE>;
+  DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_TOTAL));
+  hipLaunchKernelGGL(kern, dim3(a.B * k.G), dim3(NT), G::LDS_TOTAL, st, k);
+  DS_LAUNCH_CHECK();
+  {
+    static char name[64] = {0};
+    if (!name[0]) snprintf(name, sizeof(name), "conv3x3_rw_kernel<%d,%d,%d,%d>", NCH, RPW, NSK, MODE);
+    ds_set_last_conv_kernel(name);
+  }
+  return 0;
+}
+
+int rw_rows_per_wave(const ConvArgs& a) { return (a.Cin == 64 && a.H % 16 == 0) ? 8 : 4; }
+
+}  // namespace
+
+// The layers this kernel takes over: bf16 3x3, 64 couts, 64 or 128 input channels (one tensor or the in-place concat of
+// two), input raw or GroupNorm + SiLU, optional folded 1x1 skip on 64 / 128 raw channels, whole tiles.
+bool ds_conv_rw_eligible(const ConvArgs& a) {
+  if (getenv("DIFFSEP_NO_RW")) return false;
+  if (!(a.dtype == DS_BF16 && a.taps == 9 && (a.Cin == 64 || a.Cin == 128) && a.Cout == CO && a.w_bs == 0 &&
+        (a.w_chunked == 0 || a.w_chunked == KC) && a.bias_mode == 0 && !a.div_b && a.W % TW == 0 && a.H % 8 == 0 &&
+        a.H >= 32 && a.W >= 32 && a.ldy >= CO && a.ldy % 8 == 0 && (!a.res || (a.ldr >= CO && a.ldr % 8 == 0))))
+    return false;
+  if (a.x2 ? !(a.C1 % KC == 0 && a.C1 > 0 && a.C1 < a.Cin && a.ldx % 8 == 0 && a.ldx2 % 8 == 0) : a.ldx % 8 != 0) return false;
+  const bool gn = a.gn_scale || a.gn_acc1;
+  if (gn && !a.gn_act) return false;  // (affine without SiLU does not occur in front of a 3x3 convolution)
+  if (a.gn_acc1 && !(a.gn_groups > 0 && a.Cin % a.gn_groups == 0 && (!a.x2 || a.gn_acc2))) return false;
+  if (a.sx) {
+    if (!(a.sw && !a.res && (a.sCin == 64 || a.sCin == 128) && a.ldsx % 8 == 0 &&
+          (!a.sx2 || (a.sC1 % KC == 0 && a.sC1 > 0 && a.sC1 < a.sCin && a.ldsx2 % 8 == 0)) &&
+          (a.sw_chunked == 0 || ((a.sw_chunked & (a.sw_chunked - 1)) == 0 && a.sw_chunked >= 16))))
+      return false;
+    if (a.Cin == 128) return false;  // (no layer of the network has both; the register file would not hold it either)
+  }
+  if (a.res && a.Cin == 128) return false;  // (the residual rides as a skip: same limit)
+  // measured (tools/rw_bench.py): with a residual the two short identity-skip phases cost more than they save against
+  // the weight-stationary kernel (163 vs 145 us at 256^2): those launches (Conv_1 of the plain blocks) stay there
+  if (a.res && !getenv("DIFFSEP_RW_RES")) return false;
+  return true;
+}
+
+int ds_launch_conv_rw(const ConvArgs& a, hipStream_t st) {
+  RwK k;
+  k.x = reinterpret_cast<const bf16_t*>(a.x); k.x_bs = a.x_bs; k.ldx = a.ldx; k.C1 = a.x2 ? a.C1 : a.Cin;
+  k.x2 = reinterpret_cast<const bf16_t*>(a.x2); k.x2_bs = a.x2_bs; k.ldx2 = a.x2 ? a.ldx2 : a.ldx;
+  k.w = reinterpret_cast<const bf16_t*>(a.w); k.w_chunked = a.w_chunked;
+  k.gn_scale = a.gn_scale; k.gn_shift = a.gn_shift;
+  k.gn_acc1 = a.gn_acc1; k.gn_acc2 = a.gn_acc2; k.gn_gamma = a.gn_gamma; k.gn_beta = a.gn_beta;
+  k.gn_groups = a.gn_groups; k.gn_inv_count = a.gn_inv_count; k.gn_eps = a.gn_eps;
+  k.bias = a.bias; k.bias_b = a.bias_b; k.bias_b_ld = a.bias_b_ld;
+  k.res = reinterpret_cast<const bf16_t*>(a.res); k.res_bs = a.res_bs; k.ldr = a.ldr;
+  k.out_scale = a.out_scale;
+  k.y = reinterpret_cast<bf16_t*>(a.y); k.y_bs = a.y_bs; k.ldy = a.ldy;
+  k.stats = a.stats_acc;
+  k.sx = reinterpret_cast<const bf16_t*>(a.sx); k.sx_bs = a.sx_bs; k.ldsx = a.ldsx; k.sC1 = a.sx2 ? a.sC1 : a.sCin;
+  k.sx2 = reinterpret_cast<const bf16_t*>(a.sx2); k.sx2_bs = a.sx2_bs; k.ldsx2 = a.sx2 ? a.ldsx2 : a.ldsx;
+  k.sw = reinterpret_cast<const bf16_t*>(a.sw); k.sw_chunked = a.sw_chunked; k.sw_shift = a.sw_chunked ? __builtin_ctz(a.sw_chunked) : 0;
+  k.sCin = a.sCin;
+  k.H = a.H; k.W = a.W; k.G = 0; k.tiles_x = 0; k.tiles_per_img = 0;
+  if (a.res) {  // the residual [B][H][W][64] as a folded skip with identity weights (sw = null): exact in the fp32 accumulators
+    k.sx = reinterpret_cast<const bf16_t*>(a.res); k.sx_bs = a.res_bs; k.ldsx = a.ldr; k.sC1 = CO;
+    k.sx2 = nullptr; k.sx2_bs = 0; k.ldsx2 = a.ldr; k.sw = nullptr; k.sw_chunked = 0; k.sw_shift = 0; k.sCin = CO;
+  }
+  const int mode = ((a.gn_scale || a.gn_acc1) && a.gn_act) ? 2 : 0;
+  const int nsk = a.sx ? a.sCin / KC : (a.res ? 2 : 0);
+  const int rpw = rw_rows_per_wave(a);
+#define RW_GO(NCH_, RPW_, NSK_) return mode == 2 ? rw_launch<NCH_, RPW_, NSK_, 2>(k, a, st) : rw_launch<NCH_, RPW_, NSK_, 0>(k, a, st)
+  if (a.Cin == 128) RW_GO(4, 4, 0);
+  if (rpw == 8) {
+    if (nsk == 0) RW_GO(2, 8, 0);
+    if (nsk == 2) RW_GO(2, 8, 2);
+    RW_GO(2, 8, 4);
+  }
+  if (nsk == 0) RW_GO(2, 4, 0);
+  if (nsk == 2) RW_GO(2, 4, 2);
+  RW_GO(2, 4, 4);
+#undef RW_GO
+}

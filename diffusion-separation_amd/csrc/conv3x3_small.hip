@@ -548,6 +548,11 @@ int launch_small(const SmK& k, const ConvArgs& a, hipStream_t st) {
   }
   dim3 grid(k.tiles_x * cdiv(a.H, SmTile<GW>::THT), a.Cout / NS, a.B);
   hipLaunchKernelGGL((conv3x3_small_kernel<GW, PC, NS, MODE, ESZ>), grid, dim3(SmTile<GW>::NT), LDS, st, k);
+  {
+    static char name[64] = {0};
+    if (!name[0]) snprintf(name, sizeof(name), "conv3x3_small_kernel<%d,%d,%d,%d,%d>", GW, PC, NS, MODE, ESZ);
+    ds_set_last_conv_kernel(name);
+  }
   DS_LAUNCH_CHECK();
   return 0;
 }

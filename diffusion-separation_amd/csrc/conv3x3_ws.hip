@@ -877,6 +877,7 @@ int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st) {
       attr_done = true;                                                                                            \
     }                                                                                                              \
     hipLaunchKernelGGL((conv3x3_ws1_kernel<M_, S_>), grid, block, LDS_TOTAL, st, k);                               \
+    ds_set_last_conv_kernel("conv3x3_ws1_kernel<" #M_ "," #S_ ">");                                                \
   } while (0)
   if (skb == 8) { if (mode == 1) DS_WS_LAUNCH(1, 8); else DS_WS_LAUNCH(2, 8); }
   else if (skb == 4) { if (mode == 1) DS_WS_LAUNCH(1, 4); else DS_WS_LAUNCH(2, 4); }
@@ -905,6 +906,7 @@ int ds_launch_conv_thin(const ConvArgs& a, hipStream_t st) {
   if (k.G > tiles) k.G = tiles;
   k.tiles_x = a.W / TW; k.tiles_per_img = tiles;
   hipLaunchKernelGGL(conv3x3_thin_in_kernel, dim3(a.B * k.G), dim3(512), THIN_LDS, st, k);
+  ds_set_last_conv_kernel("conv3x3_thin_in_kernel");
   DS_LAUNCH_CHECK();
   return 0;
 }
@@ -941,6 +943,7 @@ int ds_launch_conv_thin_out(const ConvArgs& a, hipStream_t st) {
     attr_done = true;
   }
   hipLaunchKernelGGL(conv3x3_thin_out_kernel, dim3(a.B * k.G), dim3(512), TO_LDS, st, k);
+  ds_set_last_conv_kernel("conv3x3_thin_out_kernel");
   DS_LAUNCH_CHECK();
   return 0;
 }

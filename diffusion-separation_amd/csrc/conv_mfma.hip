@@ -855,8 +855,19 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   grid.z = a.B;
   hipLaunchKernelGGL(kern, grid, dim3(NT), LDS, st, k);
   DS_LAUNCH_CHECK();
+  {
+    static char name[128] = {0};
+    if (!name[0])
+      snprintf(name, sizeof(name), "conv_mfma_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "float", TAPS,
+               TH, TW, BN, WM, WN, KC, EP, OCC, SP, NT);
+    ds_set_last_conv_kernel(name);
+  }
   return 0;
 }
+
+static thread_local const char* g_last_conv_kernel = "";
+const char* ds_last_conv_kernel() { return g_last_conv_kernel; }
+void ds_set_last_conv_kernel(const char* name) { g_last_conv_kernel = name; }
 
 template <typename T, int SP = 0>
 static int launch_typed(const ConvArgs& a, hipStream_t st) {
@@ -910,8 +921,9 @@ int ds_conv_chunk(int taps, int dtype) {
 
 // Which instantiation ds_launch_conv picks (profiling label): 0/1/2 = 3x3 {8x32xBN64, 8x32xBN32, 8x8xBN64},
 // 3/4/5 = the same tiles for 1x1 / GEMM, 6 = the weight-stationary 64 -> 64 kernel (conv3x3_ws.hip), 7 = the
-// small-image kernel (conv3x3_small.hip).
+// small-image kernel (conv3x3_small.hip), 8 = the register-weight kernel (conv3x3_rw.hip).
 int ds_conv_config_id(const ConvArgs& a) {
+  if (ds_conv_rw_eligible(a)) return 8;
   if (ds_conv_ws_eligible(a) || ds_conv_thin_eligible(a) || ds_conv_thin_out_eligible(a)) return 6;
   if (ds_conv_small_eligible(a)) return 7;
   if (a.taps == 9) {
@@ -938,6 +950,7 @@ int ds_launch_conv(const ConvArgs& a, hipStream_t st) {
     DS_CHECK(M * mld * esz < 2147483647L, "conv: image too large for 32-bit buffer offsets");
     DS_CHECK((long)a.Cout * a.taps * a.Cin * esz < 2147483647L, "conv: weight tensor too large");
   }
+  if (ds_conv_rw_eligible(a)) return ds_launch_conv_rw(a, st);
   if (ds_conv_ws_eligible(a)) return ds_launch_conv_ws(a, st);
   if (ds_conv_thin_eligible(a)) return ds_launch_conv_thin(a, st);
   if (ds_conv_thin_out_eligible(a)) return ds_launch_conv_thin_out(a, st);

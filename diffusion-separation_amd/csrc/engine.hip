@@ -351,11 +351,12 @@ struct diffsep_engine {
   int split = 0;
   // optional per-launch timing of the MFMA kernels (HIP events on the launch stream)
   bool prof = false;
-  struct ProfRec { hipEvent_t a, b; double flops, bytes; int cls; };
+  struct ProfRec { hipEvent_t a, b; double flops, bytes; int cls; const char* kernel; int B, H, W, Cin, Cout, taps, sCin, res; float ms; };
+  std::vector<ProfRec> prof_done;  // the records of the last profile_begin .. profile_end span, with their times
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
 };
-#define DS_NCLS 8
+#define DS_NCLS 9
 static hipEvent_t prof_event(diffsep_engine* e) {
   if (!e->ev_pool.empty()) { hipEvent_t v = e->ev_pool.back(); e->ev_pool.pop_back(); return v; }
   hipEvent_t v = nullptr;
@@ -374,9 +375,12 @@ static int conv_launch_prof(diffsep_engine* e, const ConvArgs& a, hipStream_t st
                      ((double)a.taps * a.Cin + (a.sx ? a.sCin : 0)) * a.Cout);
   }
   r.cls = ds_conv_config_id(a);
+  r.B = a.B; r.H = a.H; r.W = a.W; r.Cin = a.Cin; r.Cout = a.Cout; r.taps = a.taps; r.sCin = a.sx ? a.sCin : 0; r.res = a.res != nullptr;
+  r.ms = 0.f;
   hipEventRecord(r.a, st);
   const int rc = ds_launch_conv(a, st);
   hipEventRecord(r.b, st);
+  r.kernel = ds_last_conv_kernel();
   e->prof_recs.push_back(r);
   return rc;
 }
@@ -949,8 +953,9 @@ extern "C" int32_t diffsep_engine_set_graph(diffsep_engine* e, int32_t enable) {
 
 // Per-launch timing of the MFMA contraction kernels inside the real launch sequence: between
 // profile_begin and profile_end every conv/GEMM launch is bracketed by HIP events on its stream
-// (graph replay is bypassed meanwhile).  Arrays have 8 entries: 3x3 {8x32xBN64, 8x32xBN32, 8x8xBN64},
-// then the same three tiles for 1x1/GEMM, the weight-stationary 64 -> 64 3x3 kernel, the small-image 3x3 kernel.  flops = algorithmic 2*taps*Cin*Cout*H*W*B (unpadded).
+// (graph replay is bypassed meanwhile).  Arrays have 9 entries: 3x3 {8x32xBN64, 8x32xBN32, 8x8xBN64},
+// then the same three tiles for 1x1/GEMM, the weight-stationary 64 -> 64 3x3 kernel, the small-image 3x3 kernel, the
+// register-weight 3x3 kernel.  flops = algorithmic 2*taps*Cin*Cout*H*W*B (unpadded).
 extern "C" int32_t diffsep_engine_profile_begin(diffsep_engine* e) {
   DS_CHECK(e, "null engine");
   e->prof = true;
@@ -962,9 +967,12 @@ extern "C" int32_t diffsep_engine_profile_end(diffsep_engine* e, double* flops, 
   DS_CHECK(e && flops && ms && launches, "profile_end: null argument");
   DS_HIP(hipDeviceSynchronize());
   for (int i = 0; i < DS_NCLS; ++i) { flops[i] = 0; ms[i] = 0; launches[i] = 0; if (bytes) bytes[i] = 0; }
+  e->prof_done.clear();
   for (auto& r : e->prof_recs) {
     float t = 0.f;
     hipEventElapsedTime(&t, r.a, r.b);
+    r.ms = t;
+    e->prof_done.push_back(r);
     flops[r.cls] += r.flops;
     if (bytes) bytes[r.cls] += r.bytes;
     ms[r.cls] += t;
@@ -974,6 +982,23 @@ extern "C" int32_t diffsep_engine_profile_end(diffsep_engine* e, double* flops, 
   }
   e->prof_recs.clear();
   e->prof = false;
+  return 0;
+}
+
+// The launches of the last profile_begin .. profile_end span one by one (call after profile_end): kernel instantiation
+// with its template arguments, problem shape, algorithmic flops / bytes, duration.
+extern "C" int32_t diffsep_engine_profile_records(diffsep_engine* e, diffsep_prof_record* out, int32_t cap, int32_t* n) {
+  DS_CHECK(e && n, "profile_records: null argument");
+  *n = (int32_t)e->prof_done.size();
+  if (!out) return 0;
+  for (int i = 0; i < *n && i < cap; ++i) {
+    const auto& r = e->prof_done[i];
+    diffsep_prof_record& o = out[i];
+    memset(&o, 0, sizeof(o));
+    snprintf(o.kernel, sizeof(o.kernel), "%s", r.kernel ? r.kernel : "");
+    o.B = r.B; o.H = r.H; o.W = r.W; o.Cin = r.Cin; o.Cout = r.Cout; o.taps = r.taps; o.skip_cin = r.sCin; o.has_res = r.res;
+    o.cls = r.cls; o.flops = r.flops; o.bytes = r.bytes; o.ms = r.ms;
+  }
   return 0;
 }
 

@@ -35,6 +35,12 @@ class SamplerExt(C.Structure):
                 ("tail_engine", C.c_void_p), ("tail_steps", C.c_int32), ("head_steps", C.c_int32)]
 
 
+class ProfRecord(C.Structure):  # diffsep_prof_record
+    _fields_ = [("kernel", C.c_char * 128), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+                ("Cout", C.c_int32), ("taps", C.c_int32), ("skip_cin", C.c_int32), ("has_res", C.c_int32),
+                ("cls", C.c_int32), ("_pad", C.c_int32), ("flops", C.c_double), ("bytes", C.c_double), ("ms", C.c_double)]
+
+
 class DiffsepError(RuntimeError):
     pass
 
@@ -66,6 +72,7 @@ _SIGS = {
     "diffsep_engine_profile_begin": (_I, [_P]),
     "diffsep_engine_profile_end": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L),
                                         C.POINTER(C.c_double)]),
+    "diffsep_engine_profile_records": (_I, [_P, C.POINTER(ProfRecord), _I, C.POINTER(_I)]),
     "diffsep_upfirdn2d": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "diffsep_groupnorm_act": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _L, _P]),
     "diffsep_conv2d": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),

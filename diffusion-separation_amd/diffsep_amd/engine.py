@@ -90,7 +90,7 @@ class Engine:
         check(lib().diffsep_engine_set_graph(self._h, int(bool(enable))))
 
     CONV_CLASSES = ("conv3x3_8x32xN64", "conv3x3_8x32xN32", "conv3x3_8x8xN64", "gemm1x1_256xN64", "gemm1x1_256xN32",
-                    "gemm1x1_64xN64", "conv3x3_ws_64to64", "conv3x3_small_16couts")
+                    "gemm1x1_64xN64", "conv3x3_ws_64to64", "conv3x3_small_16couts", "conv3x3_rw_regweights")
 
     def profile_begin(self):
         check(lib().diffsep_engine_profile_begin(self._h))
@@ -98,9 +98,22 @@ class Engine:
     def profile_end(self):
         """{class: (algorithmic flops, milliseconds, launches, algorithmic bytes)} of the MFMA kernels since
         profile_begin."""
-        fl, ms, n, by = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int64 * 8)(), (C.c_double * 8)()
+        nc = len(self.CONV_CLASSES)
+        fl, ms, n, by = (C.c_double * nc)(), (C.c_double * nc)(), (C.c_int64 * nc)(), (C.c_double * nc)()
         check(lib().diffsep_engine_profile_end(self._h, fl, ms, n, by))
         return {k: (fl[i], ms[i], int(n[i]), by[i]) for i, k in enumerate(self.CONV_CLASSES)}
+
+    def profile_records(self):
+        """The launches of the last profile_begin .. profile_end span, one dict per launch: kernel instantiation (real
+        template arguments), shape, algorithmic flops / bytes, milliseconds."""
+        from ._lib import ProfRecord
+        n = C.c_int32(0)
+        check(lib().diffsep_engine_profile_records(self._h, None, 0, C.byref(n)))
+        buf = (ProfRecord * max(1, n.value))()
+        check(lib().diffsep_engine_profile_records(self._h, buf, n.value, C.byref(n)))
+        return [dict(kernel=r.kernel.decode(), B=r.B, H=r.H, W=r.W, Cin=r.Cin, Cout=r.Cout, taps=r.taps,
+                     skip_cin=r.skip_cin, has_res=bool(r.has_res), cls=r.cls, flops=r.flops, bytes=r.bytes, ms=r.ms)
+                for r in buf[:n.value]]
 
     def padded_frames(self, T):
         return int(lib().diffsep_padded_frames(C.byref(self.cfg), T))

@@ -182,12 +182,22 @@ int32_t diffsep_pc_sample_ex(diffsep_engine* e, const diffsep_sde_config* sde, c
 int32_t diffsep_engine_set_graph(diffsep_engine* e, int32_t enable);
 
 /* Measurement hook (bench.py): between begin and end every MFMA conv/GEMM launch of the engine is
- * bracketed by HIP events on its launch stream (graph replay bypassed).  Outputs are 8-entry arrays
- * indexed by kernel instantiation: 3x3 {8x32 tile x 64 cout, 8x32 x 32, 8x8 x 64}, then the same
- * tiles for 1x1 / GEMM, the weight-stationary 64 -> 64 3x3 kernel, the small-image 3x3 kernel: summed algorithmic flops, summed milliseconds, launch counts and (bytes, nullable)
+ * bracketed by HIP events on its launch stream (graph replay bypassed).  Outputs are 9-entry arrays
+ * indexed by kernel class: 3x3 {8x32 tile x 64 cout, 8x32 x 32, 8x8 x 64}, then the same
+ * tiles for 1x1 / GEMM, the weight-stationary 64 -> 64 3x3 kernel, the small-image 3x3 kernel, the register-weight
+ * 3x3 kernel (conv3x3_rw.hip): summed algorithmic flops, summed milliseconds, launch counts and (bytes, nullable)
  * summed algorithmic HBM bytes = every operand read once + the output written once. */
 int32_t diffsep_engine_profile_begin(diffsep_engine* e);
 int32_t diffsep_engine_profile_end(diffsep_engine* e, double* flops, double* ms, int64_t* launches, double* bytes);
+/* The launches of that span one by one (call after profile_end; out may be NULL to query *n): the kernel instantiation
+ * with its template arguments, the problem shape, algorithmic flops / bytes and the measured duration. */
+typedef struct diffsep_prof_record {
+  char kernel[128];
+  int32_t B, H, W, Cin, Cout, taps, skip_cin, has_res, cls, _pad;
+  double flops, bytes;
+  double ms;
+} diffsep_prof_record;
+int32_t diffsep_engine_profile_records(diffsep_engine* e, diffsep_prof_record* out, int32_t cap, int32_t* n);
 
 /* ------------------------------------------------------------------ unit entry points
  * (used by the parity tests; the engine calls the same launchers internally). */

@@ -1,0 +1,45 @@
+#!/bin/bash
+# Per-phase cycle counters of the register-weight conv kernel (profiling build: -DRW_TIMING).  Run via gpurun.
+set -e
+cd $(dirname $0)/../diffusion-separation_amd/csrc
+mkdir -p ../abl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC -DRW_TIMING $RW_EXTRA -c conv3x3_rw.hip -o /tmp/rw_timing.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../abl/lib_rwtiming.so /tmp/rw_timing.o build/conv_mfma.o build/conv3x3_ws.o build/conv3x3_small.o build/norm.o build/stft.o build/sde.o build/engine.o
+cd ../..
+DIFFSEP_LIB=$PWD/diffusion-separation_amd/abl/lib_rwtiming.so python - <<'PY'
+import ctypes, sys, os, torch
+sys.path.insert(0, "diffusion-separation_amd")
+from diffsep_amd import ops
+l = ctypes.CDLL(os.environ["DIFFSEP_LIB"])
+names = ["prologue (tables, weights, chunk 0)", "barrier wait", "3x3 chunk phases", "skip chunk phases", "epilogue", "tail (statistics)"]
+import os
+BS = [int(v) for v in os.environ.get('RW_B', '16').split(',')]
+for (ci, H, W, fused, B) in [(c, hh, ww, f, bb) for bb in BS for (c, hh, ww, f) in [(64, 256, 256, 2), (64, 256, 256, 1), (64, 256, 256, 0), (128, 256, 256, 1), (128, 256, 256, 0), (64, 128, 128, 1)]]:
+    co, k = 64, 3
+    x = torch.randn(B, H, W, ci, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(co, 9, ci, device="cuda") / (9 * ci) ** 0.5).to(torch.bfloat16)
+    b = torch.randn(co, device="cuda")
+    sc = torch.rand(B, ci, device="cuda") + 0.5; sh = torch.randn(B, ci, device="cuda") * 0.1
+    res = torch.randn(B, H, W, co, device="cuda").to(torch.bfloat16)
+    y = torch.zeros(B, H, W, co, device="cuda", dtype=torch.bfloat16)
+    _, st = ops.conv2d_fused(x, w, b, co, k, out=y, stats=True)
+    if fused == 2:    # Conv_1 of a plain block: GroupNorm + SiLU, bias, residual, 1/sqrt(2), statistics
+        run = lambda: ops.conv2d_fused(x, w, b, co, k, gn=(sc, sh), gn_act=1, res=res, out_scale=0.7071, out=y, stats=st)
+    elif fused == 1:  # Conv_0: GroupNorm + SiLU, bias, statistics
+        run = lambda: ops.conv2d_fused(x, w, b, co, k, gn=(sc, sh), gn_act=1, out=y, stats=st)
+    else:
+        run = lambda: ops.conv2d_fused(x, w, b, co, k, out=y)
+    for _ in range(2): run()
+    torch.cuda.synchronize()
+    out = (ctypes.c_ulonglong * 16)()
+    l.diffsep_rw_debug_read(out, 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): run()
+    e1.record(); torch.cuda.synchronize()
+    l.diffsep_rw_debug_read(out, 1)
+    nb = out[15]; tot = sum(out[i] for i in range(8))
+    print(f"B={B} {ci}->64 {H}x{W} {['plain', 'GN+SiLU+stats', 'GN+SiLU+stats+residual'][fused]}: {e0.elapsed_time(e1)/5*1e3:.1f} us/launch, {tot/nb:.0f} ticks/block (wave 0), {nb//5} blocks")
+    for i in range(6):
+        print(f"    {names[i]:36s} {out[i]/nb:9.0f}  {100*out[i]/tot:5.1f} %")
+PY
