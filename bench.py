@@ -266,6 +266,7 @@ def main():
             def reserve(self, B, T): pass
             def profile_begin(self): pass
             def profile_end(self): return {"conv3x3_8x32xN64": (1.0, 1.0, 1, 1.0)}
+            def profile_records(self): return []
             def device_bytes(self): return 0
         K = max(1, args.in_flight)
         engs = [_Eng() for _ in range(K)]
@@ -371,7 +372,8 @@ def main():
         eng.profile_begin()
         step(10_000, collect=False, w=0)  # rank 0 only: no collective in this untimed pass
         prof = eng.profile_end()
-        dom = max(prof, key=lambda k: prof[k][1])  # the kernel instantiation with the most GPU time
+        recs = eng.profile_records()
+        dom = max(prof, key=lambda k: prof[k][1])  # the kernel class with the most GPU time
         fl, ms, n, by = prof[dom]
         tot_ms = sum(v[1] for v in prof.values())
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -393,7 +395,33 @@ def main():
         # the bound is whichever floor of an average launch is higher: HBM at 8 TB/s or dense MFMA at `peak`
         hbm_floor_us = by / max(n, 1) / HBM_PEAK_BPS * 1e6
         mfma_floor_us = fl / max(n, 1) / (peak * 1e12) * 1e6
-        kname = KERNEL_NAMES.get(dom, dom) % {"dt": args.dtype}
+        # per (kernel instantiation, problem shape): launches, average duration, fractions of both roofs; the
+        # instantiation (real template arguments) with the most GPU time names the roofline object
+        by_shape, by_kernel = {}, {}
+        for r in recs:
+            key = (r["kernel"], r["taps"], r["Cin"], r["Cout"], r["H"], r["W"], r["skip_cin"], r["has_res"])
+            a = by_shape.setdefault(key, [0, 0.0, 0.0, 0.0])
+            a[0] += 1; a[1] += r["ms"]; a[2] += r["flops"]; a[3] += r["bytes"]
+            b_ = by_kernel.setdefault(r["kernel"], [0, 0.0, 0.0, 0.0])
+            b_[0] += 1; b_[1] += r["ms"]; b_[2] += r["flops"]; b_[3] += r["bytes"]
+        per_shape = []
+        for (kn, taps, ci, co, H_, W_, sk, hr), (n_, ms_, fl_, by_) in sorted(by_shape.items(), key=lambda kv: -kv[1][1]):
+            if ms_ <= 0 or H_ * W_ < 128 * 128:
+                continue
+            per_shape.append({"kernel": kn, "shape": "%dx%d %d->%d%s%s @%dx%d" % (3 if taps == 9 else 1, 3 if taps == 9 else 1, ci, co,
+                                                                                  " +skip%d" % sk if sk else "", " +res" if hr else "", H_, W_),
+                              "launches": n_, "avg_us": round(ms_ / n_ * 1e3, 1),
+                              "frac_mfma": round(fl_ / (ms_ * 1e-3) / 1e12 / peak, 4),
+                              "frac_hbm": round(by_ / (ms_ * 1e-3) / HBM_PEAK_BPS, 4)})
+        dom_k = max(by_kernel, key=lambda k: by_kernel[k][1]) if by_kernel else None
+        kname = dom_k or (KERNEL_NAMES.get(dom, dom) % {"dt": args.dtype})
+        if dom_k:  # the roofline object describes this one instantiation
+            n, ms, fl, by = by_kernel[dom_k]
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            hbm_floor_us = by / max(n, 1) / HBM_PEAK_BPS * 1e6
+            mfma_floor_us = fl / max(n, 1) / (peak * 1e12) * 1e6
+            if dom_k.startswith("conv3x3_ws1") or not dom_k.startswith("conv_mfma_kernel<bf16,9,"):
+                traffic = traffic_source = None  # (the PMC file holds the generic 3x3 tile's traffic only)
         if hbm_floor_us > mfma_floor_us:
             gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             roof = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": HBM_PEAK_BPS / 1e9,
@@ -405,6 +433,9 @@ def main():
                 "flops_per_launch": fl / max(n, 1), "algorithmic_bytes_per_launch": by / max(n, 1),
                 "hbm_floor_us": round(hbm_floor_us, 2), "mfma_floor_us": round(mfma_floor_us, 2),
                 "achieved_tflops": round(ach, 2),
+                "gpu_time_share_of_mfma_kernels": round(ms / tot_ms, 4) if tot_ms > 0 else None,
+                "per_shape": per_shape[:24],
+                "per_instantiation_ms": {k: round(v[1], 2) for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][1])[:16]},
                 "per_kernel_ms": {k: round(v[1], 2) for k, v in prof.items() if v[2]},
                 # every MFMA kernel class of the step against both roofs (algorithmic flops / bytes over its summed time)
                 "per_kernel_roofline": {k: {"launches": v[2], "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1),

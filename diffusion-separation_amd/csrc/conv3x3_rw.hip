@@ -84,6 +84,7 @@ struct RwK {
   const bf16_t* sx2; long sx2_bs; int ldsx2;
   const bf16_t* sw; int sw_chunked; int sw_shift; int sCin;
   int H, W, G, tiles_x, tiles_per_img;
+  int dbg;  // profiling builds: bit 0 = stores fall outside the tensor, bit 1 = loads do
 };
 
 // k-steps whose weight fragments live in LDS instead of registers (the LAST ones in K order): the fourth chunk of the
@@ -281,8 +282,16 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     const unsigned ld2 = (unsigned)(CONV ? (second ? p.ldx2 : p.ldx) : (second ? p.ldsx2 : p.ldsx)) * 2u;
     const unsigned co2 = (unsigned)((second ? CB - c1 : CB) * 2) + (unsigned)slot * 16u;
     const __amdgpu_buffer_rsrc_t r = CONV ? (second ? rx2 : rx1) : (second ? rs2 : rs1);
+#ifdef RW_ABL_FULLLINE  // (timing only, wrong data: the same bytes per instruction as 8 pixels x 128 B instead of 16 x 64 B)
+    const unsigned off = __umul24((unsigned)(g.pix0 + (tid >> 3) + 32 * k), ld2) + (unsigned)(tid & 7) * 16u;
+#else
     const unsigned off = __umul24((unsigned)(rel + g.pix0), ld2) + co2;
+#endif
+#ifdef RW_TIMING
+    pa[k] = ld16(r, (piece_ok(P_, g, k) && !(p.dbg & 2)) ? off : OOB, 0);
+#else
     pa[k] = ld16(r, piece_ok(P_, g, k) ? off : OOB, 0);
+#endif
   };
   float gsc[8], gsh[8];
   auto act_tab = [&](int c) __attribute__((always_inline)) {  // scale / shift of this thread's 8 channels of chunk c
@@ -323,8 +332,16 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
         so.z = ok ? so.z : 0u;
         so.w = ok ? so.w : 0u;
       }
+#ifdef RW_ABL_NOLDSW
+      asm volatile("" :: "v"(so));
+#else
       *reinterpret_cast<u32x4_t*>(sA + sl * LDS_A + ldo0 + k * (NT / 4) * AROW) = so;
+#endif
+#ifdef RW_ABL_NOLOAD
+      pa[k][0] += rel;
+#else
       issue_one(P2_, g2, k, rel);
+#endif
     }
   };
 
@@ -354,26 +371,55 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   // store.  (There are no loads in the epilogue: a residual rides through the ring as two raw chunks that meet identity
   // fragments — see the launcher.  vmcnt retires in order and counts stores: residual rows loaded between the stores
   // were measured waiting for the acknowledgement of every earlier store, 1350 cycles per row on an idle chip.)
-  auto epi_unit = [&](const TileG& g, int r, int j) __attribute__((always_inline)) {
+  // The two units of a row leave together: v_permlane16_swap regroups their 16-byte pieces so that one store covers
+  // 16 pixels x 64 contiguous bytes (the wave's 32 couts) instead of 32 pixels x 32 bytes — half the write requests.
+  u32x4_t ov0;  // the row's first half, waiting for the second
+  const int srow = lane >> 4;  // after the regrouping lane L holds, of pixel L & 15 (+ 16 in the second store), the piece:
+  const unsigned spiece = (unsigned)(cg * 64 + (srow & 1) * 32 + (srow >> 1) * 16);  // byte offset in the pixel's 128 B
+  auto epi_unit = [&](const TileG& g, int r, int j, const float4& t0, const float4& t1) __attribute__((always_inline)) {
     float v[8];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {  // (bias + temb bias) * out_scale of the quad's couts: an LDS broadcast read
-      const float4 t = *reinterpret_cast<const float4*>(sTab + 2 * CIN + cg * 32 + 8 * (2 * j + q) + 4 * h);
-      v[4 * q] = fmaf(acc[r][8 * j + 4 * q], osc, t.x);
-      v[4 * q + 1] = fmaf(acc[r][8 * j + 4 * q + 1], osc, t.y);
-      v[4 * q + 2] = fmaf(acc[r][8 * j + 4 * q + 2], osc, t.z);
-      v[4 * q + 3] = fmaf(acc[r][8 * j + 4 * q + 3], osc, t.w);
-    }
+    v[0] = fmaf(acc[r][8 * j + 0], osc, t0.x); v[1] = fmaf(acc[r][8 * j + 1], osc, t0.y);
+    v[2] = fmaf(acc[r][8 * j + 2], osc, t0.z); v[3] = fmaf(acc[r][8 * j + 3], osc, t0.w);
+    v[4] = fmaf(acc[r][8 * j + 4], osc, t1.x); v[5] = fmaf(acc[r][8 * j + 5], osc, t1.y);
+    v[6] = fmaf(acc[r][8 * j + 6], osc, t1.z); v[7] = fmaf(acc[r][8 * j + 7], osc, t1.w);
     // (always taken: a branch here would cut the half-phase's instruction stream into separately scheduled pieces)
+#ifndef RW_ABL_NOSTATS
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       ssum[8 * j + e] += v[e];
       ssq[8 * j + e] = fmaf(v[e], v[e], ssq[8 * j + e]);
     }
+#endif
     u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-    swap_halves(ov);
-    const int pix = g.pix0 + (pg * RPW + r) * p.W + l32;
-    __builtin_amdgcn_raw_buffer_store_b128(ov, ry, __umul24((unsigned)pix, (unsigned)p.ldy * 2u) + (unsigned)((cg * 32 + 16 * j + 8 * h) * 2), 0, 0);
+    swap_halves(ov);  // lane (pixel l32, half h): couts 16 j + 8 h .. + 7
+    if (j == 0) {
+      ov0 = ov;
+    } else {
+      u32x4_t a = ov0, b2 = ov;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        auto q = __builtin_amdgcn_permlane16_swap(a[d], b2[d], false, false);
+        a[d] = q[0]; b2[d] = q[1];
+      }
+      const int pix = g.pix0 + (pg * RPW + r) * p.W + (lane & 15);
+      const unsigned o = __umul24((unsigned)pix, (unsigned)p.ldy * 2u) + spiece;
+#ifdef RW_TIMING
+      const unsigned o1 = (p.dbg & 1) ? OOB : o, o2 = (p.dbg & 1) ? OOB : o + 16u * (unsigned)p.ldy * 2u;
+#else
+      const unsigned o1 = o, o2 = o + 16u * (unsigned)p.ldy * 2u;
+#endif
+#ifdef RW_ABL_NOSTORE
+      asm volatile("" :: "v"(a), "v"(b2), "v"(o1), "v"(o2));
+#else
+      __builtin_amdgcn_raw_buffer_store_b128(a, ry, o1, 0, 0);    // pixels 0 .. 15 of the row
+      __builtin_amdgcn_raw_buffer_store_b128(b2, ry, o2, 0, 0);   // pixels 16 .. 31
+#endif
+    }
+  };
+  // (bias + temb bias) * out_scale of the unit's two cout quads: LDS broadcast reads, issued ahead of the k-step's MFMAs
+  auto epi_bias = [&](int j, float4& t0, float4& t1) __attribute__((always_inline)) {
+    t0 = *reinterpret_cast<const float4*>(sTab + 2 * CIN + cg * 32 + 8 * (2 * j) + 4 * h);
+    t1 = *reinterpret_cast<const float4*>(sTab + 2 * CIN + cg * 32 + 8 * (2 * j + 1) + 4 * h);
   };
 
   // ---- one HALF of a phase: the MFMAs of chunk (phase P, ring slot P & 1) for the wave's rows [HF * RH, HF * RH + RH),
@@ -420,6 +466,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
 #pragma unroll
       for (int u = u0; u < u1; ++u)
         if ((u & 3) == 3) rels[u >> 2] = sDesc[(u >> 2) * NT + tid];
+      float4 eb[2][2];  // bias of this k-step's epilogue units (at most two)
+#pragma unroll
+      for (int e = e0; e < e1; ++e) epi_bias(e & 1, eb[(e - e0) & 1][0], eb[(e - e0) & 1][1]);
       if (W0 + ks + 1 >= NWR && ks + 1 < NK) wln = *reinterpret_cast<const u32x4_t*>(sWl + (W0 + ks + 1 - NWR) * 2048);
       const u32x4_t wk = W0 + ks < NWR ? wf[W0 + ks < NWR ? W0 + ks : 0] : wl;
 #pragma unroll
@@ -435,11 +484,15 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
         if (ks + 2 < NK) bf[ks & 1][r] = ldb(ks + 2, r);
       }
       wl = wln;
+#ifndef RW_ABL_NOSTAGE
 #pragma unroll
       for (int u = u0; u < u1; ++u)
         unit(std::integral_constant<int, C1>{}, std::integral_constant<int, C2>{}, g1, g2, SL ^ 1, u, (u & 3) == 3 ? rels[u >> 2] : 0);
+#endif
+#ifndef RW_ABL_NOEPI
 #pragma unroll
-      for (int e = e0; e < e1; ++e) epi_unit(ge, ER0 + (e >> 1), e & 1);
+      for (int e = e0; e < e1; ++e) epi_unit(ge, ER0 + (e >> 1), e & 1, eb[(e - e0) & 1][0], eb[(e - e0) & 1][1]);
+#endif
       // the k-step's instruction mix, spread evenly: every MFMA (32 cycles on the matrix pipe) is followed by its share
       // of the VALU work and one fragment read, so that neither pipe waits for the other
       {
@@ -480,6 +533,13 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     auto run = [&](auto self, auto P_) __attribute__((always_inline)) {
       constexpr int P = decltype(P_)::value;
       sync_lds();
+#ifdef RW_SKEW
+      // the four waves run the same instruction stream: without a skew their vector-memory instructions reach the CU's
+      // one address path together and three of four wait in its queue
+      if (wave == 1) __builtin_amdgcn_s_sleep(RW_SKEW);
+      if (wave == 2) __builtin_amdgcn_s_sleep(2 * RW_SKEW);
+      if (wave == 3) __builtin_amdgcn_s_sleep(3 * RW_SKEW);
+#endif
       RT_MARK(1)
       half(P_, std::integral_constant<int, 0>{}, std::integral_constant<bool, P == 0>{}, gp, (P + 1 < NPH ? gc : gn), (P + 2 < NPH ? gc : gn));
       if constexpr (P == 0) {
@@ -498,7 +558,11 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   }
   // the second half of the last tile's rows
 #pragma unroll
-  for (int e = 0; e < RH * 2; ++e) epi_unit(gp, RH + (e >> 1), e & 1);
+  for (int e = 0; e < RH * 2; ++e) {
+    float4 t0, t1;
+    epi_bias(e & 1, t0, t1);
+    epi_unit(gp, RH + (e >> 1), e & 1, t0, t1);
+  }
   RT_MARK(4)
   if (has_stats) {
     __syncthreads();
@@ -614,6 +678,7 @@ int ds_launch_conv_rw(const ConvArgs& a, hipStream_t st) {
   k.sw = reinterpret_cast<const bf16_t*>(a.sw); k.sw_chunked = a.sw_chunked; k.sw_shift = a.sw_chunked ? __builtin_ctz(a.sw_chunked) : 0;
   k.sCin = a.sCin;
   k.H = a.H; k.W = a.W; k.G = 0; k.tiles_x = 0; k.tiles_per_img = 0;
+  k.dbg = getenv("DIFFSEP_RW_DBG") ? atoi(getenv("DIFFSEP_RW_DBG")) : 0;
   if (a.res) {  // the residual [B][H][W][64] as a folded skip with identity weights (sw = null): exact in the fp32 accumulators
     k.sx = reinterpret_cast<const bf16_t*>(a.res); k.sx_bs = a.res_bs; k.ldsx = a.ldr; k.sC1 = CO;
     k.sx2 = nullptr; k.sx2_bs = 0; k.ldsx2 = a.ldr; k.sw = nullptr; k.sw_chunked = 0; k.sw_shift = 0; k.sCin = CO;

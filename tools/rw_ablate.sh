@@ -1,0 +1,11 @@
+#!/bin/bash
+# Ablations of the register-weight conv kernel (results are wrong by construction: timing only).  Run via gpurun.
+set -e
+cd $(dirname $0)/../diffusion-separation_amd/csrc
+mkdir -p ../abl
+for v in "" "-DRW_ABL_FULLLINE" "" "-DRW_ABL_FULLLINE" "-DRW_ABL_NOLOAD"; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC $v -mllvm -pragma-unroll-threshold=1000000 -c conv3x3_rw.hip -o /tmp/rw_a.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../abl/lib_rwa.so /tmp/rw_a.o build/conv_mfma.o build/conv3x3_ws.o build/conv3x3_small.o build/norm.o build/stft.o build/sde.o build/engine.o
+  echo "== variant: ${v:-shipped}"
+  (cd ../.. && DIFFSEP_LIB=$PWD/diffusion-separation_amd/abl/lib_rwa.so python tools/rw_bench.py 10 2>&1 | grep -v amdgpu | grep -v "res" | grep "64->64 conv0  \|64->64 plain\|cat(64,64)->64 conv0  ")
+done
