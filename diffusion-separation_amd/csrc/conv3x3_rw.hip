@@ -64,8 +64,11 @@ __device__ inline void sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barr
 
 constexpr int CO = 64;                // output channels of the layer
 constexpr int TW = 32, HW_ = TW + 2;  // tile width, halo row
-constexpr int KC = 32;                // channels per chunk
-constexpr int AROW = KC * 2 + 16;     // 80 B: LDS pitch of a halo pixel (16 consecutive rows = 16 distinct bank slots)
+constexpr int KC = 64;                // channels per chunk: a pixel's chunk is ONE full 128-byte line of a 64-channel tensor
+constexpr int NKB = KC / 16;          // 16-channel k-blocks per tap
+constexpr int KSC = 9 * NKB;          // k-steps of a 3x3 chunk
+constexpr int AROW = KC * 2 + 16;     // 144 B: LDS pitch of a halo pixel (16 consecutive rows = 16 distinct bank slots)
+constexpr int PPL = KC / 8;           // 16-byte pieces (lanes) per pixel
 constexpr int NT = 256;
 
 struct RwK {
@@ -89,59 +92,31 @@ struct RwK {
 
 // k-steps whose weight fragments live in LDS instead of registers (the LAST ones in K order): the fourth chunk of the
 // 128-channel layers and the 128-channel skip — what the 512-entry register file does not hold beside the accumulators
-constexpr int rw_lds_ksteps(int nch, int rpw, int nsk) { return nch == 4 ? 18 : (rpw == 8 && nsk == 4 ? 8 : 0); }
+constexpr int rw_lds_ksteps(int nch, int rpw, int nsk) { return nch == 2 ? 18 : 0; }
 
 template <int NCH, int RPW, int NSK>
 struct RwGeom {
   static constexpr int TH = 2 * RPW, HH_ = TH + 2, HP = HH_ * HW_;
-  static constexpr int NL = (HP * 4 + NT - 1) / NT;       // 16-byte pieces per thread and chunk
-  static constexpr int LDS_A = NL * (NT / 4) * AROW;      // one ring slot (whole passes of the block: no predicated writes)
+  static constexpr int NL = (HP * PPL + NT - 1) / NT;     // 16-byte pieces per thread and chunk
+  static constexpr int LDS_A = NL * (NT / PPL) * AROW;    // one ring slot (whole passes of the block: no predicated writes)
   static constexpr int CIN = NCH * KC, SCIN = NSK * KC;
   static constexpr int LDS_TAB = (2 * CIN + CO) * 4;      // GN scale, GN shift, (bias + temb bias) * out_scale
   static constexpr int LDS_DESC = NL * NT * 4;
   static constexpr int NPH = NCH + NSK;                   // phases (chunks) per tile
-  static constexpr int NKS = NCH * 18 + NSK * 2;          // k-steps = weight fragments per wave
+  static constexpr int NKS = NCH * KSC + NSK * NKB;       // k-steps = weight fragments per wave
   static constexpr int NWL = rw_lds_ksteps(NCH, RPW, NSK), NWR = NKS - NWL;  // fragments in LDS / in registers
   static constexpr int LDS_WL = NWL * 2 * 64 * 16;        // [k-step][cout group][lane] x 16 B
   static constexpr int OFF_TAB = 2 * LDS_A, OFF_WL = OFF_TAB + ((LDS_TAB + 15) & ~15), OFF_DESC = OFF_WL + LDS_WL;
   static constexpr int LDS_TOTAL = OFF_DESC + LDS_DESC;
-  // chunk of phase P: [0, NCH) = 3x3 chunk, NCH + s = skip chunk s.  The skip chunks sit between the first and the last
-  // 3x3 chunk: a tile's first and last phase are long ones (they carry the epilogue of the other half-tile)
-  static constexpr int chunk_of(int P) { return NSK == 0 ? P : (P == 0 ? 0 : (P <= NSK ? NCH + P - 1 : P - NSK)); }
-  static_assert(NPH % 2 == 0, "the ring slot of a chunk must not depend on the tile");
+  // chunk of phase P: [0, NCH) = 3x3 chunk, NCH + s = skip chunk s.  The skip chunks come first: the tile's LAST phase is
+  // a long one (it carries the epilogue of the first half-tile)
+  static constexpr int chunk_of(int P) { return P < NSK ? NCH + P : P - NSK; }
   static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget of one CU");
   static_assert(NT * 36 * 4 <= LDS_TOTAL, "the statistics reduce reuses the block's LDS");
 };
 
-// GN affine + SiLU on 8 bf16 channels.  sc / sh: the affine; sm / hm: the same affine times -log2(e) (the argument of
-// the sigmoid's exp2), so that z and the exponent come from two independent FMAs
-template <int MODE>
-__device__ inline u32x4_t act8(const u32x4_t& u, const float* sc, const float* sh, const float* sm, const float* hm) {
-  float f[8];
-  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
-  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
-  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
-  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float z = fmaf(f[j], sc[j], sh[j]);
-    if (MODE == 2) {
-      const float e = __builtin_amdgcn_exp2f(fmaf(f[j], sm[j], hm[j]));
-      f[j] = z * __builtin_amdgcn_rcpf(1.0f + e);
-    } else {
-      f[j] = z;
-    }
-  }
-  u32x4_t o;
-  o.x = pack_bf16x2(f[0], f[1]);
-  o.y = pack_bf16x2(f[2], f[3]);
-  o.z = pack_bf16x2(f[4], f[5]);
-  o.w = pack_bf16x2(f[6], f[7]);
-  return o;
-}
-
-// NCH: 32-channel chunks of the 3x3 input (2: 64 channels, 4: 128 = one or two sources); RPW: pixel rows per wave
-// (tile = 2 RPW x 32); NSK: 32-channel chunks of the folded 1x1 skip (0, 2, 4); MODE: 0 raw input, 2 GroupNorm + SiLU
+// NCH: 64-channel chunks of the 3x3 input (1: 64 channels, 2: 128 = one or two sources); RPW: pixel rows per wave
+// (tile = 2 RPW x 32); NSK: 64-channel chunks of the folded 1x1 skip (0, 1, 2); MODE: 0 raw input, 2 GroupNorm + SiLU
 template <int NCH, int RPW, int NSK, int MODE>
 __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   using G = RwGeom<NCH, RPW, NSK>;
@@ -187,20 +162,20 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   if (tid < CO)
     sTab[2 * CIN + tid] =
         ((p.bias ? p.bias[tid] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + tid] : 0.f)) * p.out_scale;
-  const int slot = tid & 3;
-  // staging pieces of this thread: piece k = halo pixel (tid >> 2) + 64 k, 16-byte slot tid & 3.  Relative pixel index
+  const int slot = tid & (PPL - 1);
+  // staging pieces of this thread: piece k = halo pixel tid / PPL + (NT / PPL) k, 16-byte slot tid % PPL.  Relative pixel index
   // in LDS (read one k-step ahead of its use), 5 flag bits per piece in two registers: bits 0..3 = the piece lies in the
   // top / bottom / left / right halo line, bit 4 = beyond the halo tile
   unsigned fl0 = 0, fl1 = 0;
 #pragma unroll
   for (int k = 0; k < NL; ++k) {
     const int v = tid + NT * k;
-    const int pix = v >> 2, hy = pix / HW_, hx = pix - hy * HW_;
+    const int pix = v / PPL, hy = pix / HW_, hx = pix - hy * HW_;
     const unsigned flg = pix < HP ? (hy == 0 ? 1u : 0u) | (hy == G::HH_ - 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == HW_ - 1 ? 8u : 0u) : 16u;
     sDesc[k * NT + tid] = pix < HP ? (hy - 1) * p.W + (hx - 1) : 0;
     if (k < 6) fl0 |= flg << (5 * k); else fl1 |= flg << (5 * (k - 6));
   }
-  const int ldo0 = (tid >> 2) * AROW + slot * 16;  // piece k is NT / 4 = 64 pixels further
+  const int ldo0 = (tid / PPL) * AROW + slot * 16;  // piece k is NT / PPL pixels further
 
   const int M = p.H * p.W;
   const __amdgpu_buffer_rsrc_t rx1 = rsrc(p.x + (long)b * p.x_bs, (unsigned)M * p.ldx * 2u);
@@ -220,25 +195,26 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     const __amdgpu_buffer_rsrc_t rw = rsrc(p.w, 9u * CO * CIN * 2u);
     const __amdgpu_buffer_rsrc_t rsw = (NSK && p.sw) ? rsrc(p.sw, (unsigned)CO * G::SCIN * 2u) : rsrc(p.w, 0u);
     const int co = cg * 32 + l32;
-    // 3x3: [64][9][Cin]: (co * 9 + tap) * Cin + ch; chunk-major [Cin/32][9][64][32]: ((c * 9 + tap) * 64 + co) * 32 + ch % 32
+    // 3x3: [64][9][Cin]: (co * 9 + tap) * Cin + ch; chunk-major [Cin/32][9][64][32]: ((ch / 32 * 9 + tap) * 64 + co) * 32 + ch % 32
     const bool wc = p.w_chunked != 0;  // (uniform: the per-fragment part of the offset is a scalar select)
-    const unsigned vlane = wc ? (unsigned)((co * KC + h * 8) * 2) : (unsigned)((co * 9 * CIN + h * 8) * 2);
+    const unsigned vlane = wc ? (unsigned)((co * 32 + h * 8) * 2) : (unsigned)((co * 9 * CIN + h * 8) * 2);
     // skip: [64][sCin]: co * sCin + ch; chunk-major [sCin/kc][64][kc] (kc >= 16: a 16-channel k-block never straddles a
     // layout chunk): ((ch / kc) * 64 + co) * kc + ch % kc
     const bool sc_ = NSK && p.sw_chunked != 0;
     const int kcs = sc_ ? p.sw_chunked : 16;
     const unsigned vl2 = sc_ ? (unsigned)((co * kcs + h * 8) * 2) : (unsigned)((co * G::SCIN + h * 8) * 2);
     auto load_one = [&](int ks) __attribute__((always_inline)) {
-      if (ks < NCH * 18) {
-        const int c = ks / 18, tap = (ks % 18) / 2, kb = ks % 2;
-        const unsigned so = wc ? (unsigned)(((c * 9 + tap) * CO * KC + kb * 16) * 2) : (unsigned)((tap * CIN + c * KC + kb * 16) * 2);
+      if (ks < NCH * KSC) {
+        const int c = ks / KSC, tap = (ks % KSC) / NKB, kb = ks % NKB;
+        const int chb = c * KC + kb * 16;  // first channel of the k-block (this lane: + 8 h)
+        const unsigned so = wc ? (unsigned)((((chb >> 5) * 9 + tap) * CO * 32 + (chb & 31)) * 2) : (unsigned)((tap * CIN + chb) * 2);
         put_w(ks, ld16(rw, vlane, so));
       } else {
-        const int k2 = ks - NCH * 18;
-        const unsigned so = sc_ ? (unsigned)(((((k2 * 16) >> p.sw_shift) * CO) * kcs + ((k2 * 16) & (kcs - 1))) * 2) : (unsigned)(k2 * 16 * 2);
+        const int chb = (ks - NCH * KSC) * 16;
+        const unsigned so = sc_ ? (unsigned)((((chb >> p.sw_shift) * CO) * kcs + (chb & (kcs - 1))) * 2) : (unsigned)(chb * 2);
         u32x4_t f = ld16(rsw, vl2, so);
-        if (!p.sw) {  // residual as a skip with identity weights: channel 16 k2 + 8 h + j feeds cout co with weight 1
-          const int d = co - (16 * k2 + 8 * h);  // the lane's 8 channels hold the 1 at position d (if 0 <= d < 8)
+        if (!p.sw) {  // residual as a skip with identity weights: channel chb + 8 h + j feeds cout co with weight 1
+          const int d = co - (chb + 8 * h);  // the lane's 8 channels hold the 1 at position d (if 0 <= d < 8)
 #pragma unroll
           for (int e = 0; e < 4; ++e) f[e] = d == 2 * e ? 0x3f80u : (d == 2 * e + 1 ? 0x3f800000u : 0u);
         }
@@ -293,6 +269,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     pa[k] = ld16(r, piece_ok(P_, g, k) ? off : OOB, 0);
 #endif
   };
+  // every input of the launch is activated (no raw skip / residual chunk shares the accumulators): the activation may
+  // leave a constant factor to the epilogue
+  constexpr bool FOLD = MODE == 2 && NSK == 0;
   float gsc[8], gsh[8];
   auto act_tab = [&](int c) __attribute__((always_inline)) {  // scale / shift of this thread's 8 channels of chunk c
     if constexpr (MODE != 0) {
@@ -301,6 +280,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
       const float4 s0 = ts[0], s1 = ts[1], h0 = th[0], h1 = th[1];
       gsc[0] = s0.x; gsc[1] = s0.y; gsc[2] = s0.z; gsc[3] = s0.w; gsc[4] = s1.x; gsc[5] = s1.y; gsc[6] = s1.z; gsc[7] = s1.w;
       gsh[0] = h0.x; gsh[1] = h0.y; gsh[2] = h0.z; gsh[3] = h0.w; gsh[4] = h1.x; gsh[5] = h1.y; gsh[6] = h1.z; gsh[7] = h1.w;
+      if constexpr (FOLD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { gsc[j] *= -1.4426950408889634f; gsh[j] *= -1.4426950408889634f; }
+      }
     }
   };
   // Staging runs in UNITS of one dword (two channels) so that its VALU work spreads evenly over the k-steps of a phase:
@@ -315,8 +298,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
       const float lo = __uint_as_float(w << 16), hi = __uint_as_float(w & 0xffff0000u);
       float z0 = fmaf(lo, gsc[2 * d], gsh[2 * d]), z1 = fmaf(hi, gsc[2 * d + 1], gsh[2 * d + 1]);
       if (MODE == 2) {
-        const float e0 = __builtin_amdgcn_exp2f(z0 * -1.4426950408889634f);
-        const float e1 = __builtin_amdgcn_exp2f(z1 * -1.4426950408889634f);
+        // FOLD: the affine carries the factor -log2(e), z IS the exponent of the sigmoid's exp2 and the staged value is
+        // silu(GN(x)) / -ln 2; the epilogue multiplies the accumulators back (exact in fp32, one multiply per element less)
+        const float e0 = __builtin_amdgcn_exp2f(FOLD ? z0 : z0 * -1.4426950408889634f);
+        const float e1 = __builtin_amdgcn_exp2f(FOLD ? z1 : z1 * -1.4426950408889634f);
         z0 *= __builtin_amdgcn_rcpf(1.0f + e0);
         z1 *= __builtin_amdgcn_rcpf(1.0f + e1);
       }
@@ -335,7 +320,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
 #ifdef RW_ABL_NOLDSW
       asm volatile("" :: "v"(so));
 #else
-      *reinterpret_cast<u32x4_t*>(sA + sl * LDS_A + ldo0 + k * (NT / 4) * AROW) = so;
+      *reinterpret_cast<u32x4_t*>(sA + sl * LDS_A + ldo0 + k * (NT / PPL) * AROW) = so;
 #endif
 #ifdef RW_ABL_NOLOAD
       pa[k][0] += rel;
@@ -355,7 +340,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   for (int j = 0; j < 16; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
   constexpr int RES_AHEAD = 2;  // residual rows requested ahead of the row being finished
   const bool has_stats = p.stats != nullptr;
-  const float osc = p.out_scale;
+  const float osc = FOLD ? p.out_scale * -0.6931471805599453f : p.out_scale;
   // fragment base of this lane: pixel (row pg * RPW, column l32) of the halo tile, k-half h
   const int fbase = (pg * RPW * HW_ + l32) * AROW + h * 16;
 
@@ -429,69 +414,109 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   // of the accumulators thus always runs under the MFMAs of the other half: no second accumulator set, no phase in
   // which all waves of the chip store at once.
   constexpr int RH = RPW / 2;
-  auto half = [&](auto P_, auto HF_, auto EPI_, const TileG& ge, const TileG& g1, const TileG& g2) __attribute__((always_inline)) {
+  constexpr int DEPTH = RH >= 4 ? 2 : 4;  // pixel fragments are read DEPTH k-steps (>= 8 MFMAs) ahead of their use
+  auto half = [&](auto P_, auto HF_, auto EPI_, int slot_r, const TileG& ge, const TileG& g1, const TileG& g2) __attribute__((always_inline)) {
     constexpr int P = decltype(P_)::value, HF = decltype(HF_)::value;
     constexpr bool EPI = decltype(EPI_)::value;
     constexpr int C = G::chunk_of(P);
     constexpr bool CONV = C < NCH;
-    constexpr int NK = CONV ? 18 : 2;
-    constexpr int W0 = CONV ? C * 18 : NCH * 18 + (C - NCH) * 2;
+    constexpr int NK = CONV ? KSC : NKB;
+    constexpr int W0 = CONV ? C * KSC : NCH * KSC + (C - NCH) * NKB;
     constexpr int C1 = G::chunk_of((P + 1) % NPH), C2 = G::chunk_of((P + 2) % NPH);
-    constexpr int SL = P & 1;
     constexpr int NU = NL * 4, NE = RH * 2;
     constexpr int R0 = HF * RH, ER0 = HF ? 0 : RH;
-    const char* fb = sA + SL * LDS_A + fbase + R0 * HW_ * AROW;
+    const char* fb = sA + slot_r * LDS_A + fbase + R0 * HW_ * AROW;
+#ifndef RW_BUILTIN_MFMA
+    if constexpr (EPI) {  // the rows this half finishes were last written by asm MFMAs: 12 wait states before a VALU read
+#pragma unroll
+      for (int r = 0; r < RH; ++r) asm volatile("s_nop 11" : "+v"(acc[ER0 + r]));
+    }
+#endif
     if constexpr (HF == 0 && C1 < NCH) act_tab(C1);
     auto ldb = [&](int ks, int r) __attribute__((always_inline)) {
-      const int tap = CONV ? ks / 2 : 4, kb = ks % 2;
+      const int tap = CONV ? ks / NKB : 4, kb = ks % NKB;
       const int dy = tap / 3, dx = tap % 3;
       return *reinterpret_cast<const u32x4_t*>(fb + ((r + dy) * HW_ + dx) * AROW + kb * 32);
     };
-    // pixel fragments: two k-steps in flight (a read is issued 2 RH MFMAs ahead of its use)
-    u32x4_t bf[2][RH];
+    u32x4_t bf[DEPTH][RH];
 #pragma unroll
-    for (int r = 0; r < RH; ++r) bf[0][r] = ldb(0, r);
+    for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-    for (int r = 0; r < RH; ++r) bf[1][r] = ldb(1, r);
+      for (int r = 0; r < RH; ++r)
+        if (d < NK) bf[d][r] = ldb(d, r);
     // weight fragment of k-step ks: a register, or (the last NWL k-steps) an LDS read issued one k-step ahead
     u32x4_t wl = {0, 0, 0, 0}, wln = {0, 0, 0, 0};
     if constexpr (W0 >= NWR) wl = *reinterpret_cast<const u32x4_t*>(sWl + (W0 - NWR) * 2048);
+    int rels[2][NL];
+    float4 eb[2][NE][2];
+    {  // (the first k-step's operands: the one exposed round trip of the half)
+      const int s0 = HF * NK, ua = s0 * NU / (2 * NK), ub = (s0 + 1) * NU / (2 * NK);
+#pragma unroll
+      for (int u = ua; u < ub; ++u)
+        if ((u & 3) == 3) rels[0][u >> 2] = sDesc[(u >> 2) * NT + tid];
+      if (EPI) {
+#pragma unroll
+        for (int e = 0; e < NE / NK + (NE % NK ? 1 : 0); ++e)
+          if (e < (1 * NE) / NK) epi_bias(e & 1, eb[0][e][0], eb[0][e][1]);
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
       const int sl = HF * NK + ks;  // slot of this k-step in the phase's staging schedule
       const int u0 = sl * NU / (2 * NK), u1 = (sl + 1) * NU / (2 * NK);
       const int e0 = EPI ? ks * NE / NK : 0, e1 = EPI ? (ks + 1) * NE / NK : 0;
-      // relative pixel indices of the pieces that complete in this k-step (read ahead of the MFMAs, used after them)
-      int rels[NL];
+      // LDS operands of the NEXT k-step's staging / epilogue units, read a whole k-step ahead of their use (a read
+      // issued and consumed inside one k-step waits for the LDS round trip behind the fragment reads already queued):
+      // relative pixel indices of the pieces that complete, bias of the epilogue units
+      if (ks + 1 < NK) {
+        const int sn = sl + 1, un0 = sn * NU / (2 * NK), un1 = (sn + 1) * NU / (2 * NK);
 #pragma unroll
-      for (int u = u0; u < u1; ++u)
-        if ((u & 3) == 3) rels[u >> 2] = sDesc[(u >> 2) * NT + tid];
-      float4 eb[2][2];  // bias of this k-step's epilogue units (at most two)
+        for (int u = un0; u < un1; ++u)
+          if ((u & 3) == 3) rels[(ks + 1) & 1][u >> 2] = sDesc[(u >> 2) * NT + tid];
+        if (EPI) {
+          const int en0 = (ks + 1) * NE / NK, en1 = (ks + 2) * NE / NK;
 #pragma unroll
-      for (int e = e0; e < e1; ++e) epi_bias(e & 1, eb[(e - e0) & 1][0], eb[(e - e0) & 1][1]);
+          for (int e = en0; e < en1; ++e) epi_bias(e & 1, eb[(ks + 1) & 1][e - en0][0], eb[(ks + 1) & 1][e - en0][1]);
+        }
+      }
       if (W0 + ks + 1 >= NWR && ks + 1 < NK) wln = *reinterpret_cast<const u32x4_t*>(sWl + (W0 + ks + 1 - NWR) * 2048);
       const u32x4_t wk = W0 + ks < NWR ? wf[W0 + ks < NWR ? W0 + ks : 0] : wl;
 #pragma unroll
       for (int r = 0; r < RH; ++r) {
+#ifndef RW_BUILTIN_MFMA
+        // Inline asm: the register-resident weight fragment is pinned to the accumulator half of the register file ("a")
+        // and feeds the MFMA from there; accumulators, pixel fragments and everything the VALU touches live in the
+        // architectural half.  (With the builtin hipcc kept the weights in VGPRs and shuttled accumulators, statistics
+        // and staged pieces through AGPRs: 200 v_accvgpr moves per tile.)  What the compiler does not know about an asm
+        // MFMA: the 12 wait states between its result and a VALU read — the guard at the start of every half.
+        if (W0 + ks < NWR) {
+          if (P == 0 && ks == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc[R0 + r]) : "a"(wk), "v"(bf[ks % DEPTH][r]));
+          else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[R0 + r]) : "a"(wk), "v"(bf[ks % DEPTH][r]));
+        } else {  // LDS-resident fragment: straight from the ds_read's VGPRs (no VALU copy in front of the MFMA)
+          if (P == 0 && ks == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc[R0 + r]) : "v"(wk), "v"(bf[ks % DEPTH][r]));
+          else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[R0 + r]) : "v"(wk), "v"(bf[ks % DEPTH][r]));
+        }
+#else
         if (P == 0 && ks == 0) {  // a tile's first MFMA of a row starts from zero (the row's epilogue has run)
           const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           acc[R0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wk),
-                                                                __builtin_bit_cast(bf16x8, bf[ks & 1][r]), zero, 0, 0, 0);
+                                                                __builtin_bit_cast(bf16x8, bf[ks % DEPTH][r]), zero, 0, 0, 0);
         } else {
           acc[R0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wk),
-                                                                __builtin_bit_cast(bf16x8, bf[ks & 1][r]), acc[R0 + r], 0, 0, 0);
+                                                                __builtin_bit_cast(bf16x8, bf[ks % DEPTH][r]), acc[R0 + r], 0, 0, 0);
         }
-        if (ks + 2 < NK) bf[ks & 1][r] = ldb(ks + 2, r);
+#endif
+        if (ks + DEPTH < NK) bf[ks % DEPTH][r] = ldb(ks + DEPTH, r);
       }
       wl = wln;
 #ifndef RW_ABL_NOSTAGE
 #pragma unroll
       for (int u = u0; u < u1; ++u)
-        unit(std::integral_constant<int, C1>{}, std::integral_constant<int, C2>{}, g1, g2, SL ^ 1, u, (u & 3) == 3 ? rels[u >> 2] : 0);
+        unit(std::integral_constant<int, C1>{}, std::integral_constant<int, C2>{}, g1, g2, slot_r ^ 1, u, (u & 3) == 3 ? rels[ks & 1][u >> 2] : 0);
 #endif
 #ifndef RW_ABL_NOEPI
 #pragma unroll
-      for (int e = e0; e < e1; ++e) epi_unit(ge, ER0 + (e >> 1), e & 1, eb[(e - e0) & 1][0], eb[(e - e0) & 1][1]);
+      for (int e = e0; e < e1; ++e) epi_unit(ge, ER0 + (e >> 1), e & 1, eb[ks & 1][e - e0][0], eb[ks & 1][e - e0][1]);
 #endif
       // the k-step's instruction mix, spread evenly: every MFMA (32 cycles on the matrix pipe) is followed by its share
       // of the VALU work and one fragment read, so that neither pipe waits for the other
@@ -511,7 +536,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
 
   // ---- prologue: the first phase's chunk into slot 0, the second phase's chunk in flight
   TileG gc = tile_geom(0);
-  constexpr int CH0 = G::chunk_of(0), CH1 = G::chunk_of(1);
+  constexpr int CH0 = G::chunk_of(0), CH1 = G::chunk_of(1 % NPH);
+  const TileG g1st = NPH > 1 ? gc : tile_geom(1);  // the tile of the second phase
   {
     // the first chunk's loads go out ahead of the weights (loads return in order: the tile can be staged while the
     // weight fragments are still streaming in; the MFMAs then wait for them fragment by fragment)
@@ -523,32 +549,33 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     // (staging the first chunk re-issues every piece as the second one)
 #pragma unroll
     for (int u = 0; u < NL * 4; ++u)
-      unit(std::integral_constant<int, CH0>{}, std::integral_constant<int, CH1>{}, gc, gc, 0, u, sDesc[(u >> 2) * NT + tid]);
+      unit(std::integral_constant<int, CH0>{}, std::integral_constant<int, CH1>{}, gc, g1st, 0, u, sDesc[(u >> 2) * NT + tid]);
   }
   RT_MARK(0)
   TileG gp = tile_geom(nt);  // "previous tile" of the first one: no tile (its stores fall outside every tensor)
+  int ph = 0;                 // phases done: the chunk of phase ph sits in ring slot ph & 1
   for (int i = 0; i < nt; ++i) {
-    const TileG gn = tile_geom(i + 1);
+    const TileG gn = tile_geom(i + 1), gnn = tile_geom(i + 2);
     // phase P stages the chunk of phase P + 1 and issues that of phase P + 2: both belong to the next tile once they wrap
     auto run = [&](auto self, auto P_) __attribute__((always_inline)) {
       constexpr int P = decltype(P_)::value;
       sync_lds();
 #ifdef RW_SKEW
-      // the four waves run the same instruction stream: without a skew their vector-memory instructions reach the CU's
-      // one address path together and three of four wait in its queue
       if (wave == 1) __builtin_amdgcn_s_sleep(RW_SKEW);
       if (wave == 2) __builtin_amdgcn_s_sleep(2 * RW_SKEW);
       if (wave == 3) __builtin_amdgcn_s_sleep(3 * RW_SKEW);
 #endif
       RT_MARK(1)
-      half(P_, std::integral_constant<int, 0>{}, std::integral_constant<bool, P == 0>{}, gp, (P + 1 < NPH ? gc : gn), (P + 2 < NPH ? gc : gn));
+      const int slot_r = ph & 1;
+      half(P_, std::integral_constant<int, 0>{}, std::integral_constant<bool, P == 0>{}, slot_r, gp, ((P + 1) / NPH == 0 ? gc : gn), ((P + 2) / NPH == 0 ? gc : ((P + 2) / NPH == 1 ? gn : gnn)));
       if constexpr (P == 0) {
         if (i == 0) {  // (the first tile has no predecessor: what that epilogue summed up was not an output)
 #pragma unroll
           for (int j = 0; j < 16; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
         }
       }
-      half(P_, std::integral_constant<int, 1>{}, std::integral_constant<bool, P == NPH - 1>{}, gc, (P + 1 < NPH ? gc : gn), (P + 2 < NPH ? gc : gn));
+      half(P_, std::integral_constant<int, 1>{}, std::integral_constant<bool, P == NPH - 1>{}, slot_r, gc, ((P + 1) / NPH == 0 ? gc : gn), ((P + 2) / NPH == 0 ? gc : ((P + 2) / NPH == 1 ? gn : gnn)));
+      ++ph;
       RT_MARK(G::chunk_of(P) < NCH ? 2 : 3)
       if constexpr (P + 1 < NPH) self(self, std::integral_constant<int, P + 1>{});
     };
@@ -557,6 +584,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     gc = gn;
   }
   // the second half of the last tile's rows
+#ifndef RW_BUILTIN_MFMA
+#pragma unroll
+  for (int r = 0; r < RH; ++r) asm volatile("s_nop 11" : "+v"(acc[RH + r]));
+#endif
 #pragma unroll
   for (int e = 0; e < RH * 2; ++e) {
     float4 t0, t1;
@@ -630,8 +661,6 @@ int rw_launch(const RwK& k0, const ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
-int rw_rows_per_wave(const ConvArgs& a) { return (a.Cin == 64 && a.H % 16 == 0) ? 8 : 4; }
-
 }  // namespace
 
 // The layers this kernel takes over: bf16 3x3, 64 couts, 64 or 128 input channels (one tensor or the in-place concat of
@@ -639,7 +668,7 @@ int rw_rows_per_wave(const ConvArgs& a) { return (a.Cin == 64 && a.H % 16 == 0) 
 bool ds_conv_rw_eligible(const ConvArgs& a) {
   if (getenv("DIFFSEP_NO_RW")) return false;
   if (!(a.dtype == DS_BF16 && a.taps == 9 && (a.Cin == 64 || a.Cin == 128) && a.Cout == CO && a.w_bs == 0 &&
-        (a.w_chunked == 0 || a.w_chunked == KC) && a.bias_mode == 0 && !a.div_b && a.W % TW == 0 && a.H % 8 == 0 &&
+        (a.w_chunked == 0 || a.w_chunked == 32) && a.bias_mode == 0 && !a.div_b && a.W % TW == 0 && a.H % 8 == 0 &&
         a.H >= 32 && a.W >= 32 && a.ldy >= CO && a.ldy % 8 == 0 && (!a.res || (a.ldr >= CO && a.ldr % 8 == 0))))
     return false;
   if (a.x2 ? !(a.C1 % KC == 0 && a.C1 > 0 && a.C1 < a.Cin && a.ldx % 8 == 0 && a.ldx2 % 8 == 0) : a.ldx % 8 != 0) return false;
@@ -684,17 +713,11 @@ int ds_launch_conv_rw(const ConvArgs& a, hipStream_t st) {
     k.sx2 = nullptr; k.sx2_bs = 0; k.ldsx2 = a.ldr; k.sw = nullptr; k.sw_chunked = 0; k.sw_shift = 0; k.sCin = CO;
   }
   const int mode = ((a.gn_scale || a.gn_acc1) && a.gn_act) ? 2 : 0;
-  const int nsk = a.sx ? a.sCin / KC : (a.res ? 2 : 0);
-  const int rpw = rw_rows_per_wave(a);
-#define RW_GO(NCH_, RPW_, NSK_) return mode == 2 ? rw_launch<NCH_, RPW_, NSK_, 2>(k, a, st) : rw_launch<NCH_, RPW_, NSK_, 0>(k, a, st)
-  if (a.Cin == 128) RW_GO(4, 4, 0);
-  if (rpw == 8) {
-    if (nsk == 0) RW_GO(2, 8, 0);
-    if (nsk == 2) RW_GO(2, 8, 2);
-    RW_GO(2, 8, 4);
-  }
-  if (nsk == 0) RW_GO(2, 4, 0);
-  if (nsk == 2) RW_GO(2, 4, 2);
-  RW_GO(2, 4, 4);
+  const int nsk = a.sx ? a.sCin / KC : (a.res ? 1 : 0);
+#define RW_GO(NCH_, NSK_) return mode == 2 ? rw_launch<NCH_, 4, NSK_, 2>(k, a, st) : rw_launch<NCH_, 4, NSK_, 0>(k, a, st)
+  if (a.Cin == 128) RW_GO(2, 0);
+  if (nsk == 0) RW_GO(1, 0);
+  if (nsk == 1) RW_GO(1, 1);
+  RW_GO(1, 2);
 #undef RW_GO
 }
