@@ -46,7 +46,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 GFLOP_PER_NFE = {64: 133.83, 128: 532.89}  # SURVEY.md §8d, per utterance at W=256 (probe-counted 2*MAC)
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "split": 2500.0 / 3}  # MI355X_MICROARCH.md: dense MFMA peaks (split: 3 bf16 MFMAs per product)
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "split": 2500.0 / 3}  # MI355X_MICROARCH.md: dense MFMA peaks (split: 3 bf16 MFMAs per product)
 HBM_PEAK_BPS = 8.0e12                          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 KERNEL_NAMES = {"conv3x3_8x32xN64": "conv_mfma_kernel<%(dt)s,9,8,32,64,2,2>",
                 "conv3x3_ws_64to64": "conv3x3_ws1_kernel<%(dt)s> (weight-stationary 64->64)",
@@ -206,7 +206,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16, help="utterances per GPU")
     ap.add_argument("--nf", type=int, default=64)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "split"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32", "split"])
     ap.add_argument("--samples", type=int, default=32000, help="samples per utterance (4 s at 8 kHz)")
     ap.add_argument("-N", type=int, default=30)
     ap.add_argument("--corrector-steps", type=int, default=1)
@@ -277,7 +277,7 @@ def main():
     else:
         from diffsep_amd import _lib, ops
         from diffsep_amd.engine import Engine, pack_state_dict, param_table
-        dt_flag = {"bf16": _lib.BF16, "f32": _lib.F32, "split": _lib.F32_SPLIT}[args.dtype]
+        dt_flag = {"bf16": _lib.BF16, "f16": _lib.F16, "f32": _lib.F32, "split": _lib.F32_SPLIT}[args.dtype]
         cfg = _lib.model_config(nf=args.nf, num_sources=S, dtype=dt_flag)
         sd = synth.synth_state_dict([(n, s) for n, s, _ in param_table(cfg)], 7)
         K = max(1, args.in_flight)

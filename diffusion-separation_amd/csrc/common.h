@@ -41,18 +41,40 @@ void ds_set_error(const std::string& s);
     }                                                                                  \
   } while (0)
 #define DS_LAUNCH_CHECK() DS_HIP(hipGetLastError())
+// hipFuncAttributeMaxDynamicSharedMemorySize lives per DEVICE: set it once per device ordinal (an engine may sit on any GPU
+// of the process; legal during stream capture)
+#define DS_FUNC_LDS_ONCE(kern, bytes)                                                                              \
+  do {                                                                                                             \
+    static bool done_[32] = {};                                                                                    \
+    int dev_ = 0;                                                                                                  \
+    (void)hipGetDevice(&dev_);                                                                                     \
+    if (dev_ < 0 || dev_ >= 32 || !done_[dev_]) {                                                                  \
+      DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes))); \
+      if (dev_ >= 0 && dev_ < 32) done_[dev_] = true;                                                              \
+    }                                                                                                              \
+  } while (0)
 
-// ---------------------------------------------------------------- scalar conversions
+// ---------------------------------------------------------------- 16-bit storage format
+// The 16-bit tensors of the engine ("bf16_t" = raw 16 bits) are bfloat16 by default and IEEE half precision when the
+// library is built with -DDS_HALF_F16 (libdiffsep_hip_f16.so): the same kernels at the same MFMA rate with 11 instead
+// of 8 significand bits — one score evaluation is 2.3e-3 instead of 1.9e-2 from fp32 (tools/probes/storage_dtype_probe.py).
+// Everything that touches stored 16-bit values goes through h2f / f2h / pack_h2 / h_lo / h_hi / mfma_h*; the split mode's
+// hi / lo planes (fp32 tensors as two bfloat16 halves) are bfloat16 in both builds (pack_bf16x2, bf_lo / bf_hi, mfma_bf*).
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4_acc;
 __host__ __device__ inline float bf2f(bf16_t v) {
   union { uint32_t u; float f; } c; c.u = ((uint32_t)v) << 16; return c.f;
 }
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 // two floats -> packed bf16x2 (RNE): one v_cvt_pk_bf16_f32 on gfx950
 __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
   f32x2_t v = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ inline float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ inline float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 __host__ __device__ inline bf16_t f2bf(float f) {  // round-to-nearest-even
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_bit_cast(unsigned short, (__bf16)f);
@@ -63,6 +85,42 @@ __host__ __device__ inline bf16_t f2bf(float f) {  // round-to-nearest-even
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+__device__ inline f32x16 mfma_bf32(const uint4& a, const uint4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ inline f32x4_acc mfma_bf16(const uint4& a, const uint4& b, const f32x4_acc& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+#ifdef DS_HALF_F16
+#define DS_HALF_NAME "f16"
+#define DS_MFMA_H32_ASM "v_mfma_f32_32x32x16_f16"
+#define DS_H_ONE 0x3c00u   // 1.0
+__host__ __device__ inline float h2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__host__ __device__ inline bf16_t f2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+__device__ inline uint32_t pack_h2(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+__device__ inline float h_lo(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[0]; }
+__device__ inline float h_hi(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[1]; }
+__device__ inline f32x16 mfma_h32(const uint4& a, const uint4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ inline f32x4_acc mfma_h16(const uint4& a, const uint4& b, const f32x4_acc& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+#else
+#define DS_HALF_NAME "bf16"
+#define DS_MFMA_H32_ASM "v_mfma_f32_32x32x16_bf16"
+#define DS_H_ONE 0x3f80u   // 1.0
+__host__ __device__ inline float h2f(bf16_t v) { return bf2f(v); }
+__host__ __device__ inline bf16_t f2h(float f) { return f2bf(f); }
+__device__ inline uint32_t pack_h2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+__device__ inline float h_lo(uint32_t w) { return bf_lo(w); }
+__device__ inline float h_hi(uint32_t w) { return bf_hi(w); }
+__device__ inline f32x16 mfma_h32(const uint4& a, const uint4& b, const f32x16& c) { return mfma_bf32(a, b, c); }
+__device__ inline f32x4_acc mfma_h16(const uint4& a, const uint4& b, const f32x4_acc& c) { return mfma_bf16(a, b, c); }
+#endif
 
 template <typename T> struct Elt;
 template <> struct Elt<float> {
@@ -72,8 +130,8 @@ template <> struct Elt<float> {
 };
 template <> struct Elt<bf16_t> {
   static constexpr int KV = 8;
-  __device__ static inline float ld(const bf16_t* p) { return bf2f(*p); }
-  __device__ static inline void st(bf16_t* p, float v) { *p = f2bf(v); }
+  __device__ static inline float ld(const bf16_t* p) { return h2f(*p); }
+  __device__ static inline void st(bf16_t* p, float v) { *p = f2h(v); }
 };
 
 // 8 consecutive channels <-> 8 floats (the elementwise kernels' unit of work: C % 8 == 0 always).
@@ -85,10 +143,10 @@ template <> __device__ inline void load8<float>(const float* p, float* f) {
 }
 template <> __device__ inline void load8<bf16_t>(const bf16_t* p, float* f) {
   uint4 u = *reinterpret_cast<const uint4*>(p);
-  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
-  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
-  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
-  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+  f[0] = h_lo(u.x); f[1] = h_hi(u.x);
+  f[2] = h_lo(u.y); f[3] = h_hi(u.y);
+  f[4] = h_lo(u.z); f[5] = h_hi(u.z);
+  f[6] = h_lo(u.w); f[7] = h_hi(u.w);
 }
 template <typename T> __device__ inline void store8(T* p, const float* f);
 template <> __device__ inline void store8<float>(float* p, const float* f) {
@@ -97,10 +155,10 @@ template <> __device__ inline void store8<float>(float* p, const float* f) {
 }
 template <> __device__ inline void store8<bf16_t>(bf16_t* p, const float* f) {
   uint4 u;
-  u.x = pack_bf16x2(f[0], f[1]);
-  u.y = pack_bf16x2(f[2], f[3]);
-  u.z = pack_bf16x2(f[4], f[5]);
-  u.w = pack_bf16x2(f[6], f[7]);
+  u.x = pack_h2(f[0], f[1]);
+  u.y = pack_h2(f[2], f[3]);
+  u.z = pack_h2(f[4], f[5]);
+  u.w = pack_h2(f[6], f[7]);
   *reinterpret_cast<uint4*>(p) = u;
 }
 

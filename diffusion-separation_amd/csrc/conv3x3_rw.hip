@@ -216,7 +216,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
         if (!p.sw) {  // residual as a skip with identity weights: channel chb + 8 h + j feeds cout co with weight 1
           const int d = co - (chb + 8 * h);  // the lane's 8 channels hold the 1 at position d (if 0 <= d < 8)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) f[e] = d == 2 * e ? 0x3f80u : (d == 2 * e + 1 ? 0x3f800000u : 0u);
+          for (int e = 0; e < 4; ++e) f[e] = d == 2 * e ? DS_H_ONE : (d == 2 * e + 1 ? DS_H_ONE << 16 : 0u);
         }
         put_w(ks, f);
       }
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     const int k = u >> 2, d = u & 3;
     const unsigned w = pa[k][d];
     if constexpr (P1 < NCH && MODE != 0) {
-      const float lo = __uint_as_float(w << 16), hi = __uint_as_float(w & 0xffff0000u);
+      const float lo = h_lo(w), hi = h_hi(w);
       float z0 = fmaf(lo, gsc[2 * d], gsh[2 * d]), z1 = fmaf(hi, gsc[2 * d + 1], gsh[2 * d + 1]);
       if (MODE == 2) {
         // FOLD: the affine carries the factor -log2(e), z IS the exponent of the sigmoid's exp2 and the staged value is
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
         z0 *= __builtin_amdgcn_rcpf(1.0f + e0);
         z1 *= __builtin_amdgcn_rcpf(1.0f + e1);
       }
-      so[d] = pack_bf16x2(z0, z1);
+      so[d] = pack_h2(z0, z1);
     } else {
       so[d] = w;
     }
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
       ssq[8 * j + e] = fmaf(v[e], v[e], ssq[8 * j + e]);
     }
 #endif
-    u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    u32x4_t ov = {pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
     swap_halves(ov);  // lane (pixel l32, half h): couts 16 j + 8 h .. + 7
     if (j == 0) {
       ov0 = ov;
@@ -490,20 +490,18 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
         // and staged pieces through AGPRs: 200 v_accvgpr moves per tile.)  What the compiler does not know about an asm
         // MFMA: the 12 wait states between its result and a VALU read — the guard at the start of every half.
         if (W0 + ks < NWR) {
-          if (P == 0 && ks == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc[R0 + r]) : "a"(wk), "v"(bf[ks % DEPTH][r]));
-          else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[R0 + r]) : "a"(wk), "v"(bf[ks % DEPTH][r]));
+          if (P == 0 && ks == 0) asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, 0" : "=v"(acc[R0 + r]) : "a"(wk), "v"(bf[ks % DEPTH][r]));
+          else asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, %0" : "+v"(acc[R0 + r]) : "a"(wk), "v"(bf[ks % DEPTH][r]));
         } else {  // LDS-resident fragment: straight from the ds_read's VGPRs (no VALU copy in front of the MFMA)
-          if (P == 0 && ks == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc[R0 + r]) : "v"(wk), "v"(bf[ks % DEPTH][r]));
-          else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[R0 + r]) : "v"(wk), "v"(bf[ks % DEPTH][r]));
+          if (P == 0 && ks == 0) asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, 0" : "=v"(acc[R0 + r]) : "v"(wk), "v"(bf[ks % DEPTH][r]));
+          else asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, %0" : "+v"(acc[R0 + r]) : "v"(wk), "v"(bf[ks % DEPTH][r]));
         }
 #else
         if (P == 0 && ks == 0) {  // a tile's first MFMA of a row starts from zero (the row's epilogue has run)
           const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc[R0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wk),
-                                                                __builtin_bit_cast(bf16x8, bf[ks % DEPTH][r]), zero, 0, 0, 0);
+          acc[R0 + r] = mfma_h32(__builtin_bit_cast(uint4, wk), __builtin_bit_cast(uint4, bf[ks % DEPTH][r]), zero);
         } else {
-          acc[R0 + r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wk),
-                                                                __builtin_bit_cast(bf16x8, bf[ks % DEPTH][r]), acc[R0 + r], 0, 0, 0);
+          acc[R0 + r] = mfma_h32(__builtin_bit_cast(uint4, wk), __builtin_bit_cast(uint4, bf[ks % DEPTH][r]), acc[R0 + r]);
         }
 #endif
         if (ks + DEPTH < NK) bf[ks % DEPTH][r] = ldb(ks + DEPTH, r);
@@ -650,7 +648,7 @@ int rw_launch(const RwK& k0, const ConvArgs& a, hipStream_t st) {
   k.tiles_x = a.W / TW;
   k.tiles_per_img = tiles;
   auto kern = conv3x3_rw_kernel<NCH, RPW, NSK, MODE>;
-  DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_TOTAL));
+  DS_FUNC_LDS_ONCE(kern, G::LDS_TOTAL);
   hipLaunchKernelGGL(kern, dim3(a.B * k.G), dim3(NT), G::LDS_TOTAL, st, k);
   DS_LAUNCH_CHECK();
   {

@@ -116,20 +116,20 @@ __device__ inline float row16_sum(float v) {
 template <bool ACT>
 __device__ inline uint4 gn8(const uint4& u, const float* sc, const float* sh) {
   float f[8];
-  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
-  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
-  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
-  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+  f[0] = h_lo(u.x); f[1] = h_hi(u.x);
+  f[2] = h_lo(u.y); f[3] = h_hi(u.y);
+  f[4] = h_lo(u.z); f[5] = h_hi(u.z);
+  f[6] = h_lo(u.w); f[7] = h_hi(u.w);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float v = f[j] * sc[j] + sh[j];
     f[j] = ACT ? silu_t<bf16_t>(v) : v;
   }
   uint4 o;
-  o.x = pack_bf16x2(f[0], f[1]);
-  o.y = pack_bf16x2(f[2], f[3]);
-  o.z = pack_bf16x2(f[4], f[5]);
-  o.w = pack_bf16x2(f[6], f[7]);
+  o.x = pack_h2(f[0], f[1]);
+  o.y = pack_h2(f[2], f[3]);
+  o.z = pack_h2(f[4], f[5]);
+  o.w = pack_h2(f[6], f[7]);
   return o;
 }
 
@@ -148,8 +148,8 @@ __device__ inline void split4(const uint4& v, uint2& hi, uint2& lo) {
   const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
   hi.x = pack_bf16x2(f0, f1);
   hi.y = pack_bf16x2(f2, f3);
-  lo.x = pack_bf16x2(f0 - __uint_as_float(hi.x << 16), f1 - __uint_as_float(hi.x & 0xffff0000u));
-  lo.y = pack_bf16x2(f2 - __uint_as_float(hi.y << 16), f3 - __uint_as_float(hi.y & 0xffff0000u));
+  lo.x = pack_bf16x2(f0 - bf_lo(hi.x), f1 - bf_hi(hi.x));
+  lo.y = pack_bf16x2(f2 - bf_lo(hi.y), f3 - bf_hi(hi.y));
 }
 
 // tile shapes by image width: 16 columns x 8 rows on 8 waves, 8 x 8 on 8 waves (4 of them multiply: 512 threads keep the two
@@ -361,16 +361,13 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
           for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
             for (int h = 0; h < NH; ++h)
-              acc[h][kb & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                  __builtin_bit_cast(bf16x8, wf[set][term == 0 ? 1 : 0][h][kb]),
-                  __builtin_bit_cast(bf16x8, xf[set][term == 1 ? 1 : 0][kb]), acc[h][kb & 1], 0, 0, 0);
+              acc[h][kb & 1] = mfma_bf16(wf[set][term == 0 ? 1 : 0][h][kb], xf[set][term == 1 ? 1 : 0][kb], acc[h][kb & 1]);
       } else {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
           for (int h = 0; h < NH; ++h)
-            acc[h][kb & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[set][0][h][kb]),
-                                                                     __builtin_bit_cast(bf16x8, xf[set][0][kb]), acc[h][kb & 1], 0, 0, 0);
+            acc[h][kb & 1] = mfma_h16(wf[set][0][h][kb], xf[set][0][kb], acc[h][kb & 1]);
       }
     };
     if (raw) {  // folded 1x1 convolution: the centre tap only
@@ -492,11 +489,11 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
       const u32x4_t ov = {__float_as_uint(v[h][0]), __float_as_uint(v[h][1]), __float_as_uint(v[h][2]), __float_as_uint(v[h][3])};
       __builtin_amdgcn_raw_buffer_store_b128(ov, ry, yo, 0, 0);
     } else {
-      v[h][0] = fmaf(__uint_as_float(rres[h].x << 16), osc, v[h][0]);
-      v[h][1] = fmaf(__uint_as_float(rres[h].x & 0xffff0000u), osc, v[h][1]);
-      v[h][2] = fmaf(__uint_as_float(rres[h].y << 16), osc, v[h][2]);
-      v[h][3] = fmaf(__uint_as_float(rres[h].y & 0xffff0000u), osc, v[h][3]);
-      st8(ry, yo, make_uint2(pack_bf16x2(v[h][0], v[h][1]), pack_bf16x2(v[h][2], v[h][3])));
+      v[h][0] = fmaf(h_lo(rres[h].x), osc, v[h][0]);
+      v[h][1] = fmaf(h_hi(rres[h].x), osc, v[h][1]);
+      v[h][2] = fmaf(h_lo(rres[h].y), osc, v[h][2]);
+      v[h][3] = fmaf(h_hi(rres[h].y), osc, v[h][3]);
+      st8(ry, yo, make_uint2(pack_h2(v[h][0], v[h][1]), pack_h2(v[h][2], v[h][3])));
     }
   }
   ST_MARK(7)
@@ -540,12 +537,7 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
 template <int GW, int PC, int NS, int MODE, int ESZ>
 int launch_small(const SmK& k, const ConvArgs& a, hipStream_t st) {
   constexpr int LDS = SmGeom<GW, PC, NS, ESZ>::LDS;
-  static bool attr_done = false;
-  if (!attr_done) {
-    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_small_kernel<GW, PC, NS, MODE, ESZ>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_done = true;
-  }
+  DS_FUNC_LDS_ONCE((conv3x3_small_kernel<GW, PC, NS, MODE, ESZ>), LDS);
   dim3 grid(k.tiles_x * cdiv(a.H, SmTile<GW>::THT), a.Cout / NS, a.B);
   hipLaunchKernelGGL((conv3x3_small_kernel<GW, PC, NS, MODE, ESZ>), grid, dim3(SmTile<GW>::NT), LDS, st, k);
   {

@@ -58,6 +58,14 @@ extern "C" int diffsep_ws_debug_read(unsigned long long* out, int reset) {
 
 namespace {
 
+// (fragments are declared as bf16x8 = 8 raw 16-bit values; the MFMA is the storage format's)
+__device__ inline f32x16 mfma_h32x(bf16x8 a, bf16x8 b, f32x16 c, int, int, int) {
+  return mfma_h32(__builtin_bit_cast(uint4, a), __builtin_bit_cast(uint4, b), c);
+}
+__device__ inline f32x4_acc mfma_h16x(bf16x8 a, bf16x8 b, f32x4_acc c, int, int, int) {
+  return mfma_h16(__builtin_bit_cast(uint4, a), __builtin_bit_cast(uint4, b), c);
+}
+
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 constexpr unsigned OOB = 0x80000000u;
 
@@ -124,20 +132,20 @@ struct WsK {
 template <bool ACT>
 __device__ inline uint4 gn8(const uint4& u, const float* sc, const float* sh) {
   float f[8];
-  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
-  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
-  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
-  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+  f[0] = h_lo(u.x); f[1] = h_hi(u.x);
+  f[2] = h_lo(u.y); f[3] = h_hi(u.y);
+  f[4] = h_lo(u.z); f[5] = h_hi(u.z);
+  f[6] = h_lo(u.w); f[7] = h_hi(u.w);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float v = f[j] * sc[j] + sh[j];
     f[j] = ACT ? silu_t<bf16_t>(v) : v;
   }
   uint4 o;
-  o.x = pack_bf16x2(f[0], f[1]);
-  o.y = pack_bf16x2(f[2], f[3]);
-  o.z = pack_bf16x2(f[4], f[5]);
-  o.w = pack_bf16x2(f[6], f[7]);
+  o.x = pack_h2(f[0], f[1]);
+  o.y = pack_h2(f[2], f[3]);
+  o.z = pack_h2(f[4], f[5]);
+  o.w = pack_h2(f[6], f[7]);
   return o;
 }
 
@@ -361,8 +369,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
         acc[0][0] += (float)(__builtin_bit_cast(uint4, pf).x ^ __builtin_bit_cast(uint4, w0).x);
         acc[1][0] += (float)(__builtin_bit_cast(uint4, pf).y ^ __builtin_bit_cast(uint4, w1).y);
 #else
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, pf, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, pf, acc[1], 0, 0, 0);
+        acc[0] = mfma_h32x(w0, pf, acc[0], 0, 0, 0);
+        acc[1] = mfma_h32x(w1, pf, acc[1], 0, 0, 0);
 #endif
         const int s = tap * 2 + kb;
         if (s < NA1 && loads) issue_one(c, s);                    // chunk q + 2 -> the set chunk q came from
@@ -387,8 +395,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const bf16x8 xf = __builtin_bit_cast(bf16x8, xsk[i]);
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wsk[0][(SKB > 4 ? 4 : 0) * c + i]), xf, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wsk[1][(SKB > 4 ? 4 : 0) * c + i]), xf, acc[1], 0, 0, 0);
+          acc[0] = mfma_h32x(__builtin_bit_cast(bf16x8, wsk[0][(SKB > 4 ? 4 : 0) * c + i]), xf, acc[0], 0, 0, 0);
+          acc[1] = mfma_h32x(__builtin_bit_cast(bf16x8, wsk[1][(SKB > 4 ? 4 : 0) * c + i]), xf, acc[1], 0, 0, 0);
         }
       }
     }
@@ -440,10 +448,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
       for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], osc, bz[j]);
       if (has_res) {
         const uint4 u = rres[s4];
-        v[0] = fmaf(__uint_as_float(u.x << 16), osc, v[0]); v[1] = fmaf(__uint_as_float(u.x & 0xffff0000u), osc, v[1]);
-        v[2] = fmaf(__uint_as_float(u.y << 16), osc, v[2]); v[3] = fmaf(__uint_as_float(u.y & 0xffff0000u), osc, v[3]);
-        v[4] = fmaf(__uint_as_float(u.z << 16), osc, v[4]); v[5] = fmaf(__uint_as_float(u.z & 0xffff0000u), osc, v[5]);
-        v[6] = fmaf(__uint_as_float(u.w << 16), osc, v[6]); v[7] = fmaf(__uint_as_float(u.w & 0xffff0000u), osc, v[7]);
+        v[0] = fmaf(h_lo(u.x), osc, v[0]); v[1] = fmaf(h_hi(u.x), osc, v[1]);
+        v[2] = fmaf(h_lo(u.y), osc, v[2]); v[3] = fmaf(h_hi(u.y), osc, v[3]);
+        v[4] = fmaf(h_lo(u.z), osc, v[4]); v[5] = fmaf(h_hi(u.z), osc, v[5]);
+        v[6] = fmaf(h_lo(u.w), osc, v[6]); v[7] = fmaf(h_hi(u.w), osc, v[7]);
       }
       if (has_stats) {
 #pragma unroll
@@ -452,7 +460,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws1_kernel(WsK p) {
           ssq[j] = fmaf(v[j], v[j], ssq[j]);
         }
       }
-      u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+      u32x4_t ov = {pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
       WS_STORE(ov, ry, o + (unsigned)(s4 * 8 * p.ldy * 2), 0, 0);
     }
 #pragma unroll
@@ -596,8 +604,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin_in_kernel(ThinK p) {
       const int tap = 2 * kb + h < 9 ? 2 * kb + h : 8;  // (the missing tenth tap multiplies zero weights)
       const bf16x8 pf = __builtin_bit_cast(
           bf16x8, *reinterpret_cast<const uint4*>(sx + ((wave + tap / 3) * HW_ + l32 + tap % 3) * 16));
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[0][kb]), pf, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[1][kb]), pf, acc[1], 0, 0, 0);
+      acc[0] = mfma_h32x(__builtin_bit_cast(bf16x8, wf[0][kb]), pf, acc[0], 0, 0, 0);
+      acc[1] = mfma_h32x(__builtin_bit_cast(bf16x8, wf[1][kb]), pf, acc[1], 0, 0, 0);
     }
     // epilogue: the wave's 32 pixels x 64 couts through its private scratch, 8 pixels at a time, as full 128-byte lines
     const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
@@ -625,7 +633,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin_in_kernel(ThinK p) {
           ssq[j] = fmaf(v[j], v[j], ssq[j]);
         }
       }
-      u32x4_t ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+      u32x4_t ov = {pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
       WS_STORE(ov, ry, o + (unsigned)(s4 * 8 * p.ldy * 2), 0, 0);
     }
   }
@@ -789,7 +797,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin_out_kernel(ThinOutK p) {
           for (int g = 0; g < 2; ++g) {
             const bf16x8 xf = __builtin_bit_cast(
                 bf16x8, *reinterpret_cast<const uint4*>(sX + ((wave + tap / 3) * HW_ + 16 * g + tap % 3) * TO_PROW + foff + kb * 64));
-            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[g], 0, 0, 0);
+            acc[g] = mfma_h16x(wf, xf, acc[g], 0, 0, 0);
           }
         }
     }
@@ -801,14 +809,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin_out_kernel(ThinOutK p) {
         const int m = (ty * TH + wave) * p.W + tx * TW + 16 * g + l16;
         const uint2 rv = ld8(rr, (unsigned)((m * p.ldr + 4 * q) * 2));
         float v[4];
-        v[0] = acc[g][0] + bz[0] + __uint_as_float(rv.x << 16);
-        v[1] = acc[g][1] + bz[1] + __uint_as_float(rv.x & 0xffff0000u);
-        v[2] = acc[g][2] + bz[2] + __uint_as_float(rv.y << 16);
-        v[3] = acc[g][3] + bz[3] + __uint_as_float(rv.y & 0xffff0000u);
+        v[0] = acc[g][0] + bz[0] + h_lo(rv.x);
+        v[1] = acc[g][1] + bz[1] + h_hi(rv.x);
+        v[2] = acc[g][2] + bz[2] + h_lo(rv.y);
+        v[3] = acc[g][3] + bz[3] + h_hi(rv.y);
 #pragma unroll
         for (int i2 = 0; i2 < 4; ++i2)
           if (4 * q + i2 >= p.Cout) v[i2] = 0.f;
-        st8(ry, (unsigned)((m * p.ldy + 4 * q) * 2), make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])));
+        st8(ry, (unsigned)((m * p.ldy + 4 * q) * 2), make_uint2(pack_h2(v[0], v[1]), pack_h2(v[2], v[3])));
       }
     }
   }
@@ -870,12 +878,7 @@ int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st) {
   const dim3 grid(a.B * k.G), block(512);
 #define DS_WS_LAUNCH(M_, S_)                                                                                       \
   do {                                                                                                             \
-    static bool attr_done = false;                                                                                 \
-    if (!attr_done) {                                                                                              \
-      DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws1_kernel<M_, S_>),                        \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));                          \
-      attr_done = true;                                                                                            \
-    }                                                                                                              \
+    DS_FUNC_LDS_ONCE((conv3x3_ws1_kernel<M_, S_>), LDS_TOTAL);                                                     \
     hipLaunchKernelGGL((conv3x3_ws1_kernel<M_, S_>), grid, block, LDS_TOTAL, st, k);                               \
     ds_set_last_conv_kernel("conv3x3_ws1_kernel<" #M_ "," #S_ ">");                                                \
   } while (0)
@@ -936,12 +939,7 @@ int ds_launch_conv_thin_out(const ConvArgs& a, hipStream_t st) {
   k.H = a.H; k.W = a.W; k.G = ws_blocks_per_image(a) * 2;  // two blocks per CU
   if (k.G > tiles) k.G = tiles;
   k.tiles_x = a.W / TW; k.tiles_per_img = tiles;
-  static bool attr_done = false;
-  if (!attr_done) {
-    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_thin_out_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               TO_LDS));
-    attr_done = true;
-  }
+  DS_FUNC_LDS_ONCE(conv3x3_thin_out_kernel, TO_LDS);
   hipLaunchKernelGGL(conv3x3_thin_out_kernel, dim3(a.B * k.G), dim3(512), TO_LDS, st, k);
   ds_set_last_conv_kernel("conv3x3_thin_out_kernel");
   DS_LAUNCH_CHECK();

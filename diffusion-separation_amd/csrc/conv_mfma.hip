@@ -59,15 +59,17 @@ template <> struct Mma<float> {
     c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
   }
 };
-template <> struct Mma<bf16_t> {
+template <> struct Mma<bf16_t> {  // the engine's 16-bit storage format (bfloat16, or half precision with -DDS_HALF_F16)
   __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
 #ifdef ABL_NOMFMA
     c[0] += __uint_as_float(a.x ^ b.x);
     return;
 #endif
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
-                                                0);
+    c = mfma_h32(a, b, c);
   }
+};
+struct MmaBf {  // true bfloat16 operands: the hi / lo planes of the split mode
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) { c = mfma_bf32(a, b, c); }
 };
 
 // fp32 value = hi + lo with hi, lo bf16 (|error| <= 2^-17 |v|): the operands of the "split" mode, in which an fp32 conv
@@ -76,8 +78,8 @@ __device__ inline void split4(const uint4& v, uint2& hi, uint2& lo) {
   const float f0 = __uint_as_float(v.x), f1 = __uint_as_float(v.y), f2 = __uint_as_float(v.z), f3 = __uint_as_float(v.w);
   hi.x = pack_bf16x2(f0, f1);
   hi.y = pack_bf16x2(f2, f3);
-  lo.x = pack_bf16x2(f0 - __uint_as_float(hi.x << 16), f1 - __uint_as_float(hi.x & 0xffff0000u));
-  lo.y = pack_bf16x2(f2 - __uint_as_float(hi.y << 16), f3 - __uint_as_float(hi.y & 0xffff0000u));
+  lo.x = pack_bf16x2(f0 - bf_lo(hi.x), f1 - bf_hi(hi.x));
+  lo.y = pack_bf16x2(f2 - bf_lo(hi.y), f3 - bf_hi(hi.y));
 }
 
 // GN-apply (+SiLU) on one 16-byte vector of KV channels
@@ -98,20 +100,20 @@ template <> struct GnVec<bf16_t> {
   template <bool ACT>
   __device__ static inline uint4 run(const uint4& u, const float* sc, const float* sh) {
     float f[8];
-    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
-    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
-    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
-    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+    f[0] = h_lo(u.x); f[1] = h_hi(u.x);
+    f[2] = h_lo(u.y); f[3] = h_hi(u.y);
+    f[4] = h_lo(u.z); f[5] = h_hi(u.z);
+    f[6] = h_lo(u.w); f[7] = h_hi(u.w);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = f[j] * sc[j] + sh[j];
       f[j] = ACT ? silu_t<bf16_t>(v) : v;
     }
     uint4 o;
-    o.x = pack_bf16x2(f[0], f[1]);
-    o.y = pack_bf16x2(f[2], f[3]);
-    o.z = pack_bf16x2(f[4], f[5]);
-    o.w = pack_bf16x2(f[6], f[7]);
+    o.x = pack_h2(f[0], f[1]);
+    o.y = pack_h2(f[2], f[3]);
+    o.z = pack_h2(f[4], f[5]);
+    o.w = pack_h2(f[6], f[7]);
     return o;
   }
 };
@@ -124,10 +126,10 @@ template <> __device__ inline void unpack8<float>(const uint4* u, float* f) {
   f[6] = __uint_as_float(u[1].z); f[7] = __uint_as_float(u[1].w);
 }
 template <> __device__ inline void unpack8<bf16_t>(const uint4* u, float* f) {
-  f[0] = __uint_as_float(u[0].x << 16); f[1] = __uint_as_float(u[0].x & 0xffff0000u);
-  f[2] = __uint_as_float(u[0].y << 16); f[3] = __uint_as_float(u[0].y & 0xffff0000u);
-  f[4] = __uint_as_float(u[0].z << 16); f[5] = __uint_as_float(u[0].z & 0xffff0000u);
-  f[6] = __uint_as_float(u[0].w << 16); f[7] = __uint_as_float(u[0].w & 0xffff0000u);
+  f[0] = h_lo(u[0].x); f[1] = h_hi(u[0].x);
+  f[2] = h_lo(u[0].y); f[3] = h_hi(u[0].y);
+  f[4] = h_lo(u[0].z); f[5] = h_hi(u[0].z);
+  f[6] = h_lo(u[0].w); f[7] = h_hi(u[0].w);
 }
 
 template <typename T> __device__ inline void pack8(const float* f, uint4* u);
@@ -136,7 +138,7 @@ template <> __device__ inline void pack8<float>(const float* f, uint4* u) {
   u[1] = make_uint4(__float_as_uint(f[4]), __float_as_uint(f[5]), __float_as_uint(f[6]), __float_as_uint(f[7]));
 }
 template <> __device__ inline void pack8<bf16_t>(const float* f, uint4* u) {
-  u[0] = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+  u[0] = make_uint4(pack_h2(f[0], f[1]), pack_h2(f[2], f[3]), pack_h2(f[4], f[5]), pack_h2(f[6], f[7]));
 }
 
 struct ConvK {  // kernel-side copy of ConvArgs (typed by the template)
@@ -530,15 +532,15 @@ __global__ __launch_bounds__(NT, OCC) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-              for (int j = 0; j < WN; ++j) Mma<bf16_t>::run(bfl[j], af[i], acc[i][j]);
+              for (int j = 0; j < WN; ++j) MmaBf::run(bfl[j], af[i], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-              for (int j = 0; j < WN; ++j) Mma<bf16_t>::run(bfr[j], afl[i], acc[i][j]);
+              for (int j = 0; j < WN; ++j) MmaBf::run(bfr[j], afl[i], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-              for (int j = 0; j < WN; ++j) Mma<bf16_t>::run(bfr[j], af[i], acc[i][j]);
+              for (int j = 0; j < WN; ++j) MmaBf::run(bfr[j], af[i], acc[i][j]);
           } else {
 #pragma unroll
             for (int i = 0; i < WM; ++i)
@@ -814,11 +816,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   using G = ConvGeom<T, TAPS, TH, TW, BN, KC, EP, NT>;
   constexpr int LDS = G::LDS + 4096;  // + the [2][Cin <= 512] GroupNorm table of the accumulator mode
   auto kern = conv_mfma_kernel<T, TAPS, TH, TW, BN, WM, WN, KC, EP, OCC, SP, NT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_done = true;
-  }
+  DS_FUNC_LDS_ONCE(kern, LDS);
   ConvK k;
   k.x = a.x; k.x_bs = a.x_bs; k.ldx = a.ldx; k.C1 = a.x2 ? a.C1 : a.Cin;
   k.x2 = a.x2; k.x2_bs = a.x2_bs; k.ldx2 = a.ldx2;
@@ -858,7 +856,7 @@ static int launch_cfg(const ConvArgs& a, hipStream_t st) {
   {
     static char name[128] = {0};
     if (!name[0])
-      snprintf(name, sizeof(name), "conv_mfma_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "float", TAPS,
+      snprintf(name, sizeof(name), "conv_mfma_kernel<%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? DS_HALF_NAME : "float", TAPS,
                TH, TW, BN, WM, WN, KC, EP, OCC, SP, NT);
     ds_set_last_conv_kernel(name);
   }

@@ -7,7 +7,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/diffsep_hip.h"
@@ -332,6 +334,10 @@ struct diffsep_engine {
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
   bool graph_ok = false;
+  // the captured graphs of the plans seen so far, keyed by (B, T): every plan lays its tensors out in the ONE arena, so a
+  // graph stays valid until the arena is reallocated.  graph / gexec / graph_ok above are the current plan's entry.
+  struct GraphRec { hipGraph_t g; hipGraphExec_t x; };
+  std::map<std::pair<int, long>, GraphRec> graphs;
   int use_graph = 1;
   bool warmed = false;
   int64_t weight_bytes = 0;
@@ -769,9 +775,14 @@ static int score_forward_impl(diffsep_engine* e, const float* xt, const float* t
   return 0;
 }
 
+// Forget every captured graph (the arena moved, graphs were switched off, the engine goes away).  The caller has made sure
+// that none of them is still executing.
 static void drop_graph(diffsep_engine* e) {
-  if (e->gexec) hipGraphExecDestroy(e->gexec);
-  if (e->graph) hipGraphDestroy(e->graph);
+  for (auto& kv : e->graphs) {
+    if (kv.second.x) hipGraphExecDestroy(kv.second.x);
+    if (kv.second.g) hipGraphDestroy(kv.second.g);
+  }
+  e->graphs.clear();
   e->gexec = nullptr;
   e->graph = nullptr;
   e->graph_ok = false;
@@ -782,7 +793,9 @@ static void drop_graph(diffsep_engine* e) {
 static int ensure_plan(diffsep_engine* e, int B, long T, hipStream_t st) {
   if (e->planB == B && e->planT == T && e->arena) return 0;
   DS_CHECK(B >= 1 && T >= 1, "empty batch or signal");
-  drop_graph(e);
+  // a plan seen before keeps its captured graph (one per (B, T): evaluate / separate alternate between a few widths and
+  // the short last batch of each); only the layout and the zero padding of the arena are re-established below
+  e->graph = nullptr; e->gexec = nullptr; e->graph_ok = false;
   const int S = e->cfg.num_sources;
   const size_t nst = (size_t)B * S * T;
   // state region
@@ -799,6 +812,7 @@ static int ensure_plan(diffsep_engine* e, int B, long T, hipStream_t st) {
   const size_t need = e->top + e->stats_need + 8192;
   if (need > e->cap) {
     DS_HIP(hipStreamSynchronize(st));
+    drop_graph(e);  // their addresses die with the old arena (nothing is in flight after the synchronisation)
     if (e->arena) DS_HIP(hipFree(e->arena));
     e->arena = nullptr;
     e->cap = 0;
@@ -824,6 +838,10 @@ static int ensure_plan(diffsep_engine* e, int B, long T, hipStream_t st) {
   e->st_seeds = (unsigned long long*)e_alloc(e, (size_t)B * 8);
   e->planB = B;
   e->planT = T;
+  {
+    auto it = e->graphs.find(std::make_pair(B, T));
+    if (it != e->graphs.end()) { e->graph = it->second.g; e->gexec = it->second.x; e->graph_ok = true; }
+  }
   e->ts_dev.clear();
   // a new plan is captured at its first score evaluation (hipFuncSetAttribute inside the launchers is not a stream
   // operation and is legal during capture)
@@ -1065,6 +1083,7 @@ static int run_nfe(diffsep_engine* e, int B, long T, hipStream_t st) {
         e->graph = g;
         DS_HIP(hipGraphInstantiate(&e->gexec, e->graph, nullptr, nullptr, 0));
         e->graph_ok = true;
+        e->graphs[std::make_pair(B, (long)T)] = diffsep_engine::GraphRec{e->graph, e->gexec};
       }
     }
     if (e->graph_ok) {

@@ -487,12 +487,7 @@ static int gn_apply_typed(const void* x, int ldx, const float* scale, const floa
   if (aff && mode == 1 && C % 64 == 0 && tot2 >= 262144) {
     const int th = cdiv(H, 4), tw = cdiv(W, 8);
     const long nblk = (long)B * th * tw * (C / 64);
-    static bool attr_done = false;
-    if (!attr_done) {
-      DS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gn_resample_up_tiled_kernel<T>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, gn_resample_up_tiled_lds<T>()));
-      attr_done = true;
-    }
+    DS_FUNC_LDS_ONCE((gn_resample_up_tiled_kernel<T>), gn_resample_up_tiled_lds<T>());
     hipLaunchKernelGGL((gn_resample_up_tiled_kernel<T>), dim3((unsigned)nblk), dim3(256), gn_resample_up_tiled_lds<T>(), st,
                        (const T*)x, ldx, scale, shift, C, (T*)y, ldy, (T*)xr, ldxr, B, H, W, act, tw, th);
     DS_LAUNCH_CHECK();

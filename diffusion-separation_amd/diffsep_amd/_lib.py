@@ -4,10 +4,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# Two builds of the same sources: the 16-bit storage format of dtype code 1 is bfloat16 in libdiffsep_hip.so and IEEE half
+# precision in libdiffsep_hip_f16.so (csrc/Makefile, -DDS_HALF_F16).  DIFFSEP_LIB overrides the first one (profiling builds).
 LIB_PATH = os.environ.get("DIFFSEP_LIB", os.path.join(os.path.dirname(_HERE), "libdiffsep_hip.so"))
+LIB_PATHS = {"bf16": LIB_PATH, "f16": os.environ.get("DIFFSEP_LIB_F16", os.path.join(os.path.dirname(_HERE), "libdiffsep_hip_f16.so"))}
 
 F32, BF16 = 0, 1
 F32_SPLIT = 2  # fp32 tensors; matrix products as 3 bf16 MFMAs on hi / lo halves (include/diffsep_hip.h)
+F16 = 3        # Python-side only: dtype code 1 (16-bit storage) of the half-precision build
 SDE_MIX, SDE_PRIORMIX = 0, 1
 PRED_REVERSE_DIFFUSION, PRED_EULER_MARUYAMA, PRED_NONE = 0, 1, 2
 CORR_ALD2, CORR_NONE, CORR_ALD, CORR_LANGEVIN = 0, 1, 2, 3
@@ -105,12 +109,16 @@ _SIGS = {
 EXPORTS = tuple(_SIGS.keys())
 
 
-def lib():
-    """Load (once) and return the HIP library; raises if it has not been built."""
+def lib(kind="bf16"):
+    """Load (once) and return the HIP library of a storage variant ("bf16": libdiffsep_hip.so, "f16":
+    libdiffsep_hip_f16.so); raises if it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise DiffsepError(f"{LIB_PATH} not found: build it with __graft_entry__.build() or "
+        _lib = {}
+    if kind not in _lib:
+        path = LIB_PATHS[kind]
+        if not os.path.exists(path):
+            raise DiffsepError(f"{path} not found: build it with __graft_entry__.build() or "
                                "`make -C diffusion-separation_amd/csrc` (hipcc, gfx950). There is no CPU fallback.")
         # On a GPU box torch must have brought the HIP runtime up BEFORE this library is loaded: loaded first (e.g.
         # __graft_entry__.build() followed by smoke() in one process), its device calls then failed with "no
@@ -121,18 +129,23 @@ def lib():
                 torch.cuda.init()
         except Exception:
             pass
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(path)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = l
-    return _lib
+        _lib[kind] = l
+    return _lib[kind]
 
 
-def check(rc):
+def check(rc, l=None):
     if rc != 0:
-        raise DiffsepError(lib().diffsep_last_error().decode("utf-8", "replace"))
+        raise DiffsepError((l or lib()).diffsep_last_error().decode("utf-8", "replace"))
+
+
+def half_kind(dtype_code):
+    """storage variant of a dtype code: F16 lives in the half-precision build, everything else in the default one"""
+    return "f16" if dtype_code == F16 else "bf16"
 
 
 def model_config(nf=64, num_sources=2, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, attn_resolution=16,

@@ -82,11 +82,17 @@ def WSJ0_mix(path, n_spkr=2, fs=16000, cut="max", split="train", max_len_s=None,
     return wsj0_mix(path, n_spkr=n_spkr, fs=fs, cut=cut, split=split, max_n_samples=max_n_samples, mix_dir=mix_dir)
 
 
-def NoisyDataset(audio_path, audio_len=None, fs=16000, augmentation=False, split="test"):
-    """The reference's constructor keywords (datasets/vctk_demand.py:22-32) over `voicebank_demand`; only whole
-    utterances are served (the reference does that for split == "test"; `audio_len` is ignored there too)."""
+def NoisyDataset(audio_path, audio_len=4, fs=16000, augmentation=False, split="train"):
+    """The reference's constructor keywords and defaults (datasets/vctk_demand.py:21-28) over `voicebank_demand`.  Only
+    whole utterances are served — what the reference does for split == "test" (`audio_len` is ignored there too,
+    vctk_demand.py:59-61); its split == "train" items are random crops / tilings of audio_len seconds with shuffled
+    noise, a training-time behaviour that is not part of the inference path: asking for it raises."""
     if augmentation:
         raise NotImplementedError("augmentation is a training-time feature; not part of the inference path")
+    if split == "train":
+        raise NotImplementedError("NoisyDataset(split='train') serves random training crops in the reference "
+                                  "(vctk_demand.py:63-99): not part of the inference path; use split='test' or "
+                                  "voicebank_demand(root, split='train') for whole utterances")
     return voicebank_demand(audio_path, fs=fs, split=split)
 
 

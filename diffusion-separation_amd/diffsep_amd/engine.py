@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import F32, BF16, check, lib
+from ._lib import F32, BF16, F16, check, lib
 
 
 def _stream_ptr(device=None):
@@ -20,9 +20,20 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def _c_cfg(cfg):
+    """the C-side view of a model config: the Python-only dtype code F16 is code 1 (16-bit storage) of the f16 build"""
+    if cfg.dtype != F16:
+        return cfg
+    c2 = _lib.ModelConfig()
+    C.memmove(C.byref(c2), C.byref(cfg), C.sizeof(cfg))
+    c2.dtype = BF16
+    return c2
+
+
 def param_table(cfg):
     """[(name, shape, offset)] in the canonical (reference state_dict) order."""
     l = lib()
+    cfg = _c_cfg(cfg)
     n = l.diffsep_param_count(C.byref(cfg))
     if n < 0:
         check(1)
@@ -39,7 +50,7 @@ def param_table(cfg):
 
 def pack_state_dict(cfg, state, prefix=""):
     """Flatten {name: array/tensor} into the float32 blob the engine expects. Missing keys raise."""
-    total = lib().diffsep_param_total(C.byref(cfg))
+    total = lib().diffsep_param_total(C.byref(_c_cfg(cfg)))
     blob = np.empty(total, dtype=np.float32)
     for name, shape, off in param_table(cfg):
         key = prefix + name
@@ -60,17 +71,21 @@ class Engine:
         if not torch.cuda.is_available():
             raise _lib.DiffsepError("no GPU visible: the separation engine has no CPU path")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        # dtype F16 = the 16-bit engine (code 1) of the half-precision build of the library
+        self.kind = _lib.half_kind(cfg.dtype)
+        self._L = lib(self.kind)
+        cfg = _c_cfg(cfg)
         self.cfg = cfg
         blob = np.ascontiguousarray(weights_blob, dtype=np.float32)
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
-            check(lib().diffsep_engine_create(C.byref(cfg), blob.ctypes.data_as(C.c_void_p), blob.size,
-                                              C.byref(self._h)))
+            check(self._L.diffsep_engine_create(C.byref(cfg), blob.ctypes.data_as(C.c_void_p), blob.size,
+                                                C.byref(self._h)), self._L)
         self.S = cfg.num_sources
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().diffsep_engine_destroy(self._h)
+            self._L.diffsep_engine_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -84,23 +99,23 @@ class Engine:
         return self.cfg.dtype
 
     def device_bytes(self):
-        return int(lib().diffsep_engine_device_bytes(self._h))
+        return int(self._L.diffsep_engine_device_bytes(self._h))
 
     def set_graph(self, enable):
-        check(lib().diffsep_engine_set_graph(self._h, int(bool(enable))))
+        check(self._L.diffsep_engine_set_graph(self._h, int(bool(enable))), self._L)
 
     CONV_CLASSES = ("conv3x3_8x32xN64", "conv3x3_8x32xN32", "conv3x3_8x8xN64", "gemm1x1_256xN64", "gemm1x1_256xN32",
                     "gemm1x1_64xN64", "conv3x3_ws_64to64", "conv3x3_small_16couts", "conv3x3_rw_regweights")
 
     def profile_begin(self):
-        check(lib().diffsep_engine_profile_begin(self._h))
+        check(self._L.diffsep_engine_profile_begin(self._h), self._L)
 
     def profile_end(self):
         """{class: (algorithmic flops, milliseconds, launches, algorithmic bytes)} of the MFMA kernels since
         profile_begin."""
         nc = len(self.CONV_CLASSES)
         fl, ms, n, by = (C.c_double * nc)(), (C.c_double * nc)(), (C.c_int64 * nc)(), (C.c_double * nc)()
-        check(lib().diffsep_engine_profile_end(self._h, fl, ms, n, by))
+        check(self._L.diffsep_engine_profile_end(self._h, fl, ms, n, by), self._L)
         return {k: (fl[i], ms[i], int(n[i]), by[i]) for i, k in enumerate(self.CONV_CLASSES)}
 
     def profile_records(self):
@@ -108,15 +123,15 @@ class Engine:
         template arguments), shape, algorithmic flops / bytes, milliseconds."""
         from ._lib import ProfRecord
         n = C.c_int32(0)
-        check(lib().diffsep_engine_profile_records(self._h, None, 0, C.byref(n)))
+        check(self._L.diffsep_engine_profile_records(self._h, None, 0, C.byref(n)), self._L)
         buf = (ProfRecord * max(1, n.value))()
-        check(lib().diffsep_engine_profile_records(self._h, buf, n.value, C.byref(n)))
+        check(self._L.diffsep_engine_profile_records(self._h, buf, n.value, C.byref(n)), self._L)
         return [dict(kernel=r.kernel.decode(), B=r.B, H=r.H, W=r.W, Cin=r.Cin, Cout=r.Cout, taps=r.taps,
                      skip_cin=r.skip_cin, has_res=bool(r.has_res), cls=r.cls, flops=r.flops, bytes=r.bytes, ms=r.ms)
                 for r in buf[:n.value]]
 
     def padded_frames(self, T):
-        return int(lib().diffsep_padded_frames(C.byref(self.cfg), T))
+        return int(self._L.diffsep_padded_frames(C.byref(self.cfg), T))
 
     def bucket_length(self, W):
         """The longest signal whose padded frame count is W = 64 k: F = 1 + (T + n_fft - hop) // hop <= W.  Mixed-length
@@ -135,20 +150,20 @@ class Engine:
         assert S == self.S and mix.shape == (B, 1, T) and t.shape == (B,)
         out = torch.empty_like(xt)
         with torch.cuda.device(self.device):
-            check(lib().diffsep_score_forward(self._h, _ptr(xt), _ptr(t), _ptr(mix), _ptr(out), B, T,
-                                              _stream_ptr(self.device)))
+            check(self._L.diffsep_score_forward(self._h, _ptr(xt), _ptr(t), _ptr(mix), _ptr(out), B, T,
+                                              _stream_ptr(self.device)), self._L)
         return out
 
     def reserve(self, B, T):
         """Size the workspace for batches of up to B x T samples now (later, smaller plans never reallocate)."""
         with torch.cuda.device(self.device):
-            check(lib().diffsep_engine_reserve(self._h, int(B), int(T), _stream_ptr(self.device)))
+            check(self._L.diffsep_engine_reserve(self._h, int(B), int(T), _stream_ptr(self.device)), self._L)
 
     def debug_arena(self):
         """(uint8 view of the workspace arena, offset of the forward region): every intermediate tensor of the last
         forward, in launch order.  Debug / test aid."""
         base, nb, fb = C.c_void_p(), C.c_int64(), C.c_int64()
-        check(lib().diffsep_engine_debug_arena(self._h, C.byref(base), C.byref(nb), C.byref(fb)))
+        check(self._L.diffsep_engine_debug_arena(self._h, C.byref(base), C.byref(nb), C.byref(fb)), self._L)
 
         class _Raw:
             __cuda_array_interface__ = {"shape": (nb.value,), "typestr": "|u1", "data": (base.value, False), "version": 2}
@@ -161,8 +176,8 @@ class Engine:
         cout = ((2 * self.S + 7) // 8) * 8
         y = torch.zeros((B, H, W, cout), dtype=x_nhwc.dtype, device=x_nhwc.device)
         with torch.cuda.device(self.device):
-            check(lib().diffsep_backbone_forward(self._h, _ptr(x_nhwc.contiguous()), _ptr(t), _ptr(y), B, W,
-                                                 _stream_ptr(self.device)))
+            check(self._L.diffsep_backbone_forward(self._h, _ptr(x_nhwc.contiguous()), _ptr(t), _ptr(y), B, W,
+                                                 _stream_ptr(self.device)), self._L)
         return y
 
     def pc_sample(self, mix_norm, sde, N=30, corrector_steps=1, snr=0.5, eps=0.03, denoise=True,
@@ -170,8 +185,10 @@ class Engine:
                   seeds=None, tail=None, tail_steps=0, head_steps=0):
         """The whole sampler (sdes.get_pc_sampler(...)()).  sde: dict(kind, ndim, d_lambda, sigma_min, sigma_max).
         Extensions (diffsep_sampler_ext): lengths [B] = a zero-padded batch of utterances of different lengths that share
-        one padded frame count; seeds [B] = per-utterance device-RNG seeds; tail / tail_steps = evaluate the score of the
-        last tail_steps reverse steps on another Engine (the fp32 one behind a bf16 one)."""
+        one padded frame count; seeds [B] = per-utterance device-RNG seeds; tail / head_steps / tail_steps = evaluate the
+        score of the FIRST head_steps and / or the last tail_steps reverse steps on another Engine (dtype "hybrid" of
+        pl_model: a split-fp32 engine for the first HYBRID_HEAD_STEPS steps of a 16-bit one — the early steps carry
+        the rounding error)."""
         mix_norm = self._f32(mix_norm)
         B, one, T = mix_norm.shape
         assert one == 1
@@ -209,8 +226,8 @@ class Engine:
             if tail is not None and (tail_steps > 0 or head_steps > 0):
                 ext.tail_engine, ext.tail_steps, ext.head_steps = tail._h, int(tail_steps), int(head_steps)
         with torch.cuda.device(self.device):
-            check(lib().diffsep_pc_sample_ex(self._h, C.byref(sc), C.byref(sm), C.byref(ext) if ext is not None else None,
+            check(self._L.diffsep_pc_sample_ex(self._h, C.byref(sc), C.byref(sm), C.byref(ext) if ext is not None else None,
                                              _ptr(mix_norm), _ptr(out), B, T, _ptr(noise), seed,
                                              ts.ctypes.data_as(C.c_void_p) if ts is not None else None, C.byref(nfe),
-                                             _stream_ptr(self.device)))
+                                             _stream_ptr(self.device)), self._L)
         return out, int(nfe.value)

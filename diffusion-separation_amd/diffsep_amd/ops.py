@@ -12,9 +12,14 @@ from .engine import _ptr, _stream_ptr
 def _dt(t):
     if t.dtype == torch.float32:
         return F32
-    if t.dtype == torch.bfloat16:
+    if t.dtype in (torch.bfloat16, torch.float16):  # the 16-bit storage format of the library _L(t) picks
         return BF16
-    raise TypeError("float32 or bfloat16 expected")
+    raise TypeError("float32, bfloat16 or float16 expected")
+
+
+def _L(t):
+    """the library build whose 16-bit storage format is t's: half-precision tensors go to libdiffsep_hip_f16.so"""
+    return lib("f16" if (t is not None and t.dtype == torch.float16) else "bf16")
 
 
 def _dts(t, split):
@@ -52,14 +57,14 @@ def pack_conv_weight(w, dtype, chunk=0):
 
 
 def conv2d_chunk(ksize, dtype):
-    return lib().diffsep_conv2d_chunk(ksize, F32 if dtype == torch.float32 else BF16)
+    return lib().diffsep_conv2d_chunk(ksize, F32 if dtype == torch.float32 else BF16)  # (the same in both builds)
 
 
 def upfirdn2d(x, up):
     B, H, W, Cc = x.shape
     Ho, Wo = (2 * H, 2 * W) if up else (H // 2, W // 2)
     y = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
-    check(lib().diffsep_upfirdn2d(_ptr(x), _ptr(y), B, H, W, Cc, Cc, Cc, int(up), _dt(x), _stream_ptr()))
+    check(_L(x).diffsep_upfirdn2d(_ptr(x), _ptr(y), B, H, W, Cc, Cc, Cc, int(up), _dt(x), _stream_ptr()), _L(x))
     return y
 
 
@@ -69,8 +74,8 @@ def groupnorm_act(x, gamma, beta, groups, eps=1e-6, act=1, resample=0, want_xr=F
     y = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
     xr = torch.empty_like(y) if want_xr else None
     ws = torch.empty(B * 64 * Cc * 16 + 2 * B * Cc * 4 + 4096, dtype=torch.uint8, device=x.device)
-    check(lib().diffsep_groupnorm_act(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(xr), B, H, W, Cc, Cc, Cc, Cc,
-                                      groups, eps, act, resample, _dt(x), _ptr(ws), ws.numel(), _stream_ptr()))
+    check(_L(x).diffsep_groupnorm_act(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(xr), B, H, W, Cc, Cc, Cc, Cc,
+                                      groups, eps, act, resample, _dt(x), _ptr(ws), ws.numel(), _stream_ptr()), _L(x))
     return (y, xr) if want_xr else y
 
 
@@ -78,9 +83,9 @@ def conv2d(x, wpacked, bias, cout, ksize, bias_b=None, res=None, out_scale=1.0, 
     B, H, W, Cin = x.shape
     cp = cout if cout_pad is None else cout_pad
     y = torch.zeros((B, H, W, cp), dtype=x.dtype, device=x.device)
-    check(lib().diffsep_conv2d(_ptr(x), _ptr(wpacked), _ptr(bias), _ptr(bias_b), _ptr(res), _ptr(y), B, H, W, Cin,
+    check(_L(x).diffsep_conv2d(_ptr(x), _ptr(wpacked), _ptr(bias), _ptr(bias_b), _ptr(res), _ptr(y), B, H, W, Cin,
                                cout, ksize, Cin, res.shape[-1] if res is not None else 0, cp, out_scale, _dt(x),
-                               _stream_ptr()))
+                               _stream_ptr()), _L(x))
     return y
 
 
@@ -91,9 +96,9 @@ def groupnorm_stats(x, gamma, beta, groups, eps=1e-6, x2=None):
     scale = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
     shift = torch.empty_like(scale)
     ws = torch.empty(B * 64 * Cc * 16 + 4096, dtype=torch.uint8, device=x.device)
-    check(lib().diffsep_groupnorm_stats(_ptr(x), _ptr(x2), C1, _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift), B, H,
+    check(_L(x).diffsep_groupnorm_stats(_ptr(x), _ptr(x2), C1, _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift), B, H,
                                         W, Cc, C1, x2.shape[-1] if x2 is not None else 0, groups, eps, _dt(x), _ptr(ws),
-                                        ws.numel(), _stream_ptr()))
+                                        ws.numel(), _stream_ptr()), _L(x))
     return scale, shift
 
 
@@ -116,11 +121,11 @@ def conv2d_fused(x, wpacked, bias, cout, ksize, x2=None, gn=None, gn_act=1, bias
     elif stats is not False:
         st = stats
     a1, a2, gam, bet, grp = gn_acc if gn_acc is not None else (None, None, None, None, 0)
-    check(lib().diffsep_conv2d_fused(_ptr(x), _ptr(x2), C1, _ptr(sc), _ptr(sh), gn_act, _ptr(wpacked), _ptr(bias),
+    check(_L(x).diffsep_conv2d_fused(_ptr(x), _ptr(x2), C1, _ptr(sc), _ptr(sh), gn_act, _ptr(wpacked), _ptr(bias),
                                      _ptr(bias_b), _ptr(res), _ptr(y), B, H, W, Cin, cout, ksize, C1,
                                      x2.shape[-1] if x2 is not None else 0, res.shape[-1] if res is not None else 0, cp,
                                      out_scale, _dts(x, split), _ptr(st), w_chunk, _ptr(a1), _ptr(a2), _ptr(gam), _ptr(bet), grp,
-                                     _stream_ptr()))
+                                     _stream_ptr()), _L(x))
     return (y, st) if stats is not False else y
 
 
@@ -139,8 +144,8 @@ def attention(q, k, vt, split=False):
     assert vt.shape == (B, Cc, Lp)
     o = torch.empty_like(q)
     ws = torch.empty(2 * (B * L * Lp * q.element_size() + 256), dtype=torch.uint8, device=q.device)
-    check(lib().diffsep_attention(_ptr(q), _ptr(k), _ptr(vt), _ptr(o), B, L, Cc, Cc, _dts(q, split), _ptr(ws), ws.numel(),
-                                  _stream_ptr()))
+    check(_L(q).diffsep_attention(_ptr(q), _ptr(k), _ptr(vt), _ptr(o), B, L, Cc, Cc, _dts(q, split), _ptr(ws), ws.numel(),
+                                  _stream_ptr()), _L(q))
     return o
 
 
@@ -151,9 +156,9 @@ def resblock_forward(params, x, temb, out_ch, up=False, down=False):
     blob = np.ascontiguousarray(np.concatenate([np.asarray(p, np.float32).reshape(-1) for p in params]))
     Ho, Wo = (2 * H, 2 * W) if up else ((H // 2, W // 2) if down else (H, W))
     y = torch.empty((B, Ho, Wo, out_ch), dtype=x.dtype, device=x.device)
-    check(lib().diffsep_resblock_forward(cin, out_ch, int(up), int(down), temb.shape[1], _dt(x),
+    check(_L(x).diffsep_resblock_forward(cin, out_ch, int(up), int(down), temb.shape[1], _dt(x),
                                          blob.ctypes.data_as(C.c_void_p), blob.size, _ptr(x.contiguous()),
-                                         _ptr(temb.contiguous()), _ptr(y), B, H, W, _stream_ptr()))
+                                         _ptr(temb.contiguous()), _ptr(y), B, H, W, _stream_ptr()), _L(x))
     return y
 
 
@@ -162,8 +167,8 @@ def attnblock_forward(params, x):
     B, H, W, Cc = x.shape
     blob = np.ascontiguousarray(np.concatenate([np.asarray(p, np.float32).reshape(-1) for p in params]))
     y = torch.empty_like(x)
-    check(lib().diffsep_attnblock_forward(Cc, _dt(x), blob.ctypes.data_as(C.c_void_p), blob.size, _ptr(x.contiguous()),
-                                          _ptr(y), B, H, W, _stream_ptr()))
+    check(_L(x).diffsep_attnblock_forward(Cc, _dt(x), blob.ctypes.data_as(C.c_void_p), blob.size, _ptr(x.contiguous()),
+                                          _ptr(y), B, H, W, _stream_ptr()), _L(x))
     return y
 
 
@@ -172,9 +177,9 @@ def stft_pack(xt, mix, W, cpad, n_fft=510, hop=128, exponent=0.5, factor=0.33, s
     y = torch.empty((B, n_fft // 2 + 1, W, cpad), dtype=dtype, device=xt.device)
     F_ = 1 + (T + n_fft - hop) // hop
     ws = torch.empty(2 * ((B * (S + 1) * F_ + 8) * 512 + 64), dtype=torch.float32, device=xt.device)
-    check(lib().diffsep_stft_pack(_ptr(xt), _ptr(mix), _ptr(y), B, S, T, n_fft, hop, exponent, factor, W, cpad,
+    check(_L(y).diffsep_stft_pack(_ptr(xt), _ptr(mix), _ptr(y), B, S, T, n_fft, hop, exponent, factor, W, cpad,
                                   int(shift), F32 if dtype == torch.float32 else BF16, _ptr(ws), ws.numel() * 4,
-                                  _stream_ptr()))
+                                  _stream_ptr()), _L(y))
     return y
 
 
@@ -183,8 +188,8 @@ def istft_unpack(x, S, T, n_fft=510, hop=128, exponent=0.5, factor=0.33):
     F_ = 1 + (T + n_fft - hop) // hop
     out = torch.empty((B, S, T), dtype=torch.float32, device=x.device)
     ws = torch.empty(2 * (B * S * F_ * 512 + 64), dtype=torch.float32, device=x.device)
-    check(lib().diffsep_istft_unpack(_ptr(x), _ptr(out), B, S, T, n_fft, hop, exponent, factor, W, cpad, _dt(x),
-                                     _ptr(ws), ws.numel() * 4, _stream_ptr()))
+    check(_L(x).diffsep_istft_unpack(_ptr(x), _ptr(out), B, S, T, n_fft, hop, exponent, factor, W, cpad, _dt(x),
+                                     _ptr(ws), ws.numel() * 4, _stream_ptr()), _L(x))
     return out
 
 

@@ -26,7 +26,8 @@ class ScoreModelNCSNpp:
         # Every backbone argument that changes NCSNpp.forward and is not a parameter of the engine must hold the value
         # the engine implements (models/ncsnpp.py:45-70 constructor defaults): a checkpoint trained otherwise would
         # load and silently produce wrong scores.
-        supported = dict(scale_by_sigma=True, nonlinearity="swish", dropout=0.0, resamp_with_conv=True,
+        # (dropout does nothing at inference: any value loads)
+        supported = dict(scale_by_sigma=True, nonlinearity="swish", resamp_with_conv=True,
                          conditional=True, fir=True, fir_kernel=[1, 3, 3, 1], skip_rescale=True,
                          resblock_type="biggan", progressive="output_skip", progressive_input="input_skip",
                          progressive_combine="sum", init_scale=0.0, fourier_scale=16, image_size=256,
@@ -37,9 +38,8 @@ class ScoreModelNCSNpp:
         # (arguments NCSNpp does not know are swallowed by its **unused_kwargs, ncsnpp.py:68: ignored here too)
         if len(tuple(ba.get("attn_resolutions", (16,)))) != 1:
             raise NotImplementedError("the engine implements exactly one attention resolution")
-        for k, want in (("num_channels_in", 2 * num_sources + 2), ("num_channels_out", 2 * num_sources)):
-            if k in ba and ba[k] != want:
-                raise NotImplementedError(f"backbone_args.{k}={ba[k]} (ScoreModelNCSNpp sets {want}, score_models.py:24-26)")
+        # num_channels_in / num_channels_out of the config are overwritten with 2 S + 2 / 2 S exactly as the reference does
+        # (models/score_models.py:24-26): whatever a checkpoint's config says there loads
         if stft_args["n_fft"] != 510 or stft_args["n_fft"] // 2 + 1 != 256:
             raise NotImplementedError("n_fft must be 510 (image height 256 = NCSNpp image_size; the DFT tables hold 510 taps)")
         self.num_sources = num_sources
@@ -49,7 +49,7 @@ class ScoreModelNCSNpp:
             nf=ba.get("nf", 128), num_sources=num_sources, ch_mult=tuple(ba.get("ch_mult", (1, 1, 2, 2, 2, 2, 2))),
             num_res_blocks=ba.get("num_res_blocks", 2), attn_resolution=tuple(ba.get("attn_resolutions", (16,)))[0],
             n_fft=stft_args["n_fft"], hop=stft_args["hop_length"], spec_abs_exponent=abs(spec_abs_exponent),
-            spec_factor=spec_factor, dtype={"bf16": _lib.BF16, "f32": _lib.F32, "fp32": _lib.F32, "split": _lib.F32_SPLIT}[dtype])
+            spec_factor=spec_factor, dtype={"bf16": _lib.BF16, "f16": _lib.F16, "fp16": _lib.F16, "f32": _lib.F32, "fp32": _lib.F32, "split": _lib.F32_SPLIT}[dtype])
         self.device = device
         self._engine = None
         # random init like the reference constructor (no checkpoint yet): synthetic variance-scaling weights

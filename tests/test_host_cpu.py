@@ -172,10 +172,12 @@ def test_wsj0_mix_and_noisy_dataset_layouts(tmp_path):
     noisy_t, tgt_t = datasets.NoisyDataset(tmp_path / "vb", split="test")[0]
     assert noisy_t.shape == (1, 700) and tgt_t.shape == (2, 700)
     assert torch.equal(tgt_t[0:1] + tgt_t[1:2], noisy_t) or (tgt_t.sum(0, keepdim=True) - noisy_t).abs().max() < 1e-6
-    noisy_tr, tgt_tr = datasets.NoisyDataset(tmp_path / "vb", split="train")[0]      # whole utterances on every split
+    noisy_tr, tgt_tr = datasets.voicebank_demand(tmp_path / "vb", split="train")[0]  # whole utterances through the resolver
     assert noisy_tr.shape == (1, 700) and tgt_tr.shape == (2, 700)
+    with pytest.raises(NotImplementedError):  # the reference's default split serves random training crops
+        datasets.NoisyDataset(tmp_path / "vb")
     with pytest.raises(NotImplementedError):
-        datasets.NoisyDataset(tmp_path / "vb", augmentation=True)
+        datasets.NoisyDataset(tmp_path / "vb", augmentation=True, split="test")
     with pytest.raises(ValueError):
         datasets.NoisyDataset(tmp_path / "vb", split="val")
 
