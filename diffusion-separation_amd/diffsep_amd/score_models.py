@@ -15,7 +15,7 @@ from .engine import Engine, pack_state_dict, param_table
 
 class ScoreModelNCSNpp:
     def __init__(self, num_sources, stft_args, backbone_args, transform="exponent", spec_abs_exponent=0.5,
-                 spec_factor=3.0, spec_trans_learnable=False, dtype="bf16", device=None, init_seed=0):
+                 spec_factor=3.0, spec_trans_learnable=False, dtype="f16", device=None, init_seed=0):
         if transform != "exponent":
             raise NotImplementedError("only transform='exponent' runs on the accelerated path")
         if spec_trans_learnable:

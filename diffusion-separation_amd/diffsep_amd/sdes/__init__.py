@@ -53,6 +53,12 @@ def _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, d
         raise ValueError("seed= / seeds= / lengths= are extensions of the fused engine sampler; this request "
                          "(intermediate, true_mean or a user predictor / corrector) runs the generic loop")
 
+    if not fused and getattr(score_fn, "tail_engine", lambda: None)() is not None:
+        # dtype="hybrid" is a schedule of the fused sampler (two engines inside one call): the step-by-step loop would
+        # evaluate every step on the 16-bit model alone, silently
+        raise ValueError("dtype='hybrid' needs the fused engine sampler; this request (intermediate, true_mean or a user "
+                         "predictor / corrector) runs the generic loop: build the model with dtype='f16', 'split' or 'f32'")
+
     def pc_sampler():
         with torch.no_grad():
             ns = sde.N * (corrector.n_steps + 1)
