@@ -19,7 +19,14 @@
 static thread_local std::string g_err;
 void ds_set_error(const std::string& s) { g_err = s; }
 extern "C" const char* diffsep_last_error(void) { return g_err.c_str(); }
-extern "C" const char* diffsep_version(void) { return "diffsep-hip 0.1 (gfx950)"; }
+extern "C" const char* diffsep_version(void) {
+    // which build of the library this is: 16-bit tensors stored as bfloat16 or (-DDS_HALF_F16) as IEEE half precision
+#ifdef DS_HALF_F16
+    return "diffsep-hip 0.3 (gfx950, 16-bit storage f16)";
+#else
+    return "diffsep-hip 0.3 (gfx950, 16-bit storage bf16)";
+#endif
+}
 
 // ------------------------------------------------------------------ architecture description
 struct PRef { long off = -1; long numel = 0; };  // into the flat fp32 blob

@@ -16,8 +16,10 @@ from diffsep_amd import synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_library_loads_and_exports_header_symbols():
-    l = _lib.lib()
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_library_loads_and_exports_header_symbols(kind):
+    # both builds of the library (16-bit tensors as bfloat16 / as IEEE half precision) export the same C-ABI
+    l = _lib.lib(kind)
     hdr = open(os.path.join(ROOT, "include", "diffsep_hip.h")).read()
     declared = set(re.findall(r"\b(diffsep_[a-z0-9_]+)\s*\(", hdr))
     assert len(declared) >= 25
@@ -25,6 +27,7 @@ def test_library_loads_and_exports_header_symbols():
         assert hasattr(l, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     assert b"gfx950" in l.diffsep_version()
+    assert (b"storage f16" in l.diffsep_version()) == (kind == "f16")
 
 
 @pytest.mark.parametrize("nf,S", [(16, 2), (16, 3), (64, 2), (128, 2)])
