@@ -30,6 +30,30 @@ def test_library_loads_and_exports_header_symbols(kind):
     assert (b"storage f16" in l.diffsep_version()) == (kind == "f16")
 
 
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_no_packed_fp32_valu_in_any_kernel(kind, tmp_path):
+    """The wrong GroupNorm sums under co-resident kernels (profiles/experiments/README.md, "Streams") came from a site
+    where a scalar VALU result fed a packed-FP32 instruction.  The build bans the instruction class (Makefile:
+    -fno-slp-vectorize, -fno-vectorize for sde.hip); this disassembles every gfx950 code object of the library and
+    checks that none is left."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump of the ROCm toolchain is not installed")
+    so = shutil.copy(_lib.LIB_PATHS[kind], tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, capture_output=True)
+    objs = sorted(p for p in os.listdir(tmp_path) if p.endswith("gfx950"))
+    assert len(objs) >= 8  # one code object per .hip source
+    kernels = 0
+    for o in objs:
+        asm = subprocess.run([objdump, "-d", str(tmp_path / o)], check=True, capture_output=True, text=True).stdout
+        kernels += len(re.findall(r"^[0-9a-f]+ <_Z\w+>:", asm, re.M))
+        hits = re.findall(r"v_pk_(?:fma|mul|add)_f32", asm)
+        assert not hits, f"{len(hits)} packed-FP32 instructions in {o}"
+    assert kernels > 100
+
+
 @pytest.mark.parametrize("nf,S", [(16, 2), (16, 3), (64, 2), (128, 2)])
 def test_param_table_is_reference_state_dict_order(golden, nf, S):
     _, meta = golden
