@@ -260,6 +260,48 @@ def test_bench_strong_scaling_sequencing_gloo():
     assert res["ranks_seen"] == [[0, 0], [1, 1]]
 
 
+def test_evaluate_cli_two_ranks_balanced_gloo(tmp_path):
+    # `python -m diffsep_amd.evaluate --balance` end to end on 2 CPU ranks over gloo, the device replaced by the stand-ins
+    # of tests/evaluate_gloo_rank.py: both ranks separate a share, the gathered <split>.json holds every utterance
+    # once, in order, and each record equals the one a single rank computes (seeds and batching do not depend on the
+    # world size or on the deal); the balanced deal differs from the contiguous one
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    argv = ["--synthetic", "13", "--samples", "6000", "--samples-max", "30000", "--synthetic-weights", "16", "-N", "3",
+            "--batch", "3", "--streams", "2", "--seed", "5"]
+
+    def run(world, extra, out):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs = []
+        for r in range(world):
+            e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world)) if world > 1 else env
+            procs.append(subprocess.Popen([sys.executable, os.path.join(here, "evaluate_gloo_rank.py")] + argv + extra +
+                                          ["-o", str(out)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        outs = [p.communicate(timeout=240) for p in procs]
+        assert all(p.returncode == 0 for p in procs), [o[1][-800:] for o in outs]
+        calls = [eval([l for l in o[0].splitlines() if l.startswith("CALLS")][0].split(" ", 2)[2]) for o in outs]
+        return json.load(open(out / "test.json")), json.load(open(out / "test_summary.json")), calls
+
+    one, s1, c1 = run(1, [], tmp_path / "w1")
+    bal, s2, c2 = run(2, ["--balance"], tmp_path / "w2b")
+    con, s3, c3 = run(2, [], tmp_path / "w2c")
+    strip = lambda rs: [{k: v for k, v in r.items() if k != "runtime"} for r in rs]
+    assert [r["batch_idx"] for r in bal] == list(range(13)) == [r["batch_idx"] for r in con]
+    assert strip(bal) == strip(one) == strip(con)
+    assert s2["world_size"] == 2 and s2["number"] == 13 and s1["world_size"] == 1 and s2["si_sdr"] == s1["si_sdr"]
+    # every rank separated something in both deals; the timed calls (warm-up = K calls of the first batch excluded)
+    for calls in (c2, c3):
+        assert all(len(c) > 2 for c in calls)
+        assert sum(b for c in calls for b, _ in c[2:]) == 13
+    # contiguous ranges give rank 1 the remainder (7 of 13), the balanced deal alternates by length (7 / 6)
+    assert [sum(b for b, _ in c[2:]) for c in c3] == [6, 7] and [sum(b for b, _ in c[2:]) for c in c2] == [7, 6]
+    assert c2 != c3
+
+
 def test_plan_batches_buckets_by_padded_width():
     from diffsep_amd.evaluate import plan_batches
     width = lambda T: 64 * ((1 + (T + 382) // 128 + 63) // 64)
