@@ -67,12 +67,17 @@ def pack_state_dict(cfg, state, prefix=""):
 class Engine:
     """Owns the repacked weights and workspace on the current CUDA(HIP) device."""
 
-    def __init__(self, cfg, weights_blob, device=None):
+    def __init__(self, cfg, weights_blob, device=None, lib_kind=None):
+        """lib_kind: which build of the library creates the engine ("bf16" / "f16"); default = by dtype (F16 lives in the
+        half-precision build, everything else in the default one).  The fp32 engines are the same in both builds: pass
+        lib_kind="f16" for a split / fp32 engine that serves as the head engine of an F16 one (pc_sample(tail=...))."""
         if not torch.cuda.is_available():
             raise _lib.DiffsepError("no GPU visible: the separation engine has no CPU path")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         # dtype F16 = the 16-bit engine (code 1) of the half-precision build of the library
-        self.kind = _lib.half_kind(cfg.dtype)
+        self.kind = _lib.half_kind(cfg.dtype) if lib_kind is None else lib_kind
+        if cfg.dtype in (F16, BF16) and self.kind != _lib.half_kind(cfg.dtype):
+            raise _lib.DiffsepError("a 16-bit engine lives in the library build of its storage format")
         self._L = lib(self.kind)
         cfg = _c_cfg(cfg)
         self.cfg = cfg
@@ -224,6 +229,9 @@ class Engine:
                 ext.seeds_host = sa.ctypes.data_as(C.POINTER(C.c_uint64))
                 keep.append(sa)
             if tail is not None and (tail_steps > 0 or head_steps > 0):
+                if tail.kind != self.kind:  # an engine handle means something to the library that created it only
+                    raise _lib.DiffsepError(f"the other engine was created by the '{tail.kind}' build of the library, this one "
+                                            f"by the '{self.kind}' build: create it with Engine(..., lib_kind='{self.kind}')")
                 ext.tail_engine, ext.tail_steps, ext.head_steps = tail._h, int(tail_steps), int(head_steps)
         with torch.cuda.device(self.device):
             check(self._L.diffsep_pc_sample_ex(self._h, C.byref(sc), C.byref(sm), C.byref(ext) if ext is not None else None,

@@ -105,7 +105,7 @@ def main(argv=None):
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32", "split", "hybrid"],
                     help="f16 (default): 16-bit tensors in IEEE half precision, 50 dB from the fp32 result after 60 network "
                          "evaluations; bf16: the same kernels on bfloat16 tensors (32 dB); split / f32: fp32 tensors (bf16x3 / "
-                         "exact fp32 matrix products); hybrid: bf16 with the first reverse steps on a split engine")
+                         "exact fp32 matrix products); hybrid: f16 with the first reverse steps on a split engine")
     ap.add_argument("-o", "--output-dir", type=Path, default=Path("results"))
     ap.add_argument("--save-wav", action="store_true")
     ap.add_argument("--seed", type=int, default=0, help="torch.manual_seed before the first utterance: the i-th "

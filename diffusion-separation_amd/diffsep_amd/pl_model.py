@@ -67,9 +67,10 @@ def default_config(nf=64, n_speakers=2, fs=8000, spec_factor=0.33):
 # dtype="split": fp32 tensors, every matrix product as three bf16 MFMAs on the hi / lo bf16 halves of both operands
 # (DIFFSEP_F32_SPLIT): 4e-5 relative RMS / >= 79 dB from the exact fp32 engine after 60 NFE at 1.9x its speed
 # (tools/probes/split_probe.py) — the fast mode that meets the parity bar.
-# dtype="hybrid": such a split-fp32 engine evaluates the score of the FIRST HYBRID_HEAD_STEPS reverse steps, the bf16
-# engine the rest.  Measured (tools/hybrid_probe.py): a score error enters the state scaled by the step size
-# G(t)^2, which is ~100x larger at t = 1 than at t = 0.03, so the bf16 rounding of the EARLY steps is what separates the
+# dtype="hybrid": such a split-fp32 engine evaluates the score of the FIRST HYBRID_HEAD_STEPS reverse steps, a 16-bit
+# engine the rest (f16 storage since round 3: at nf = 128, N = 30, 62.5 dB from the fp32 result where f16 alone has 36.0 dB
+# and the bf16 hybrid of round 2 43.9 dB, tests/test_fullsize_gpu.py).  Measured on bf16 (tools/hybrid_probe.py, DESIGN.md
+# section 2): a score error enters the state scaled by the step size G(t)^2, which is ~100x larger at t = 1 than at t = 0.03, so the bf16 rounding of the EARLY steps is what separates the
 # bf16 trajectory from the fp32 one (fp32 for the last 5 / 15 / 25 steps: 31.1 / 31.2 / 31.8 dB agreement, i.e. nothing;
 # fp32 for the first 5 / 10 / 15: 42 / 46 / 49 dB).  10 steps = >= 42 dB on every utterance measured.
 HYBRID_HEAD_STEPS = 10
@@ -81,7 +82,7 @@ class DiffSepModel:
         mean / 46 dB min from the fp32 result after 60 network evaluations, inside the 1e-3 RMS parity bar, at the speed of
         "bf16"), "bf16" (the same kernels on bfloat16 tensors: 32 dB / 25 dB), "f32" (exact fp32 MFMAs: parity with the
         reference to 1e-7), "split" (fp32 tensors, bf16x3 matrix products: parity to 4e-5 at twice the speed of "f32") or
-        "hybrid": a "split" engine for the first head_steps reverse steps, bf16 for the rest (extensions: the reference has
+        "hybrid": a "split" engine for the first head_steps reverse steps, f16 for the rest (extensions: the reference has
         one precision)."""
         self.config = config
         sm = dict(cfg_get(config, "model.score_model"))
@@ -89,11 +90,11 @@ class DiffSepModel:
         sm["stft_args"] = dict(sm["stft_args"])
         sm["backbone_args"] = {k: v for k, v in dict(sm["backbone_args"]).items()}
         self.dtype = dtype
-        self.score_model = ScoreModelNCSNpp(dtype="bf16" if dtype == "hybrid" else dtype, device=device,
+        self.score_model = ScoreModelNCSNpp(dtype="f16" if dtype == "hybrid" else dtype, device=device,
                                             init_seed=init_seed, **sm)
         self.tail_model, self.head_steps = None, 0
         if dtype == "hybrid":
-            self.tail_model = ScoreModelNCSNpp(dtype="split", device=device, init_seed=init_seed, **sm)
+            self.tail_model = ScoreModelNCSNpp(dtype="split", device=device, init_seed=init_seed, lib_kind="f16", **sm)
             self.head_steps = HYBRID_HEAD_STEPS if head_steps is None else int(head_steps)
         sd = dict(cfg_get(config, "model.sde"))
         target = str(sd.pop("_target_", "sdes.sdes.MixSDE"))

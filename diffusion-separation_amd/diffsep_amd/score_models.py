@@ -15,7 +15,7 @@ from .engine import Engine, pack_state_dict, param_table
 
 class ScoreModelNCSNpp:
     def __init__(self, num_sources, stft_args, backbone_args, transform="exponent", spec_abs_exponent=0.5,
-                 spec_factor=3.0, spec_trans_learnable=False, dtype="f16", device=None, init_seed=0):
+                 spec_factor=3.0, spec_trans_learnable=False, dtype="f16", device=None, init_seed=0, lib_kind=None):
         if transform != "exponent":
             raise NotImplementedError("only transform='exponent' runs on the accelerated path")
         if spec_trans_learnable:
@@ -51,6 +51,7 @@ class ScoreModelNCSNpp:
             n_fft=stft_args["n_fft"], hop=stft_args["hop_length"], spec_abs_exponent=abs(spec_abs_exponent),
             spec_factor=spec_factor, dtype={"bf16": _lib.BF16, "f16": _lib.F16, "fp16": _lib.F16, "f32": _lib.F32, "fp32": _lib.F32, "split": _lib.F32_SPLIT}[dtype])
         self.device = device
+        self.lib_kind = lib_kind  # (Engine: which build of the library; None = by dtype)
         self._engine = None
         # random init like the reference constructor (no checkpoint yet): synthetic variance-scaling weights
         self._state = synth.synth_state_dict([(n, s) for n, s, _ in param_table(self.cfg)], init_seed)
@@ -93,7 +94,7 @@ class ScoreModelNCSNpp:
     def engine(self):
         """The device-resident engine (created lazily on the current / configured device)."""
         if self._engine is None:
-            self._engine = Engine(self.cfg, pack_state_dict(self.cfg, self._state), device=self.device)
+            self._engine = Engine(self.cfg, pack_state_dict(self.cfg, self._state), device=self.device, lib_kind=self.lib_kind)
         return self._engine
 
     # ---- reference forward ---------------------------------------------------------------

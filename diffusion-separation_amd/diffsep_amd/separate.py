@@ -97,7 +97,7 @@ def main(argv=None):
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32", "split", "hybrid"],
                     help="f16 (default): 16-bit tensors in IEEE half precision, 50 dB from the fp32 result after 60 network "
                          "evaluations; bf16: the same kernels on bfloat16 tensors (32 dB); split / f32: fp32 tensors (bf16x3 / "
-                         "exact fp32 matrix products); hybrid: bf16 with the first reverse steps on a split engine")
+                         "exact fp32 matrix products); hybrid: f16 with the first reverse steps on a split engine")
     ap.add_argument("--fp32-steps", type=int, default=None, help="--dtype hybrid: the first K reverse steps run on the fp32 engine")
     ap.add_argument("--batch", type=int, default=1, help="files per engine call (equal padded width)")
     ap.add_argument("--streams", type=int, default=1, help="engine calls in flight: K engines on K HIP streams")

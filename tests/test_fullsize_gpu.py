@@ -1,0 +1,204 @@
+"""BASELINE.json configs[3] and configs[4] at their real size, and the precision gates of the published width nf = 128,
+all through the C-ABI.
+  configs[4]  wsj0_mix 3 speakers, N = 200 predictor steps + 2 corrector steps each = 600 network evaluations per
+              utterance, long utterances (T = 100000 samples = 12.5 s at 8 kHz, 785 frames -> W = 832): finite,
+              deterministic, graph replay == eager launches, a mixed-length batch == its utterances alone (bit for bit)
+  configs[3]  VoiceBank-DEMAND enhancement: 16 kHz, 10 s (T = 160000, 1253 frames -> W = 1280), PriorMixSDE, nf = 128,
+              N = 30: one score evaluation against the CPU oracle, then the 60-evaluation sampler
+  nf = 128    (config/experiment/icassp-separation.yaml:14-18) N = 30 samplers at T = 32000, B = 2: bf16 / f16 / hybrid
+              against the fp32 engine (SI-SDR gates from the measurement printed below), split against the CPU oracle
+              (< 1e-3 RMS on the waveform: the parity bar)
+Throughput and device bytes of both configurations are printed (DESIGN.md section 5b quotes them)."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import diffsep_oracle as O
+from diffsep_amd import _lib, ops, synth
+from diffsep_amd.engine import Engine, pack_state_dict, param_table
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = "cuda"
+SDE2 = dict(ndim=2, d_lambda=2.0, sigma_min=0.05, sigma_max=0.5)
+SDE3 = dict(ndim=3, d_lambda=2.0, sigma_min=0.05, sigma_max=0.5)
+PSDE = dict(kind=_lib.SDE_PRIORMIX, ndim=2, d_lambda=2.0, sigma_min=0.05, sigma_max=0.5, avg_len=510)
+
+
+def rms(a):
+    return float(a.detach().double().pow(2).mean().sqrt())
+
+
+def rel_rms(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return rms(a - b) / (rms(b) + 1e-30)
+
+
+def si_sdr(est, ref):
+    est, ref = est.double().cpu(), ref.double().cpu()
+    a = (est * ref).sum(-1, keepdim=True) / (ref * ref).sum(-1, keepdim=True)
+    return 10 * torch.log10(((a * ref) ** 2).sum(-1) / ((est - a * ref) ** 2).sum(-1))
+
+
+def rnd(tag, shape, scale=1.0):
+    return torch.from_numpy(synth.synth_noise(tag, shape)) * scale
+
+
+_ENG = {}
+
+
+def engine(nf, S, dtype, spec_factor=0.33, seed=7, lib_kind=None):
+    key = (nf, S, dtype, spec_factor, lib_kind)
+    if key not in _ENG:
+        cfg = _lib.model_config(nf=nf, num_sources=S, dtype=dtype, spec_factor=spec_factor)
+        sd = synth.synth_state_dict([(n, s) for n, s, _ in param_table(cfg)], seed)
+        _ENG[key] = (Engine(cfg, pack_state_dict(cfg, sd), lib_kind=lib_kind), sd)
+    return _ENG[key]
+
+
+def timed(fn):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = fn()
+    torch.cuda.synchronize()
+    return out, time.perf_counter() - t0
+
+
+# ------------------------------------------------------------------------------------------------ configs[4]
+@pytest.mark.parametrize("dtype", [_lib.F32, _lib.F16])
+def test_configs4_three_speakers_600_evaluations_long_utterances(dtype):
+    eng, _ = engine(16, 3, dtype)
+    T, N, cs = 100000, 200, 2
+    assert eng.padded_frames(T) == 832
+    lens = [T, 99000, 98500]                       # 785 / 777 / 773 frames: all W = 832
+    assert len({eng.padded_frames(L) for L in lens}) == 1
+    B = len(lens)
+    mixn = torch.zeros(B, 1, T, device=DEV)
+    for b, L in enumerate(lens):
+        mixn[b, :, :L] = ops.normalize_batch(torch.from_numpy(synth.synth_mixture(b, T=L, n_src=3)[0])[None].to(DEV))[0][0]
+    seeds = [11, 22, 33]
+    kw = dict(N=N, corrector_steps=cs, snr=0.5, eps=0.03, denoise=True)
+    eng.pc_sample(mixn, SDE3, lengths=lens, seeds=seeds, **kw)  # (plan + graph capture)
+    (out, nfe), dt = timed(lambda: eng.pc_sample(mixn, SDE3, lengths=lens, seeds=seeds, **kw))
+    assert nfe == N * (1 + cs) == 600 and out.shape == (B, 3, T)
+    # (random-init weights are no score function: 600 steps drift to an RMS of ~80, they do not denoise)
+    assert torch.isfinite(out).all() and 1e-3 < rms(out) < 1e3
+    print(f"\n[configs[4] nf16 S3 N200+2 dtype {dtype}] {B} x {T / 8000:.1f} s in {dt:.2f} s = {B / dt:.2f} utt/s, "
+          f"{600 * B / dt:.0f} evaluations/s, device bytes {eng.device_bytes() / 2 ** 20:.0f} MiB")
+    again, _ = eng.pc_sample(mixn, SDE3, lengths=lens, seeds=seeds, **kw)
+    assert torch.equal(again, out)                 # deterministic (hipGraph replay both times)
+    eng.set_graph(False)
+    try:
+        eager, _ = eng.pc_sample(mixn, SDE3, lengths=lens, seeds=seeds, **kw)
+    finally:
+        eng.set_graph(True)
+    assert torch.equal(eager, out)                 # graph replay == eager launches
+    for b, L in enumerate(lens):
+        assert float(out[b, :, L:].abs().max() if L < T else 0.0) == 0.0
+        if dtype == _lib.F32:                      # every utterance exactly as a B = 1 call on it alone
+            one, _ = eng.pc_sample(mixn[b:b + 1, :, :L].contiguous(), SDE3, seed=seeds[b], **kw)
+            assert torch.equal(out[b, :, :L], one[0]), b
+
+
+def test_configs4_score_evaluation_long_utterance_vs_oracle():
+    # one evaluation of the 3-source network at T = 100000 against the CPU oracle (fp32: summation order only)
+    cfg = O.default_config(16, 3)
+    eng, sd = engine(16, 3, _lib.F32)
+    T = 100000
+    mix = torch.from_numpy(synth.synth_mixture(3, T=T, n_src=3)[0])[None]
+    mixn, _, _ = O.normalize_batch(mix)
+    xt = O.prior_sampling(cfg, mixn, rnd("c4.z", (1, 3, T)))
+    t = torch.tensor([0.31])
+    ref = O.score_forward(O.to_torch(sd), cfg, xt, t, mixn)
+    out = eng.score(xt.to(DEV), t.to(DEV), mixn.to(DEV))
+    assert rel_rms(out, ref) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ configs[3]
+def test_configs3_enhancement_16khz_ten_seconds_nf128():
+    cfg = O.default_config(128, 2, spec_factor=0.15)
+    eng32, sd = engine(128, 2, _lib.F32, spec_factor=0.15)
+    T, N = 160000, 30
+    assert eng32.padded_frames(T) == 1280
+    mix = torch.from_numpy(synth.synth_batch(1, T=T, fs=16000)[0])
+    mixn, _, _ = O.normalize_batch(mix)
+    xt = O.prior_sampling(cfg, mixn, rnd("c3.z", (1, 2, T)))  # (any state does for one evaluation of the network)
+    t = torch.tensor([0.52])
+    ref = O.score_forward(O.to_torch(sd), cfg, xt, t, mixn)
+    out = eng32.score(xt.to(DEV), t.to(DEV), mixn.to(DEV))
+    r = rel_rms(out, ref)
+    print(f"\n[configs[3] nf128 16 kHz 10 s, one score evaluation, fp32 vs oracle] rel rms {r:.3e}")
+    assert r < 1e-4
+    eng16, _ = engine(128, 2, _lib.F16, spec_factor=0.15)
+    r16 = rel_rms(eng16.score(xt.to(DEV), t.to(DEV), mixn.to(DEV)), ref)
+    print(f"[configs[3] the same evaluation, f16 engine] rel rms {r16:.3e}")
+    assert r16 < 8e-3
+    kw = dict(N=N, corrector_steps=1, snr=0.5, eps=0.03, denoise=True, seed=5)
+    mn = mixn.to(DEV)
+    eng16.pc_sample(mn, PSDE, **kw)
+    (sep, nfe), dt = timed(lambda: eng16.pc_sample(mn, PSDE, **kw))
+    assert nfe == 60 and torch.isfinite(sep).all() and 1e-3 < rms(sep) < 1e3
+    print(f"[configs[3] f16 sampler, 60 evaluations, B = 1] {dt * 1e3:.0f} ms = {1 / dt:.2f} utt/s, {10.0 / dt:.1f}x real "
+          f"time, device bytes {eng16.device_bytes() / 2 ** 20:.0f} MiB")
+    again, _ = eng16.pc_sample(mn, PSDE, **kw)
+    assert torch.equal(again, sep)
+    ref32, _ = eng32.pc_sample(mn, PSDE, **kw)
+    s = si_sdr(sep, ref32)
+    print(f"[configs[3] f16 vs fp32 engine after 60 evaluations] SI-SDR {s.flatten().tolist()}")
+    assert float(s.min()) > 28.0  # (measured 34.2 / 32.5 dB: the wider network at 10 s amplifies rounding more than nf = 64 at 4 s does)
+
+
+# ------------------------------------------------------------------------------------------------ nf = 128 gates
+def test_nf128_sampler_precision_gates_vs_fp32_engine():
+    T, N, B = 32000, 30, 2
+    eng32, _ = engine(128, 2, _lib.F32, spec_factor=0.15)
+    mix = torch.from_numpy(synth.synth_batch(B, T=T)[0]).to(DEV)
+    mn, _, _ = ops.normalize_batch(mix)
+    kw = dict(N=N, corrector_steps=1, snr=0.5, eps=0.03, denoise=True, seed=3)
+    ref, _ = eng32.pc_sample(mn, SDE2, **kw)
+    got = {}
+    for name, dt in (("f16", _lib.F16), ("bf16", _lib.BF16)):
+        eng, _ = engine(128, 2, dt, spec_factor=0.15)
+        sep, nfe = eng.pc_sample(mn, SDE2, **kw)
+        assert nfe == 60 and torch.isfinite(sep).all()
+        got[name] = si_sdr(sep, ref)
+    engs, _ = engine(128, 2, _lib.F32_SPLIT, spec_factor=0.15)
+    engb, _ = engine(128, 2, _lib.BF16, spec_factor=0.15)
+    sep, _ = engb.pc_sample(mn, SDE2, tail=engs, head_steps=10, **kw)
+    got["hybrid"] = si_sdr(sep, ref)
+    engh, _ = engine(128, 2, _lib.F16, spec_factor=0.15)
+    with pytest.raises(_lib.DiffsepError):  # a handle of the other build of the library
+        engh.pc_sample(mn, SDE2, tail=engs, head_steps=10, **kw)
+    engs16, _ = engine(128, 2, _lib.F32_SPLIT, spec_factor=0.15, lib_kind="f16")
+    sep, _ = engh.pc_sample(mn, SDE2, tail=engs16, head_steps=10, **kw)
+    got["hybrid_f16"] = si_sdr(sep, ref)
+    sep, _ = engs.pc_sample(mn, SDE2, **kw)
+    got["split"] = si_sdr(sep, ref)
+    for k, s in got.items():
+        print(f"\n[nf128 N30 {k} vs fp32 engine] SI-SDR mean {float(s.mean()):.2f} min {float(s.min()):.2f} dB")
+    # gates: a few dB under the measurement (f16 36.0 / 35.4, bf16 19.4 / 17.9, hybrid (bf16 + split head) 43.9 / 42.7, hybrid_f16 62.5 / 61.6, split 77.7 / 77.0 dB
+    # mean / min)
+    assert float(got["f16"].mean()) > 33.0 and float(got["f16"].min()) > 32.0
+    assert float(got["bf16"].mean()) > 16.5 and float(got["bf16"].min()) > 15.0
+    assert float(got["hybrid"].mean()) > 40.0 and float(got["hybrid"].min()) > 39.0
+    assert float(got["hybrid_f16"].mean()) > 56.0 and float(got["hybrid_f16"].min()) > 55.0
+    assert float(got["split"].min()) > 60.0
+
+
+def test_nf128_split_sampler_parity_with_oracle():
+    # the parity bar at the published width: 60 evaluations of the split engine against the CPU oracle, same noise
+    cfg = O.default_config(128, 2, spec_factor=0.15)
+    T, N = 32000, 30
+    eng, sd = engine(128, 2, _lib.F32_SPLIT, spec_factor=0.15)
+    mix = torch.from_numpy(synth.synth_batch(1, T=T)[0])
+    draws = [rnd(f"n128.z{i}", (1, 2, T)) for i in range(1 + 2 * N)]
+    ref, nfe = O.separate(O.to_torch(sd), cfg, mix, draws, N=N, corrector_steps=1, snr=0.5, eps=0.03, denoise=True)
+    mn, _, _ = ops.normalize_batch(mix.to(DEV))
+    sep, nfe2 = eng.pc_sample(mn, SDE2, N=N, corrector_steps=1, snr=0.5, eps=0.03, denoise=True,
+                              noise=torch.stack(draws).to(DEV))
+    out = ops.scale_output(mix.to(DEV), sep).cpu()
+    d = rms(out - ref)
+    print(f"\n[nf128 split N30 vs oracle] out rms {rms(ref):.4f} diff rms {d:.3e} rel {rel_rms(out, ref):.3e}")
+    assert nfe == nfe2 == 60 and d < 1e-3

@@ -425,7 +425,7 @@ def test_hybrid_schedule_head_on_fp32_engine():
 
 def test_hybrid_model_api():
     m = _model16("hybrid")
-    assert m.tail_engine() is not None and m.head_steps > 0 and m.score_model.cfg.dtype == _lib.BF16
+    assert m.tail_engine() is not None and m.head_steps > 0 and m.score_model.engine().kind == m.tail_engine().kind == "f16"
     mixn = ops.normalize_batch(torch.from_numpy(synth.synth_batch(2, T=4000)[0]).to(DEV))[0]
     a, nfe = m.get_pc_sampler("reverse_diffusion", "ald2", mixn, N=4, seed=9)()
     b, _ = m.get_pc_sampler("reverse_diffusion", "ald2", mixn, N=4, seed=9)()

@@ -3,7 +3,8 @@
 set -e
 cd $(dirname $0)/../diffusion-separation_amd/csrc
 mkdir -p ../abl
-for v in "" "-DRW_ABL_FULLLINE" "" "-DRW_ABL_FULLLINE" "-DRW_ABL_NOLOAD"; do
+VARIANTS=("" "-DRW_ABL_NOEPI" "-DRW_ABL_NOSTAGE" "-DRW_ABL_NOEPI -DRW_ABL_NOSTAGE" "-DRW_ABL_NOSTORE" "-DRW_ABL_NOLOAD" "-DRW_ABL_NOSTATS")
+for v in "${VARIANTS[@]}"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC $v -mllvm -pragma-unroll-threshold=1000000 -c conv3x3_rw.hip -o /tmp/rw_a.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../abl/lib_rwa.so /tmp/rw_a.o build/conv_mfma.o build/conv3x3_ws.o build/conv3x3_small.o build/norm.o build/stft.o build/sde.o build/engine.o
   echo "== variant: ${v:-shipped}"
