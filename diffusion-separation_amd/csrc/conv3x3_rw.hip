@@ -62,7 +62,6 @@ __device__ inline u32x4_t ld16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned
 // block barrier that orders LDS traffic only (a __syncthreads() would also drain the global prefetch)
 __device__ inline void sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-constexpr int CO = 64;                // output channels of the layer
 constexpr int TW = 32, HW_ = TW + 2;  // tile width, halo row
 constexpr int KC = 64;                // channels per chunk: a pixel's chunk is ONE full 128-byte line of a 64-channel tensor
 constexpr int NKB = KC / 16;          // 16-channel k-blocks per tap
@@ -92,11 +91,16 @@ struct RwK {
 
 // k-steps whose weight fragments live in LDS instead of registers (the LAST ones in K order): the fourth chunk of the
 // 128-channel layers and the 128-channel skip — what the 512-entry register file does not hold beside the accumulators
-constexpr int rw_lds_ksteps(int nch, int rpw, int nsk) { return nch == 2 ? 18 : 0; }
+// With 4 cout groups (128 couts, 128 input channels) a wave holds 72 fragments of the 3x3 weights: 64 fill the 256
+// accumulator registers, the last 8 and every skip fragment live in LDS
+constexpr int rw_lds_ksteps(int nch, int rpw, int nsk, int ncg) { return ncg == 4 ? nch * KSC - 64 + nsk * NKB : (nch == 2 ? 18 : 0); }
 
-template <int NCH, int RPW, int NSK>
+// NCG: cout groups of 32 (2: 64 couts, the block's 4 waves = 2 cout groups x 2 pixel groups; 4: 128 couts, 4 cout
+// groups on ONE pixel group — the same staging and epilogue work per wave for twice the MFMAs)
+template <int NCH, int RPW, int NSK, int NCG>
 struct RwGeom {
-  static constexpr int TH = 2 * RPW, HH_ = TH + 2, HP = HH_ * HW_;
+  static constexpr int CO = 32 * NCG, PGN = 4 / NCG;
+  static constexpr int TH = PGN * RPW, HH_ = TH + 2, HP = HH_ * HW_;
   static constexpr int NL = (HP * PPL + NT - 1) / NT;     // 16-byte pieces per thread and chunk
   static constexpr int LDS_A = NL * (NT / PPL) * AROW;    // one ring slot (whole passes of the block: no predicated writes)
   static constexpr int CIN = NCH * KC, SCIN = NSK * KC;
@@ -104,8 +108,9 @@ struct RwGeom {
   static constexpr int LDS_DESC = NL * NT * 4;
   static constexpr int NPH = NCH + NSK;                   // phases (chunks) per tile
   static constexpr int NKS = NCH * KSC + NSK * NKB;       // k-steps = weight fragments per wave
-  static constexpr int NWL = rw_lds_ksteps(NCH, RPW, NSK), NWR = NKS - NWL;  // fragments in LDS / in registers
-  static constexpr int LDS_WL = NWL * 2 * 64 * 16;        // [k-step][cout group][lane] x 16 B
+  static constexpr int NWL = rw_lds_ksteps(NCH, RPW, NSK, NCG), NWR = NKS - NWL;  // fragments in LDS / in registers
+  static constexpr int LDS_WL = NWL * NCG * 64 * 16;      // [k-step][cout group][lane] x 16 B
+  static constexpr int WL_STEP = NCG * 64 * 16;
   static constexpr int OFF_TAB = 2 * LDS_A, OFF_WL = OFF_TAB + ((LDS_TAB + 15) & ~15), OFF_DESC = OFF_WL + LDS_WL;
   static constexpr int LDS_TOTAL = OFF_DESC + LDS_DESC;
   // chunk of phase P: [0, NCH) = 3x3 chunk, NCH + s = skip chunk s.  The skip chunks come first: the tile's LAST phase is
@@ -117,9 +122,10 @@ struct RwGeom {
 
 // NCH: 64-channel chunks of the 3x3 input (1: 64 channels, 2: 128 = one or two sources); RPW: pixel rows per wave
 // (tile = 2 RPW x 32); NSK: 64-channel chunks of the folded 1x1 skip (0, 1, 2); MODE: 0 raw input, 2 GroupNorm + SiLU
-template <int NCH, int RPW, int NSK, int MODE>
+template <int NCH, int RPW, int NSK, int MODE, int NCG>
 __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
-  using G = RwGeom<NCH, RPW, NSK>;
+  using G = RwGeom<NCH, RPW, NSK, NCG>;
+  constexpr int CO = G::CO, PGN = G::PGN;
   constexpr int TH = G::TH, HP = G::HP, LDS_A = G::LDS_A, NL = G::NL, NPH = G::NPH, NKS = G::NKS, CIN = G::CIN, NWR = G::NWR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, h = lane >> 5;
-  const int cg = wave & 1, pg = wave >> 1;
+  const int cg = wave % NCG, pg = wave / NCG;
   const int b = blockIdx.x / p.G, part = blockIdx.x % p.G;
   const int t0 = (int)((long)part * p.tiles_per_img / p.G);
   const int nt = (int)((long)(part + 1) * p.tiles_per_img / p.G) - t0;
@@ -186,10 +192,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
 
   // ---- this wave's weight fragments: cout cg * 32 + l32, k-step (chunk, tap, kb): channels 32 chunk + 16 kb + 8 h ..
   u32x4_t wf[NWR > 0 ? NWR : 1];
-  char* sWl = smem + G::OFF_WL + (cg * 64 + lane) * 16;  // + (ks - NWR) * 2048
+  char* sWl = smem + G::OFF_WL + (cg * 64 + lane) * 16;  // + (ks - NWR) * WL_STEP
   auto put_w = [&](int ks, const u32x4_t& v) __attribute__((always_inline)) {
     if (ks < NWR) wf[ks] = v;
-    else if (pg == 0) *reinterpret_cast<u32x4_t*>(sWl + (ks - NWR) * 2048) = v;
+    else if (pg == 0) *reinterpret_cast<u32x4_t*>(sWl + (ks - NWR) * G::WL_STEP) = v;
   };
   auto load_weights = [&]() __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t rw = rsrc(p.w, 9u * CO * CIN * 2u);
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
         if (d < NK) bf[d][r] = ldb(d, r);
     // weight fragment of k-step ks: a register, or (the last NWL k-steps) an LDS read issued one k-step ahead
     u32x4_t wl = {0, 0, 0, 0}, wln = {0, 0, 0, 0};
-    if constexpr (W0 >= NWR) wl = *reinterpret_cast<const u32x4_t*>(sWl + (W0 - NWR) * 2048);
+    if constexpr (W0 >= NWR) wl = *reinterpret_cast<const u32x4_t*>(sWl + (W0 - NWR) * G::WL_STEP);
     int rels[2][NL];
     float4 eb[2][NE][2];
     {  // (the first k-step's operands: the one exposed round trip of the half)
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
           for (int e = en0; e < en1; ++e) epi_bias(e & 1, eb[(ks + 1) & 1][e - en0][0], eb[(ks + 1) & 1][e - en0][1]);
         }
       }
-      if (W0 + ks + 1 >= NWR && ks + 1 < NK) wln = *reinterpret_cast<const u32x4_t*>(sWl + (W0 + ks + 1 - NWR) * 2048);
+      if (W0 + ks + 1 >= NWR && ks + 1 < NK) wln = *reinterpret_cast<const u32x4_t*>(sWl + (W0 + ks + 1 - NWR) * G::WL_STEP);
       const u32x4_t wk = W0 + ks < NWR ? wf[W0 + ks < NWR ? W0 + ks : 0] : wl;
 #pragma unroll
       for (int r = 0; r < RH; ++r) {
@@ -609,9 +615,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
       const int co = tid >> 1, st = tid & 1;
       const int wcg = co >> 5, c32 = co & 31, q = c32 >> 3, hh = (c32 >> 2) & 1, i = c32 & 3;
       double a = 0.0;
-      for (int wpg = 0; wpg < 2; ++wpg)
+      for (int wpg = 0; wpg < PGN; ++wpg)
         for (int l = 0; l < 32; ++l) {
-          const int t = (wpg * 2 + wcg) * 64 + hh * 32 + l;
+          const int t = (wpg * NCG + wcg) * 64 + hh * 32 + l;
           a += (double)red[t * RED_ROW + st * 16 + 4 * q + i];
         }
       ds_stat_add(p.stats + ((long)b * CO + co) * 2 + st, (long long)llrint(a * (st ? DS_STAT_SQ_SCALE : DS_STAT_SUM_SCALE)));
@@ -639,21 +645,21 @@ int rw_blocks_per_image(const ConvArgs& a, int tiles) {
   return g;
 }
 
-template <int NCH, int RPW, int NSK, int MODE>
+template <int NCH, int RPW, int NSK, int MODE, int NCG>
 int rw_launch(const RwK& k0, const ConvArgs& a, hipStream_t st) {
-  using G = RwGeom<NCH, RPW, NSK>;
+  using G = RwGeom<NCH, RPW, NSK, NCG>;
   RwK k = k0;
   const int tiles = (a.H / G::TH) * (a.W / TW);
   k.G = rw_blocks_per_image(a, tiles);
   k.tiles_x = a.W / TW;
   k.tiles_per_img = tiles;
-  auto kern = conv3x3_rw_kernel<NCH, RPW, NSK, MODE>;
+  auto kern = conv3x3_rw_kernel<NCH, RPW, NSK, MODE, NCG>;
   DS_FUNC_LDS_ONCE(kern, G::LDS_TOTAL);
   hipLaunchKernelGGL(kern, dim3(a.B * k.G), dim3(NT), G::LDS_TOTAL, st, k);
   DS_LAUNCH_CHECK();
   {
     static char name[64] = {0};
-    if (!name[0]) snprintf(name, sizeof(name), "conv3x3_rw_kernel<%d,%d,%d,%d>", NCH, RPW, NSK, MODE);
+    if (!name[0]) snprintf(name, sizeof(name), "conv3x3_rw_kernel<%d,%d,%d,%d,%d>", NCH, RPW, NSK, MODE, NCG);
     ds_set_last_conv_kernel(name);
   }
   return 0;
@@ -665,10 +671,12 @@ int rw_launch(const RwK& k0, const ConvArgs& a, hipStream_t st) {
 // two), input raw or GroupNorm + SiLU, optional folded 1x1 skip on 64 / 128 raw channels, whole tiles.
 bool ds_conv_rw_eligible(const ConvArgs& a) {
   if (getenv("DIFFSEP_NO_RW")) return false;
-  if (!(a.dtype == DS_BF16 && a.taps == 9 && (a.Cin == 64 || a.Cin == 128) && a.Cout == CO && a.w_bs == 0 &&
-        (a.w_chunked == 0 || a.w_chunked == 32) && a.bias_mode == 0 && !a.div_b && a.W % TW == 0 && a.H % 8 == 0 &&
+  const int CO = a.Cout;
+  if (!(a.dtype == DS_BF16 && a.taps == 9 && ((CO == 64 && (a.Cin == 64 || a.Cin == 128)) || (CO == 128 && a.Cin == 128)) &&
+        a.w_bs == 0 && (a.w_chunked == 0 || a.w_chunked == 32) && a.bias_mode == 0 && !a.div_b && a.W % TW == 0 && a.H % 8 == 0 &&
         a.H >= 32 && a.W >= 32 && a.ldy >= CO && a.ldy % 8 == 0 && (!a.res || (a.ldr >= CO && a.ldr % 8 == 0))))
     return false;
+  if (CO == 128 && getenv("DIFFSEP_NO_RW128")) return false;
   if (a.x2 ? !(a.C1 % KC == 0 && a.C1 > 0 && a.C1 < a.Cin && a.ldx % 8 == 0 && a.ldx2 % 8 == 0) : a.ldx % 8 != 0) return false;
   const bool gn = a.gn_scale || a.gn_acc1;
   if (gn && !a.gn_act) return false;  // (affine without SiLU does not occur in front of a 3x3 convolution)
@@ -678,12 +686,20 @@ bool ds_conv_rw_eligible(const ConvArgs& a) {
           (!a.sx2 || (a.sC1 % KC == 0 && a.sC1 > 0 && a.sC1 < a.sCin && a.ldsx2 % 8 == 0)) &&
           (a.sw_chunked == 0 || ((a.sw_chunked & (a.sw_chunked - 1)) == 0 && a.sw_chunked >= 16))))
       return false;
-    if (a.Cin == 128) return false;  // (no layer of the network has both; the register file would not hold it either)
+    if (a.Cin == 128 && CO == 64) return false;  // (no layer of the network has both; the register file would not hold it either)
   }
-  if (a.res && a.Cin == 128) return false;  // (the residual rides as a skip: same limit)
+  if (a.res && a.Cin == 128 && CO == 64) return false;  // (the residual rides as a skip: same limit)
+  if (CO == 128) {  // 4 cout groups: the skip / residual fragments live in LDS; every such layer normalises its input
+    if ((a.sx || a.res) && !gn) return false;
+    return true;
+  }
   // measured (tools/rw_bench.py): with a residual the two short identity-skip phases cost more than they save against
   // the weight-stationary kernel (163 vs 145 us at 256^2): those launches (Conv_1 of the plain blocks) stay there
   if (a.res && !getenv("DIFFSEP_RW_RES")) return false;
+  // measured (tools/shape_table.py, B = 16): on 128 x 128 images the 64-channel launches without a 128-channel skip are
+  // 10 % faster on the weight-stationary kernel (41.3 vs 37 us, 45.1 vs 41.8 us): too few tiles per block to pay for the
+  // weight prologue
+  if (a.Cin == 64 && a.sCin != 128 && (long)a.H * a.W <= 128 * 128 && !getenv("DIFFSEP_RW_SMALL")) return false;
   return true;
 }
 
@@ -707,12 +723,18 @@ int ds_launch_conv_rw(const ConvArgs& a, hipStream_t st) {
   k.H = a.H; k.W = a.W; k.G = 0; k.tiles_x = 0; k.tiles_per_img = 0;
   k.dbg = getenv("DIFFSEP_RW_DBG") ? atoi(getenv("DIFFSEP_RW_DBG")) : 0;
   if (a.res) {  // the residual [B][H][W][64] as a folded skip with identity weights (sw = null): exact in the fp32 accumulators
-    k.sx = reinterpret_cast<const bf16_t*>(a.res); k.sx_bs = a.res_bs; k.ldsx = a.ldr; k.sC1 = CO;
-    k.sx2 = nullptr; k.sx2_bs = 0; k.ldsx2 = a.ldr; k.sw = nullptr; k.sw_chunked = 0; k.sw_shift = 0; k.sCin = CO;
+    k.sx = reinterpret_cast<const bf16_t*>(a.res); k.sx_bs = a.res_bs; k.ldsx = a.ldr; k.sC1 = a.Cout;
+    k.sx2 = nullptr; k.sx2_bs = 0; k.ldsx2 = a.ldr; k.sw = nullptr; k.sw_chunked = 0; k.sw_shift = 0; k.sCin = a.Cout;
   }
   const int mode = ((a.gn_scale || a.gn_acc1) && a.gn_act) ? 2 : 0;
-  const int nsk = a.sx ? a.sCin / KC : (a.res ? 1 : 0);
-#define RW_GO(NCH_, NSK_) return mode == 2 ? rw_launch<NCH_, 4, NSK_, 2>(k, a, st) : rw_launch<NCH_, 4, NSK_, 0>(k, a, st)
+  const int nsk = a.sx ? a.sCin / KC : (a.res ? a.Cout / KC : 0);
+  if (a.Cout == 128) {  // 128 -> 128: 4 cout groups
+    if (mode == 0) return rw_launch<2, 4, 0, 0, 4>(k, a, st);
+    if (nsk == 0) return rw_launch<2, 4, 0, 2, 4>(k, a, st);
+    if (nsk == 1) return rw_launch<2, 4, 1, 2, 4>(k, a, st);
+    return rw_launch<2, 4, 2, 2, 4>(k, a, st);
+  }
+#define RW_GO(NCH_, NSK_) return mode == 2 ? rw_launch<NCH_, 4, NSK_, 2, 2>(k, a, st) : rw_launch<NCH_, 4, NSK_, 0, 2>(k, a, st)
   if (a.Cin == 128) RW_GO(2, 0);
   if (nsk == 0) RW_GO(1, 0);
   if (nsk == 1) RW_GO(1, 1);

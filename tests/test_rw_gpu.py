@@ -14,6 +14,21 @@ from diffsep_amd import ops, synth
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _every_eligible_launch_on_the_rw_kernel():
+    """The dispatch keeps residual launches and small 64-channel images on the weight-stationary kernel (faster there);
+    this module tests the register-weight kernel on them too."""
+    import os
+    old = {k: os.environ.get(k) for k in ("DIFFSEP_RW_RES", "DIFFSEP_RW_SMALL")}
+    os.environ.update(DIFFSEP_RW_RES="1", DIFFSEP_RW_SMALL="1")
+    yield
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 DEV = "cuda"
 DT = torch.bfloat16
 
@@ -68,6 +83,44 @@ def test_rw_conv3x3_matches_torch(B, H, W, C1, C2, act):
     assert rel_rms(y2.float(), ref2) < 4e-3
 
 
+# ---- 128 -> 128 couts: 4 cout groups on one 4 x 32 pixel group (tiles of 4 rows), skip / residual fragments in LDS
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (3, 64, 96), (16, 64, 64), (2, 40, 64), (1, 128, 256), (130, 32, 32)])
+@pytest.mark.parametrize("C1,C2", [(128, 0), (64, 64)])
+@pytest.mark.parametrize("extra", ["none", "res"])  # (the folded skips: test_rw128_resblock_vs_oracle)
+def test_rw128_conv3x3_matches_torch(B, H, W, C1, C2, extra):
+    C, CO = C1 + C2, 128
+    if extra != "none" and (B, H, W) in ((1, 128, 256), (130, 32, 32)) and C2:
+        pytest.skip("covered by the single-tensor input")
+    a = (rnd(f"rw8.a{B}{H}{C1}", (B, H, W, C1), 1.2) + 0.1).to(DEV, DT)
+    bt = (rnd(f"rw8.b{B}{H}{C2}", (B, H, W, C2), 0.9) - 0.2).to(DEV, DT) if C2 else None
+    w = rnd(f"rw8.w{C}", (CO, C, 3, 3), 1.0 / math.sqrt(9 * C))
+    bias, bb = rnd("rw8.bias", (CO,), 0.1).to(DEV), rnd(f"rw8.bb{B}", (B, CO), 0.1).to(DEV)
+    sc = (1.0 + rnd(f"rw8.sc{B}{C}", (B, C), 0.2)).to(DEV)
+    sh = rnd(f"rw8.sh{B}{C}", (B, C), 0.2).to(DEV)
+    xf = torch.cat([a.float(), bt.float()], -1) if C2 else a.float()
+    xa = F.silu(xf * sc[:, None, None, :] + sh[:, None, None, :]).to(DT).float()
+    wq = w.to(DT).float()
+    ref = F.conv2d(xa.cpu().permute(0, 3, 1, 2), wq, bias.cpu(), padding=1).permute(0, 2, 3, 1) + bb.cpu()[:, None, None, :]
+    kw = {}
+    if extra == "res":
+        res = rnd(f"rw8.r{B}{H}", (B, H, W, CO)).to(DEV, DT)
+        ref = ref + res.float().cpu()
+        kw = dict(res=res)
+    ref = ref * 0.70710678
+    for chunk in (0, ops.conv2d_chunk(3, DT)):
+        wp = ops.pack_conv_weight(w, DT, chunk=chunk).to(DEV) if chunk else ops.pack_conv_weight(w, DT).to(DEV)
+        y, st = ops.conv2d_fused(a, wp, bias, CO, 3, x2=bt, gn=(sc, sh), gn_act=1, bias_b=bb, out_scale=0.70710678, stats=True,
+                                 w_chunk=chunk, **kw)
+        assert rel_rms(y.float(), ref) < 4e-3
+        s = ops.stats_to_float(st)
+        assert torch.allclose(s[..., 0].cpu(), ref.double().sum((1, 2)), rtol=2e-3, atol=2e-3 * H * W)
+        assert torch.allclose(s[..., 1].cpu(), (ref.double() ** 2).sum((1, 2)), rtol=2e-3, atol=2e-3 * H * W)
+    if extra == "none":  # raw input (the launch behind a FIR resampling kernel): no GroupNorm, no bias, no statistics
+        y2 = ops.conv2d_fused(a, ops.pack_conv_weight(w, DT).to(DEV), None, CO, 3, x2=bt)
+        ref2 = F.conv2d(xf.cpu().permute(0, 3, 1, 2), wq, None, padding=1).permute(0, 2, 3, 1)
+        assert rel_rms(y2.float(), ref2) < 4e-3
+
+
 def test_rw_conv3x3_zero_padding_is_exact():
     # an all-ones image through GroupNorm + SiLU with shift: every border pixel must see ZERO padding (not silu(shift))
     B, H, W, C = 2, 32, 64, 64
@@ -108,6 +161,24 @@ def test_rw_conv3x3_groupnorm_from_producer_accumulators(C1, C2):
 RB = [("GroupNorm_0.weight", "cin"), ("GroupNorm_0.bias", "cin"), ("Conv_0.weight", "w0"), ("Conv_0.bias", "cout"),
       ("Dense_0.weight", "d"), ("Dense_0.bias", "cout"), ("GroupNorm_1.weight", "cout"), ("GroupNorm_1.bias", "cout"),
       ("Conv_1.weight", "w1"), ("Conv_1.bias", "cout"), ("Conv_2.weight", "w2"), ("Conv_2.bias", "cout")]
+
+
+@pytest.mark.parametrize("cin,B,H,W,up,down", [(128, 3, 32, 64, False, False), (64, 2, 64, 32, False, False),
+                                               (128, 2, 32, 32, True, False), (128, 2, 64, 128, False, True), (256, 2, 32, 64, False, False)])
+def test_rw128_resblock_vs_oracle(cin, B, H, W, up, down):
+    # 128-cout residual blocks: plain (Conv_1 + residual), widening 64 -> 128 (Conv_1 + folded 64-channel skip), FIR up /
+    # down (raw-input Conv_0, Conv_1 + folded 128-channel skip), 256 -> 128 (Conv_0 and the 256-channel skip stay on the
+    # generic tile)
+    cout = 128
+    shp = dict(cin=(cin,), cout=(cout,), w0=(cout, cin, 3, 3), w1=(cout, cout, 3, 3), w2=(cout, cin, 1, 1), d=(cout, 64))
+    tbl = [(n, shp[k]) for n, k in RB if not (n.startswith("Conv_2") and cin == cout and not up and not down)]
+    sd = synth.synth_state_dict(tbl, 33)
+    if "Conv_2.weight" in sd:
+        sd["Conv_2.weight"] = (sd["Conv_2.weight"] * 3.0).astype(np.float32)
+    x, temb = rnd(f"rw8rb.x{cin}{H}{W}{B}", (B, cin, H, W)), rnd("rw8rb.t", (B, 64))
+    ref = O._res_block(O.to_torch(sd), "", x, temb, up=up, down=down)
+    yb = ops.resblock_forward([sd[n] for n, _ in tbl], ops.to_nhwc(x).to(DT).to(DEV), temb.to(DEV), cout, up=up, down=down)
+    assert rel_rms(ops.to_nchw(yb).float(), ref) < 1.5e-2
 
 
 @pytest.mark.parametrize("cin,B,H,W,up,down", [(128, 3, 32, 64, False, False), (128, 2, 40, 32, False, False),

@@ -39,7 +39,9 @@ for (ci, H, W, fused, B) in [(c, hh, ww, f, bb) for bb in BS for (c, hh, ww, f) 
     e1.record(); torch.cuda.synchronize()
     l.diffsep_rw_debug_read(out, 1)
     nb = out[15]; tot = sum(out[i] for i in range(8))
-    print(f"B={B} {ci}->64 {H}x{W} {['plain', 'GN+SiLU+stats', 'GN+SiLU+stats+residual'][fused]}: {e0.elapsed_time(e1)/5*1e3:.1f} us/launch, {tot/nb:.0f} ticks/block (wave 0), {nb//5} blocks")
+    if nb == 0:
+        continue  # (this launch did not run on the register-weight kernel)
+    print(f"B={B} {ci}->64 {H}x{W} {['plain', 'GN+SiLU+stats', 'GN+SiLU+stats+residual'][fused]}: {e0.elapsed_time(e1)/5*1e3:.1f} us/launch, {tot/nb:.0f} ticks/block (wave 0), {nb//5} blocks -> {tot/nb/(e0.elapsed_time(e1)/5*1e3)/1e3:.2f} ticks/ns")
     for i in range(6):
         print(f"    {names[i]:36s} {out[i]/nb:9.0f}  {100*out[i]/tot:5.1f} %")
 PY
