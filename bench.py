@@ -382,19 +382,6 @@ def main():
         ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
         traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_conv3x3.json")
-        if os.path.exists(pmc):
-            try:
-                tkey = {"conv3x3_8x32xN64": f"hbm_bytes_per_launch_{args.dtype}_B{B}",
-                        "conv3x3_ws_64to64": f"hbm_bytes_per_launch_ws_{args.dtype}_B{B}"}.get(dom)
-                pj = json.load(open(pmc))
-                traffic = pj.get(tkey) if tkey else None
-                traffic = round(traffic) if traffic else None
-                traffic_source = ("profiles/pmc_conv3x3.json: rocprofv3 --pmc passes of tools/pmc_bench.sh (FETCH_SIZE and "
-                                  "WRITE_SIZE in separate runs, guide correction 2*FETCH + WRITE), measured at commit %s — "
-                                  "NOT collected in this run" % pj.get("commit", "unrecorded (round 1)")) if traffic else None
-            except Exception:
-                traffic = None
         # the bound is whichever floor of an average launch is higher: HBM at 8 TB/s or dense MFMA at `peak`
         hbm_floor_us = by / max(n, 1) / HBM_PEAK_BPS * 1e6
         mfma_floor_us = fl / max(n, 1) / (peak * 1e12) * 1e6
@@ -423,8 +410,28 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             hbm_floor_us = by / max(n, 1) / HBM_PEAK_BPS * 1e6
             mfma_floor_us = fl / max(n, 1) / (peak * 1e12) * 1e6
-            if dom_k.startswith("conv3x3_ws1") or not dom_k.startswith("conv_mfma_kernel<bf16,9,"):
-                traffic = traffic_source = None  # (the PMC file holds the generic 3x3 tile's traffic only)
+        # HBM bytes per launch of that instantiation from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs of
+        # tools/pmc_traffic.sh with the guide's correction 2 * FETCH + WRITE), and its MFMA utilisation per shader cycle
+        pmc_util = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_conv3x3.json")))
+            ent = pj.get("by_instantiation", {}).get(kname) if pj.get("dtype") == args.dtype and args.nf == 64 and B == 16 else None
+            if ent:
+                traffic = ent["hbm_bytes_per_launch_guide_formula"]
+                traffic_source = ("profiles/pmc_conv3x3.json: rocprofv3 --pmc passes of tools/pmc_traffic.sh (FETCH_SIZE and WRITE_SIZE in "
+                                  "separate runs, guide correction 2*FETCH + WRITE, average over the %d launches of this instantiation in a "
+                                  "4-step sampler), measured at commit %s - NOT collected in this run" % (ent["launches"], pj.get("commit")))
+        except Exception:
+            traffic = traffic_source = None
+        try:
+            pu = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_mfma_util.json")))
+            for k_, v_ in pu.get("kernels", {}).items():
+                if k_.split(" grid ")[0] == kname and pu.get("dtype") == args.dtype:
+                    pmc_util = {"mfma_util_per_shader_cycle": v_.get("mfma_util"), "shader_clock_ghz": v_.get("shader_clock_ghz"),
+                                "valu_per_mfma": v_.get("valu_per_mfma"), "lds_per_mfma": v_.get("lds_per_mfma"),
+                                "source": "profiles/r03_pmc_mfma_util.json (tools/pmc_r03.sh, commit %s) - NOT collected in this run" % pu.get("commit")}
+        except Exception:
+            pmc_util = None
         if hbm_floor_us > mfma_floor_us:
             gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             roof = {"bound": "hbm", "kernel": kname, "achieved": round(gbs, 1), "peak": HBM_PEAK_BPS / 1e9,
@@ -432,7 +439,7 @@ def main():
         else:
             roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4)}
-        roof.update({"traffic": traffic, "traffic_source": traffic_source, "launches": n, "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
+        roof.update({"traffic": traffic, "traffic_source": traffic_source, "pmc": pmc_util, "launches": n, "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
                 "flops_per_launch": fl / max(n, 1), "algorithmic_bytes_per_launch": by / max(n, 1),
                 "hbm_floor_us": round(hbm_floor_us, 2), "mfma_floor_us": round(mfma_floor_us, 2),
                 "achieved_tflops": round(ach, 2),

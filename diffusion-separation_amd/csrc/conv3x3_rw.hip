@@ -487,6 +487,14 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
       }
       if (W0 + ks + 1 >= NWR && ks + 1 < NK) wln = *reinterpret_cast<const u32x4_t*>(sWl + (W0 + ks + 1 - NWR) * G::WL_STEP);
       const u32x4_t wk = W0 + ks < NWR ? wf[W0 + ks < NWR ? W0 + ks : 0] : wl;
+      // RW_DEP: the k-step's LAST pixel fragment rides along as an unused operand of every MFMA of the k-step: the
+      // compiler then waits ONCE per k-step (for the newest fragment) instead of once per MFMA — one s_waitcnt less per
+      // MFMA in a stream whose issue slots are the bottleneck (the fragments were read DEPTH k-steps ago)
+#ifdef RW_NO_DEP
+#define RW_DEP
+#else
+#define RW_DEP , "v"(bf[ks % DEPTH][RH - 1])
+#endif
 #pragma unroll
       for (int r = 0; r < RH; ++r) {
 #ifndef RW_BUILTIN_MFMA
@@ -496,11 +504,11 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
         // and staged pieces through AGPRs: 200 v_accvgpr moves per tile.)  What the compiler does not know about an asm
         // MFMA: the 12 wait states between its result and a VALU read — the guard at the start of every half.
         if (W0 + ks < NWR) {
-          if (P == 0 && ks == 0) asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, 0" : "=v"(acc[R0 + r]) : "a"(wk), "v"(bf[ks % DEPTH][r]));
-          else asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, %0" : "+v"(acc[R0 + r]) : "a"(wk), "v"(bf[ks % DEPTH][r]));
+          if (P == 0 && ks == 0) asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, 0" : "=v"(acc[R0 + r]) : "a"(wk), "v"(bf[ks % DEPTH][r]) RW_DEP);
+          else asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, %0" : "+v"(acc[R0 + r]) : "a"(wk), "v"(bf[ks % DEPTH][r]) RW_DEP);
         } else {  // LDS-resident fragment: straight from the ds_read's VGPRs (no VALU copy in front of the MFMA)
-          if (P == 0 && ks == 0) asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, 0" : "=v"(acc[R0 + r]) : "v"(wk), "v"(bf[ks % DEPTH][r]));
-          else asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, %0" : "+v"(acc[R0 + r]) : "v"(wk), "v"(bf[ks % DEPTH][r]));
+          if (P == 0 && ks == 0) asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, 0" : "=v"(acc[R0 + r]) : "v"(wk), "v"(bf[ks % DEPTH][r]) RW_DEP);
+          else asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, %0" : "+v"(acc[R0 + r]) : "v"(wk), "v"(bf[ks % DEPTH][r]) RW_DEP);
         }
 #else
         if (P == 0 && ks == 0) {  // a tile's first MFMA of a row starts from zero (the row's epilogue has run)

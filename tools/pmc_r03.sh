@@ -13,12 +13,12 @@ CMD="python bench.py --dtype $DT --in-flight 1 --steps 1 --warmup 0 -N 4 --no-cp
 rm -rf /tmp/pmc_r03
 rocprofv3 --kernel-trace --pmc $P1 -d /tmp/pmc_r03/p1 -o pmc --output-format csv -- $CMD > $OUT/run1.log 2>&1
 rocprofv3 --kernel-trace --pmc $P2 -d /tmp/pmc_r03/p2 -o pmc --output-format csv -- $CMD > $OUT/run2.log 2>&1
-python - "$OUT" "$CMD" <<'PY'
+DT=$DT python - "$OUT" "$CMD" <<'PY'
 import csv, glob, json, os, re, sys
 out, cmd = sys.argv[1], sys.argv[2]
 def short(k):
     m = re.search(r"((?:conv3x3_rw|conv3x3_ws1|conv_mfma|conv3x3_small|conv3x3_thin_in|conv3x3_thin_out)_kernel(?:<[^>]*>)?)", k)
-    return m.group(1).replace("_Float16", "f16").replace("unsigned short", "bf16").replace(" ", "") if m else None
+    return m.group(1).replace("unsigned short", os.environ.get("DT", "bf16")).replace("float", "f32").replace(" ", "") if m else None
 res, dur = {}, {}
 for p in ("p1", "p2"):
     disp = {}
@@ -62,7 +62,8 @@ for k, c in res.items():
         o["lds_bank_conflict_cycles_per_lds_inst"] = round(s["SQ_LDS_BANK_CONFLICT"] / max(s["SQ_INSTS_LDS"], 1), 3)
     summ[k] = o
 summ = dict(sorted(summ.items(), key=lambda kv: -kv[1].get("gui_active_cycles", 0) * kv[1]["launches"]))
-doc = {"command": "rocprofv3 --kernel-trace --pmc <8 counters> -- " + cmd + "  (two passes, tools/pmc_r03.sh)",
+doc = {"commit": os.environ.get("COMMIT", "unrecorded"), "dtype": os.environ.get("DT", "bf16"),
+       "command": "rocprofv3 --kernel-trace --pmc <8 counters> -- " + cmd + "  (two passes, tools/pmc_r03.sh)",
        "note": "GRBM_GUI_ACTIVE is summed over the 8 XCDs; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs): per "
                "shader CYCLE, whatever the clock; shader_clock_ghz = GRBM_GUI_ACTIVE / 8 / kernel duration of the same dispatches; "
                "SQ_INSTS_VALU includes the MFMAs (subtracted in valu_per_mfma); wave states as fractions of SQ_WAVE_CYCLES",
