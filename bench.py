@@ -27,8 +27,9 @@ Prints ONE JSON line (rank 0).  Extra objects:
                  the host cores for a bounded number of network evaluations and scaled to utt/s.
   precision / <other>_mode / fp32_parity_mode / split_parity_mode — the same step in the other precision modes on the
                  driver's clock, and every mode's agreement with the exact fp32 engine's output on the same noise (SI-SDR,
-                 relative and absolute RMS; the parity bar is 1e-3 absolute RMS).  value_parity_grade = the fastest mode
-                 inside that bar.
+                 relative and absolute RMS).  The parity bar is 1e-3 absolute RMS on the waveforms; on the quiet synthetic
+                 outputs (RMS 0.014) that alone would pass a 2.6 % relative error, so value_parity_grade = the fastest
+                 mode inside 1e-3 absolute AND 1 % relative RMS (>= 40 dB) of the fp32 engine.
   nf128        — the published model width (nf = 128) in the main dtype: utt/s, one batch alone, dominant kernel.
 """
 import argparse
@@ -522,8 +523,8 @@ def main():
                     "rel_rms_vs_fp32": float("%.3e" % rel[k]), "abs_rms_vs_fp32": float("%.3e" % absr[k])}
         extra_json = {
             "precision": {"note": "separated waveforms (input scale: mixture peak 0.9, output RMS %.3f) of each mode against the "
-                                  "exact fp32 engine's on the same noise (B = %d, %d NFE); the parity bar is 1e-3 absolute "
-                                  "RMS (the fp32 engine itself is 6e-8 from the CPU oracle, tests/test_engine_gpu.py)"
+                                  "exact fp32 engine's on the same noise (B = %d, %d NFE); parity-grade = inside 1e-3 absolute "
+                                  "AND 1e-2 relative RMS (the fp32 engine itself is 6e-8 from the CPU oracle, tests/test_engine_gpu.py)"
                                   % (float(o32.double().pow(2).mean().sqrt()), B, nfe),
                           args.dtype: quality(args.dtype), other: quality(other), "split": quality("split")},
             other + "_mode": {"utt_per_s": round(ups[other], 3), "batches_in_flight": K,
@@ -539,7 +540,7 @@ def main():
                                           "halves (tests/test_split_gpu.py)"}}
         # parity-grade throughput: the fastest mode inside the 1e-3 absolute RMS bar
         extra_json["_ups"] = {other: ups[other], "split": ups["split"], "f32": ups["f32"]}
-        extra_json["_abs"] = absr
+        extra_json["_abs"] = {k: max(absr[k] / 1e-3, rel[k] / 1e-2) for k in absr}  # (inside the bar: < 1)
         for e in e32 + esp + eot:
             e.close()
         if args.nf != 128 and not args.no_nf128:
@@ -599,9 +600,10 @@ def main():
         ups_ = extra_json.pop("_ups", None)
         abs_ = extra_json.pop("_abs", None)
         if ups_ is not None:
-            # parity-grade throughput: the fastest of the measured modes whose output is inside the 1e-3 absolute RMS bar
+            # parity-grade throughput: the fastest of the measured modes whose output is inside 1e-3 absolute and 1 %
+            # relative RMS of the exact fp32 engine's
             cand = {args.dtype: value, **ups_}
-            ok = {k: v for k, v in cand.items() if k == "f32" or abs_.get(k, 1.0) < 1e-3}
+            ok = {k: v for k, v in cand.items() if k == "f32" or abs_.get(k, 9.0) < 1.0}
             best = max(ok, key=lambda k: ok[k])
             res["value_parity_grade"] = round(ok[best], 4)
             res["parity_grade_mode"] = best
