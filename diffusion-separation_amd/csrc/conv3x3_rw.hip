@@ -1,5 +1,6 @@
-// conv3x3_rw.hip — 3x3 convolution with REGISTER-resident weights for the 64-cout layers of the large levels
-// (64 -> 64, cat(64, 64) -> 64, each optionally with the folded 1x1 skip of ResnetBlockBigGANpp; bf16, gfx950).
+// conv3x3_rw.hip — 3x3 convolution with REGISTER-resident weights for the 16-bit layers of the large levels: 64 couts
+// (64 -> 64, cat(64, 64) -> 64, optionally with the folded 1x1 skip of ResnetBlockBigGANpp on 64 / 128 raw channels) and
+// 128 -> 128 (optional folded 64 / 128-channel skip or residual); gfx950, bfloat16 or (-DDS_HALF_F16) fp16 storage.
 // Reference: layers.py:141-156 (ddpm_conv3x3), layerspp.py:291-323 (ResnetBlockBigGANpp), ncsnpp.py:411 (the concat).
 //
 // Why another kernel: the generic tile (conv_mfma.hip) re-streams the weights for every 256-pixel tile and runs
@@ -7,24 +8,33 @@
 // MFMA peak); the weight-stationary kernel (conv3x3_ws.hip) keeps the weights in LDS and spends its MFMA phase on LDS
 // fragment traffic (1.5 reads per MFMA).  Here:
 //
-//   * one block of 4 waves per CU, ONE wave per SIMD with the whole 512-entry register file: a wave owns 32 couts
-//     (cg = wave & 1) and keeps ALL of their weight fragments in registers for the whole launch (144 registers per 64
-//     input channels; hipcc places part of them in the accumulator half of the file and feeds them to the MFMAs from
-//     there) — no weight traffic at all after the prologue, through HBM, L2, L1 or LDS;
-//   * a wave's pixel group (pg = wave >> 1) is RPW rows x 32 pixels of a (2 RPW) x 32 tile: every weight fragment is
-//     used by RPW consecutive MFMAs on independent accumulators, the only LDS traffic of the MFMA stream is ONE
-//     ds_read_b128 (the pixel fragment) per MFMA;
-//   * persistent blocks walk a contiguous raster range of tiles; the input goes chunk by chunk (32 channels) through a
-//     2-slot halo ring: while the MFMAs of chunk q run, the same wave activates chunk q + 1 in registers (GroupNorm
-//     affine + SiLU), writes it to the other slot and re-issues the freed registers as the loads of chunk q + 2 — a
-//     global load has a whole chunk phase to land, and one LDS-only barrier per chunk is the only synchronisation;
-//   * the K loop is fully unrolled (every MFMA names its own weight registers); a scheduling barrier per k-step keeps
-//     the compiler's interleave local (RPW MFMAs + RPW fragment reads + one staging operation);
-//   * the folded 1x1 skip (Conv_2 on the raw block input) is NSK extra chunks that use only the centre tap;
-//   * epilogue per pixel row through a wave-private LDS scratch into pixel-major order: bias + temb bias, residual,
-//     1/sqrt(2), statistics for the next GroupNorm, bf16 packing, 64-byte row segments.
+//   * one block of 4 waves per CU, ONE wave per SIMD with the whole 512-entry register file.  A wave owns 32 couts
+//     (cg) and keeps ALL of their weight fragments in registers for the whole launch (144 registers per 64 input
+//     channels, pinned to the accumulator half of the file by inline-asm MFMAs with "a" operands) — no weight traffic
+//     at all after the prologue, through HBM, L2, L1 or LDS.  What the file does not hold beside the accumulators (the
+//     last k-steps of the 128-channel layers, the skip fragments of the 128-cout variant) is read from LDS one k-step
+//     ahead (RwGeom::NWL);
+//   * NCG = 2 (64 couts): the block's waves are 2 cout groups x 2 pixel groups of RPW rows x 32 pixels, tile (2 RPW) x 32;
+//     NCG = 4 (128 couts): 4 cout groups on ONE pixel group, tile RPW x 32 — the same staging and epilogue work per wave
+//     for twice the MFMAs.  Every weight fragment is used by RPW / 2 consecutive MFMAs on independent accumulators; the
+//     only LDS traffic of the MFMA stream is ONE ds_read_b128 (the pixel fragment) per MFMA;
+//   * persistent blocks walk a contiguous raster range of tiles of one image; the input goes chunk by chunk (KC = 64
+//     channels: a pixel's chunk is one full 128-byte line) through a 2-slot halo ring: while the MFMAs of chunk q run,
+//     the same wave activates chunk q + 1 in registers (GroupNorm affine + SiLU, one dword = "unit" at a time), writes
+//     it to the other slot and re-issues the freed registers as the loads of chunk q + 2 — a global load has a whole
+//     chunk phase to land, and one LDS-only barrier per chunk is the only synchronisation;
+//   * the K loop is fully unrolled (every MFMA names its own weight registers; needs -mllvm
+//     -pragma-unroll-threshold=1000000, see the Makefile); a scheduling barrier per k-step keeps the compiler's
+//     interleave local (MFMAs + fragment reads + the k-step's share of the staging and epilogue units);
+//   * the folded 1x1 skip (Conv_2 on the raw block input) is NSK extra chunks that use only the centre tap; a residual
+//     rides through the same path as a skip with identity weights (a residual LOAD between the epilogue's stores would
+//     wait for every earlier store: vmcnt retires in order);
+//   * each phase runs in two halves of the wave's rows: the epilogue of one half (bias + temb bias, 1/sqrt(2),
+//     statistics for the next GroupNorm, packing, v_permlane32_swap / v_permlane16_swap into 64-byte row pieces,
+//     buffer_store_b128 — all in the accumulator layout, no LDS) runs under the MFMAs of the other half.
 //
-// K order (chunk, tap, 16-channel block) is the same as in conv_mfma.hip / conv3x3_ws.hip.
+// What bounds it: the issue slots of the single in-order wave (<= 5 instructions fit under a
+// 32-cycle MFMA, the GroupNorm variant has ~9).  K order (chunk, tap, 16-channel block) as in conv_mfma.hip / conv3x3_ws.hip.
 #include <stdlib.h>
 
 #include <type_traits>

@@ -17,7 +17,12 @@
  *   - waveforms are float32 [B, S, T] / [B, 1, T] contiguous, exactly as the reference passes them;
  *   - image-like activations at the unit-op level are NHWC ("pixel-major") with an explicit pixel
  *     stride `ld` (elements): element (b,h,w,c) lives at ((b*H + h)*W + w)*ld + c.  dtype is
- *     DIFFSEP_F32 or DIFFSEP_BF16 (raw bfloat16 bits), C and ld multiples of 8;
+ *     DIFFSEP_F32 or DIFFSEP_BF16 (16-bit storage), C and ld multiples of 8;
+ *   - the library is built twice from the same sources and exports this same interface both times:
+ *     libdiffsep_hip.so stores the 16-bit tensors (code DIFFSEP_BF16) as raw bfloat16 bits,
+ *     libdiffsep_hip_f16.so (-DDS_HALF_F16) as IEEE half precision: the same kernels and speed with 11
+ *     instead of 8 significand bits (one score evaluation 2.4e-3 instead of 2.5e-2 from fp32).
+ *     diffsep_version() names the build.  Handles and 16-bit buffers of one build mean nothing to the other;
  *   - an engine handle is bound to the device that was current at creation, owns the repacked
  *     weights + workspace, and is not thread-safe (the reference is one Python thread per process
  *     per GPU: evaluate_mp.py:339,510-513).  The parameter-table queries (diffsep_param_count / _info /
@@ -69,7 +74,7 @@ typedef struct {
   int32_t hop;              /* 128 */
   float spec_abs_exponent;  /* 0.5 */
   float spec_factor;        /* 0.33 (0.15 published) */
-  int32_t dtype;            /* DIFFSEP_F32 (exact), DIFFSEP_F32_SPLIT (parity-grade, 2x faster) or DIFFSEP_BF16 (throughput) */
+  int32_t dtype;            /* DIFFSEP_F32 (exact), DIFFSEP_F32_SPLIT (parity-grade, 2x faster) or DIFFSEP_BF16 (16-bit storage: throughput) */
 } diffsep_model_config;
 
 /* sdes/sdes.py:217-240 (MixSDE ctor), :397-450 (PriorMixSDE ctor). */
