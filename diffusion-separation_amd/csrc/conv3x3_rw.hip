@@ -249,14 +249,17 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   // geometry of the tile a chunk belongs to (wave-uniform): first pixel, border mask (which halo lines lie outside
   // the image); tiles past the block's range get a pixel index beyond every tensor (the hardware returns zeros)
   struct TileG { int pix0; unsigned edge; };
-  auto tile_geom = [&](int i) {
+  auto geom_at = [&](int ty, int tx, bool valid) {
     TileG g;
-    const int t = t0 + i;
-    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
     const int y0 = ty * TH, x0 = tx * TW;
     g.edge = (y0 == 0 ? 1u : 0u) | (y0 + TH == p.H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + TW == p.W ? 8u : 0u);
-    g.pix0 = i < nt ? y0 * p.W + x0 : 0x3fffff;
+    g.pix0 = valid ? y0 * p.W + x0 : 0x3fffff;
     return g;
+  };
+  auto tile_geom = [&](int i) {
+    const int t = t0 + i;
+    const int ty = t / p.tiles_x;
+    return geom_at(ty, t - ty * p.tiles_x, i < nt);
   };
   // piece k of a chunk of type P is valid (inside the image / an interior pixel for the skip chunks)
   auto piece_ok = [&](auto P_, const TileG& g, int k) __attribute__((always_inline)) {
@@ -318,10 +321,23 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
         // silu(GN(x)) / -ln 2; the epilogue multiplies the accumulators back (exact in fp32, one multiply per element less)
         const float e0 = __builtin_amdgcn_exp2f(FOLD ? z0 : z0 * -1.4426950408889634f);
         const float e1 = __builtin_amdgcn_exp2f(FOLD ? z1 : z1 * -1.4426950408889634f);
+#ifdef DS_HALF_F16
+        // z * sigmoid straight into the two halves of the staged dword (v_fma_mixlo / mixhi: fp32 operands, one rounding to
+        // fp16): one instruction per dword less than multiply, multiply, v_cvt_pk
+        const float r0 = __builtin_amdgcn_rcpf(1.0f + e0), r1 = __builtin_amdgcn_rcpf(1.0f + e1);
+        unsigned pk;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(pk) : "v"(z0), "v"(r0));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(pk) : "v"(z1), "v"(r1));
+        so[d] = pk;
+      } else {
+        so[d] = pack_h2(z0, z1);
+      }
+#else
         z0 *= __builtin_amdgcn_rcpf(1.0f + e0);
         z1 *= __builtin_amdgcn_rcpf(1.0f + e1);
       }
       so[d] = pack_h2(z0, z1);
+#endif
     } else {
       so[d] = w;
     }
@@ -576,8 +592,12 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   RT_MARK(0)
   TileG gp = tile_geom(nt);  // "previous tile" of the first one: no tile (its stores fall outside every tensor)
   int ph = 0;                 // phases done: the chunk of phase ph sits in ring slot ph & 1
+  // tile i + 2 by increments (a division per tile and geometry is ~45 scalar instructions in a stream whose issue slots
+  // are the bottleneck)
+  TileG gnc = tile_geom(1);
+  int ty2 = (t0 + 2) / p.tiles_x, tx2 = (t0 + 2) - ty2 * p.tiles_x;
   for (int i = 0; i < nt; ++i) {
-    const TileG gn = tile_geom(i + 1), gnn = tile_geom(i + 2);
+    const TileG gn = gnc, gnn = geom_at(ty2, tx2, i + 2 < nt);
     // phase P stages the chunk of phase P + 1 and issues that of phase P + 2: both belong to the next tile once they wrap
     auto run = [&](auto self, auto P_) __attribute__((always_inline)) {
       constexpr int P = decltype(P_)::value;
@@ -604,6 +624,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     run(run, std::integral_constant<int, 0>{});
     gp = gc;
     gc = gn;
+    gnc = gnn;
+    if (++tx2 == p.tiles_x) { tx2 = 0; ++ty2; }
   }
   // the second half of the last tile's rows
 #ifndef RW_BUILTIN_MFMA

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "diffusion-separation_amd"))
 from diffsep_amd import ops  # noqa: E402
 
-DT = torch.bfloat16
+DT = torch.float16 if os.environ.get("RW_DT") == "f16" else torch.bfloat16  # (RW_DT=f16: the half-precision build)
 CASES = [  # (name, C1, C2, H, W, mode)   mode: conv0 = GN+SiLU, bias, temb, stats; conv1res = + residual, 1/sqrt(2); plain
     ("64->64 conv0", 64, 0, 256, 256, "conv0"), ("64->64 conv1+res", 64, 0, 256, 256, "res"), ("64->64 plain", 64, 0, 256, 256, "plain"),
     ("cat(64,64)->64 conv0", 64, 64, 256, 256, "conv0"), ("cat(64,64)->64 plain", 64, 64, 256, 256, "plain"),
