@@ -321,23 +321,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
         // silu(GN(x)) / -ln 2; the epilogue multiplies the accumulators back (exact in fp32, one multiply per element less)
         const float e0 = __builtin_amdgcn_exp2f(FOLD ? z0 : z0 * -1.4426950408889634f);
         const float e1 = __builtin_amdgcn_exp2f(FOLD ? z1 : z1 * -1.4426950408889634f);
-#ifdef DS_HALF_F16
-        // z * sigmoid straight into the two halves of the staged dword (v_fma_mixlo / mixhi: fp32 operands, one rounding to
-        // fp16): one instruction per dword less than multiply, multiply, v_cvt_pk
-        const float r0 = __builtin_amdgcn_rcpf(1.0f + e0), r1 = __builtin_amdgcn_rcpf(1.0f + e1);
-        unsigned pk;
-        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(pk) : "v"(z0), "v"(r0));
-        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(pk) : "v"(z1), "v"(r1));
-        so[d] = pk;
-      } else {
-        so[d] = pack_h2(z0, z1);
-      }
-#else
         z0 *= __builtin_amdgcn_rcpf(1.0f + e0);
         z1 *= __builtin_amdgcn_rcpf(1.0f + e1);
       }
       so[d] = pack_h2(z0, z1);
-#endif
     } else {
       so[d] = w;
     }
