@@ -103,7 +103,10 @@ struct RwK {
 // 128-channel layers and the 128-channel skip — what the 512-entry register file does not hold beside the accumulators
 // With 4 cout groups (128 couts, 128 input channels) a wave holds 72 fragments of the 3x3 weights: 64 fill the 256
 // accumulator registers, the last 8 and every skip fragment live in LDS
-constexpr int rw_lds_ksteps(int nch, int rpw, int nsk, int ncg) { return ncg == 4 ? nch * KSC - 64 + nsk * NKB : (nch == 2 ? 18 : 0); }
+#ifndef RW_NWL2
+#define RW_NWL2 8  // (64 fragments fill the 256 accumulator registers; tools/rw_ab.sh "-DRW_NWL2=18" "" for the A/B)
+#endif
+constexpr int rw_lds_ksteps(int nch, int rpw, int nsk, int ncg) { return ncg == 4 ? nch * KSC - 64 + nsk * NKB : (nch == 2 ? RW_NWL2 : 0); }
 
 // NCG: cout groups of 32 (2: 64 couts, the block's 4 waves = 2 cout groups x 2 pixel groups; 4: 128 couts, 4 cout
 // groups on ONE pixel group — the same staging and epilogue work per wave for twice the MFMAs)
