@@ -720,6 +720,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin_out_kernel(ThinOutK p) {
   const int nsteps = nt * npass;
   if (nsteps > 0) issue(0);
   f32x4 acc[2];
+  uint2 rvq[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
   for (int s_ = 0; s_ < nsteps; ++s_) {
     const int i = s_ / npass, ps = s_ - i * npass;
     const int t = t0 + i;
@@ -786,6 +787,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin_out_kernel(ThinOutK p) {
         }
       }
       __syncthreads();
+      // the residual of this tile's outputs goes out BEFORE the next step's loads (loads return in order: the epilogue
+      // then waits for these two only) and lands during the MFMAs instead of in front of the stores
+      if (ps == npass - 1 && q < 2) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int m = (ty * TH + wave) * p.W + tx * TW + 16 * g + l16;
+          rvq[g] = ld8(rr, (unsigned)((m * p.ldr + 4 * q) * 2));
+        }
+      }
       if (s_ + 1 < nsteps) issue(s_ + 1);
       // ---- wave = pixel row `wave` of the tile: two 16-pixel groups x 16 (8 real) couts
 #pragma unroll
@@ -807,7 +817,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin_out_kernel(ThinOutK p) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const int m = (ty * TH + wave) * p.W + tx * TW + 16 * g + l16;
-        const uint2 rv = ld8(rr, (unsigned)((m * p.ldr + 4 * q) * 2));
+        const uint2 rv = rvq[g];
         float v[4];
         v[0] = acc[g][0] + bz[0] + h_lo(rv.x);
         v[1] = acc[g][1] + bz[1] + h_hi(rv.x);

@@ -116,6 +116,25 @@ def test_configs4_score_evaluation_long_utterance_vs_oracle():
     assert rel_rms(out, ref) < 1e-4
 
 
+@pytest.mark.parametrize("dtype,tol", [(_lib.F16, 5e-3), (_lib.BF16, 4e-2)])
+def test_nf64_long_utterances_score_vs_oracle(dtype, tol):
+    # the 16-bit engines at nf = 64 on 12.5 s utterances (W = 832: 26 tile columns of the register-weight kernel, 6656
+    # tiles per image at 256 rows), B = 3 so that a block's tile range straddles image rows: against the CPU oracle
+    cfg = O.default_config(64, 2)
+    eng, sd = engine(64, 2, dtype)
+    T, B = 100000, 3
+    mix = torch.from_numpy(synth.synth_batch(B, T=T)[0])
+    mixn, _, _ = O.normalize_batch(mix)
+    xt = O.prior_sampling(cfg, mixn, rnd("l64.z", (B, 2, T)))
+    t = torch.tensor([0.8, 0.4, 0.05])
+    ref = O.score_forward(O.to_torch(sd), cfg, xt, t, mixn)
+    out = eng.score(xt.to(DEV), t.to(DEV), mixn.to(DEV))
+    for b in range(B):
+        r = rel_rms(out[b], ref[b])
+        print(f"\n[nf64 T=100000 dtype {dtype} utterance {b}] rel rms vs oracle {r:.3e}")
+        assert r < tol
+
+
 # ------------------------------------------------------------------------------------------------ configs[3]
 def test_configs3_enhancement_16khz_ten_seconds_nf128():
     cfg = O.default_config(128, 2, spec_factor=0.15)
