@@ -1,4 +1,5 @@
 cd /root/repo
-python -m pytest tests/test_kernels_gpu.py -x -q -k "pyramid" 2>&1 | tail -2
-python -m pytest tests/test_fullsize_gpu.py -x -q -s -k "long_utterances" 2>&1 | grep -a "^\[nf64\|passed\|failed"
-python tools/shape_table.py 64 f16 2>/dev/null | grep "thin_out\|total"
+for i in 1 2; do
+python bench.py --no-cpu-baseline --no-extra-modes --no-roofline 2>/dev/null | python -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print('folded ', d['value'], d['one_batch_alone_ms'])"
+DIFFSEP_GN_ARRAYS=1 python bench.py --no-cpu-baseline --no-extra-modes --no-roofline 2>/dev/null | python -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print('arrays ', d['value'], d['one_batch_alone_ms'])"
+done
