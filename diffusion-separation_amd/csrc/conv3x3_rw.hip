@@ -721,6 +721,9 @@ bool ds_conv_rw_eligible(const ConvArgs& a) {
   if (a.res && a.Cin == 128 && CO == 64) return false;  // (the residual rides as a skip: same limit)
   if (CO == 128) {  // 4 cout groups: the skip / residual fragments live in LDS; every such layer normalises its input
     if ((a.sx || a.res) && !gn) return false;
+    // fewer 4 x 32 tiles than CUs (the 32^2 level at B = 16): a block's 295 KB weight prologue serves one tile and half
+    // the chip idles — the generic tile is as fast there (22.6 vs 23.6 us) and leaves room for the other streams' blocks
+    if ((long)a.B * (a.H / 4) * (a.W / TW) < 256 && !getenv("DIFFSEP_RW_SMALL")) return false;
     return true;
   }
   // measured (tools/rw_bench.py): with a residual the two short identity-skip phases cost more than they save against
