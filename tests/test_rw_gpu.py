@@ -18,11 +18,11 @@ torch.set_grad_enabled(False)
 
 @pytest.fixture(autouse=True, scope="module")
 def _every_eligible_launch_on_the_rw_kernel():
-    """The dispatch keeps residual launches and small 64-channel images on the weight-stationary kernel (faster there);
-    this module tests the register-weight kernel on them too."""
+    """The dispatch keeps small images (64-channel launches at <= 128^2, 128-cout launches with fewer tiles than CUs) on
+    the weight-stationary / generic kernels (faster there); this module tests the register-weight kernel on them too."""
     import os
-    old = {k: os.environ.get(k) for k in ("DIFFSEP_RW_RES", "DIFFSEP_RW_SMALL")}
-    os.environ.update(DIFFSEP_RW_RES="1", DIFFSEP_RW_SMALL="1")
+    old = {k: os.environ.get(k) for k in ("DIFFSEP_RW_SMALL",)}
+    os.environ.update(DIFFSEP_RW_SMALL="1")
     yield
     for k, v in old.items():
         if v is None:

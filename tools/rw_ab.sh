@@ -8,6 +8,6 @@ for v in "$1" "$2"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../abl/lib_rwa.so /tmp/rw_a.o build/conv_mfma.o build/conv3x3_ws.o build/conv3x3_small.o build/norm.o build/stft.o build/sde.o build/engine.o
   for rep in 1 2; do
     echo "== variant: ${v:-shipped} (run $rep)"
-    (cd ../.. && DIFFSEP_RW_RES=1 DIFFSEP_LIB=$PWD/diffusion-separation_amd/abl/lib_rwa.so python tools/rw_bench.py 10 "$3" 2>&1 | grep -v amdgpu)
+    (cd ../.. && DIFFSEP_LIB=$PWD/diffusion-separation_amd/abl/lib_rwa.so python tools/rw_bench.py 10 "$3" 2>&1 | grep -v amdgpu)
   done
 done
