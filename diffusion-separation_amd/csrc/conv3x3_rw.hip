@@ -729,10 +729,11 @@ bool ds_conv_rw_eligible(const ConvArgs& a) {
   // a residual rides as an identity-weight skip chunk: 138 us at 256^2 against 159 us on the weight-stationary kernel
   // (+1 % end to end; DIFFSEP_NO_RW_RES=1 for the A/B)
   if (a.res && getenv("DIFFSEP_NO_RW_RES")) return false;
-  // measured (tools/shape_table.py, B = 16): on 128 x 128 images the 64-channel launches without a 128-channel skip are
-  // 10 % faster on the weight-stationary kernel (41.3 vs 37 us, 45.1 vs 41.8 us): too few tiles per block to pay for the
-  // weight prologue
-  if (a.Cin == 64 && a.sCin != 128 && (long)a.H * a.W <= 128 * 128 && !getenv("DIFFSEP_RW_SMALL")) return false;
+  // fewer 8 x 32 tiles than CUs: a block's weight prologue would serve a single tile and part of the chip idles — those
+  // launches stay on the weight-stationary / generic kernels.  (Round 3 first kept every 64-channel launch at <= 128^2
+  // there: 41.3 vs 37 us; with the tile geometry by increments the register-weight kernel is the faster one at 128^2 too —
+  // Conv_0 41.8 vs 46.5 us, + residual 45.0 vs 48.2, + skip64 46.1 vs 52.0, raw 35.1 vs 42.3; +1 % end to end.)
+  if ((long)a.B * (a.H / 8) * (a.W / TW) < 256 && !getenv("DIFFSEP_RW_SMALL")) return false;
   return true;
 }
 
