@@ -657,7 +657,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   RT_FLUSH
 }
 
-int rw_blocks_per_image(const ConvArgs& a, int tiles) {
+int rw_num_cus() {
   static int cus = 0;
   if (!cus) {
     int dev = 0;
@@ -666,6 +666,11 @@ int rw_blocks_per_image(const ConvArgs& a, int tiles) {
       cus = prop.multiProcessorCount;
     if (cus <= 0) cus = 256;
   }
+  return cus;
+}
+
+int rw_blocks_per_image(const ConvArgs& a, int tiles) {
+  const int cus = rw_num_cus();
   int g = cus / a.B;
 #ifdef RW_TIMING  // (experiments: fewer, fatter blocks)
   if (getenv("DIFFSEP_RW_G")) g = atoi(getenv("DIFFSEP_RW_G"));
@@ -723,7 +728,7 @@ bool ds_conv_rw_eligible(const ConvArgs& a) {
     if ((a.sx || a.res) && !gn) return false;
     // fewer 4 x 32 tiles than CUs (the 32^2 level at B = 16): a block's 295 KB weight prologue serves one tile and half
     // the chip idles — the generic tile is as fast there (22.6 vs 23.6 us) and leaves room for the other streams' blocks
-    if ((long)a.B * (a.H / 4) * (a.W / TW) < 256 && !getenv("DIFFSEP_RW_SMALL")) return false;
+    if ((long)a.B * (a.H / 4) * (a.W / TW) < rw_num_cus() && !getenv("DIFFSEP_RW_SMALL")) return false;
     return true;
   }
   // a residual rides as an identity-weight skip chunk: 138 us at 256^2 against 159 us on the weight-stationary kernel
@@ -733,7 +738,7 @@ bool ds_conv_rw_eligible(const ConvArgs& a) {
   // launches stay on the weight-stationary / generic kernels.  (Round 3 first kept every 64-channel launch at <= 128^2
   // there: 41.3 vs 37 us; with the tile geometry by increments the register-weight kernel is the faster one at 128^2 too —
   // Conv_0 41.8 vs 46.5 us, + residual 45.0 vs 48.2, + skip64 46.1 vs 52.0, raw 35.1 vs 42.3; +1 % end to end.)
-  if ((long)a.B * (a.H / 8) * (a.W / TW) < 256 && !getenv("DIFFSEP_RW_SMALL")) return false;
+  if ((long)a.B * (a.H / 8) * (a.W / TW) < rw_num_cus() && !getenv("DIFFSEP_RW_SMALL")) return false;
   return true;
 }
 
