@@ -1,5 +1,5 @@
 cd /root/repo
-export COMMIT=58ee7a9
+export COMMIT=886bf21
 timeout 900 bash tools/pmc_r03.sh gpurun_out/pmc_r03 f16 > gpurun_out/pmc_r03.log 2>&1
 timeout 900 bash tools/pmc_traffic.sh gpurun_out/pmc_traffic f16 > gpurun_out/pmc_traffic.log 2>&1
 cp gpurun_out/pmc_traffic/pmc_conv3x3.json profiles/pmc_conv3x3.json
