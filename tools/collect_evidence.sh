@@ -1,3 +1,7 @@
+#!/bin/bash
+# Everything under profiles/r03_* in one GPU call: PMC passes, per-shape tables, the full bench line, the rocprofv3 kernel
+# trace of the bench command.  Run via gpurun from the repo root, then copy gpurun_out/{pmc_*,r03_*} into profiles/
+# (tools/kernel_stats_md.py turns r03_kernel_stats.csv into the markdown table).
 cd /root/repo
 export COMMIT=886bf21
 timeout 900 bash tools/pmc_r03.sh gpurun_out/pmc_r03 f16 > gpurun_out/pmc_r03.log 2>&1
