@@ -522,7 +522,7 @@ def main():
         hyb = None
         if args.dtype == "f16":
             from diffsep_amd.pl_model import HYBRID_HEAD_STEPS
-            ehd = [Engine(_lib.model_config(nf=args.nf, num_sources=S, dtype=_lib.F32_SPLIT), blob, lib_kind="f16") for _ in range(K2)]
+            ehd = [Engine(_lib.model_config(nf=args.nf, num_sources=S, dtype=_lib.F32_SPLIT), blob, lib_kind="f16") for _ in range(K)]
 
             def run_h(i, w):
                 with on_stream(w):
@@ -531,14 +531,14 @@ def main():
                                                denoise=True, seed=2000 + i, tail=ehd[w], head_steps=HYBRID_HEAD_STEPS)
                     out = ops.scale_output(mix, sep)
                 keep[w] = (mn, sep, out)
-            for w in range(K2):
+            for w in range(K):
                 run_h(w, w); run_h(w, w)
             sync()
             t4 = time.perf_counter()
-            for i in range(6):
-                run_h(i, i % K2)
+            for i in range(args.steps):
+                run_h(i, i % K)
             sync()
-            ups["hybrid"] = B * 6 / (time.perf_counter() - t4)
+            ups["hybrid"] = B * args.steps / (time.perf_counter() - t4)
             oh = ops.scale_output(mix, engs[0].pc_sample(mix_norm0, sde, tail=ehd[0], head_steps=HYBRID_HEAD_STEPS, **kw)[0])
             q["hybrid"] = si_sdr_db(oh, o32)
             rel["hybrid"] = float(((oh - o32).double().pow(2).mean() / o32.double().pow(2).mean()).sqrt())
@@ -557,8 +557,8 @@ def main():
                                   % (float(o32.double().pow(2).mean().sqrt()), B, nfe),
                           args.dtype: quality(args.dtype), other: quality(other), "split": quality("split"),
                           **({"hybrid": quality("hybrid")} if hyb else {})},
-            **({"hybrid_mode": {"utt_per_s": round(ups["hybrid"], 3), "batches_in_flight": K2,
-                                "note": "split engine for the first 10 reverse steps, f16 engine after (pl_model dtype='hybrid')"}}
+            **({"hybrid_mode": {"utt_per_s": round(ups["hybrid"], 3), "batches_in_flight": K, "head_steps": HYBRID_HEAD_STEPS,
+                                "note": "split engine for the first head_steps reverse steps, f16 engine after (pl_model dtype='hybrid')"}}
                if hyb else {}),
             other + "_mode": {"utt_per_s": round(ups[other], 3), "batches_in_flight": K,
                               "note": "the same kernels on the other 16-bit storage format (bf16: libdiffsep_hip.so, f16: "

@@ -67,13 +67,17 @@ def default_config(nf=64, n_speakers=2, fs=8000, spec_factor=0.33):
 # dtype="split": fp32 tensors, every matrix product as three bf16 MFMAs on the hi / lo bf16 halves of both operands
 # (DIFFSEP_F32_SPLIT): 4e-5 relative RMS / >= 79 dB from the exact fp32 engine after 60 NFE at 1.9x its speed
 # (tools/probes/split_probe.py) — the fast mode that meets the parity bar.
-# dtype="hybrid": such a split-fp32 engine evaluates the score of the FIRST HYBRID_HEAD_STEPS reverse steps, a 16-bit
-# engine the rest (f16 storage since round 3: at nf = 128, N = 30, 62.5 dB from the fp32 result where f16 alone has 36.0 dB
-# and the bf16 hybrid of round 2 43.9 dB, tests/test_fullsize_gpu.py).  Measured on bf16 (tools/hybrid_probe.py, DESIGN.md
-# section 2): a score error enters the state scaled by the step size G(t)^2, which is ~100x larger at t = 1 than at t = 0.03, so the bf16 rounding of the EARLY steps is what separates the
-# bf16 trajectory from the fp32 one (fp32 for the last 5 / 15 / 25 steps: 31.1 / 31.2 / 31.8 dB agreement, i.e. nothing;
-# fp32 for the first 5 / 10 / 15: 42 / 46 / 49 dB).  10 steps = >= 42 dB on every utterance measured.
-HYBRID_HEAD_STEPS = 10
+# dtype="hybrid": such a split-fp32 engine evaluates the score of the FIRST HYBRID_HEAD_STEPS reverse steps, the f16 engine
+# the rest.  A score error enters the state scaled by the step size G(t)^2, which is ~100x larger at t = 1 than at
+# t = 0.03, so the rounding of the EARLY steps is what separates a 16-bit trajectory from the fp32 one (measured on bf16 in
+# round 2, tools/hybrid_probe.py: fp32 for the LAST 5 / 15 / 25 steps buys nothing, for the FIRST 5 / 10 / 15 it buys 9 / 14 /
+# 17 dB).  With the f16 engine (tools/probes/hybrid_f16_probe.py; SI-SDR against the exact fp32 engine, mean / min dB at
+# nf = 64 | nf = 128; time of one batch relative to f16 alone):
+#   K = 0:  51.1 / 44.4 | 38.9 / 32.7   1.00        K = 5:  60.1 / 56.3 | 56.9 / 55.1   1.23
+#   K = 2:  55.9 / 51.8 | 50.9 / 47.2   1.09        K = 7:  61.9 / 58.9 | 59.9 / 58.5   1.32
+#   K = 3:  57.5 / 54.6 | 53.3 / 49.7   1.14        K = 10: 63.9 / 60.8 | 62.6 / 61.3   1.46
+# K = 5 is the first value with >= 55 dB on every utterance at both widths.
+HYBRID_HEAD_STEPS = 5
 
 
 class DiffSepModel:

@@ -193,6 +193,9 @@ def test_nf128_sampler_precision_gates_vs_fp32_engine():
     engs16, _ = engine(128, 2, _lib.F32_SPLIT, spec_factor=0.15, lib_kind="f16")
     sep, _ = engh.pc_sample(mn, SDE2, tail=engs16, head_steps=10, **kw)
     got["hybrid_f16"] = si_sdr(sep, ref)
+    from diffsep_amd.pl_model import HYBRID_HEAD_STEPS
+    sep, _ = engh.pc_sample(mn, SDE2, tail=engs16, head_steps=HYBRID_HEAD_STEPS, **kw)
+    got["hybrid_default"] = si_sdr(sep, ref)
     sep, _ = engs.pc_sample(mn, SDE2, **kw)
     got["split"] = si_sdr(sep, ref)
     for k, s in got.items():
@@ -203,6 +206,7 @@ def test_nf128_sampler_precision_gates_vs_fp32_engine():
     assert float(got["bf16"].mean()) > 13.0 and float(got["bf16"].min()) > 11.0  # (16.6 - 19.4 / 14.3 - 17.9 dB depending on which kernels run: not a usable mode at this width)
     assert float(got["hybrid"].mean()) > 40.0 and float(got["hybrid"].min()) > 39.0
     assert float(got["hybrid_f16"].mean()) > 56.0 and float(got["hybrid_f16"].min()) > 55.0
+    assert float(got["hybrid_default"].min()) > 50.0  # (dtype="hybrid" as shipped: pl_model.HYBRID_HEAD_STEPS, measured 55 - 57)
     assert float(got["split"].min()) > 60.0
 
 

@@ -411,13 +411,12 @@ def test_hybrid_schedule_head_on_fp32_engine():
     assert torch.equal(eb.pc_sample(mixn, SDE, tail=ef, head_steps=0, tail_steps=0, **kw)[0], b16)
     assert torch.equal(eb.pc_sample(mixn, SDE, tail=ef, head_steps=N, **kw)[0], f32)
     assert torch.equal(eb.pc_sample(mixn, SDE, tail=ef, tail_steps=N, **kw)[0], f32)
-    from diffsep_amd.pl_model import HYBRID_HEAD_STEPS
     res = {}
-    for H, K in ((0, 0), (0, 10), (5, 0), (HYBRID_HEAD_STEPS, 0)):
+    for H, K in ((0, 0), (0, 10), (5, 0), (10, 0)):
         out, _ = eb.pc_sample(mixn, SDE, tail=ef, head_steps=H, tail_steps=K, **kw)
         res[(H, K)] = float(si_sdr(out, f32).min())
     print(f"\n[hybrid] min SI-SDR(out, fp32 out) in dB by (fp32 head steps, fp32 tail steps): {res}")
-    assert res[(HYBRID_HEAD_STEPS, 0)] > 40.0 and res[(HYBRID_HEAD_STEPS, 0)] > res[(0, 0)] + 8.0
+    assert res[(10, 0)] > 40.0 and res[(10, 0)] > res[(0, 0)] + 8.0 and res[(5, 0)] > res[(0, 0)] + 4.0
     assert res[(0, 10)] < res[(0, 0)] + 3.0   # the tail is not where the precision goes
     with pytest.raises(_lib.DiffsepError):
         eb.pc_sample(mixn, SDE, tail=eb, head_steps=2, **kw)
