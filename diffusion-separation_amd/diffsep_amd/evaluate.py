@@ -102,8 +102,8 @@ def main(argv=None):
     ap.add_argument("--snr", type=float, default=None)
     ap.add_argument("--corrector-steps", type=int, default=None)
     ap.add_argument("--schedule", type=str, default=None)
-    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32", "split", "hybrid"],
-                    help="f16 (default): 16-bit tensors in IEEE half precision, 50 dB from the fp32 result after 60 network "
+    ap.add_argument("--dtype", default="auto", choices=["auto", "f16", "bf16", "f32", "split", "hybrid"],
+                    help="auto (default): f16 for backbones up to nf = 64, hybrid for wider ones; f16: 16-bit tensors in IEEE half precision, 50 dB from the fp32 result after 60 network "
                          "evaluations; bf16: the same kernels on bfloat16 tensors (32 dB); split / f32: fp32 tensors (bf16x3 / "
                          "exact fp32 matrix products); hybrid: f16 with the first reverse steps on a split engine")
     ap.add_argument("-o", "--output-dir", type=Path, default=Path("results"))
@@ -253,7 +253,7 @@ def main(argv=None):
         summary = datasets.summarize([{k: v for k, v in r.items() if k not in ("batch_idx", "perm")} for r in flat])
         tot_rt = sum(r["runtime"] for r in flat)
         summary.update({"rtf": tot_rt / max(sum(r["len_s"] for r in flat), 1e-9), "world_size": world,
-                        "streams": K, "batch": args.batch, "engine_calls_rank0": len(batches), "dtype": args.dtype,
+                        "streams": K, "batch": args.batch, "engine_calls_rank0": len(batches), "dtype": model.dtype,
                         "utt_per_s_rank0": len(mine) / max(wall, 1e-9),
                         # metrics this build does not compute (third-party C code, out of scope: DESIGN.md section 7)
                         "not_computed": ["pesq", "stoi"]})

@@ -81,14 +81,18 @@ HYBRID_HEAD_STEPS = 5
 
 
 class DiffSepModel:
-    def __init__(self, config, dtype="f16", device=None, init_seed=0, head_steps=None):
-        """dtype: "f16" (default: 16-bit tensors in IEEE half precision — the half-precision build of the library — 50 dB
+    def __init__(self, config, dtype="auto", device=None, init_seed=0, head_steps=None):
+        """dtype: "auto" (default) = "f16" for backbones up to nf = 64 and "hybrid" for wider ones — the rounding of a
+        16-bit engine grows with the width (f16 alone: 50 dB from the fp32 result at nf = 64, 36 - 39 dB at the published
+        nf = 128; hybrid: 60 / 57 dB at 1.23x the time); "f16" ( 16-bit tensors in IEEE half precision — the half-precision build of the library — 50 dB
         mean / 46 dB min from the fp32 result after 60 network evaluations, inside the 1e-3 RMS parity bar, at the speed of
         "bf16"), "bf16" (the same kernels on bfloat16 tensors: 32 dB / 25 dB), "f32" (exact fp32 MFMAs: parity with the
         reference to 1e-7), "split" (fp32 tensors, bf16x3 matrix products: parity to 4e-5 at twice the speed of "f32") or
         "hybrid": a "split" engine for the first head_steps reverse steps, f16 for the rest (extensions: the reference has
         one precision)."""
         self.config = config
+        if dtype == "auto":
+            dtype = "f16" if int(cfg_get(config, "model.score_model.backbone_args.nf", 128)) <= 64 else "hybrid"
         sm = dict(cfg_get(config, "model.score_model"))
         sm.pop("_target_", None)
         sm["stft_args"] = dict(sm["stft_args"])
@@ -115,7 +119,7 @@ class DiffSepModel:
 
     # ---- checkpoint ----------------------------------------------------------------------
     @classmethod
-    def load_from_checkpoint(cls, path, dtype="f16", device=None, use_ema=True, head_steps=None):
+    def load_from_checkpoint(cls, path, dtype="auto", device=None, use_ema=True, head_steps=None):
         """Lightning .ckpt / HF checkpoint.pt: {'state_dict', 'hyper_parameters': {'config'}, 'ema'}
         (pl_model.py:100,642-673).  Inference runs on the EMA shadow weights (pl_model.py:655-660)."""
         ckpt = torch.load(str(path), map_location="cpu", weights_only=False)

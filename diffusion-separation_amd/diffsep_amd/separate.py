@@ -94,8 +94,8 @@ def main(argv=None):
     ap.add_argument("--denoise", type=bool, default=True)
     ap.add_argument("-s", "--schedule", type=str, default=None)
     ap.add_argument("--synthetic-weights", type=int, default=0, metavar="NF")
-    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32", "split", "hybrid"],
-                    help="f16 (default): 16-bit tensors in IEEE half precision, 50 dB from the fp32 result after 60 network "
+    ap.add_argument("--dtype", default="auto", choices=["auto", "f16", "bf16", "f32", "split", "hybrid"],
+                    help="auto (default): f16 for backbones up to nf = 64, hybrid for wider ones; f16: 16-bit tensors in IEEE half precision, 50 dB from the fp32 result after 60 network "
                          "evaluations; bf16: the same kernels on bfloat16 tensors (32 dB); split / f32: fp32 tensors (bf16x3 / "
                          "exact fp32 matrix products); hybrid: f16 with the first reverse steps on a split engine")
     ap.add_argument("--fp32-steps", type=int, default=None, help="--dtype hybrid: the first K reverse steps run on the fp32 engine")

@@ -51,8 +51,9 @@ class _ScoreModel:
 class _Model:
     calls = []  # (batch size, padded length) of every sampler call of this rank
 
-    def __init__(self, *a, **k):
+    def __init__(self, *a, dtype="auto", **k):
         self.config = default_config(nf=16)
+        self.dtype = "f16" if dtype == "auto" else dtype
         self.score_model = _ScoreModel()
 
     def tail_engine(self):

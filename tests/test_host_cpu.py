@@ -302,6 +302,20 @@ def test_evaluate_cli_two_ranks_balanced_gloo(tmp_path):
     assert c2 != c3
 
 
+def test_model_dtype_auto_picks_by_width():
+    # dtype="auto" (the default of DiffSepModel and of both CLIs): f16 up to nf = 64, hybrid (split head + f16) for wider
+    # backbones, whose 16-bit rounding costs more agreement with fp32 (tests/test_fullsize_gpu.py)
+    from diffsep_amd.pl_model import DiffSepModel, default_config, enhancement_config, HYBRID_HEAD_STEPS
+    m = DiffSepModel(default_config(nf=16))
+    assert m.dtype == "f16" and m.tail_model is None
+    m = DiffSepModel(default_config(nf=64), dtype="auto")
+    assert m.dtype == "f16"
+    m = DiffSepModel(enhancement_config(nf=128))
+    assert m.dtype == "hybrid" and m.tail_model is not None and m.head_steps == HYBRID_HEAD_STEPS
+    assert m.tail_model.lib_kind == "f16" and m.score_model.cfg.dtype != m.tail_model.cfg.dtype
+    assert DiffSepModel(default_config(nf=128), dtype="f16").dtype == "f16"
+
+
 def test_plan_batches_buckets_by_padded_width():
     from diffsep_amd.evaluate import plan_batches
     width = lambda T: 64 * ((1 + (T + 382) // 128 + 63) // 64)
