@@ -181,23 +181,39 @@ def main(argv=None):
     records = []
     pending = [None] * K  # per worker: the batch whose sampler is running on its stream
 
-    def stage(group, w):
-        """load, pad, upload and normalise one batch on worker w's stream -> (mix, mix_n, tgt_n, lens)"""
+    def host_stage(group):
+        """load and pad one batch on the host (runs on a loader thread, ahead of the GPU): pinned mix / tgt + lengths"""
         items = [get(i) for i in group]
         # padded to the longest length of the batch's width bucket: one workspace plan / captured graph per (B, W)
         mix, tgt, lens = datasets.pad_batch(items, side="right",
                                             to=eng0.bucket_length(eng0.padded_frames(max(lengths[i] for i in group))))
         # pinned staging + asynchronous copies: a pageable host->device copy serialises the whole device
-        mix = mix.contiguous().pin_memory().to("cuda", non_blocking=True)
-        tgt = tgt.contiguous().pin_memory().to("cuda", non_blocking=True)
+        return mix.contiguous().pin_memory(), tgt.contiguous().pin_memory(), lens
+
+    # the reference's DataLoader has worker processes; here two loader threads read / synthesise and pad the next batches
+    # while the GPU separates the current ones (wav decoding and numpy release the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+    loader = ThreadPoolExecutor(max_workers=2)
+    ahead = {}
+
+    def prefetch(j):
+        for jj in range(j, min(j + 2 * K + 2, len(batches))):
+            if jj not in ahead:
+                ahead[jj] = loader.submit(host_stage, batches[jj])
+
+    def stage(group, w, j=None):
+        """upload and normalise one batch on worker w's stream -> (mix, mix_n, tgt_n, lens)"""
+        mix, tgt, lens = ahead.pop(j).result() if j in ahead else host_stage(group)
+        mix = mix.to("cuda", non_blocking=True)
+        tgt = tgt.to("cuda", non_blocking=True)
         mix_n, tgt_n = torch.zeros_like(mix), torch.zeros_like(tgt)
         for b, L in enumerate(lens):  # every utterance is normalised over ITS samples (pl_model.py:81-88)
             (m_b, t_b), *_ = models[w].normalize_batch((mix[b:b + 1, :, :L], tgt[b:b + 1, :, :L]))
             mix_n[b, :, :L], tgt_n[b, :, :L] = m_b[0], t_b[0]
         return mix, mix_n, tgt_n, lens
 
-    def launch(group, w):
-        mix, mix_n, tgt_n, lens = stage(group, w)
+    def launch(group, w, j=None):
+        mix, mix_n, tgt_n, lens = stage(group, w, j)
         sampler = models[w].get_pc_sampler("reverse_diffusion", "ald2", mix_n, N=N, corrector_steps=cs, snr=snr,
                                            denoise=True, intermediate=False, schedule=args.schedule,
                                            lengths=lens, seeds=[seeds[i] for i in group])
@@ -235,15 +251,18 @@ def main(argv=None):
     # One host thread drives all K streams (a thread per stream was measured SLOWER: 10.7 instead of 17 utt/s at K = 4;
     # concurrent launches serialise inside the HIP runtime and a launch that waits for queue space holds them all up).
     t_all = time.perf_counter()
+    prefetch(0)
     for j, group in enumerate(batches):
         w = j % K
         finish(w)  # the worker's previous batch (oldest in flight)
+        prefetch(j)
         with torch.cuda.stream(streams[w]):
-            pending[w] = launch(group, w)
+            pending[w] = launch(group, w, j)
     for w in range(K):
         finish(w)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t_all
+    loader.shutdown()
     allrec = gather_objects(records)
     if rank == 0:
         flat = sorted([r for part in allrec for r in part], key=lambda r: r["batch_idx"])
