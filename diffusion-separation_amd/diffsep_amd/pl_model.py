@@ -149,6 +149,18 @@ class DiffSepModel:
             self.tail_model.to(device)
         return self
 
+    def fallback_model(self):
+        """A bf16 twin of this model (same weights, fp32 exponent range), created on first use.  IEEE half precision
+        overflows at 65504: an f16 / hybrid run that returns non-finite samples is repeated on it by the CLIs (bfloat16
+        has the range of fp32 and 8 significand bits: 32 dB instead of 50 from the fp32 result — and finite)."""
+        if self.dtype in ("bf16", "f32", "split"):
+            return None
+        if getattr(self, "_fallback", None) is None:
+            fb = DiffSepModel(self.config, dtype="bf16", device=self.score_model.device)
+            fb.score_model.load_state_dict(self.score_model.state_dict())
+            self._fallback = fb
+        return self._fallback
+
     def tail_engine(self):
         """the (split-)fp32 engine of dtype="hybrid" (None otherwise)"""
         return self.tail_model.engine() if self.tail_model is not None and self.head_steps > 0 else None

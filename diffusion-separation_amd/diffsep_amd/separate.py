@@ -141,10 +141,20 @@ def main(argv=None):
     def finish(w):
         if in_flight[w] is None:
             return
-        group, lens, srs, sep = in_flight[w]
+        group, lens, srs, sep, mix_d, sds = in_flight[w]
         in_flight[w] = None
         streams[w].synchronize()
         sep = sep.cpu()
+        if not bool(torch.isfinite(sep).all()):
+            # half precision overflows at 65504 (bfloat16 and fp32 do not): repeat the batch on the model's bf16 twin
+            fb = models[w].fallback_model()
+            if fb is None:
+                raise RuntimeError(f"non-finite samples for {[files[i].name for i in group]}")
+            print(f"Warning: non-finite samples for {[files[i].name for i in group]} with dtype {models[w].dtype}: repeating in bf16")
+            with torch.cuda.stream(streams[w]):
+                sep = separate_on_device(mix_d, fb, kw, args.device, lengths=lens, seeds=sds)
+            streams[w].synchronize()
+            sep = sep.cpu()
         for b, i in enumerate(group):
             for k in range(sep.shape[1]):
                 d = args.output_dir / f"s{k}"
@@ -163,10 +173,11 @@ def main(argv=None):
             srs.append(sr)
         mix, _, lens = datasets.pad_batch(items, side="right",
                                           to=eng.bucket_length(eng.padded_frames(max(lengths[i] for i in group))))
+        sds = [seeds[i] for i in group] if seeds is not None else None
         with torch.cuda.stream(streams[w]):
-            sep = separate_on_device(mix.pin_memory().to(args.device, non_blocking=True), models[w], kw, args.device,
-                                     lengths=lens, seeds=[seeds[i] for i in group] if seeds is not None else None)
-        in_flight[w] = (group, lens, srs, sep)
+            mix_d = mix.pin_memory().to(args.device, non_blocking=True)
+            sep = separate_on_device(mix_d, models[w], kw, args.device, lengths=lens, seeds=sds)
+        in_flight[w] = (group, lens, srs, sep, mix_d, sds)
     for w in range(K):
         finish(w)
     print(f"separated {len(files)} files into {args.output_dir}")

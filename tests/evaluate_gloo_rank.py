@@ -59,6 +59,9 @@ class _Model:
     def tail_engine(self):
         return None
 
+    def fallback_model(self):
+        return None if self.dtype == "bf16" else _Model(dtype="bf16")
+
     def normalize_batch(self, batch):
         mix, tgt = batch
         mean, std = mix.mean(dim=(1, 2), keepdim=True), mix.std(dim=(1, 2), keepdim=True).clamp(min=1e-5)
@@ -73,6 +76,8 @@ class _Model:
             for b, (L, s) in enumerate(zip(lengths, seeds)):  # a function of the utterance and ITS seed only
                 z = torch.randn(2, L, generator=torch.Generator().manual_seed(int(s) % (2 ** 31)))
                 est[b, :, :L] = torch.stack([0.7 * y[b, 0, :L], 0.3 * y[b, 0, :L].flip(-1)]) + 0.05 * z
+            if os.environ.get("EVAL_TEST_OVERFLOW") and self.dtype != "bf16" and y.shape[0] == 3:
+                est[0, 0, 5] = float("inf")  # (an f16 overflow in the full batches: evaluate must repeat them in bf16)
             return est, N * (1 + corrector_steps)
         return fn
 
