@@ -11,7 +11,7 @@ import ctypes, sys, os, torch
 sys.path.insert(0, "diffusion-separation_amd")
 from diffsep_amd import ops
 l = ctypes.CDLL(os.environ["DIFFSEP_LIB"])
-names = ["prologue (tables, weights, chunk 0)", "barrier wait", "3x3 chunk phases", "skip chunk phases", "epilogue", "tail (statistics)"]
+names = ["prologue: staging of the first chunk", "barrier wait", "3x3 chunk phases", "skip chunk phases", "epilogue", "tail (statistics)", "prologue: tables + descriptors", "prologue: first loads + weight fragments issued, barrier"]
 import os
 BS = [int(v) for v in os.environ.get('RW_B', '16').split(',')]
 for (ci, H, W, fused, B) in [(c, hh, ww, f, bb) for bb in BS for (c, hh, ww, f) in [(64, 256, 256, 2), (64, 256, 256, 1), (64, 256, 256, 0), (128, 256, 256, 1), (128, 256, 256, 0), (64, 128, 128, 1)]]:
@@ -42,6 +42,6 @@ for (ci, H, W, fused, B) in [(c, hh, ww, f, bb) for bb in BS for (c, hh, ww, f) 
     if nb == 0:
         continue  # (this launch did not run on the register-weight kernel)
     print(f"B={B} {ci}->64 {H}x{W} {['plain', 'GN+SiLU+stats', 'GN+SiLU+stats+residual'][fused]}: {e0.elapsed_time(e1)/5*1e3:.1f} us/launch, {tot/nb:.0f} ticks/block (wave 0), {nb//5} blocks -> {tot/nb/(e0.elapsed_time(e1)/5*1e3)/1e3:.2f} ticks/ns")
-    for i in range(6):
+    for i in range(8):
         print(f"    {names[i]:36s} {out[i]/nb:9.0f}  {100*out[i]/tot:5.1f} %")
 PY
