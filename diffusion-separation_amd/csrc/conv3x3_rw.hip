@@ -17,7 +17,8 @@
 //   * NCG = 2 (64 couts): the block's waves are 2 cout groups x 2 pixel groups of RPW rows x 32 pixels, tile (2 RPW) x 32;
 //     NCG = 4 (128 couts): 4 cout groups on ONE pixel group, tile RPW x 32 — the same staging and epilogue work per wave
 //     for twice the MFMAs.  Every weight fragment is used by RPW / 2 consecutive MFMAs on independent accumulators; the
-//     only LDS traffic of the MFMA stream is ONE ds_read_b128 (the pixel fragment) per MFMA;
+//     only LDS traffic of the MFMA stream is the pixel fragments: K runs (kx, 16-channel block) outside and ky inside, so
+//     the RPW / 2 + 2 input-row fragments of a group serve three k-steps (2/3 of a ds_read_b128 per MFMA);
 //   * persistent blocks walk a contiguous raster range of tiles of one image; the input goes chunk by chunk (KC = 64
 //     channels: a pixel's chunk is one full 128-byte line) through a 2-slot halo ring: while the MFMAs of chunk q run,
 //     the same wave activates chunk q + 1 in registers (GroupNorm affine + SiLU, one dword = "unit" at a time), writes
@@ -460,15 +461,42 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
       const int dy = tap / 3, dx = tap % 3;
       return *reinterpret_cast<const u32x4_t*>(fb + ((r + dy) * HW_ + dx) * AROW + kb * 32);
     };
+#ifdef RW_NO_ROWREUSE
     u32x4_t bf[DEPTH][RH];
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
       for (int r = 0; r < RH; ++r)
         if (d < NK) bf[d][r] = ldb(d, r);
-    // weight fragment of k-step ks: a register, or (the last NWL k-steps) an LDS read issued one k-step ahead
+    auto widx = [](int ks) { return ks; };
+#define RW_FRAG(ks, r) bf[(ks) % DEPTH][r]
+#define RW_FRAG_LAST(ks) bf[(ks) % DEPTH][RH - 1]
+#else
+    // K order inside a 3x3 chunk: (kx, 16-channel block) groups outside, ky inside.  The RH rows of this half use the
+    // pixel fragments of input rows R0 .. R0 + RH + 1 at the group's (kx, block): each is read ONCE per group and serves up
+    // to three k-steps (ky) — RH + 2 fragment reads per 3 RH MFMAs instead of 3 RH, and one wait per group.  (A skip
+    // chunk has one k-step per group: the centre tap.)
+    constexpr int SUB = CONV ? 3 : 1, RFN = CONV ? RH + 2 : RH, NG = NK / SUB;
+    static_assert(SUB * RH >= RFN, "the next group's fragments are read in the MFMA slots of the current one");
+    auto ldg = [&](int g, int j) __attribute__((always_inline)) {  // fragment j of group g = kx * NKB + block
+      const int dx = CONV ? g / NKB : 1, kb = g % NKB, row = CONV ? j : j + 1;
+      return *reinterpret_cast<const u32x4_t*>(fb + (row * HW_ + dx) * AROW + kb * 32);
+    };
+    u32x4_t rf[2][RFN];
+#pragma unroll
+    for (int j = 0; j < RFN; ++j) rf[0][j] = ldg(0, j);
+    // k-step ks of this order -> its weight fragment in the (tap, block) order of load_weights
+    auto widx = [](int ks) {
+      if (!CONV) return ks;
+      const int g = ks / 3, dy = ks % 3, dx = g / NKB, kb = g % NKB;
+      return (dy * 3 + dx) * NKB + kb;
+    };
+#define RW_FRAG(ks, r) rf[((ks) / SUB) & 1][(r) + (CONV ? (ks) % SUB : 0)]
+#define RW_FRAG_LAST(ks) rf[((ks) / SUB) & 1][RFN - 1]
+#endif
+    // weight fragment of k-step ks: a register, or (the last NWL fragments) an LDS read issued one k-step ahead
     u32x4_t wl = {0, 0, 0, 0}, wln = {0, 0, 0, 0};
-    if constexpr (W0 >= NWR) wl = *reinterpret_cast<const u32x4_t*>(sWl + (W0 - NWR) * G::WL_STEP);
+    if constexpr (W0 + widx(0) >= NWR) wl = *reinterpret_cast<const u32x4_t*>(sWl + (W0 + widx(0) - NWR) * G::WL_STEP);
     int rels[2][NL];
     float4 eb[2][NE][2];
     {  // (the first k-step's operands: the one exposed round trip of the half)
@@ -501,15 +529,16 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
           for (int e = en0; e < en1; ++e) epi_bias(e & 1, eb[(ks + 1) & 1][e - en0][0], eb[(ks + 1) & 1][e - en0][1]);
         }
       }
-      if (W0 + ks + 1 >= NWR && ks + 1 < NK) wln = *reinterpret_cast<const u32x4_t*>(sWl + (W0 + ks + 1 - NWR) * G::WL_STEP);
-      const u32x4_t wk = W0 + ks < NWR ? wf[W0 + ks < NWR ? W0 + ks : 0] : wl;
+      const int wi = W0 + widx(ks), win = W0 + widx(ks + 1 < NK ? ks + 1 : ks);
+      if (win >= NWR && ks + 1 < NK) wln = *reinterpret_cast<const u32x4_t*>(sWl + (win - NWR) * G::WL_STEP);
+      const u32x4_t wk = wi < NWR ? wf[wi < NWR ? wi : 0] : wl;
       // RW_DEP: the k-step's LAST pixel fragment rides along as an unused operand of every MFMA of the k-step: the
       // compiler then waits ONCE per k-step (for the newest fragment) instead of once per MFMA — one s_waitcnt less per
       // MFMA in a stream whose issue slots are the bottleneck (the fragments were read DEPTH k-steps ago)
 #ifdef RW_NO_DEP
 #define RW_DEP
 #else
-#define RW_DEP , "v"(bf[ks % DEPTH][RH - 1])
+#define RW_DEP , "v"(RW_FRAG_LAST(ks))
 #endif
 #pragma unroll
       for (int r = 0; r < RH; ++r) {
@@ -519,22 +548,29 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
         // architectural half.  (With the builtin hipcc kept the weights in VGPRs and shuttled accumulators, statistics
         // and staged pieces through AGPRs: 200 v_accvgpr moves per tile.)  What the compiler does not know about an asm
         // MFMA: the 12 wait states between its result and a VALU read — the guard at the start of every half.
-        if (W0 + ks < NWR) {
-          if (P == 0 && ks == 0) asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, 0" : "=v"(acc[R0 + r]) : "a"(wk), "v"(bf[ks % DEPTH][r]) RW_DEP);
-          else asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, %0" : "+v"(acc[R0 + r]) : "a"(wk), "v"(bf[ks % DEPTH][r]) RW_DEP);
+        if (wi < NWR) {
+          if (P == 0 && ks == 0) asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, 0" : "=v"(acc[R0 + r]) : "a"(wk), "v"(RW_FRAG(ks, r)) RW_DEP);
+          else asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, %0" : "+v"(acc[R0 + r]) : "a"(wk), "v"(RW_FRAG(ks, r)) RW_DEP);
         } else {  // LDS-resident fragment: straight from the ds_read's VGPRs (no VALU copy in front of the MFMA)
-          if (P == 0 && ks == 0) asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, 0" : "=v"(acc[R0 + r]) : "v"(wk), "v"(bf[ks % DEPTH][r]) RW_DEP);
-          else asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, %0" : "+v"(acc[R0 + r]) : "v"(wk), "v"(bf[ks % DEPTH][r]) RW_DEP);
+          if (P == 0 && ks == 0) asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, 0" : "=v"(acc[R0 + r]) : "v"(wk), "v"(RW_FRAG(ks, r)) RW_DEP);
+          else asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, %0" : "+v"(acc[R0 + r]) : "v"(wk), "v"(RW_FRAG(ks, r)) RW_DEP);
         }
 #else
         if (P == 0 && ks == 0) {  // a tile's first MFMA of a row starts from zero (the row's epilogue has run)
           const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          acc[R0 + r] = mfma_h32(__builtin_bit_cast(uint4, wk), __builtin_bit_cast(uint4, bf[ks % DEPTH][r]), zero);
+          acc[R0 + r] = mfma_h32(__builtin_bit_cast(uint4, wk), __builtin_bit_cast(uint4, RW_FRAG(ks, r)), zero);
         } else {
-          acc[R0 + r] = mfma_h32(__builtin_bit_cast(uint4, wk), __builtin_bit_cast(uint4, bf[ks % DEPTH][r]), acc[R0 + r]);
+          acc[R0 + r] = mfma_h32(__builtin_bit_cast(uint4, wk), __builtin_bit_cast(uint4, RW_FRAG(ks, r)), acc[R0 + r]);
         }
 #endif
+#ifdef RW_NO_ROWREUSE
         if (ks + DEPTH < NK) bf[ks % DEPTH][r] = ldb(ks + DEPTH, r);
+#else
+        {  // the next group's fragments, one per MFMA slot of this group
+          const int g = ks / SUB, q = (ks % SUB) * RH + r;
+          if (q < RFN && g + 1 < NG) rf[(g + 1) & 1][q] = ldg(g + 1, q);
+        }
+#endif
       }
       wl = wln;
 #ifndef RW_ABL_NOSTAGE
