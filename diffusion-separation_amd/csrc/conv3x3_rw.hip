@@ -425,9 +425,18 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     }
   };
   // (bias + temb bias) * out_scale of the unit's two cout quads: LDS broadcast reads, issued ahead of the k-step's MFMAs
+  // Where the register file has room (64-channel layers: 144 - 176 of the 256 accumulator registers hold weights) the
+  // lane's 16 values stay in registers for the whole launch: 8 LDS reads per half-phase less
+  constexpr bool BIAS_REGS = NWR * 4 <= 176;
+  float4 breg[2][2];
   auto epi_bias = [&](int j, float4& t0, float4& t1) __attribute__((always_inline)) {
-    t0 = *reinterpret_cast<const float4*>(sTab + 2 * CIN + cg * 32 + 8 * (2 * j) + 4 * h);
-    t1 = *reinterpret_cast<const float4*>(sTab + 2 * CIN + cg * 32 + 8 * (2 * j + 1) + 4 * h);
+    if constexpr (BIAS_REGS) {
+      t0 = breg[j][0];
+      t1 = breg[j][1];
+    } else {
+      t0 = *reinterpret_cast<const float4*>(sTab + 2 * CIN + cg * 32 + 8 * (2 * j) + 4 * h);
+      t1 = *reinterpret_cast<const float4*>(sTab + 2 * CIN + cg * 32 + 8 * (2 * j + 1) + 4 * h);
+    }
   };
 
   // ---- one HALF of a phase: the MFMAs of chunk (phase P, ring slot P & 1) for the wave's rows [HF * RH, HF * RH + RH),
@@ -609,6 +618,13 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     for (int k = 0; k < NL; ++k) issue_one(std::integral_constant<int, CH0>{}, gc, k, sDesc[k * NT + tid]);
     load_weights();
     sync_lds();  // tables (and the LDS-resident weight fragments) visible
+    if constexpr (BIAS_REGS) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        breg[j][0] = *reinterpret_cast<const float4*>(sTab + 2 * CIN + cg * 32 + 8 * (2 * j) + 4 * h);
+        breg[j][1] = *reinterpret_cast<const float4*>(sTab + 2 * CIN + cg * 32 + 8 * (2 * j + 1) + 4 * h);
+      }
+    }
     act_tab(CH0);
     // (staging the first chunk re-issues every piece as the second one)
 #pragma unroll
