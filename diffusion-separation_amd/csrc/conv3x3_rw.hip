@@ -429,6 +429,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   // lane's 16 values stay in registers for the whole launch: 8 LDS reads per half-phase less
   constexpr bool BIAS_REGS = NWR * 4 <= 176;
   float4 breg[2][2];
+  int relreg[NL];  // ... and so do the relative pixel indices of the thread's staging pieces
   auto epi_bias = [&](int j, float4& t0, float4& t1) __attribute__((always_inline)) {
     if constexpr (BIAS_REGS) {
       t0 = breg[j][0];
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
       const int s0 = HF * NK, ua = s0 * NU / (2 * NK), ub = (s0 + 1) * NU / (2 * NK);
 #pragma unroll
       for (int u = ua; u < ub; ++u)
-        if ((u & 3) == 3) rels[0][u >> 2] = sDesc[(u >> 2) * NT + tid];
+        if ((u & 3) == 3) rels[0][u >> 2] = BIAS_REGS ? relreg[u >> 2] : sDesc[(u >> 2) * NT + tid];
       if (EPI) {
 #pragma unroll
         for (int e = 0; e < NE / NK + (NE % NK ? 1 : 0); ++e)
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
         const int sn = sl + 1, un0 = sn * NU / (2 * NK), un1 = (sn + 1) * NU / (2 * NK);
 #pragma unroll
         for (int u = un0; u < un1; ++u)
-          if ((u & 3) == 3) rels[(ks + 1) & 1][u >> 2] = sDesc[(u >> 2) * NT + tid];
+          if ((u & 3) == 3) rels[(ks + 1) & 1][u >> 2] = BIAS_REGS ? relreg[u >> 2] : sDesc[(u >> 2) * NT + tid];
         if (EPI) {
           const int en0 = (ks + 1) * NE / NK, en1 = (ks + 2) * NE / NK;
 #pragma unroll
@@ -619,6 +620,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     load_weights();
     sync_lds();  // tables (and the LDS-resident weight fragments) visible
     if constexpr (BIAS_REGS) {
+#pragma unroll
+      for (int k = 0; k < NL; ++k) relreg[k] = sDesc[k * NT + tid];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         breg[j][0] = *reinterpret_cast<const float4*>(sTab + 2 * CIN + cg * 32 + 8 * (2 * j) + 4 * h);
