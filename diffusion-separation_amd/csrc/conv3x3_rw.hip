@@ -427,7 +427,11 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   // (bias + temb bias) * out_scale of the unit's two cout quads: LDS broadcast reads, issued ahead of the k-step's MFMAs
   // Where the register file has room (64-channel layers: 144 - 176 of the 256 accumulator registers hold weights) the
   // lane's 16 values stay in registers for the whole launch: 8 LDS reads per half-phase less
+#ifdef RW_NO_BIAS_REGS4
   constexpr bool BIAS_REGS = NWR * 4 <= 176;
+#else
+  constexpr bool BIAS_REGS = NWR * 4 <= 176 || NCG == 4;  // (4 cout groups: 4-row tiles leave VGPRs free)
+#endif
   float4 breg[2][2];
   int relreg[NL];  // ... and so do the relative pixel indices of the thread's staging pieces
   auto epi_bias = [&](int j, float4& t0, float4& t1) __attribute__((always_inline)) {
