@@ -427,11 +427,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   // (bias + temb bias) * out_scale of the unit's two cout quads: LDS broadcast reads, issued ahead of the k-step's MFMAs
   // Where the register file has room (64-channel layers: 144 - 176 of the 256 accumulator registers hold weights) the
   // lane's 16 values stay in registers for the whole launch: 8 LDS reads per half-phase less
-#ifdef RW_NO_BIAS_REGS4
-  constexpr bool BIAS_REGS = NWR * 4 <= 176;
-#else
-  constexpr bool BIAS_REGS = NWR * 4 <= 176 || NCG == 4;  // (4 cout groups: 4-row tiles leave VGPRs free)
-#endif
+  // (64-channel layers and the 4-row tiles of the 128-cout variants have the VGPRs for both tables; the 128 -> 64 variant
+  // for the bias only)
+  constexpr bool REL_REGS = NWR * 4 <= 176 || NCG == 4;
+  constexpr bool BIAS_REGS = true;
   float4 breg[2][2];
   int relreg[NL];  // ... and so do the relative pixel indices of the thread's staging pieces
   auto epi_bias = [&](int j, float4& t0, float4& t1) __attribute__((always_inline)) {
@@ -517,7 +516,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
       const int s0 = HF * NK, ua = s0 * NU / (2 * NK), ub = (s0 + 1) * NU / (2 * NK);
 #pragma unroll
       for (int u = ua; u < ub; ++u)
-        if ((u & 3) == 3) rels[0][u >> 2] = BIAS_REGS ? relreg[u >> 2] : sDesc[(u >> 2) * NT + tid];
+        if ((u & 3) == 3) rels[0][u >> 2] = REL_REGS ? relreg[u >> 2] : sDesc[(u >> 2) * NT + tid];
       if (EPI) {
 #pragma unroll
         for (int e = 0; e < NE / NK + (NE % NK ? 1 : 0); ++e)
@@ -536,7 +535,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
         const int sn = sl + 1, un0 = sn * NU / (2 * NK), un1 = (sn + 1) * NU / (2 * NK);
 #pragma unroll
         for (int u = un0; u < un1; ++u)
-          if ((u & 3) == 3) rels[(ks + 1) & 1][u >> 2] = BIAS_REGS ? relreg[u >> 2] : sDesc[(u >> 2) * NT + tid];
+          if ((u & 3) == 3) rels[(ks + 1) & 1][u >> 2] = REL_REGS ? relreg[u >> 2] : sDesc[(u >> 2) * NT + tid];
         if (EPI) {
           const int en0 = (ks + 1) * NE / NK, en1 = (ks + 2) * NE / NK;
 #pragma unroll
@@ -623,9 +622,11 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     for (int k = 0; k < NL; ++k) issue_one(std::integral_constant<int, CH0>{}, gc, k, sDesc[k * NT + tid]);
     load_weights();
     sync_lds();  // tables (and the LDS-resident weight fragments) visible
-    if constexpr (BIAS_REGS) {
+    if constexpr (REL_REGS) {
 #pragma unroll
       for (int k = 0; k < NL; ++k) relreg[k] = sDesc[k * NT + tid];
+    }
+    if constexpr (BIAS_REGS) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         breg[j][0] = *reinterpret_cast<const float4*>(sTab + 2 * CIN + cg * 32 + 8 * (2 * j) + 4 * h);
