@@ -115,11 +115,16 @@ template <int NCH, int RPW, int NSK, int NCG>
 struct RwGeom {
   static constexpr int CO = 32 * NCG, PGN = 4 / NCG;
   static constexpr int TH = PGN * RPW, HH_ = TH + 2, HP = HH_ * HW_;
-  static constexpr int NL = (HP * PPL + NT - 1) / NT;     // 16-byte pieces per thread and chunk
+  // 16-byte staging pieces per thread and chunk: NI passes over the tile's own pixels (a pass = NT / PPL = 32 pixels = one
+  // tile row: always inside the image, no flags, no selects), then NB passes over the NBP pixels of the halo border
+  static constexpr int NI = TH * TW * PPL / NT, NBP = HP - TH * TW, NB = (NBP * PPL + NT - 1) / NT;
+  static constexpr int NL = NI + NB;
+  static_assert(NT / PPL == TW && TH * TW * PPL % NT == 0, "one staging pass = one tile row");
   static constexpr int LDS_A = NL * (NT / PPL) * AROW;    // one ring slot (whole passes of the block: no predicated writes)
   static constexpr int CIN = NCH * KC, SCIN = NSK * KC;
   static constexpr int LDS_TAB = (2 * CIN + CO) * 4;      // GN scale, GN shift, (bias + temb bias) * out_scale
-  static constexpr int LDS_DESC = NL * NT * 4;
+  static constexpr int LDS_DESC = NB * NT * 4;            // relative pixel index of the border pieces
+  static_assert((NI + NB) * (NT / PPL) >= HP + NB * (NT / PPL) - NBP, "dummy pixels of the last border pass fit the slot");
   static constexpr int NPH = NCH + NSK;                   // phases (chunks) per tile
   static constexpr int NKS = NCH * KSC + NSK * NKB;       // k-steps = weight fragments per wave
   static constexpr int NWL = rw_lds_ksteps(NCH, RPW, NSK, NCG), NWR = NKS - NWL;  // fragments in LDS / in registers
@@ -183,19 +188,29 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     sTab[2 * CIN + tid] =
         ((p.bias ? p.bias[tid] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + tid] : 0.f)) * p.out_scale;
   const int slot = tid & (PPL - 1);
-  // staging pieces of this thread: piece k = halo pixel tid / PPL + (NT / PPL) k, 16-byte slot tid % PPL.  Relative pixel index
-  // in LDS (read one k-step ahead of its use), 5 flag bits per piece in two registers: bits 0..3 = the piece lies in the
-  // top / bottom / left / right halo line, bit 4 = beyond the halo tile
-  unsigned fl0 = 0, fl1 = 0;
+  // staging pieces of this thread, 16-byte slot tid % PPL of a pixel: piece k < NI = pixel (row k, column tid / PPL) of the tile
+  // itself; piece NI + kb = border pixel tid / PPL + 32 kb of the halo line (top row, bottom row, left column, right column).
+  // Border pieces carry 5 flag bits (bits 0..3 = top / bottom / left / right halo line, bit 4 = past the last border
+  // pixel), their relative pixel index (LDS table or registers) and their LDS offset (registers).
+  constexpr int NI = G::NI, NB = G::NB, NBP = G::NBP;
+  const int ixp = tid / PPL;
+  unsigned fl = 0;
+  int dstb[NB];
 #pragma unroll
-  for (int k = 0; k < NL; ++k) {
-    const int v = tid + NT * k;
-    const int pix = v / PPL, hy = pix / HW_, hx = pix - hy * HW_;
-    const unsigned flg = pix < HP ? (hy == 0 ? 1u : 0u) | (hy == G::HH_ - 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == HW_ - 1 ? 8u : 0u) : 16u;
-    sDesc[k * NT + tid] = pix < HP ? (hy - 1) * p.W + (hx - 1) : 0;
-    if (k < 6) fl0 |= flg << (5 * k); else fl1 |= flg << (5 * (k - 6));
+  for (int kb = 0; kb < NB; ++kb) {
+    const int bi = ixp + (NT / PPL) * kb;
+    int hy, hx;
+    if (bi < HW_) { hy = 0; hx = bi; }
+    else if (bi < 2 * HW_) { hy = G::HH_ - 1; hx = bi - HW_; }
+    else if (bi < 2 * HW_ + TH) { hy = 1 + bi - 2 * HW_; hx = 0; }
+    else { hy = 1 + bi - 2 * HW_ - TH; hx = HW_ - 1; }
+    const bool in = bi < NBP;
+    const unsigned flg = in ? (hy == 0 ? 1u : 0u) | (hy == G::HH_ - 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == HW_ - 1 ? 8u : 0u) : 16u;
+    sDesc[kb * NT + tid] = in ? (hy - 1) * p.W + (hx - 1) : 0;
+    dstb[kb] = (in ? hy * HW_ + hx : HP + (bi - NBP)) * AROW + slot * 16;  // (the pieces past the border: unused pixels of the slot)
+    fl |= flg << (5 * kb);
   }
-  const int ldo0 = (tid / PPL) * AROW + slot * 16;  // piece k is NT / PPL pixels further
+  const int ldi0 = (HW_ + 1 + ixp) * AROW + slot * 16;  // tile pixel (0, ixp): piece k < NI is HW_ pixels (one halo row) further
 
   const int M = p.H * p.W;
   const __amdgpu_buffer_rsrc_t rx1 = rsrc(p.x + (long)b * p.x_bs, (unsigned)M * p.ldx * 2u);
@@ -268,8 +283,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   // piece k of a chunk of type P is valid (inside the image / an interior pixel for the skip chunks)
   auto piece_ok = [&](auto P_, const TileG& g, int k) __attribute__((always_inline)) {
     constexpr int P = decltype(P_)::value;
-    const unsigned em = (P < NCH ? (g.edge | 16u) : 31u) << (5 * (k < 6 ? k : k - 6));  // (scalar)
-    return ((k < 6 ? fl0 : fl1) & em) == 0u;
+    const unsigned em = (P < NCH ? (g.edge | 16u) : 31u) << (5 * (k - NI));  // (scalar; border pieces only)
+    return (fl & em) == 0u;
   };
   // source of chunk P (compile time): descriptor, pixel pitch in bytes, byte offset of this thread's 8 channels
   auto issue_one = [&](auto P_, const TileG& g, int k, int rel) __attribute__((always_inline)) {
@@ -281,11 +296,16 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     const unsigned ld2 = (unsigned)(CONV ? (second ? p.ldx2 : p.ldx) : (second ? p.ldsx2 : p.ldsx)) * 2u;
     const unsigned co2 = (unsigned)((second ? CB - c1 : CB) * 2) + (unsigned)slot * 16u;
     const __amdgpu_buffer_rsrc_t r = CONV ? (second ? rx2 : rx1) : (second ? rs2 : rs1);
-#ifdef RW_ABL_FULLLINE  // (timing only, wrong data: the same bytes per instruction as 8 pixels x 128 B instead of 16 x 64 B)
-    const unsigned off = __umul24((unsigned)(g.pix0 + (tid >> 3) + 32 * k), ld2) + (unsigned)(tid & 7) * 16u;
-#else
+    if constexpr (!CONV) {
+      if (k >= NI) return;  // (a skip chunk meets the centre tap only: its border pieces are never read)
+    }
+    if (k < NI) {  // a pixel of the tile itself: inside the image whenever the tile is (a tile past the block's range has a
+                   // pixel index beyond every tensor: the hardware returns zeros)
+      const unsigned off = __umul24((unsigned)(g.pix0 + k * p.W + ixp), ld2) + co2;
+      pa[k] = ld16(r, off, 0);
+      return;
+    }
     const unsigned off = __umul24((unsigned)(rel + g.pix0), ld2) + co2;
-#endif
 #ifdef RW_TIMING
     pa[k] = ld16(r, (piece_ok(P_, g, k) && !(p.dbg & 2)) ? off : OOB, 0);
 #else
@@ -333,7 +353,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
       so[d] = w;
     }
     if (d == 3) {
-      if constexpr (P1 < NCH && MODE != 0) {  // zero padding stays zero (silu(GN(0)) != 0)
+      if (P1 < NCH && MODE != 0 && k >= NI) {  // zero padding stays zero (silu(GN(0)) != 0): border pieces only
         const bool ok = piece_ok(P1_, g1, k);
         so.x = ok ? so.x : 0u;
         so.y = ok ? so.y : 0u;
@@ -343,7 +363,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
 #ifdef RW_ABL_NOLDSW
       asm volatile("" :: "v"(so));
 #else
-      *reinterpret_cast<u32x4_t*>(sA + sl * LDS_A + ldo0 + k * (NT / PPL) * AROW) = so;
+      if (P1 < NCH || k < NI)  // (border pieces of a skip chunk: nothing was loaded, nothing is read)
+        *reinterpret_cast<u32x4_t*>(sA + sl * LDS_A + (k < NI ? ldi0 + k * HW_ * AROW : dstb[k < NI ? 0 : k - NI])) = so;
 #endif
 #ifdef RW_ABL_NOLOAD
       pa[k][0] += rel;
@@ -432,7 +453,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   constexpr bool REL_REGS = NWR * 4 <= 176 || NCG == 4;
   constexpr bool BIAS_REGS = true;
   float4 breg[2][2];
-  int relreg[NL];  // ... and so do the relative pixel indices of the thread's staging pieces
+  int relreg[G::NB];  // ... and so do the relative pixel indices of the thread's border pieces
   auto epi_bias = [&](int j, float4& t0, float4& t1) __attribute__((always_inline)) {
     if constexpr (BIAS_REGS) {
       t0 = breg[j][0];
@@ -516,7 +537,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
       const int s0 = HF * NK, ua = s0 * NU / (2 * NK), ub = (s0 + 1) * NU / (2 * NK);
 #pragma unroll
       for (int u = ua; u < ub; ++u)
-        if ((u & 3) == 3) rels[0][u >> 2] = REL_REGS ? relreg[u >> 2] : sDesc[(u >> 2) * NT + tid];
+        if ((u & 3) == 3 && (u >> 2) >= NI) rels[0][u >> 2] = REL_REGS ? relreg[(u >> 2) - NI] : sDesc[((u >> 2) - NI) * NT + tid];
       if (EPI) {
 #pragma unroll
         for (int e = 0; e < NE / NK + (NE % NK ? 1 : 0); ++e)
@@ -535,7 +556,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
         const int sn = sl + 1, un0 = sn * NU / (2 * NK), un1 = (sn + 1) * NU / (2 * NK);
 #pragma unroll
         for (int u = un0; u < un1; ++u)
-          if ((u & 3) == 3) rels[(ks + 1) & 1][u >> 2] = REL_REGS ? relreg[u >> 2] : sDesc[(u >> 2) * NT + tid];
+          if ((u & 3) == 3 && (u >> 2) >= NI) rels[(ks + 1) & 1][u >> 2] = REL_REGS ? relreg[(u >> 2) - NI] : sDesc[((u >> 2) - NI) * NT + tid];
         if (EPI) {
           const int en0 = (ks + 1) * NE / NK, en1 = (ks + 2) * NE / NK;
 #pragma unroll
@@ -619,12 +640,12 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     // the first chunk's loads go out ahead of the weights (loads return in order: the tile can be staged while the
     // weight fragments are still streaming in; the MFMAs then wait for them fragment by fragment)
 #pragma unroll
-    for (int k = 0; k < NL; ++k) issue_one(std::integral_constant<int, CH0>{}, gc, k, sDesc[k * NT + tid]);
+    for (int k = 0; k < NL; ++k) issue_one(std::integral_constant<int, CH0>{}, gc, k, k < NI ? 0 : sDesc[(k < NI ? 0 : k - NI) * NT + tid]);
     load_weights();
     sync_lds();  // tables (and the LDS-resident weight fragments) visible
     if constexpr (REL_REGS) {
 #pragma unroll
-      for (int k = 0; k < NL; ++k) relreg[k] = sDesc[k * NT + tid];
+      for (int k = 0; k < NB; ++k) relreg[k] = sDesc[k * NT + tid];
     }
     if constexpr (BIAS_REGS) {
 #pragma unroll
@@ -637,7 +658,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     // (staging the first chunk re-issues every piece as the second one)
 #pragma unroll
     for (int u = 0; u < NL * 4; ++u)
-      unit(std::integral_constant<int, CH0>{}, std::integral_constant<int, CH1>{}, gc, g1st, 0, u, sDesc[(u >> 2) * NT + tid]);
+      unit(std::integral_constant<int, CH0>{}, std::integral_constant<int, CH1>{}, gc, g1st, 0, u,
+           (u >> 2) < NI ? 0 : sDesc[((u >> 2) < NI ? 0 : (u >> 2) - NI) * NT + tid]);
   }
   RT_MARK(0)
   TileG gp = tile_geom(nt);  // "previous tile" of the first one: no tile (its stores fall outside every tensor)
