@@ -183,13 +183,12 @@ def main(argv=None):
     pending = [None] * K  # per worker: the batch whose sampler is running on its stream
 
     def host_stage(group):
-        """load and pad one batch on the host (runs on a loader thread, ahead of the GPU): pinned mix / tgt + lengths"""
+        """load and pad one batch on the host (runs on a loader thread, ahead of the GPU): mix / tgt + lengths"""
         items = [get(i) for i in group]
         # padded to the longest length of the batch's width bucket: one workspace plan / captured graph per (B, W)
         mix, tgt, lens = datasets.pad_batch(items, side="right",
                                             to=eng0.bucket_length(eng0.padded_frames(max(lengths[i] for i in group))))
-        # pinned staging + asynchronous copies: a pageable host->device copy serialises the whole device
-        return mix.contiguous().pin_memory(), tgt.contiguous().pin_memory(), lens
+        return mix.contiguous(), tgt.contiguous(), lens
 
     # the reference's DataLoader has worker processes; here two loader threads read / synthesise and pad the next batches
     # while the GPU separates the current ones (wav decoding and numpy release the GIL)
@@ -205,8 +204,10 @@ def main(argv=None):
     def stage(group, w, j=None):
         """upload and normalise one batch on worker w's stream -> (mix, mix_n, tgt_n, lens)"""
         mix, tgt, lens = ahead.pop(j).result() if j in ahead else host_stage(group)
-        mix = mix.to("cuda", non_blocking=True)
-        tgt = tgt.to("cuda", non_blocking=True)
+        # pinned staging + asynchronous copies (a pageable host->device copy serialises the whole device); pinned memory is
+        # allocated on THIS thread: the loader threads make no HIP runtime call
+        mix = mix.pin_memory().to("cuda", non_blocking=True)
+        tgt = tgt.pin_memory().to("cuda", non_blocking=True)
         mix_n, tgt_n = torch.zeros_like(mix), torch.zeros_like(tgt)
         for b, L in enumerate(lens):  # every utterance is normalised over ITS samples (pl_model.py:81-88)
             (m_b, t_b), *_ = models[w].normalize_batch((mix[b:b + 1, :, :L], tgt[b:b + 1, :, :L]))

@@ -461,7 +461,9 @@ def test_evaluate_batched_equals_one_utterance_at_a_time(tmp_path):
         assert summ["number"] == len(lens) and summ["not_computed"] == ["pesq", "stoi"]
     assert json.load(open(tmp_path / "bat" / "test_summary.json"))["engine_calls_rank0"] == 2
     strip = lambda r: {k: v for k, v in r.items() if k != "runtime"}
-    assert [strip(r) for r in recs["one"]] == [strip(r) for r in recs["bat"]]
+    diff = [(a["batch_idx"], a["si_sdr"], b["si_sdr"]) for a, b in zip(recs["one"], recs["bat"]) if strip(a) != strip(b)]
+    assert not diff, f"records differ between --batch 1 and --batch 16: {diff}"
+    assert len(recs["one"]) == len(recs["bat"])
     r0 = recs["bat"][0]
     assert np.asarray(r0["si_sdr"]).shape == (1, 2) and len(r0["perm"]) == 2  # per-source lists like evaluate.py:394-405
 
