@@ -24,6 +24,8 @@
 //     the same wave activates chunk q + 1 in registers (GroupNorm affine + SiLU, one dword = "unit" at a time), writes
 //     it to the other slot and re-issues the freed registers as the loads of chunk q + 2 — a global load has a whole
 //     chunk phase to land, and one LDS-only barrier per chunk is the only synchronisation;
+//     a thread's staging pieces are first the tile's own pixels (one tile row per pass: always inside the image — no
+//     flags, no zero-padding selects) and then the pixels of the halo border, the only ones that carry flags;
 //   * the K loop is fully unrolled (every MFMA names its own weight registers; needs -mllvm
 //     -pragma-unroll-threshold=1000000, see the Makefile); a scheduling barrier per k-step keeps the compiler's
 //     interleave local (MFMAs + fragment reads + the k-step's share of the staging and epilogue units);
