@@ -161,34 +161,55 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   const int nt = (int)((long)(part + 1) * p.tiles_per_img / p.G) - t0;
   RT_DECL
 
-  // ---- tables: GroupNorm scale / shift of image b, bias; staging descriptors
-  for (int c = tid; c < CIN; c += NT) {
-    float sc = 1.f, sh = 0.f;
+  // ---- tables: GroupNorm scale / shift of image b, bias.  The operands are LOADED here, ahead of the first chunk's loads and
+  // the weight fragments (loads return in order), and turned into the LDS tables after those have been issued: the fp64
+  // statistics run while 70 - 300 KB of weights are in flight
+  static_assert(CIN <= NT && CO <= NT, "one table entry per thread");
+  constexpr int CPG_MAX = 8;  // channels per GroupNorm group: min(C / 4, 32) groups -> 4 (C <= 128) or 8 (C = 256)
+  long long t_s[CPG_MAX], t_q[CPG_MAX];
+  float t_gam = 1.f, t_bet = 0.f, t_sc = 1.f, t_sh = 0.f, t_bias = 0.f;
+#pragma unroll
+  for (int j = 0; j < CPG_MAX; ++j) { t_s[j] = 0; t_q[j] = 0; }
+  if (tid < CIN) {
+    const int c = tid;
     if (p.gn_acc1) {  // statistics straight from the producers' channel-sum accumulators
       const int C1 = p.C1, C2 = CIN - C1;
       const int cpg = CIN / p.gn_groups, g0 = (c / cpg) * cpg;
-      long long ssum = 0, ssq = 0;
-      for (int j = 0; j < cpg; ++j) {
-        const int cc = g0 + j;
-        const long long* src = cc < C1 ? p.gn_acc1 + ((long)b * C1 + cc) * 2 : p.gn_acc2 + ((long)b * C2 + (cc - C1)) * 2;
-        ssum += src[0];
-        ssq += src[1];
+#pragma unroll
+      for (int j = 0; j < CPG_MAX; ++j) {
+        if (j < cpg) {
+          const int cc = g0 + j;
+          const long long* src = cc < C1 ? p.gn_acc1 + ((long)b * C1 + cc) * 2 : p.gn_acc2 + ((long)b * C2 + (cc - C1)) * 2;
+          t_s[j] = src[0];
+          t_q[j] = src[1];
+        }
       }
-      const double mean = (double)ssum * (1.0 / DS_STAT_SUM_SCALE) * (double)p.gn_inv_count;
-      double var = (double)ssq * (1.0 / DS_STAT_SQ_SCALE) * (double)p.gn_inv_count - mean * mean;
-      if (var < 0.0) var = 0.0;
-      sc = (float)(1.0 / sqrt(var + (double)p.gn_eps)) * (p.gn_gamma ? p.gn_gamma[c] : 1.f);
-      sh = (p.gn_beta ? p.gn_beta[c] : 0.f) - (float)mean * sc;
+      t_gam = p.gn_gamma ? p.gn_gamma[c] : 1.f;
+      t_bet = p.gn_beta ? p.gn_beta[c] : 0.f;
     } else if (p.gn_scale) {
-      sc = p.gn_scale[(long)b * CIN + c];
-      sh = p.gn_shift[(long)b * CIN + c];
+      t_sc = p.gn_scale[(long)b * CIN + c];
+      t_sh = p.gn_shift[(long)b * CIN + c];
     }
-    sTab[c] = sc;
-    sTab[CIN + c] = sh;
   }
-  if (tid < CO)
-    sTab[2 * CIN + tid] =
-        ((p.bias ? p.bias[tid] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + tid] : 0.f)) * p.out_scale;
+  if (tid < CO) t_bias = (p.bias ? p.bias[tid] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + tid] : 0.f);
+  auto build_tables = [&]() __attribute__((always_inline)) {
+    if (tid < CIN) {
+      float sc = t_sc, sh = t_sh;
+      if (p.gn_acc1) {
+        long long t_ssum = 0, t_ssq = 0;
+#pragma unroll
+        for (int j = 0; j < CPG_MAX; ++j) { t_ssum += t_s[j]; t_ssq += t_q[j]; }
+        const double mean = (double)t_ssum * (1.0 / DS_STAT_SUM_SCALE) * (double)p.gn_inv_count;
+        double var = (double)t_ssq * (1.0 / DS_STAT_SQ_SCALE) * (double)p.gn_inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        sc = (float)(1.0 / sqrt(var + (double)p.gn_eps)) * t_gam;
+        sh = t_bet - (float)mean * sc;
+      }
+      sTab[tid] = sc;
+      sTab[CIN + tid] = sh;
+    }
+    if (tid < CO) sTab[2 * CIN + tid] = t_bias * p.out_scale;
+  };
   const int slot = tid & (PPL - 1);
   // staging pieces of this thread, 16-byte slot tid % PPL of a pixel: piece k < NI = pixel (row k, column tid / PPL) of the tile
   // itself; piece NI + kb = border pixel tid / PPL + 32 kb of the halo line (top row, bottom row, left column, right column).
@@ -644,6 +665,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
 #pragma unroll
     for (int k = 0; k < NL; ++k) issue_one(std::integral_constant<int, CH0>{}, gc, k, k < NI ? 0 : sDesc[(k < NI ? 0 : k - NI) * NT + tid]);
     load_weights();
+    build_tables();
     sync_lds();  // tables (and the LDS-resident weight fragments) visible
     if constexpr (REL_REGS) {
 #pragma unroll
@@ -799,7 +821,7 @@ bool ds_conv_rw_eligible(const ConvArgs& a) {
   if (a.x2 ? !(a.C1 % KC == 0 && a.C1 > 0 && a.C1 < a.Cin && a.ldx % 8 == 0 && a.ldx2 % 8 == 0) : a.ldx % 8 != 0) return false;
   const bool gn = a.gn_scale || a.gn_acc1;
   if (gn && !a.gn_act) return false;  // (affine without SiLU does not occur in front of a 3x3 convolution)
-  if (a.gn_acc1 && !(a.gn_groups > 0 && a.Cin % a.gn_groups == 0 && (!a.x2 || a.gn_acc2))) return false;
+  if (a.gn_acc1 && !(a.gn_groups > 0 && a.Cin % a.gn_groups == 0 && a.Cin / a.gn_groups <= 8 && (!a.x2 || a.gn_acc2))) return false;
   if (a.sx) {
     if (!(a.sw && !a.res && (a.sCin == 64 || a.sCin == 128) && a.ldsx % 8 == 0 &&
           (!a.sx2 || (a.sC1 % KC == 0 && a.sC1 > 0 && a.sC1 < a.sCin && a.ldsx2 % 8 == 0)) &&
