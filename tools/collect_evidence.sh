@@ -3,7 +3,7 @@
 # trace of the bench command.  Run via gpurun from the repo root, then copy gpurun_out/{pmc_*,r03_*} into profiles/
 # (tools/kernel_stats_md.py turns r03_kernel_stats.csv into the markdown table).
 cd /root/repo
-export COMMIT=8a14979
+export COMMIT=720a6a8
 timeout 900 bash tools/pmc_r03.sh gpurun_out/pmc_r03 f16 > gpurun_out/pmc_r03.log 2>&1
 timeout 900 bash tools/pmc_traffic.sh gpurun_out/pmc_traffic f16 > gpurun_out/pmc_traffic.log 2>&1
 cp gpurun_out/pmc_traffic/pmc_conv3x3.json profiles/pmc_conv3x3.json
