@@ -216,7 +216,7 @@ def test_nf128_sampler_precision_gates_vs_fp32_engine():
 def test_nf128_split_sampler_parity_with_oracle():
     # the parity bar at the published width: 60 evaluations of the split engine against the CPU oracle, same noise
     cfg = O.default_config(128, 2, spec_factor=0.15)
-    T, N = 16000, 30  # (2 s: the 60 evaluations of the nf = 128 CPU oracle take ~75 s)
+    T, N = 8000, 30  # (1 s: the 60 evaluations of the nf = 128 CPU oracle take about a minute)
     eng, sd = engine(128, 2, _lib.F32_SPLIT, spec_factor=0.15)
     mix = torch.from_numpy(synth.synth_batch(1, T=T)[0])
     draws = [rnd(f"n128.z{i}", (1, 2, T)) for i in range(1 + 2 * N)]
