@@ -19,10 +19,13 @@ share in width-bucketed batches, and ONE gather at the end collects the per-utte
 the whole set; the line carries per-rank busy times and their imbalance.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     — the dominant kernel (3x3 implicit-GEMM conv on MFMA, 8x32 pixel x 64 cout tile):
-                 algorithmic FLOPs of its launches / their summed durations, measured with HIP events
-                 on the launch stream in one extra, untimed pass of the same step right after the
-                 timed region (diffsep_engine_profile_begin/end).
+  roofline     — the MFMA kernel instantiation with the most GPU time, named by its real template arguments (round 3:
+                 the register-weight 3x3 convolution conv3x3_rw_kernel<2,4,0,2,2>, 128 -> 64 couts with GroupNorm + SiLU):
+                 algorithmic FLOPs of its launches / their summed durations, measured with HIP events on the launch
+                 stream in one extra, untimed pass of the same step right after the timed region
+                 (diffsep_engine_profile_begin / _end / _records); per_shape = the same for every (instantiation, shape)
+                 at >= 128 x 128; traffic / pmc = HBM bytes and MFMA utilisation per shader cycle of that instantiation
+                 from the committed rocprofv3 --pmc passes (profiles/pmc_conv3x3.json, profiles/r03_pmc_mfma_util.json).
   cpu_baseline — the CPU oracle (torch fp32, this repo's restatement of the reference path) timed on
                  the host cores for a bounded number of network evaluations and scaled to utt/s.
   precision / <other>_mode / fp32_parity_mode / split_parity_mode — the same step in the other precision modes on the
