@@ -405,7 +405,6 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   float ssum[16], ssq[16];  // per lane: its 16 couts (8 q + 4 h + i), summed over its pixels
 #pragma unroll
   for (int j = 0; j < 16; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
-  constexpr int RES_AHEAD = 2;  // residual rows requested ahead of the row being finished
   const bool has_stats = p.stats != nullptr;
   const float osc = FOLD ? p.out_scale * -0.6931471805599453f : p.out_scale;
   // fragment base of this lane: pixel (row pg * RPW, column l32) of the halo tile, k-half h
@@ -494,7 +493,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   // of the accumulators thus always runs under the MFMAs of the other half: no second accumulator set, no phase in
   // which all waves of the chip store at once.
   constexpr int RH = RPW / 2;
+#ifdef RW_NO_ROWREUSE
   constexpr int DEPTH = RH >= 4 ? 2 : 4;  // pixel fragments are read DEPTH k-steps (>= 8 MFMAs) ahead of their use
+#endif
   auto half = [&](auto P_, auto HF_, auto EPI_, int slot_r, const TileG& ge, const TileG& g1, const TileG& g2) __attribute__((always_inline)) {
     constexpr int P = decltype(P_)::value, HF = decltype(HF_)::value;
     constexpr bool EPI = decltype(EPI_)::value;
@@ -513,12 +514,12 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     }
 #endif
     if constexpr (HF == 0 && C1 < NCH) act_tab(C1);
+#ifdef RW_NO_ROWREUSE  // (A/B: every k-step reads its own RH fragments, DEPTH k-steps ahead)
     auto ldb = [&](int ks, int r) __attribute__((always_inline)) {
       const int tap = CONV ? ks / NKB : 4, kb = ks % NKB;
       const int dy = tap / 3, dx = tap % 3;
       return *reinterpret_cast<const u32x4_t*>(fb + ((r + dy) * HW_ + dx) * AROW + kb * 32);
     };
-#ifdef RW_NO_ROWREUSE
     u32x4_t bf[DEPTH][RH];
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
