@@ -220,7 +220,18 @@ struct ConvArgs {
   int Cin, Cout, taps;
   int dtype;
   int split;                             // fp32 only: 3 bf16 MFMAs per k-block on hi / lo halves (2^-17 products) instead of fp32 MFMAs
+  unsigned opts;                         // DS_OPT_* dispatch switches (an engine's copy, or ds_default_opts() at the unit entry points)
 };
+// Dispatch switches of the convolution launchers (A/B and test aids).  The process defaults are read from
+// the environment ONCE (DIFFSEP_NO_RW, DIFFSEP_NO_RW128, DIFFSEP_RW_SMALL, DIFFSEP_NO_RW_RES) and changed with
+// diffsep_set_option; an engine copies them at creation (diffsep_engine_set_option changes its copy and drops its captured
+// graphs), so a launch decision never reads the environment.
+#define DS_OPT_NO_RW 1u       // no register-weight 3x3 kernel (conv3x3_rw.hip): generic / weight-stationary tiles instead
+#define DS_OPT_NO_RW128 2u    // ... for its 128-cout variants only
+#define DS_OPT_RW_SMALL 4u    // register-weight kernel also for launches with fewer tiles than CUs (unit tests of small shapes)
+#define DS_OPT_NO_RW_RES 8u   // residual launches stay on the weight-stationary kernel
+unsigned ds_default_opts();
+int ds_num_cus();  // compute units of the current device (cached per device ordinal)
 int ds_launch_conv(const ConvArgs& a, hipStream_t st);
 // name (with its template arguments) of the kernel instantiation the calling thread's last ds_launch_conv ran
 const char* ds_last_conv_kernel();

@@ -764,22 +764,12 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   RT_FLUSH
 }
 
-int rw_num_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  return cus;
-}
+int rw_num_cus() { return ds_num_cus(); }
 
 int rw_blocks_per_image(const ConvArgs& a, int tiles) {
   const int cus = rw_num_cus();
   int g = cus / a.B;
-#ifdef RW_TIMING  // (experiments: fewer, fatter blocks)
+#ifdef RW_TIMING  // (profiling builds only: fewer, fatter blocks)
   if (getenv("DIFFSEP_RW_G")) g = atoi(getenv("DIFFSEP_RW_G"));
 #endif
   if (g < 1) g = 1;
@@ -812,13 +802,13 @@ int rw_launch(const RwK& k0, const ConvArgs& a, hipStream_t st) {
 // The layers this kernel takes over: bf16 3x3, 64 couts, 64 or 128 input channels (one tensor or the in-place concat of
 // two), input raw or GroupNorm + SiLU, optional folded 1x1 skip on 64 / 128 raw channels, whole tiles.
 bool ds_conv_rw_eligible(const ConvArgs& a) {
-  if (getenv("DIFFSEP_NO_RW")) return false;
+  if (a.opts & DS_OPT_NO_RW) return false;
   const int CO = a.Cout;
   if (!(a.dtype == DS_BF16 && a.taps == 9 && ((CO == 64 && (a.Cin == 64 || a.Cin == 128)) || (CO == 128 && a.Cin == 128)) &&
         a.w_bs == 0 && (a.w_chunked == 0 || a.w_chunked == 32) && a.bias_mode == 0 && !a.div_b && a.W % TW == 0 && a.H % 8 == 0 &&
         a.H >= 32 && a.W >= 32 && a.ldy >= CO && a.ldy % 8 == 0 && (!a.res || (a.ldr >= CO && a.ldr % 8 == 0))))
     return false;
-  if (CO == 128 && getenv("DIFFSEP_NO_RW128")) return false;
+  if (CO == 128 && (a.opts & DS_OPT_NO_RW128)) return false;
   if (a.x2 ? !(a.C1 % KC == 0 && a.C1 > 0 && a.C1 < a.Cin && a.ldx % 8 == 0 && a.ldx2 % 8 == 0) : a.ldx % 8 != 0) return false;
   const bool gn = a.gn_scale || a.gn_acc1;
   if (gn && !a.gn_act) return false;  // (affine without SiLU does not occur in front of a 3x3 convolution)
@@ -835,17 +825,17 @@ bool ds_conv_rw_eligible(const ConvArgs& a) {
     if ((a.sx || a.res) && !gn) return false;
     // fewer 4 x 32 tiles than CUs (the 32^2 level at B = 16): a block's 295 KB weight prologue serves one tile and half
     // the chip idles — the generic tile is as fast there (22.6 vs 23.6 us) and leaves room for the other streams' blocks
-    if ((long)a.B * (a.H / 4) * (a.W / TW) < rw_num_cus() && !getenv("DIFFSEP_RW_SMALL")) return false;
+    if ((long)a.B * (a.H / 4) * (a.W / TW) < rw_num_cus() && !(a.opts & DS_OPT_RW_SMALL)) return false;
     return true;
   }
   // a residual rides as an identity-weight skip chunk: 138 us at 256^2 against 159 us on the weight-stationary kernel
-  // (+1 % end to end; DIFFSEP_NO_RW_RES=1 for the A/B)
-  if (a.res && getenv("DIFFSEP_NO_RW_RES")) return false;
+  // (+1 % end to end; option no_rw_res for the A/B)
+  if (a.res && (a.opts & DS_OPT_NO_RW_RES)) return false;
   // fewer 8 x 32 tiles than CUs: a block's weight prologue would serve a single tile and part of the chip idles — those
   // launches stay on the weight-stationary / generic kernels.  (Round 3 first kept every 64-channel launch at <= 128^2
   // there: 41.3 vs 37 us; with the tile geometry by increments the register-weight kernel is the faster one at 128^2 too —
   // Conv_0 41.8 vs 46.5 us, + residual 45.0 vs 48.2, + skip64 46.1 vs 52.0, raw 35.1 vs 42.3; +1 % end to end.)
-  if ((long)a.B * (a.H / 8) * (a.W / TW) < rw_num_cus() && !getenv("DIFFSEP_RW_SMALL")) return false;
+  if ((long)a.B * (a.H / 8) * (a.W / TW) < rw_num_cus() && !(a.opts & DS_OPT_RW_SMALL)) return false;
   return true;
 }
 
@@ -867,7 +857,11 @@ int ds_launch_conv_rw(const ConvArgs& a, hipStream_t st) {
   k.sw = reinterpret_cast<const bf16_t*>(a.sw); k.sw_chunked = a.sw_chunked; k.sw_shift = a.sw_chunked ? __builtin_ctz(a.sw_chunked) : 0;
   k.sCin = a.sCin;
   k.H = a.H; k.W = a.W; k.G = 0; k.tiles_x = 0; k.tiles_per_img = 0;
+#ifdef RW_TIMING  // (profiling builds only: stores / loads outside the tensors)
   k.dbg = getenv("DIFFSEP_RW_DBG") ? atoi(getenv("DIFFSEP_RW_DBG")) : 0;
+#else
+  k.dbg = 0;
+#endif
   if (a.res) {  // the residual [B][H][W][64] as a folded skip with identity weights (sw = null): exact in the fp32 accumulators
     k.sx = reinterpret_cast<const bf16_t*>(a.res); k.sx_bs = a.res_bs; k.ldsx = a.ldr; k.sC1 = a.Cout;
     k.sx2 = nullptr; k.sx2_bs = 0; k.ldsx2 = a.ldr; k.sw = nullptr; k.sw_chunked = 0; k.sw_shift = 0; k.sCin = a.Cout;

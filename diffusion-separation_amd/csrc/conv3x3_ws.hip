@@ -833,14 +833,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin_out_kernel(ThinOutK p) {
 }
 
 int ws_blocks_per_image(const ConvArgs& a) {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
+  const int cus = ds_num_cus();
   const int tiles = (a.H / TH) * (a.W / TW);
   int g = cus / a.B;
   if (g < 1) g = 1;

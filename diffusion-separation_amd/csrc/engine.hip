@@ -7,7 +7,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -294,6 +296,50 @@ static int weight_chunk(int taps, int cin, int c1, int dtype) {
 // Conv_2 of a block is folded into its second 3x3 convolution when that one runs on a 64-cout tile
 static bool fuse_skip(const Module& m) { return m.has_conv2 && m.out_ch > 32; }
 
+// ------------------------------------------------------------------ process-wide options, device properties
+// Defaults of the dispatch switches: the environment is read ONCE, here (never inside a launch decision); diffsep_set_option
+// changes them for engines created later and for the unit entry points.
+static unsigned g_opts = 0;
+static std::once_flag g_opts_once;
+unsigned ds_default_opts() {
+  std::call_once(g_opts_once, [] {
+    auto on = [](const char* n) { const char* v = getenv(n); return v && *v && strcmp(v, "0") != 0; };
+    if (on("DIFFSEP_NO_RW")) g_opts |= DS_OPT_NO_RW;
+    if (on("DIFFSEP_NO_RW128")) g_opts |= DS_OPT_NO_RW128;
+    if (on("DIFFSEP_RW_SMALL")) g_opts |= DS_OPT_RW_SMALL;
+    if (on("DIFFSEP_NO_RW_RES")) g_opts |= DS_OPT_NO_RW_RES;
+  });
+  return g_opts;
+}
+int ds_num_cus() {
+  static std::atomic<int> cus[32];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+  int c = cus[dev].load(std::memory_order_relaxed);
+  if (c <= 0) {
+    hipDeviceProp_t prop;
+    c = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
+    if (c <= 0) c = 256;
+    cus[dev].store(c, std::memory_order_relaxed);
+  }
+  return c;
+}
+static int opt_bit(const char* name, unsigned* bit) {
+  static const struct { const char* n; unsigned b; } tab[] = {
+      {"no_rw", DS_OPT_NO_RW}, {"no_rw128", DS_OPT_NO_RW128}, {"rw_small", DS_OPT_RW_SMALL}, {"no_rw_res", DS_OPT_NO_RW_RES}};
+  for (const auto& t : tab)
+    if (!strcmp(name, t.n)) { *bit = t.b; return 0; }
+  return 1;
+}
+extern "C" int32_t diffsep_set_option(const char* name, int64_t value) {
+  DS_CHECK(name, "set_option: null name");
+  unsigned bit = 0;
+  if (opt_bit(name, &bit)) { ds_set_error(std::string("set_option: unknown option '") + name + "'"); return 1; }
+  ds_default_opts();
+  g_opts = value ? (g_opts | bit) : (g_opts & ~bit);
+  return 0;
+}
+
 // ------------------------------------------------------------------ engine
 struct Tn {  // NHWC view; optionally the in-place channel concat of two tensors (C1 channels from p, rest from p2)
   void* p = nullptr;
@@ -343,9 +389,16 @@ struct diffsep_engine {
   bool graph_ok = false;
   // the captured graphs of the plans seen so far, keyed by (B, T): every plan lays its tensors out in the ONE arena, so a
   // graph stays valid until the arena is reallocated.  graph / gexec / graph_ok above are the current plan's entry.
-  struct GraphRec { hipGraph_t g; hipGraphExec_t x; };
+  // The cache is an LRU of graph_cap plans (option "graph_cache", default 12: a CLI meets a handful of (batch, width bucket)
+  // pairs; the Python API passes raw signal lengths, and a loop over utterances of distinct lengths must not keep one graph of
+  // several hundred nodes per length for ever).
+  struct GraphRec { hipGraph_t g; hipGraphExec_t x; uint64_t used; };
   std::map<std::pair<int, long>, GraphRec> graphs;
+  int graph_cap = 12;
+  uint64_t graph_tick = 0;
   int use_graph = 1;
+  unsigned opts = 0;      // DS_OPT_* dispatch switches of this engine's launches (copied from the process defaults at creation)
+  unsigned ablate = 0;    // option "ablate" (measurement aid, tools/ablate_bench.py): launch classes that are SKIPPED
   bool warmed = false;
   int64_t weight_bytes = 0;
   // work never runs on the legacy null stream (it cannot be captured): a NULL `stream` argument is
@@ -453,6 +506,15 @@ static float* e_f32(diffsep_engine* e, size_t n) { return (float*)e_alloc(e, n *
 static const float* P(diffsep_engine* e, const PRef& r) { return e->d_blob + r.off; }
 static const void* PK(diffsep_engine* e, long off) { return e->d_pack + off * e->esz; }
 
+// option "ablate" (a measurement aid: what would the step cost if these launches were free?): bit 0 = every convolution /
+// GEMM of the <= 16-row levels (attention included), 1 / 2 / 5 / 6 = those of the 32 / 64 / 128 / 256-row level, 3 = the
+// gn_apply / FIR resampling kernels, 4 = gn_finalize, 7 = the STFT / iSTFT passes.  Results are garbage by construction.
+static bool ablated(const diffsep_engine* e, int H) {
+  if (!e->ablate) return false;
+  const unsigned bit = H <= 16 ? 1u : H == 32 ? 2u : H == 64 ? 4u : H == 128 ? 32u : H == 256 ? 64u : 0u;
+  return (e->ablate & bit) != 0;
+}
+
 // ---- launch helpers (skip when dry)
 // GroupNorm of a conv input: either materialised per-(b,c) scale / shift arrays, or (lazy) the producers'
 // accumulators + affine parameters, from which the consuming conv builds the table itself (no launch)
@@ -469,6 +531,7 @@ static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.B = B; a.H = x.H; a.W = x.W; a.Cin = x.C; a.Cout = Cout; a.taps = taps; a.dtype = e->cfg.dtype; a.split = e->split;
+  a.opts = e->opts;
   a.x = x.p; a.x_bs = (long)x.H * x.W * x.ld; a.ldx = x.ld;
   a.x2 = x.p2; a.x2_bs = (long)x.H * x.W * x.ld2; a.ldx2 = x.ld2; a.C1 = x.C1;
   a.gn_scale = gn ? gn->scale : nullptr; a.gn_shift = gn ? gn->shift : nullptr; a.gn_act = gn_act;
@@ -496,7 +559,7 @@ static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias
               (long)((char*)y.sa - e->stats_ptr), x.C, Cout, taps, x.H, x.W, res != nullptr, skip != nullptr,
               bias_b != nullptr, ds_conv_config_id(a));
   }
-  if (e->dry) return 0;
+  if (e->dry || ablated(e, x.H)) return 0;
   return conv_launch_prof(e, a, st);
 }
 
@@ -514,7 +577,7 @@ static int gn_stats(diffsep_engine* e, const Tn& x, const float* gamma, const fl
   aff.scale = e_f32(e, (size_t)B * x.C);
   aff.shift = e_f32(e, (size_t)B * x.C);
   if (have_acc) {
-    if (e->dry) return 0;
+    if (e->dry || (e->ablate & 16u)) return 0;
     return ds_launch_gn_finalize_acc(x.sa, x.p2 ? x.C1 : x.C, x.sa2, x.p2 ? x.C - x.C1 : 0, B, (long)x.H * x.W, groups,
                                      1e-6f, gamma, beta, aff.scale, aff.shift, st);
   }
@@ -525,7 +588,7 @@ static int gn_stats(diffsep_engine* e, const Tn& x, const float* gamma, const fl
 }
 static int gn_apply(diffsep_engine* e, const Tn& x, const GnAff* aff, const Tn* y, const Tn* xr, int B, int act,
                     int mode, hipStream_t st) {
-  if (e->dry) return 0;
+  if (e->dry || (e->ablate & 8u)) return 0;
   return ds_launch_gn_apply(x.p, x.ld, aff ? aff->scale : nullptr, aff ? aff->shift : nullptr, x.C, y ? y->p : nullptr,
                             y ? y->ld : 0, xr ? xr->p : nullptr, xr ? xr->ld : 0, B, x.H, x.W, act, mode, e->cfg.dtype,
                             st);
@@ -622,7 +685,7 @@ static int attn_block(diffsep_engine* e, const Module& m, const Tn& x, int B, Tn
   void* probs = e_alloc(e, (size_t)B * L * Lp * e->esz);
   Tn o = e_tensor(e, B, x.H, x.W, C);
   out = e_tensor(e, B, x.H, x.W, C);
-  if (!e->dry) {
+  if (!e->dry && !ablated(e, x.H)) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.dtype = e->cfg.dtype; a.split = e->split; a.B = B; a.taps = 1; a.out_scale = 1.f;
@@ -769,13 +832,13 @@ static int score_forward_impl(diffsep_engine* e, const float* xt, const float* t
   const int dft_split = e->split || c.dtype == DS_BF16;
   float* ws_f = (float*)e_alloc(e, (size_t)ds_stft_workspace_bytes(B, S, T, c.n_fft, c.hop));
   float* frames = (float*)e_alloc(e, (size_t)ds_istft_workspace_bytes(B, S, T, c.n_fft, c.hop));
-  if (!e->dry)
+  if (!e->dry && !(e->ablate & 128u))
     if (ds_launch_stft_pack(xt, mix, x0.p, B, S, T, c.n_fft, c.hop, c.spec_abs_exponent, c.spec_factor, W,
                             e->arch.cpad_in, 1, c.dtype, e->d_tab, ws_f, st, dft_split))
       return 1;
   Tn pyr;
   if (net_forward(e, x0, t, y, B, st, &pyr)) return 1;
-  if (!e->dry)
+  if (!e->dry && !(e->ablate & 128u))
     if (ds_launch_istft(pyr.p, out, B, S, T, c.n_fft, c.hop, c.spec_abs_exponent, c.spec_factor, W, pyr.ld, c.dtype,
                         e->d_tab, frames, st, dft_split, P(e, e->arch.out_w), P(e, e->arch.out_b), t, e->arch.chan_in))
       return 1;
@@ -847,7 +910,10 @@ static int ensure_plan(diffsep_engine* e, int B, long T, hipStream_t st) {
   e->planT = T;
   {
     auto it = e->graphs.find(std::make_pair(B, T));
-    if (it != e->graphs.end()) { e->graph = it->second.g; e->gexec = it->second.x; e->graph_ok = true; }
+    if (it != e->graphs.end()) {
+      e->graph = it->second.g; e->gexec = it->second.x; e->graph_ok = true;
+      it->second.used = ++e->graph_tick;
+    }
   }
   e->ts_dev.clear();
   // a new plan is captured at its first score evaluation (hipFuncSetAttribute inside the launchers is not a stream
@@ -927,7 +993,8 @@ extern "C" int32_t diffsep_engine_create(const diffsep_model_config* cfg, const 
   DS_HIP(hipMalloc((void**)&e->d_dense_b, (size_t)A.dense_total * 4));
   e->weight_bytes = (int64_t)A.total * 4 + (int64_t)A.pack_total * e->esz + (int64_t)A.dense_total * (4 * cfg->nf + 1) * 4;
   if (ds_build_stft_table(cfg->n_fft, &e->d_tab)) { delete e; return 1; }
-  if (const char* sv = getenv("DIFFSEP_DBG_ALLOC")) e->dbg_alloc = atoi(sv) != 0;
+  if (const char* sv = getenv("DIFFSEP_DBG_ALLOC")) e->dbg_alloc = atoi(sv) != 0;  // (read once, at creation)
+  e->opts = ds_default_opts();
   DS_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
   DS_HIP(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
 
@@ -974,6 +1041,38 @@ extern "C" int32_t diffsep_engine_set_graph(diffsep_engine* e, int32_t enable) {
   e->use_graph = enable;
   if (!enable) drop_graph(e);
   return 0;
+}
+
+extern "C" int32_t diffsep_engine_set_option(diffsep_engine* e, const char* name, int64_t value) {
+  DS_CHECK(e && name, "engine_set_option: null argument");
+  unsigned bit = 0;
+  if (!strcmp(name, "graph_cache")) {
+    DS_CHECK(value >= 1 && value <= 4096, "engine_set_option: graph_cache must be in [1, 4096]");
+    e->graph_cap = (int)value;
+  } else if (!strcmp(name, "ablate")) {
+    e->ablate = (unsigned)value;
+  } else if (!strcmp(name, "dbg_alloc")) {
+    e->dbg_alloc = value != 0;
+    return 0;
+  } else if (!opt_bit(name, &bit)) {
+    e->opts = value ? (e->opts | bit) : (e->opts & ~bit);
+  } else {
+    ds_set_error(std::string("engine_set_option: unknown option '") + name + "'");
+    return 1;
+  }
+  // the captured graphs froze the old launch decisions (and the cache may now be over its cap): forget them all
+  DS_HIP(hipDeviceSynchronize());
+  drop_graph(e);
+  return 0;
+}
+extern "C" int64_t diffsep_engine_get_option(const diffsep_engine* e, const char* name) {
+  if (!e || !name) return -1;
+  unsigned bit = 0;
+  if (!strcmp(name, "graph_cache")) return e->graph_cap;
+  if (!strcmp(name, "graphs_cached")) return (int64_t)e->graphs.size();
+  if (!strcmp(name, "ablate")) return e->ablate;
+  if (!opt_bit(name, &bit)) return (e->opts & bit) ? 1 : 0;
+  return -1;
 }
 
 // Per-launch timing of the MFMA contraction kernels inside the real launch sequence: between
@@ -1090,7 +1189,19 @@ static int run_nfe(diffsep_engine* e, int B, long T, hipStream_t st) {
         e->graph = g;
         DS_HIP(hipGraphInstantiate(&e->gexec, e->graph, nullptr, nullptr, 0));
         e->graph_ok = true;
-        e->graphs[std::make_pair(B, (long)T)] = diffsep_engine::GraphRec{e->graph, e->gexec};
+        if ((int)e->graphs.size() >= e->graph_cap) {  // evict the least recently used plan's graph
+          // (its last replay may still be running on this stream: wait before destroying the executable)
+          DS_HIP(hipStreamSynchronize(st));
+          while ((int)e->graphs.size() >= e->graph_cap) {
+            auto lru = e->graphs.begin();
+            for (auto it = e->graphs.begin(); it != e->graphs.end(); ++it)
+              if (it->second.used < lru->second.used) lru = it;
+            if (lru->second.x) hipGraphExecDestroy(lru->second.x);
+            if (lru->second.g) hipGraphDestroy(lru->second.g);
+            e->graphs.erase(lru);
+          }
+        }
+        e->graphs[std::make_pair(B, (long)T)] = diffsep_engine::GraphRec{e->graph, e->gexec, ++e->graph_tick};
       }
     }
     if (e->graph_ok) {
@@ -1326,6 +1437,7 @@ extern "C" int32_t diffsep_conv2d(const void* x, const void* w, const float* bia
   DS_CHECK(ksize == 1 || ksize == 3, "conv2d: ksize must be 1 or 3");
   ConvArgs a;
   memset(&a, 0, sizeof(a));
+  a.opts = ds_default_opts();
   a.x = x; a.x_bs = (long)H * W * ldx; a.ldx = ldx;
   a.w = w; a.w_bs = 0;
   a.bias = bias; a.bias_b = bias_b; a.bias_b_ld = Cout; a.bias_mode = 0;
@@ -1357,6 +1469,7 @@ extern "C" int32_t diffsep_conv2d_fused(const void* x, const void* x2, int32_t C
   DS_CHECK(ksize == 1 || ksize == 3, "conv2d: ksize must be 1 or 3");
   ConvArgs a;
   memset(&a, 0, sizeof(a));
+  a.opts = ds_default_opts();
   a.stats_acc = (long long*)stats;
   if (gn_acc1) {
     DS_CHECK(gn_groups > 0 && Cin % gn_groups == 0, "conv2d: bad GroupNorm group count");
@@ -1410,6 +1523,7 @@ static int mini_engine_init(MiniEngine& me, int dtype, int temb_dim, const float
     return 1;
   }
   e->esz = dtype == DS_F32 ? 4 : 2;
+  e->opts = ds_default_opts();
   DS_HIP(hipMalloc((void**)&e->d_blob, (size_t)A.total * 4));
   DS_HIP(hipMemcpy(e->d_blob, params_host, (size_t)A.total * 4, hipMemcpyHostToDevice));
   DS_HIP(hipMalloc((void**)&e->d_pack, (size_t)A.pack_total * e->esz + 256));

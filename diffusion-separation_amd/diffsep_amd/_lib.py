@@ -73,6 +73,9 @@ _SIGS = {
     "diffsep_pc_sample_ex": (_I, [_P, C.POINTER(SdeConfig), C.POINTER(SamplerConfig), C.POINTER(SamplerExt), _P, _P, _I,
                                   _L, _P, _U64, _P, C.POINTER(_I), _P]),
     "diffsep_engine_set_graph": (_I, [_P, _I]),
+    "diffsep_set_option": (_I, [C.c_char_p, _L]),
+    "diffsep_engine_set_option": (_I, [_P, C.c_char_p, _L]),
+    "diffsep_engine_get_option": (_L, [_P, C.c_char_p]),
     "diffsep_engine_profile_begin": (_I, [_P]),
     "diffsep_engine_profile_end": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L),
                                         C.POINTER(C.c_double)]),

@@ -109,6 +109,14 @@ class Engine:
     def set_graph(self, enable):
         check(self._L.diffsep_engine_set_graph(self._h, int(bool(enable))), self._L)
 
+    def set_option(self, name, value):
+        """diffsep_engine_set_option: "no_rw" / "no_rw128" / "rw_small" / "no_rw_res" (kernel dispatch A/B), "graph_cache"
+        (captured graphs kept, LRU), "ablate" (measurement aid).  Synchronises the device, drops the captured graphs."""
+        check(self._L.diffsep_engine_set_option(self._h, str(name).encode(), int(value)), self._L)
+
+    def get_option(self, name):
+        return int(self._L.diffsep_engine_get_option(self._h, str(name).encode()))
+
     CONV_CLASSES = ("conv3x3_8x32xN64", "conv3x3_8x32xN32", "conv3x3_8x8xN64", "gemm1x1_256xN64", "gemm1x1_256xN32",
                     "gemm1x1_64xN64", "conv3x3_ws_64to64", "conv3x3_small_16couts", "conv3x3_rw_regweights")
 

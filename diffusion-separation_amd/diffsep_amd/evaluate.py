@@ -179,7 +179,7 @@ def main(argv=None):
     # records do not depend on the number of streams, of ranks, or on how the utterances are batched or dealt
     seeds = torch.randint(0, 2 ** 62, (max(n, 1),), generator=torch.Generator().manual_seed(args.seed)).tolist()
     records = []
-    fallbacks = []  # batches repeated in bf16 after non-finite f16 samples
+    fallbacks = []  # batches repeated on the split-precision engine after non-finite f16 samples
     pending = [None] * K  # per worker: the batch whose sampler is running on its stream
 
     def host_stage(group):
@@ -218,7 +218,7 @@ def main(argv=None):
         mix, mix_n, tgt_n, lens = stage(group, w, j)
         sampler = models[w].get_pc_sampler("reverse_diffusion", "ald2", mix_n, N=N, corrector_steps=cs, snr=snr,
                                            denoise=True, intermediate=False, schedule=args.schedule,
-                                           lengths=lens, seeds=[seeds[i] for i in group])
+                                           lengths=lens, seeds=[seeds[i] for i in group], check_finite=False)
         if K == 1:
             torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -232,21 +232,17 @@ def main(argv=None):
         group, lens, tgt_n, est, nfe, t0, _alive = pending[w]
         pending[w] = None
         streams[w].synchronize()
-        if not bool(torch.isfinite(est).all()):
-            # half precision overflows at 65504 (bfloat16 and fp32 do not): repeat the batch on the model's bf16 twin
-            fb = models[w].fallback_model() if hasattr(models[w], "fallback_model") else None
-            if fb is None:
-                raise RuntimeError(f"non-finite samples for utterances {group} (dtype {models[w].dtype})")
-            print(f"[evaluate] non-finite samples in batch {group[:3]}... with dtype {models[w].dtype}: repeating it in bf16",
-                  flush=True)
-            fallbacks.append(list(group))
+        # half precision overflows at 65504: a batch with non-finite samples is repeated on the model's split-precision twin
+        # (DiffSepModel.rerun_if_nonfinite — the one place that decides; raises if that is non-finite too)
+        def rerun(fb):
             with torch.cuda.stream(streams[w]):
-                est, nfe, *_ = fb.get_pc_sampler("reverse_diffusion", "ald2", _alive[1], N=N, corrector_steps=cs, snr=snr,
-                                                 denoise=True, intermediate=False, schedule=args.schedule, lengths=lens,
-                                                 seeds=[seeds[i] for i in group])()
+                r = fb.get_pc_sampler("reverse_diffusion", "ald2", _alive[1], N=N, corrector_steps=cs, snr=snr, denoise=True,
+                                      intermediate=False, schedule=args.schedule, lengths=lens,
+                                      seeds=[seeds[i] for i in group], check_finite=False)()
             streams[w].synchronize()
-            if not bool(torch.isfinite(est).all()):
-                raise RuntimeError(f"non-finite samples for utterances {group} in bf16 too")
+            fallbacks.append(list(group))
+            return r
+        est, nfe, *_ = models[w].rerun_if_nonfinite((est, nfe), rerun, what=f"utterances {group[:3]}...")
         runtime = (time.perf_counter() - t0) / len(group)
         with torch.cuda.stream(streams[w]):
             mets = compute_metrics(est, tgt_n, n_src)
@@ -290,7 +286,7 @@ def main(argv=None):
         tot_rt = sum(r["runtime"] for r in flat)
         summary.update({"rtf": tot_rt / max(sum(r["len_s"] for r in flat), 1e-9), "world_size": world,
                         "streams": K, "batch": args.batch, "engine_calls_rank0": len(batches), "dtype": model.dtype,
-                        "utt_per_s_rank0": len(mine) / max(wall, 1e-9), "bf16_fallback_batches_rank0": len(fallbacks),
+                        "utt_per_s_rank0": len(mine) / max(wall, 1e-9), "split_fallback_batches_rank0": len(fallbacks),
                         # metrics this build does not compute (third-party C code, out of scope: DESIGN.md section 7)
                         "not_computed": ["pesq", "stoi"]})
         with open(args.output_dir / f"{args.split}_summary.json", "w") as f:

@@ -3,6 +3,7 @@ the HIP engine: checkpoint loading incl. the EMA swap (pl_model.py:642-670), nor
 forward = score_fn (:407-409), get_pc_sampler (:687-759), separate (:148-164).  Training members are out
 of scope."""
 import math
+import warnings
 
 import torch
 
@@ -116,6 +117,7 @@ class DiffSepModel:
         self.t_max = self.sde.T
         self.normalize_batch = normalize_batch
         self.denormalize_batch = denormalize_batch
+        self.fallback_batches = 0  # sampler calls repeated on fallback_model() after non-finite samples
 
     # ---- checkpoint ----------------------------------------------------------------------
     @classmethod
@@ -150,16 +152,39 @@ class DiffSepModel:
         return self
 
     def fallback_model(self):
-        """A bf16 twin of this model (same weights, fp32 exponent range), created on first use.  IEEE half precision
-        overflows at 65504: an f16 / hybrid run that returns non-finite samples is repeated on it by the CLIs (bfloat16
-        has the range of fp32 and 8 significand bits: 32 dB instead of 50 from the fp32 result — and finite)."""
+        """The parity-grade twin an f16 / hybrid run is repeated on when it returns non-finite samples: the same weights on a
+        "split" engine (fp32 tensors — the range of fp32, 4e-5 from the fp32 result; a hybrid model's own head engine).  IEEE
+        half precision ends at 65504 where bfloat16 and fp32 do not; an overflow anywhere in the network reaches the output as
+        inf / NaN (residual trunk), which is what rerun_if_nonfinite looks for.  None for the modes without a range limit
+        (bf16, f32, split).  (Round 3 fell back to bf16: finite, but 13 - 19 dB from the fp32 result at nf = 128.)"""
         if self.dtype in ("bf16", "f32", "split"):
             return None
         if getattr(self, "_fallback", None) is None:
-            fb = DiffSepModel(self.config, dtype="bf16", device=self.score_model.device)
-            fb.score_model.load_state_dict(self.score_model.state_dict())
+            fb = object.__new__(DiffSepModel)
+            fb.__dict__.update(self.__dict__)
+            fb.dtype, fb.tail_model, fb.head_steps, fb._fallback, fb.fallback_batches = "split", None, 0, None, 0
+            fb.score_model = self.tail_model if self.tail_model is not None else self.score_model.twin("split")
             self._fallback = fb
         return self._fallback
+
+    def rerun_if_nonfinite(self, result, rerun, what="a batch"):
+        """THE overflow net of the 16-bit modes, in one place: get_pc_sampler wraps every sampler it returns in it, the
+        asynchronous CLIs (evaluate, separate: several batches in flight) call it when they collect a batch.
+        result = (x, nfe, ...) of a sampler of this model; rerun(fallback_model) -> the same request on the fallback.
+        Finite: returned as is.  Otherwise the request is repeated on fallback_model() (counted in .fallback_batches, with
+        a warning) — or FloatingPointError when the mode has no fallback or the repeat is non-finite too."""
+        if bool(torch.isfinite(result[0]).all()):
+            return result
+        fb = self.fallback_model()
+        if fb is None:
+            raise FloatingPointError(f"non-finite samples for {what} (dtype {self.dtype})")
+        warnings.warn(f"non-finite samples for {what} with dtype {self.dtype} (half precision overflows at 65504): "
+                      f"repeating on the split-precision engine", RuntimeWarning, stacklevel=2)
+        self.fallback_batches = getattr(self, "fallback_batches", 0) + 1
+        again = rerun(fb)
+        if not bool(torch.isfinite(again[0]).all()):
+            raise FloatingPointError(f"non-finite samples for {what} on the split-precision engine too")
+        return again
 
     def tail_engine(self):
         """the (split-)fp32 engine of dtype="hybrid" (None otherwise)"""
@@ -178,16 +203,26 @@ class DiffSepModel:
     __call__ = forward
 
     # ---- sampler factory (pl_model.py:687-759) ---------------------------------------------
-    def get_pc_sampler(self, predictor_name, corrector_name, y, N=None, minibatch=None, schedule=None, **kwargs):
+    def get_pc_sampler(self, predictor_name, corrector_name, y, N=None, minibatch=None, schedule=None, check_finite=True,
+                       **kwargs):
+        """check_finite (extension): the returned sampler looks at its samples and repeats the request on fallback_model()
+        when an f16 / hybrid run overflowed (rerun_if_nonfinite).  That look synchronises with the sampler's stream: a caller
+        that keeps several batches in flight passes check_finite=False and calls rerun_if_nonfinite when it collects one."""
         sde = self.sde.copy()
         sde.N = self.sde.N if N is None else N
         kwargs = {"eps": self.t_eps, **kwargs}
 
-        def make(y_part):
+        def make_on(model, y_part):
             if schedule is None:
-                return sdes.get_pc_sampler(predictor_name, corrector_name, sde=sde, score_fn=self, y=y_part, **kwargs)
-            return sdes.get_pc_scheduled_sampler(predictor_name, corrector_name, sde=sde, score_fn=self, y=y_part,
+                return sdes.get_pc_sampler(predictor_name, corrector_name, sde=sde, score_fn=model, y=y_part, **kwargs)
+            return sdes.get_pc_scheduled_sampler(predictor_name, corrector_name, sde=sde, score_fn=model, y=y_part,
                                                  schedule=schedule, **kwargs)
+
+        def make(y_part):
+            inner = make_on(self, y_part)
+            if not check_finite or self.fallback_model() is None:
+                return inner
+            return lambda: self.rerun_if_nonfinite(inner(), lambda fb: make_on(fb, y_part)())
 
         if minibatch is None:
             return make(y)

@@ -56,6 +56,16 @@ class ScoreModelNCSNpp:
         # random init like the reference constructor (no checkpoint yet): synthetic variance-scaling weights
         self._state = synth.synth_state_dict([(n, s) for n, s, _ in param_table(self.cfg)], init_seed)
 
+    def twin(self, dtype, lib_kind=None):
+        """The same model (same weights, shared host copy) in another precision mode; its engine is created on first use."""
+        import ctypes as C
+        t = object.__new__(ScoreModelNCSNpp)
+        t.__dict__.update(self.__dict__)
+        t.cfg = _lib.ModelConfig.from_buffer_copy(self.cfg)
+        t.cfg.dtype = {"bf16": _lib.BF16, "f16": _lib.F16, "f32": _lib.F32, "split": _lib.F32_SPLIT}[dtype]
+        t.lib_kind, t._engine = lib_kind, None
+        return t
+
     # ---- weights ---------------------------------------------------------------------------
     def param_names(self):
         return ["backbone." + n for n, _, _ in param_table(self.cfg)]

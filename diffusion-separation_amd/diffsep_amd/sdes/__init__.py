@@ -37,6 +37,17 @@ def _engine_of(score_fn):
     return eng() if callable(eng) else eng
 
 
+class _HybridScore:
+    """score_fn of the step-by-step loop on a dtype="hybrid" model: the split-precision head model while .head is set (the
+    first head_steps reverse steps), the 16-bit model after — the schedule the fused sampler runs inside one engine call."""
+
+    def __init__(self, model):
+        self.model, self.head, self.head_steps = model, True, int(getattr(model, "head_steps", 0))
+
+    def __call__(self, xt, t, mix):
+        return (self.model.tail_model if self.head else self.model.score_model)(xt, t, mix)
+
+
 def _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, denoise, eps, snr, corrector_steps,
                   probability_flow, intermediate, schedule, seed=None, lengths=None, seeds=None):
     predictor = PredictorRegistry.get_by_name(predictor_name)(sde, score_fn, probability_flow=probability_flow)
@@ -53,11 +64,15 @@ def _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, d
         raise ValueError("seed= / seeds= / lengths= are extensions of the fused engine sampler; this request "
                          "(intermediate, true_mean or a user predictor / corrector) runs the generic loop")
 
+    # dtype="hybrid" outside the fused sampler (intermediate=True, true_mean, a user-written predictor / corrector — calls the
+    # reference supports on any model): the step-by-step loop keeps the schedule — the score of the first head_steps reverse
+    # steps comes from the model's split-precision engine, the rest from its 16-bit engine — through a score function that
+    # the loop switches per step.
+    hybrid = None
     if not fused and getattr(score_fn, "tail_engine", lambda: None)() is not None:
-        # dtype="hybrid" is a schedule of the fused sampler (two engines inside one call): the step-by-step loop would
-        # evaluate every step on the 16-bit model alone, silently
-        raise ValueError("dtype='hybrid' needs the fused engine sampler; this request (intermediate, true_mean or a user "
-                         "predictor / corrector) runs the generic loop: build the model with dtype='f16', 'split' or 'f32'")
+        hybrid = _HybridScore(score_fn)
+        predictor = PredictorRegistry.get_by_name(predictor_name)(sde, hybrid, probability_flow=probability_flow)
+        corrector = CorrectorRegistry.get_by_name(corrector_name)(sde, hybrid, snr=snr, n_steps=corrector_steps)
 
     def pc_sampler():
         with torch.no_grad():
@@ -79,6 +94,8 @@ def _make_sampler(predictor_name, corrector_name, sde, score_fn, y, true_mean, d
             ts = _timesteps(sde, eps, schedule, y.device)
             xt_mean = xt
             for i in range(sde.N):
+                if hybrid is not None:
+                    hybrid.head = i < hybrid.head_steps
                 vec_t = torch.ones(y.shape[0], device=y.device) * ts[i]
                 xt, xt_mean = corrector.update_fn(xt, vec_t, y)
                 if intermediate:

@@ -51,7 +51,7 @@ def scale_output(mix, sep):
     return ops.scale_output(mix.contiguous(), sep.contiguous())
 
 
-def separate_on_device(mix, model, sampler_kwargs, device, lengths=None, seeds=None):
+def separate_on_device(mix, model, sampler_kwargs, device, lengths=None, seeds=None, check_finite=False):
     """Enqueue the separation of mix [1,T] / [B,1,T] on the current stream; returns the device tensor [B,S,T].
     lengths [B]: mix is a right-zero-padded batch of files of those lengths (normalised and rescaled per file)."""
     mix = mix.to(device)
@@ -66,7 +66,8 @@ def separate_on_device(mix, model, sampler_kwargs, device, lengths=None, seeds=N
     extra = {} if lengths is None else {"lengths": list(lengths)}
     if seeds is not None:
         extra["seeds"] = list(seeds)
-    sampler = model.get_pc_sampler("reverse_diffusion", "ald2", mix_norm, **sampler_kwargs, **extra)
+    # (check_finite=False: the callers below collect the result later and run the model's overflow net then)
+    sampler = model.get_pc_sampler("reverse_diffusion", "ald2", mix_norm, check_finite=check_finite, **sampler_kwargs, **extra)
     with torch.no_grad():
         sep, nfe, *_ = sampler()
     if lengths is None:
@@ -79,7 +80,7 @@ def separate_on_device(mix, model, sampler_kwargs, device, lengths=None, seeds=N
 
 def separate(mix, model, sampler_kwargs, device):
     """mix [1,T] (one file, like the reference) or [B,1,T] (a batch of equal-length files)."""
-    return separate_on_device(mix, model, sampler_kwargs, device).cpu()
+    return separate_on_device(mix, model, sampler_kwargs, device, check_finite=True).cpu()
 
 
 def main(argv=None):
@@ -144,17 +145,14 @@ def main(argv=None):
         group, lens, srs, sep, mix_d, sds = in_flight[w]
         in_flight[w] = None
         streams[w].synchronize()
-        sep = sep.cpu()
-        if not bool(torch.isfinite(sep).all()):
-            # half precision overflows at 65504 (bfloat16 and fp32 do not): repeat the batch on the model's bf16 twin
-            fb = models[w].fallback_model()
-            if fb is None:
-                raise RuntimeError(f"non-finite samples for {[files[i].name for i in group]}")
-            print(f"Warning: non-finite samples for {[files[i].name for i in group]} with dtype {models[w].dtype}: repeating in bf16")
+        # half precision overflows at 65504: non-finite samples -> the batch is repeated on the model's split-precision twin
+        # (DiffSepModel.rerun_if_nonfinite, the one place that decides)
+        def rerun(fb):
             with torch.cuda.stream(streams[w]):
-                sep = separate_on_device(mix_d, fb, kw, args.device, lengths=lens, seeds=sds)
+                r = separate_on_device(mix_d, fb, kw, args.device, lengths=lens, seeds=sds)
             streams[w].synchronize()
-            sep = sep.cpu()
+            return (r,)
+        sep = models[w].rerun_if_nonfinite((sep,), rerun, what=str([files[i].name for i in group]))[0].cpu()
         for b, i in enumerate(group):
             for k in range(sep.shape[1]):
                 d = args.output_dir / f"s{k}"

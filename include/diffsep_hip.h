@@ -186,6 +186,18 @@ int32_t diffsep_pc_sample_ex(diffsep_engine* e, const diffsep_sde_config* sde, c
 /* Use hipGraph replay of the per-NFE launch sequence inside diffsep_pc_sample (default 1). */
 int32_t diffsep_engine_set_graph(diffsep_engine* e, int32_t enable);
 
+/* Options (no counterpart in the reference: A/B switches, test aids and the bound of the graph cache).
+ * Process-wide defaults of the kernel-dispatch switches "no_rw", "no_rw128", "rw_small", "no_rw_res" (0 / 1): read from the
+ * environment variables DIFFSEP_NO_RW, DIFFSEP_NO_RW128, DIFFSEP_RW_SMALL, DIFFSEP_NO_RW_RES ONCE, changed here; they apply to
+ * the unit entry points (diffsep_conv2d, ...) and are copied by every engine created afterwards. */
+int32_t diffsep_set_option(const char* name, int64_t value);
+/* Per engine: the same four switches, plus "graph_cache" (captured graphs kept, least recently used evicted; default 12),
+ * "dbg_alloc" (log workspace allocations) and "ablate" (measurement aid: bit mask of launch classes that are skipped — the
+ * results are garbage).  Synchronises the device and drops the engine's captured graphs. */
+int32_t diffsep_engine_set_option(diffsep_engine* e, const char* name, int64_t value);
+/* Current value of an engine option, "graphs_cached" = number of captured graphs held; -1 for an unknown name. */
+int64_t diffsep_engine_get_option(const diffsep_engine* e, const char* name);
+
 /* Measurement hook (bench.py): between begin and end every MFMA conv/GEMM launch of the engine is
  * bracketed by HIP events on its launch stream (graph replay bypassed).  Outputs are 9-entry arrays
  * indexed by kernel class: 3x3 {8x32 tile x 64 cout, 8x32 x 32, 8x8 x 64}, then the same

@@ -87,12 +87,12 @@ def test_f16_elementwise_kernels():
     for resample in (0, 1, 2):
         y, xr = ops.groupnorm_act(x, g, be, 16, 1e-6, act=1, resample=resample, want_xr=True) if resample else \
             (ops.groupnorm_act(x, g, be, 16, 1e-6, act=1), None)
-        hn = F.silu(F.group_norm(x.float().permute(0, 3, 1, 2), 16, g, be, eps=1e-6))
-        xx = x.float().permute(0, 3, 1, 2)
+        xx = x.float().cpu().permute(0, 3, 1, 2)  # torch fp32 on the CPU
+        hn = F.silu(F.group_norm(xx, 16, g.cpu(), be.cpu(), eps=1e-6))
         if resample == 1:
-            hn, xx = O.fir_up2(hn.cpu()), O.fir_up2(xx.cpu())
+            hn, xx = O.fir_up2(hn), O.fir_up2(xx)
         elif resample == 2:
-            hn, xx = O.fir_down2(hn.cpu()), O.fir_down2(xx.cpu())
+            hn, xx = O.fir_down2(hn), O.fir_down2(xx)
         assert rel_rms(ops.to_nchw(y).float(), hn) < 1.5e-3
         if resample:
             assert rel_rms(ops.to_nchw(xr).float(), xx) < 1.5e-3

@@ -287,13 +287,13 @@ def test_evaluate_cli_two_ranks_balanced_gloo(tmp_path):
         return json.load(open(out / "test.json")), json.load(open(out / "test_summary.json")), calls
 
     one, s1, c1 = run(1, [], tmp_path / "w1")
-    # half precision can overflow where bfloat16 cannot: a batch with non-finite samples is repeated on the bf16 twin
+    # half precision can overflow where fp32 cannot: a batch with non-finite samples is repeated on the split-precision twin
     os.environ["EVAL_TEST_OVERFLOW"] = "1"
     try:
         ovf, s0, _ = run(1, [], tmp_path / "w1o")
     finally:
         del os.environ["EVAL_TEST_OVERFLOW"]
-    assert s0["bf16_fallback_batches_rank0"] >= 1 and s1["bf16_fallback_batches_rank0"] == 0
+    assert s0["split_fallback_batches_rank0"] >= 1 and s1["split_fallback_batches_rank0"] == 0
     assert [{k: v for k, v in r.items() if k != "runtime"} for r in ovf] == [{k: v for k, v in r.items() if k != "runtime"} for r in one]
     bal, s2, c2 = run(2, ["--balance"], tmp_path / "w2b")
     con, s3, c3 = run(2, [], tmp_path / "w2c")

@@ -431,11 +431,12 @@ def test_conv_groupnorm_from_producer_accumulators(dtype, tol, C1, C2, Cout, H, 
     y = ops.conv2d_fused(a, wp, bias, Cout, k, x2=bt, gn_acc=(sa, sb, g, be, groups), gn_act=1)
     # (the accumulators hold the sums BEFORE the output was rounded to the storage dtype)
     assert rel_rms(y.float(), y_ref.float()) < (1e-5 if dtype == torch.float32 else 1e-2)
-    xcat = torch.cat([a.float(), bt.float()], -1) if C2 else a.float()
-    hn = F.silu(F.group_norm(xcat.permute(0, 3, 1, 2), groups, g, be, eps=1e-6))
+    # torch fp32 on the CPU (not MIOpen on the GPU)
+    xcat = (torch.cat([a.float(), bt.float()], -1) if C2 else a.float()).cpu()
+    hn = F.silu(F.group_norm(xcat.permute(0, 3, 1, 2), groups, g.cpu(), be.cpu(), eps=1e-6))
     if dtype == torch.bfloat16:
         hn = hn.to(dtype).float()
-    ref = F.conv2d(hn, w.to(DEV), bias, padding=k // 2).permute(0, 2, 3, 1)
+    ref = F.conv2d(hn, w, bias.cpu(), padding=k // 2).permute(0, 2, 3, 1)
     assert rel_rms(y.float(), ref) < tol
 
 

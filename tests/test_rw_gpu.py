@@ -20,15 +20,13 @@ torch.set_grad_enabled(False)
 def _every_eligible_launch_on_the_rw_kernel():
     """The dispatch keeps small images (64-channel launches at <= 128^2, 128-cout launches with fewer tiles than CUs) on
     the weight-stationary / generic kernels (faster there); this module tests the register-weight kernel on them too."""
-    import os
-    old = {k: os.environ.get(k) for k in ("DIFFSEP_RW_SMALL",)}
-    os.environ.update(DIFFSEP_RW_SMALL="1")
+    from diffsep_amd import _lib
+    libs = [_lib.lib(k) for k in ("bf16", "f16")]
+    for l in libs:
+        _lib.check(l.diffsep_set_option(b"rw_small", 1), l)
     yield
-    for k, v in old.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+    for l in libs:
+        _lib.check(l.diffsep_set_option(b"rw_small", 0), l)
 DEV = "cuda"
 DT = torch.bfloat16
 
@@ -152,9 +150,10 @@ def test_rw_conv3x3_groupnorm_from_producer_accumulators(C1, C2):
     w = rnd(f"rwa.w{C}", (64, C, 3, 3), 1.0 / math.sqrt(9 * C))
     wp = ops.pack_conv_weight(w, DT).to(DEV)
     y = ops.conv2d_fused(a, wp, None, 64, 3, x2=bt, gn_acc=(sa, sb, g, be, groups), gn_act=1)
-    xcat = torch.cat([a.float(), bt.float()], -1) if C2 else a.float()
-    hn = F.silu(F.group_norm(xcat.permute(0, 3, 1, 2), groups, g, be, eps=1e-6)).to(DT).float()
-    ref = F.conv2d(hn, w.to(DT).float().to(DEV), None, padding=1).permute(0, 2, 3, 1)
+    # reference on the CPU in fp32 (torch CPU ops, not MIOpen on the GPU), on the same 16-bit-rounded operands
+    xcat = (torch.cat([a.float(), bt.float()], -1) if C2 else a.float()).cpu()
+    hn = F.silu(F.group_norm(xcat.permute(0, 3, 1, 2), groups, g.cpu(), be.cpu(), eps=1e-6)).to(DT).float()
+    ref = F.conv2d(hn, w.to(DT).float(), None, padding=1).permute(0, 2, 3, 1)
     assert rel_rms(y.float(), ref) < 1e-2
 
 
