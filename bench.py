@@ -52,11 +52,6 @@ import torch  # noqa: E402
 GFLOP_PER_NFE = {64: 133.83, 128: 532.89}  # SURVEY.md §8d, per utterance at W=256 (probe-counted 2*MAC)
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "split": 2500.0 / 3}  # MI355X_MICROARCH.md: dense MFMA peaks (split: 3 bf16 MFMAs per product)
 HBM_PEAK_BPS = 8.0e12                          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-KERNEL_NAMES = {"conv3x3_8x32xN64": "conv_mfma_kernel<%(dt)s,9,8,32,64,2,2>",
-                "conv3x3_ws_64to64": "conv3x3_ws1_kernel<%(dt)s> (weight-stationary 64->64)",
-                "gemm1x1_256xN64": "conv_mfma_kernel<%(dt)s,1,8,32,64,2,2>",
-                "conv3x3_small_16couts": "conv3x3_small_kernel<%(dt)s> (16-cout slabs, <= 16-row levels)"}
-
 
 def cpu_baseline(nf, T, budget_s=12.0, max_nfe=12):
     """Time the oracle's score evaluation (the 99 % of the path) on the host cores."""
@@ -277,6 +272,7 @@ def main():
             def device_bytes(self): return 0
         K = max(1, args.in_flight)
         engs = [_Eng() for _ in range(K)]
+        per_engine, hbm_free, hbm_total = 0, 0, 0
         ops = types.SimpleNamespace(normalize_batch=lambda m: (m, None, None), scale_output=lambda m, s: s)
         on_stream = lambda w: contextlib.nullcontext()
         sync = lambda: None
@@ -289,7 +285,19 @@ def main():
         sd = synth.synth_state_dict([(n, s) for n, s, _ in param_table(cfg)], 7)
         K = max(1, args.in_flight)
         blob = pack_state_dict(cfg, sd)
-        engs = [Engine(cfg, blob) for _ in range(K)]  # (engines before streams: hardware queues go in creation order)
+        # every rank keeps K engines (weights + a ~3.3 GB workspace each at nf = 64, B = 16: 14 GB of the 288 GB at K = 4; eight
+        # ranks on eight GPUs hold eight such sets, one per device).  The first engine is measured and K is capped by what
+        # the device has free, so that a crowded GPU degrades to fewer batches in flight instead of failing to allocate.
+        engs = [Engine(cfg, blob)]  # (engines before streams: hardware queues go in creation order)
+        engs[0].reserve(B, T)
+        per_engine = engs[0].device_bytes()
+        hbm_free, hbm_total = torch.cuda.mem_get_info()
+        k_fit = 1 + int(max(0, hbm_free - (2 << 30)) // max(per_engine, 1))
+        if k_fit < K:
+            print("bench.py: rank %d: %d batches in flight asked, HBM has room for %d engines of %.1f GB" % (rank, K, k_fit, per_engine / 1e9),
+                  file=sys.stderr, flush=True)
+            K = max(1, k_fit)
+        engs += [Engine(cfg, blob) for _ in range(K - 1)]
         if args.no_graph:
             for e in engs:
                 e.set_graph(False)
@@ -406,9 +414,12 @@ def main():
                                                                                   " +skip%d" % sk if sk else "", " +res" if hr else "", H_, W_),
                               "launches": n_, "avg_us": round(ms_ / n_ * 1e3, 1),
                               "frac_mfma": round(fl_ / (ms_ * 1e-3) / 1e12 / peak, 4),
-                              "frac_hbm": round(by_ / (ms_ * 1e-3) / HBM_PEAK_BPS, 4)})
+                              "frac_hbm": round(by_ / (ms_ * 1e-3) / HBM_PEAK_BPS, 4),
+                              # the roof that bounds THIS shape = the higher of its two floors (64-cout layers at 256^2
+                              # sit at the machine balance: their HBM floor is the higher one)
+                              "bound": "hbm" if by_ / HBM_PEAK_BPS > fl_ / (peak * 1e12) else "mfma"})
         dom_k = max(by_kernel, key=lambda k: by_kernel[k][1]) if by_kernel else None
-        kname = dom_k or (KERNEL_NAMES.get(dom, dom) % {"dt": args.dtype})
+        kname = dom_k or dom
         if dom_k:  # the roofline object describes this one instantiation
             n, ms, fl, by = by_kernel[dom_k]
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -520,8 +531,8 @@ def main():
         absr = {k: float((v - o32).double().pow(2).mean().sqrt()) for k, v in outs_.items()}
         k32, (n32, ms32, fl32) = dominant(e32)
         ksp, (nsp, mssp, flsp) = dominant(esp)
-        # hybrid (pl_model dtype="hybrid"): a split engine of the SAME library build evaluates the first 10 reverse steps,
-        # the main 16-bit engine the rest
+        # hybrid (pl_model dtype="hybrid"): a split engine of the SAME library build evaluates the first HYBRID_HEAD_STEPS
+        # reverse steps, the main 16-bit engine the rest
         hyb = None
         if args.dtype == "f16":
             from diffsep_amd.pl_model import HYBRID_HEAD_STEPS
@@ -597,14 +608,61 @@ def main():
                                    "dominant_kernel": k128, "launches": n128, "avg_launch_us": round(ms128 / n128 * 1e3, 1),
                                    "frac_mfma": round(fl128 / (ms128 * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4),
                                    "model_tflops": round(u128 * nfe * GFLOP_PER_NFE[128] * (T / 32000.0) / 1e3, 1)}
+            if args.dtype == "f16":
+                # what dtype="auto" SHIPS at this width (pl_model: hybrid for nf > 64): a split engine for the first
+                # HYBRID_HEAD_STEPS reverse steps, the f16 engine after — throughput on the same clock and the agreement of
+                # both modes with the exact fp32 engine on the same noise
+                from diffsep_amd.pl_model import HYBRID_HEAD_STEPS
+                h128 = [Engine(_lib.model_config(nf=128, num_sources=S, dtype=_lib.F32_SPLIT), blob128, lib_kind="f16") for _ in range(K2)]
+
+                def run_h128(i, w):
+                    with on_stream(w):
+                        mn, _, _ = ops.normalize_batch(mix)
+                        sep, _ = e128[w].pc_sample(mn, sde, N=args.N, corrector_steps=args.corrector_steps, snr=0.5, eps=0.03,
+                                                   denoise=True, seed=2000 + i, tail=h128[w], head_steps=HYBRID_HEAD_STEPS)
+                        out = ops.scale_output(mix, sep)
+                    keep[w] = (mn, sep, out)
+                for w in range(K2):
+                    run_h128(w, w); run_h128(w, w)
+                sync()
+                t5 = time.perf_counter()
+                for i in range(4):
+                    run_h128(i, i % K2)
+                sync()
+                uh128 = B * 4 / (time.perf_counter() - t5)
+                f128 = Engine(_lib.model_config(nf=128, num_sources=S, dtype=_lib.F32), blob128)
+                Bq = min(B, 4)  # (the exact fp32 engine at this width: a few utterances are enough for the agreement figures)
+                mq, mnq = mix[:Bq].contiguous(), mix_norm0[:Bq].contiguous()
+                r32 = ops.scale_output(mq, f128.pc_sample(mnq, sde, **kw)[0])
+                rh = ops.scale_output(mq, e128[0].pc_sample(mnq, sde, tail=h128[0], head_steps=HYBRID_HEAD_STEPS, **kw)[0])
+                r16 = ops.scale_output(mq, e128[0].pc_sample(mnq, sde, **kw)[0])
+
+                def qual(v):
+                    q_ = si_sdr_db(v, r32)
+                    return {"si_sdr_db_vs_fp32": round(float(q_.mean()), 2), "si_sdr_db_vs_fp32_min": round(float(q_.min()), 2),
+                            "rel_rms_vs_fp32": float("%.3e" % float(((v - r32).double().pow(2).mean() / r32.double().pow(2).mean()).sqrt())),
+                            "abs_rms_vs_fp32": float("%.3e" % float((v - r32).double().pow(2).mean().sqrt()))}
+                extra_json["nf128"]["hybrid"] = {"utt_per_s": round(uh128, 3), "batches_in_flight": K2, "head_steps": HYBRID_HEAD_STEPS,
+                                                 "realtime_factor": round(uh128 * T / 8000.0, 1), **qual(rh),
+                                                 "note": "the mode dtype='auto' ships at nf > 64 (pl_model.DiffSepModel); agreement on %d utterances" % Bq}
+                extra_json["nf128"]["f16_quality"] = qual(r16)
+                f128.close()
+                for e in h128:
+                    e.close()
             for e in e128:
                 e.close()
 
     ranks_seen = [0]
+    rank_elapsed = [elapsed]
+    rank_mem = [[K, int(per_engine), int(hbm_free)]]
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        # every rank's own time over the timed region (the job's time is the slowest rank's) and memory situation
+        tt = torch.tensor([elapsed, float(K), float(per_engine), float(hbm_free)], dtype=torch.float64, device=dev)
+        parts = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(parts, tt)
+        rank_elapsed = [float(q[0]) for q in parts]
+        rank_mem = [[int(q[1]), int(q[2]), int(q[3])] for q in parts]
+        elapsed = max(rank_elapsed)
         ranks_seen = seen_ranks(dist, world, rank, local_rank, dev)
 
     if rank == 0:
@@ -630,6 +688,14 @@ def main():
             "finite": finite,
             "device_bytes": sum(e.device_bytes() for e in engs),
             "ranks_seen": ranks_seen,  # [rank, local device] of every rank that took part (all-gather)
+            # weak scaling: every rank does the same work, so max / mean of the ranks' own times is the imbalance the
+            # slowest GPU (clocks, neighbours on the fabric) imposes on the job
+            "rank_elapsed_s_per_step": [round(t_ / args.steps, 4) for t_ in rank_elapsed],
+            "imbalance_max_over_mean": round(max(rank_elapsed) / (sum(rank_elapsed) / len(rank_elapsed)), 4),
+            "hbm": {"engines_per_rank": [m_[0] for m_ in rank_mem], "bytes_per_engine": rank_mem[0][1],
+                    "free_bytes_before_engines_min": min(m_[2] for m_ in rank_mem),
+                    "note": "one process and one set of engines per GPU; GPU_MAX_HW_QUEUES=8 is per process (its own device), "
+                            "so eight ranks do not share hardware queues"},
         }
         if roof is not None:
             res["roofline"] = roof

@@ -197,6 +197,9 @@ struct ConvArgs {
   int C1;                                // channels taken from x when x2 != null
   const void* w; long w_bs;              // Bt operand: [Cout][taps][Cin]; w_bs batch stride (0 = shared)
   int w_chunked;                         // != 0: weights are chunk-major [Cin/kc][taps][Cout][kc] with kc = this value
+  // optional second copies of w / sw in the register-weight kernel's FRAGMENT-major order (conv3x3_rw.hip, ds_rw_frag_index):
+  // one load instruction of a wave = 1 KB of contiguous memory.  Null: that kernel gathers its fragments from w / sw.
+  const void* w_frag; const void* sw_frag;
   // optional fused 1x1 skip convolution on the raw block input (3x3 launches only): y += sw * cat([sx, sx2])
   const void* sx; long sx_bs; int ldsx;  //   [B][M][ldsx], sCin channels (sC1 from sx when sx2 != null)
   const void* sx2; long sx2_bs; int ldsx2; int sC1; int sCin;
@@ -230,6 +233,8 @@ struct ConvArgs {
 #define DS_OPT_NO_RW128 2u    // ... for its 128-cout variants only
 #define DS_OPT_RW_SMALL 4u    // register-weight kernel also for launches with fewer tiles than CUs (unit tests of small shapes)
 #define DS_OPT_NO_RW_RES 8u   // residual launches stay on the weight-stationary kernel
+#define DS_OPT_NO_ATTN_FUSED 64u  // attention blocks as the 11 separate launches of rounds 1 - 3 (A/B)
+#define DS_OPT_NO_WFRAG 32u   // the engine does not hand the fragment-major weight copies to the register-weight kernel (A/B)
 unsigned ds_default_opts();
 int ds_num_cus();  // compute units of the current device (cached per device ordinal)
 int ds_launch_conv(const ConvArgs& a, hipStream_t st);
@@ -239,6 +244,15 @@ void ds_set_last_conv_kernel(const char* name);
 int ds_conv_config_id(const ConvArgs& a);
 int ds_conv_chunk(int taps, int dtype);
 bool ds_conv_skip_supported(int H, int W, int Cout, int dtype);
+// layout of the fragment-major copies: element (cout co, tap, input channel ch) of a [Cout][taps][Cin] weight tensor lives at
+//   ((((ch / 64 * taps + tap) * 4 + ch % 64 / 16) * (Cout / 32) + co / 32) * 64 + (ch % 16 / 8) * 32 + co % 32) * 8 + ch % 8
+// (k-step = (64-channel chunk, tap, 16-channel block); then cout group, lane = (k-half, cout), 8 channels)
+__host__ __device__ inline long ds_rw_frag_index(int co, int tap, int ch, int taps, int Cout) {
+  return (((((long)(ch / 64) * taps + tap) * 4 + (ch % 64) / 16) * (Cout / 32) + co / 32) * 64 + ((ch % 16) / 8) * 32 + co % 32) * 8 + ch % 8;
+}
+inline bool ds_rw_frag_shape(int taps, int Cin, int Cout) {  // the weight shapes conv3x3_rw.hip can take (3x3 and folded 1x1 skip)
+  return (Cout == 64 || Cout == 128) && (Cin == 64 || Cin == 128) && (taps == 1 || !(Cout == 128 && Cin == 64));
+}
 bool ds_conv_rw_eligible(const ConvArgs& a);   // conv3x3_rw.hip: register-resident weights, 64 / 128 -> 64 bf16, >= 32-row images
 int ds_launch_conv_rw(const ConvArgs& a, hipStream_t st);
 bool ds_conv_ws_eligible(const ConvArgs& a);   // conv3x3_ws.hip: weight-stationary 64 -> 64 bf16 kernel
@@ -249,6 +263,22 @@ bool ds_conv_thin_out_eligible(const ConvArgs& a);   // conv3x3_ws.hip: the <= 8
 int ds_launch_conv_thin_out(const ConvArgs& a, hipStream_t st);
 bool ds_conv_small_eligible(const ConvArgs& a);  // conv3x3_small.hip: <= 16-row images, 16-cout slabs, bf16
 int ds_launch_conv_small(const ConvArgs& a, hipStream_t st);
+
+// attn_fused.hip: AttnBlockpp as one kernel (16-bit storage, 128 channels, <= 256 pixels per sample).  Weights in the
+// fragment-major order of ds_rw_frag_index(row, 0, column, 1, 128): wq / wv / wo = NIN_0 / 2 / 3 as [out][in], wkt = NIN_1 as
+// [in][out]; x: [B][L][ldx]; GroupNorm of x from its producer's accumulators (gn_acc) or from scale / shift arrays [B][C].
+struct AttnFusedArgs {
+  const void* x; long x_bs; int ldx;
+  const long long* gn_acc; const float* gn_gamma; const float* gn_beta; int gn_groups; float gn_inv_count; float gn_eps;
+  const float* gn_scale; const float* gn_shift;
+  const void* wq; const void* wkt; const void* wv; const void* wo;
+  const float* bq; const float* bv; const float* bo;
+  void* y; long y_bs; int ldy;
+  long long* stats;  // [B][C][2] accumulators of the output (nullable)
+  int B, L, C;
+};
+bool ds_attn_fused_eligible(int dtype, int channels, int L);
+int ds_launch_attn_fused(const AttnFusedArgs& a, hipStream_t st);
 
 // GroupNorm: stats -> per-(b,c) scale/shift -> apply(+SiLU)(+FIR resample)
 // ws layout: doubles [B][nblk][C][2] then floats scale[B][C], shift[B][C]

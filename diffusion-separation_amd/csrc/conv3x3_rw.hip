@@ -87,6 +87,7 @@ struct RwK {
   const bf16_t* x; long x_bs; int ldx; int C1;     // channels [0, C1) from x, [C1, Cin) from x2
   const bf16_t* x2; long x2_bs; int ldx2;
   const bf16_t* w; int w_chunked;                  // [64][9][Cin] or chunk-major [Cin/32][9][64][32]
+  const bf16_t* wfrag; const bf16_t* swfrag;       // optional fragment-major copies of w / sw (ds_rw_frag_index): [k-step][cout group][lane][8]
   const float* gn_scale; const float* gn_shift;    // [B][Cin] or null
   const long long* gn_acc1; const long long* gn_acc2; const float* gn_gamma; const float* gn_beta;
   int gn_groups; float gn_inv_count; float gn_eps;
@@ -250,26 +251,32 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     else if (pg == 0) *reinterpret_cast<u32x4_t*>(sWl + (ks - NWR) * G::WL_STEP) = v;
   };
   auto load_weights = [&]() __attribute__((always_inline)) {
-    const __amdgpu_buffer_rsrc_t rw = rsrc(p.w, 9u * CO * CIN * 2u);
-    const __amdgpu_buffer_rsrc_t rsw = (NSK && p.sw) ? rsrc(p.sw, (unsigned)CO * G::SCIN * 2u) : rsrc(p.w, 0u);
+    // fragment-major copies (the engine's layers): a wave's load instruction = 1 KB of contiguous memory, 8 full 128-byte lines,
+    // instead of 32-byte pieces of 32 rows (16 half-used lines that the k-block's other half touches again later)
+    const bool wfm = p.wfrag != nullptr, sfm = NSK && p.swfrag != nullptr;  // (uniform)
+    const __amdgpu_buffer_rsrc_t rw = rsrc(wfm ? p.wfrag : p.w, 9u * CO * CIN * 2u);
+    const __amdgpu_buffer_rsrc_t rsw = (NSK && p.sw) ? rsrc(sfm ? p.swfrag : p.sw, (unsigned)CO * G::SCIN * 2u) : rsrc(p.w, 0u);
+    const unsigned vfrag = (unsigned)((cg * 64 + lane) * 16);
     const int co = cg * 32 + l32;
     // 3x3: [64][9][Cin]: (co * 9 + tap) * Cin + ch; chunk-major [Cin/32][9][64][32]: ((ch / 32 * 9 + tap) * 64 + co) * 32 + ch % 32
     const bool wc = p.w_chunked != 0;  // (uniform: the per-fragment part of the offset is a scalar select)
-    const unsigned vlane = wc ? (unsigned)((co * 32 + h * 8) * 2) : (unsigned)((co * 9 * CIN + h * 8) * 2);
+    const unsigned vlane = wfm ? vfrag : (wc ? (unsigned)((co * 32 + h * 8) * 2) : (unsigned)((co * 9 * CIN + h * 8) * 2));
     // skip: [64][sCin]: co * sCin + ch; chunk-major [sCin/kc][64][kc] (kc >= 16: a 16-channel k-block never straddles a
     // layout chunk): ((ch / kc) * 64 + co) * kc + ch % kc
     const bool sc_ = NSK && p.sw_chunked != 0;
     const int kcs = sc_ ? p.sw_chunked : 16;
-    const unsigned vl2 = sc_ ? (unsigned)((co * kcs + h * 8) * 2) : (unsigned)((co * G::SCIN + h * 8) * 2);
+    const unsigned vl2 = sfm ? vfrag : (sc_ ? (unsigned)((co * kcs + h * 8) * 2) : (unsigned)((co * G::SCIN + h * 8) * 2));
     auto load_one = [&](int ks) __attribute__((always_inline)) {
       if (ks < NCH * KSC) {
         const int c = ks / KSC, tap = (ks % KSC) / NKB, kb = ks % NKB;
         const int chb = c * KC + kb * 16;  // first channel of the k-block (this lane: + 8 h)
-        const unsigned so = wc ? (unsigned)((((chb >> 5) * 9 + tap) * CO * 32 + (chb & 31)) * 2) : (unsigned)((tap * CIN + chb) * 2);
+        const unsigned so = wfm ? (unsigned)(ks * NCG * 1024)
+                                : (wc ? (unsigned)((((chb >> 5) * 9 + tap) * CO * 32 + (chb & 31)) * 2) : (unsigned)((tap * CIN + chb) * 2));
         put_w(ks, ld16(rw, vlane, so));
       } else {
         const int chb = (ks - NCH * KSC) * 16;
-        const unsigned so = sc_ ? (unsigned)((((chb >> p.sw_shift) * CO) * kcs + (chb & (kcs - 1))) * 2) : (unsigned)(chb * 2);
+        const unsigned so = sfm ? (unsigned)((ks - NCH * KSC) * NCG * 1024)
+                                : (sc_ ? (unsigned)((((chb >> p.sw_shift) * CO) * kcs + (chb & (kcs - 1))) * 2) : (unsigned)(chb * 2));
         u32x4_t f = ld16(rsw, vl2, so);
         if (!p.sw) {  // residual as a skip with identity weights: channel chb + 8 h + j feeds cout co with weight 1
           const int d = co - (chb + 8 * h);  // the lane's 8 channels hold the 1 at position d (if 0 <= d < 8)
@@ -844,6 +851,8 @@ int ds_launch_conv_rw(const ConvArgs& a, hipStream_t st) {
   k.x = reinterpret_cast<const bf16_t*>(a.x); k.x_bs = a.x_bs; k.ldx = a.ldx; k.C1 = a.x2 ? a.C1 : a.Cin;
   k.x2 = reinterpret_cast<const bf16_t*>(a.x2); k.x2_bs = a.x2_bs; k.ldx2 = a.x2 ? a.ldx2 : a.ldx;
   k.w = reinterpret_cast<const bf16_t*>(a.w); k.w_chunked = a.w_chunked;
+  k.wfrag = reinterpret_cast<const bf16_t*>(a.w_frag);
+  k.swfrag = (a.sx && a.sw) ? reinterpret_cast<const bf16_t*>(a.sw_frag) : nullptr;
   k.gn_scale = a.gn_scale; k.gn_shift = a.gn_shift;
   k.gn_acc1 = a.gn_acc1; k.gn_acc2 = a.gn_acc2; k.gn_gamma = a.gn_gamma; k.gn_beta = a.gn_beta;
   k.gn_groups = a.gn_groups; k.gn_inv_count = a.gn_inv_count; k.gn_eps = a.gn_eps;

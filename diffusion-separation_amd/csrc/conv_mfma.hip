@@ -877,6 +877,8 @@ static int launch_typed(const ConvArgs& a, hipStream_t st) {
       // (one batch alone 325.6 -> 320.6 ms, four in flight unchanged)
       const long blocks = (long)cdiv(a.W, 32) * cdiv(a.H, 8) * cdiv(a.Cout, 64) * a.B;
       if constexpr (sizeof(T) == 2) {
+      // (64-channel K stages at one block per CU for these launches — option kc64 of round 4 — shortened a block's life by
+      // 13 % and moved neither the one-batch latency nor the in-flight throughput: profiles/experiments/README.md)
       if (blocks <= 128) return launch_cfg<T, 9, 8, 16, 64, 1, 2, KC9, 1, 2, SP>(a, st);
       // many tiles and >= 128 couts: one 8-wave block computes 128 couts of a tile, so the halo tile is loaded and
       // activated once per 128 couts instead of once per 64 (nf = 128: 20.3 -> 20.9 utt/s; nf = 64: unchanged)

@@ -48,6 +48,10 @@ struct Module {
   PRef nin_w[4], nin_b[4];
   // packed (engine dtype) weight offsets in elements
   long pk0 = -1, pk1 = -1, pk2 = -1, pk_nin[4] = {-1, -1, -1, -1};
+  // second copies of Conv_0 / Conv_1 / Conv_2 in the register-weight kernel's fragment-major order (16-bit engines, the shapes
+  // that kernel takes: ds_rw_frag_shape), -1 = none
+  long pf0 = -1, pf1 = -1, pf2 = -1;
+  long pf_nin[4] = {-1, -1, -1, -1};  // attention projections in fragment-major order (attn_fused.hip; 128 channels only)
 };
 
 struct Arch {
@@ -134,6 +138,9 @@ struct ArchBuilder {
     }
     m.pk0 = pack(out, 9, in);
     m.pk1 = pack(out, 9, out);
+    if (ds_rw_frag_shape(9, in, out)) m.pf0 = pack(out, 9, in);
+    if (ds_rw_frag_shape(9, out, out)) m.pf1 = pack(out, 9, out);
+    if (m.has_conv2 && ds_rw_frag_shape(1, in, out)) m.pf2 = pack(out, 1, in);
     m.temb_off = A.dense_total;
     A.dense_total += out;
     A.mods.push_back(m);
@@ -147,6 +154,7 @@ struct ArchBuilder {
       m.nin_w[i] = add(p + "NIN_" + std::to_string(i) + ".W", {c, c});
       m.nin_b[i] = add(p + "NIN_" + std::to_string(i) + ".b", {c});
       m.pk_nin[i] = pack(c, 1, c);
+      if (c == 128) m.pf_nin[i] = pack(c, 1, c);
     }
     A.mods.push_back(m);
   }
@@ -287,6 +295,17 @@ __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ s
     Elt<T>::st(dst + d, v);
   }
 }
+// dst[ds_rw_frag_index(o, tap, i)] = src[o*so + i*si + tap*st]: the register-weight kernel's fragment-major copy (16-bit only)
+__global__ __launch_bounds__(256) void repack_frag_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int O, int I,
+                                                          int taps, long so, long si, long st) {
+  const long total = (long)O * taps * I;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int i = (int)(idx % I);
+    const long r = idx / I;
+    const int tap = (int)(r % taps), o = (int)(r / taps);
+    dst[ds_rw_frag_index(o, tap, i, taps, O)] = f2h(src[o * so + i * si + tap * st]);
+  }
+}
 // Which weights the engine keeps chunk-major: every conv whose input channels are a multiple of 64 and whose concat
 // split (c1 channels from the first source, 0 = no concat) falls on a chunk boundary
 static int weight_chunk(int taps, int cin, int c1, int dtype) {
@@ -326,7 +345,9 @@ int ds_num_cus() {
 }
 static int opt_bit(const char* name, unsigned* bit) {
   static const struct { const char* n; unsigned b; } tab[] = {
-      {"no_rw", DS_OPT_NO_RW}, {"no_rw128", DS_OPT_NO_RW128}, {"rw_small", DS_OPT_RW_SMALL}, {"no_rw_res", DS_OPT_NO_RW_RES}};
+      {"no_rw", DS_OPT_NO_RW}, {"no_rw128", DS_OPT_NO_RW128}, {"rw_small", DS_OPT_RW_SMALL}, {"no_rw_res", DS_OPT_NO_RW_RES},
+      {"no_wfrag", DS_OPT_NO_WFRAG},
+      {"no_attn_fused", DS_OPT_NO_ATTN_FUSED}};
   for (const auto& t : tab)
     if (!strcmp(name, t.n)) { *bit = t.b; return 0; }
   return 1;
@@ -505,6 +526,7 @@ static Tn e_tensor(diffsep_engine* e, int B, int H, int W, int C) {
 static float* e_f32(diffsep_engine* e, size_t n) { return (float*)e_alloc(e, n * 4); }
 static const float* P(diffsep_engine* e, const PRef& r) { return e->d_blob + r.off; }
 static const void* PK(diffsep_engine* e, long off) { return e->d_pack + off * e->esz; }
+static const void* PKF(diffsep_engine* e, long off) { return off >= 0 ? e->d_pack + off * e->esz : nullptr; }
 
 // option "ablate" (a measurement aid: what would the step cost if these launches were free?): bit 0 = every convolution /
 // GEMM of the <= 16-row levels (attention included), 1 / 2 / 5 / 6 = those of the 32 / 64 / 128 / 256-row level, 3 = the
@@ -523,11 +545,11 @@ struct GnAff {
   const long long* acc1 = nullptr; const long long* acc2 = nullptr;
   const float* gamma = nullptr; const float* beta = nullptr; int groups = 0; float inv_count = 0.f;
 };
-struct SkipConv { const Tn* x; const void* w; int chunk; };  // fused 1x1 skip convolution on the raw block input
+struct SkipConv { const Tn* x; const void* w; int chunk; const void* w_frag; };  // fused 1x1 skip convolution on the raw block input
 static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias, const float* bias_b, int bias_b_ld,
                 const Tn* res, float scale, Tn& y, int Cout, int taps, int B, const float* div_b,
                 hipStream_t st, const GnAff* gn = nullptr, int gn_act = 0, bool want_stats = false,
-                const SkipConv* skip = nullptr) {
+                const SkipConv* skip = nullptr, const void* w_frag = nullptr) {
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.B = B; a.H = x.H; a.W = x.W; a.Cin = x.C; a.Cout = Cout; a.taps = taps; a.dtype = e->cfg.dtype; a.split = e->split;
@@ -540,6 +562,8 @@ static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias
     a.gn_groups = gn->groups; a.gn_inv_count = gn->inv_count; a.gn_eps = 1e-6f;
   }
   a.w = w; a.w_bs = 0; a.w_chunked = weight_chunk(taps, x.C, x.p2 ? x.C1 : 0, e->cfg.dtype);
+  const bool use_frag = e->cfg.dtype == DS_BF16 && !(e->opts & DS_OPT_NO_WFRAG);
+  a.w_frag = use_frag ? w_frag : nullptr;
   a.bias = bias; a.bias_b = bias_b; a.bias_b_ld = bias_b_ld; a.bias_mode = 0; a.div_b = div_b;
   a.res = res ? res->p : nullptr; a.res_bs = res ? (long)res->H * res->W * res->ld : 0; a.ldr = res ? res->ld : 0;
   a.out_scale = scale;
@@ -549,6 +573,7 @@ static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias
     a.sx = sx.p; a.sx_bs = (long)sx.H * sx.W * sx.ld; a.ldsx = sx.ld;
     a.sx2 = sx.p2; a.sx2_bs = (long)sx.H * sx.W * sx.ld2; a.ldsx2 = sx.ld2; a.sC1 = sx.C1; a.sCin = sx.C;
     a.sw = skip->w; a.sw_chunked = skip->chunk;
+    a.sw_frag = use_frag ? skip->w_frag : nullptr;
   }
   if (want_stats) {  // the consumer's GroupNorm reads these partials instead of re-reading the tensor
     y.sa = e_alloc_stats(e, (size_t)B * Cout * 2 * sizeof(long long));
@@ -619,21 +644,21 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
   if (!m.has_conv2) DS_CHECK(xr.p2 == nullptr, "internal: identity skip on a concat view");
   if (mode) {
     if (conv(e, h0m, PK(e, m.pk0), P(e, m.conv0_b), temb_proj + m.temb_off, e->arch.dense_total, nullptr, 1.f, h1,
-             m.out_ch, 9, B, nullptr, st, nullptr, 0, true))
+             m.out_ch, 9, B, nullptr, st, nullptr, 0, true, nullptr, PKF(e, m.pf0)))
       return 1;
   } else {
     if (conv(e, x, PK(e, m.pk0), P(e, m.conv0_b), temb_proj + m.temb_off, e->arch.dense_total, nullptr, 1.f, h1,
-             m.out_ch, 9, B, nullptr, st, &a0, 1, true))
+             m.out_ch, 9, B, nullptr, st, &a0, 1, true, nullptr, PKF(e, m.pf0)))
       return 1;
   }
   if (gn_stats(e, h1, P(e, m.gn1_w), P(e, m.gn1_b), B, a1, st, true)) return 1;
   out = e_tensor(e, B, Ho, Wo, m.out_ch);
   if (m.has_conv2 && fuse_skip(m)) {
     DS_CHECK(ds_conv_skip_supported(Ho, Wo, m.out_ch, e->cfg.dtype), "internal: fused skip conv on an unsupported tile");
-    const SkipConv sk = {&xr, PK(e, m.pk2), weight_chunk(9, m.in_ch, m.in_c1, e->cfg.dtype)};
+    const SkipConv sk = {&xr, PK(e, m.pk2), weight_chunk(9, m.in_ch, m.in_c1, e->cfg.dtype), PKF(e, m.pf2)};
     // conv bias + Conv_2 bias: the second goes in as a "per-batch" bias with stride 0
     return conv(e, h1, PK(e, m.pk1), P(e, m.conv1_b), P(e, m.conv2_b), 0, nullptr, kInvSqrt2, out, m.out_ch, 9, B,
-                nullptr, st, &a1, 1, true, &sk);
+                nullptr, st, &a1, 1, true, &sk, PKF(e, m.pf1));
   }
   Tn skip = xr;
   if (m.has_conv2) {  // narrow blocks (<= 32 couts use the 32-cout tile, which has no skip path): separate 1x1 launch
@@ -641,7 +666,7 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
     if (conv(e, xr, PK(e, m.pk2), P(e, m.conv2_b), nullptr, 0, nullptr, 1.f, skip, m.out_ch, 1, B, nullptr, st)) return 1;
   }
   return conv(e, h1, PK(e, m.pk1), P(e, m.conv1_b), nullptr, 0, &skip, kInvSqrt2, out, m.out_ch, 9, B, nullptr, st,
-              &a1, 1, true);
+              &a1, 1, true, nullptr, PKF(e, m.pf1));
 }
 
 // attention core shared with the unit entry point: o = softmax(q k^T C^-1/2) v
@@ -672,6 +697,28 @@ static int attention_core(const void* q, const void* k, const void* vt, void* o,
 static int attn_block(diffsep_engine* e, const Module& m, const Tn& x, int B, Tn& out, hipStream_t st) {
   const int C = m.in_ch, L = x.H * x.W, Lp = rup8(L);
   DS_CHECK(x.C == C, "internal: attention channel mismatch");
+  if (ds_attn_fused_eligible(e->cfg.dtype, C, L) && !x.p2 && m.pf_nin[0] >= 0 && !(e->opts & DS_OPT_NO_ATTN_FUSED)) {
+    // the whole block in one launch (attn_fused.hip): GroupNorm from the producer's accumulators (a tensor without them — the
+    // unit entry point — gets the statistics kernels first), projections, softmax attention, output projection, residual,
+    // statistics for the consumer
+    GnAff ga;
+    if (!x.sa && gn_stats(e, x, P(e, m.gn0_w), P(e, m.gn0_b), B, ga, st)) return 1;
+    out = e_tensor(e, B, x.H, x.W, C);
+    out.sa = e_alloc_stats(e, (size_t)B * C * 2 * sizeof(long long));
+    if (!out.sa) return 1;
+    if (e->dry || ablated(e, x.H)) return 0;
+    AttnFusedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x.p; a.x_bs = (long)L * x.ld; a.ldx = x.ld;
+    a.gn_acc = x.sa; a.gn_scale = ga.scale; a.gn_shift = ga.shift; a.gn_gamma = P(e, m.gn0_w); a.gn_beta = P(e, m.gn0_b);
+    a.gn_groups = (C / 4 < 32) ? C / 4 : 32; a.gn_inv_count = (float)(1.0 / ((double)L * (C / a.gn_groups))); a.gn_eps = 1e-6f;
+    a.wq = PKF(e, m.pf_nin[0]); a.wkt = PKF(e, m.pf_nin[1]); a.wv = PKF(e, m.pf_nin[2]); a.wo = PKF(e, m.pf_nin[3]);
+    a.bq = P(e, m.nin_b[0]); a.bv = P(e, m.nin_b[2]); a.bo = P(e, m.nin_b[3]);
+    a.y = out.p; a.y_bs = (long)L * out.ld; a.ldy = out.ld;
+    a.stats = out.sa;
+    a.B = B; a.L = L; a.C = C;
+    return ds_launch_attn_fused(a, st);
+  }
   GnAff a0;
   if (gn_stats(e, x, P(e, m.gn0_w), P(e, m.gn0_b), B, a0, st)) return 1;
   Tn h = e_tensor(e, B, x.H, x.W, C);
@@ -941,6 +988,13 @@ static int repack_weight(diffsep_engine* e, const PRef& src, long pk, int O, int
   DS_LAUNCH_CHECK();
   return 0;
 }
+static int repack_frag(diffsep_engine* e, const PRef& src, long pf, int O, int I, int taps, long so, long si, long stp) {
+  if (pf < 0 || e->cfg.dtype != DS_BF16) return 0;
+  hipLaunchKernelGGL(repack_frag_kernel, dim3(cdiv((long)O * taps * I, 256)), dim3(256), 0, 0, e->d_blob + src.off,
+                     (bf16_t*)(e->d_pack) + pf, O, I, taps, so, si, stp);
+  DS_LAUNCH_CHECK();
+  return 0;
+}
 static int repack_module(diffsep_engine* e, const Module& m) {
   int rc = 0;
   switch (m.kind) {
@@ -951,6 +1005,9 @@ static int repack_module(diffsep_engine* e, const Module& m) {
       rc |= repack_weight(e, m.conv1_w, m.pk1, m.out_ch, m.out_ch, 9, (long)m.out_ch * 9, 9, 1);
       if (m.has_conv2)
         rc |= repack_weight(e, m.conv2_w, m.pk2, m.out_ch, m.in_ch, 1, m.in_ch, 1, 0, true, fuse_skip(m) ? 9 : 0, m.in_c1);
+      rc |= repack_frag(e, m.conv0_w, m.pf0, m.out_ch, m.in_ch, 9, (long)m.in_ch * 9, 9, 1);
+      rc |= repack_frag(e, m.conv1_w, m.pf1, m.out_ch, m.out_ch, 9, (long)m.out_ch * 9, 9, 1);
+      if (m.has_conv2) rc |= repack_frag(e, m.conv2_w, m.pf2, m.out_ch, m.in_ch, 1, m.in_ch, 1, 0);
       // Dense_0.weight [out][temb dim] -> columns [temb_off, temb_off + out) of the transposed concatenation
       // [temb dim][dense_total] (ds_launch_linear_t)
       rc |= ds_launch_dense_transpose(e->d_blob + m.dense_w.off, e->d_dense_w, m.out_ch, (int)(m.dense_w.numel / m.out_ch),
@@ -962,6 +1019,10 @@ static int repack_module(diffsep_engine* e, const Module& m) {
       // (the V projection is the A operand of its GEMM: it stays row-major)
       for (int i = 0; i < 4; ++i)
         rc |= repack_weight(e, m.nin_w[i], m.pk_nin[i], m.in_ch, m.in_ch, 1, 1, m.in_ch, 0, i != 2);
+      // fused attention kernel: NIN.W is [in][out]; rows of the fragment-major copy = outputs ([out][in]) for NIN_0 / 2 / 3,
+      // = inputs ([in][out]) for NIN_1 (the key projection applied to the query side: attn_fused.hip)
+      for (int i = 0; i < 4; ++i)
+        rc |= repack_frag(e, m.nin_w[i], m.pf_nin[i], m.in_ch, m.in_ch, 1, i == 1 ? m.in_ch : 1, i == 1 ? 1 : m.in_ch, 0);
       break;
     default: break;
   }
@@ -1409,6 +1470,22 @@ extern "C" int32_t diffsep_pc_sample(diffsep_engine* e, const diffsep_sde_config
 }
 
 // ------------------------------------------------------------------ unit entry points
+// The time embedding of NCSNpp.forward (ncsnpp.py:324-343): GaussianFourierProjection(log t) -> Linear -> SiLU -> Linear, with
+// the kernels net_forward launches.  temb [B][4 nf]; workspace >= B * 6 nf floats.
+extern "C" int32_t diffsep_time_embedding(const float* t, const float* fourier_w, const float* w1, const float* b1,
+                                          const float* w2, const float* b2, float* temb, int32_t B, int32_t nf,
+                                          void* workspace, int64_t workspace_bytes, void* stream) {
+  DS_CHECK(t && fourier_w && w1 && b1 && w2 && b2 && temb && workspace, "time_embedding: null pointer");
+  DS_CHECK(B >= 1 && nf >= 8 && nf % 8 == 0, "time_embedding: bad B / nf");
+  DS_CHECK(workspace_bytes >= (int64_t)B * 6 * nf * 4, "time_embedding: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* emb = (float*)workspace;
+  float* t1 = emb + (size_t)B * 2 * nf;
+  if (ds_launch_fourier(t, fourier_w, emb, B, nf, st)) return 1;
+  if (ds_launch_linear(emb, w1, b1, t1, B, 2 * nf, 4 * nf, 0, st)) return 1;
+  return ds_launch_linear(t1, w2, b2, temb, B, 4 * nf, 4 * nf, 1, st);
+}
+
 extern "C" int32_t diffsep_upfirdn2d(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ldx,
                                      int32_t ldy, int32_t up, int32_t dtype, void* stream) {
   DS_CHECK(x && y, "upfirdn2d: null pointer");

@@ -80,6 +80,7 @@ _SIGS = {
     "diffsep_engine_profile_end": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L),
                                         C.POINTER(C.c_double)]),
     "diffsep_engine_profile_records": (_I, [_P, C.POINTER(ProfRecord), _I, C.POINTER(_I)]),
+    "diffsep_time_embedding": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _L, _P]),
     "diffsep_upfirdn2d": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "diffsep_groupnorm_act": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _L, _P]),
     "diffsep_conv2d": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P]),

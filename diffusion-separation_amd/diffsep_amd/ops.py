@@ -311,6 +311,16 @@ def scale_output(mix, sep):
     return out
 
 
+def time_embedding(t, fourier_w, w1, b1, w2, b2):
+    """NCSNpp's time embedding (ncsnpp.py:324-343): t [B] -> temb [B, 4 nf]; all float32 device tensors."""
+    B, nf = t.shape[0], fourier_w.shape[0]
+    ts = [x.contiguous().float() for x in (t, fourier_w, w1, b1, w2, b2)]
+    out = torch.empty((B, 4 * nf), dtype=torch.float32, device=t.device)
+    ws = torch.empty(B * 6 * nf, dtype=torch.float32, device=t.device)
+    check(lib().diffsep_time_embedding(*[_ptr(x) for x in ts], _ptr(out), B, nf, _ptr(ws), ws.numel() * 4, _stream_ptr()))
+    return out
+
+
 def randn(n, seed, stream_id, device="cuda"):
     out = torch.empty(n, dtype=torch.float32, device=device)
     check(lib().diffsep_randn(_ptr(out), n, seed, stream_id, _stream_ptr()))

@@ -219,6 +219,14 @@ int32_t diffsep_engine_profile_records(diffsep_engine* e, diffsep_prof_record* o
 /* ------------------------------------------------------------------ unit entry points
  * (used by the parity tests; the engine calls the same launchers internally). */
 
+/* Time embedding of the backbone: temb[B][4 nf] = Linear_2(SiLU(Linear_1(GaussianFourierProjection(log t)))).
+ * Replaces: models/ncsnpp.py:324-343 (all_modules[0..2]), models/ncsnpp_utils/layerspp.py:37-47 (the projection).
+ * fourier_w [nf] (the frozen W, scale included), w1 [4 nf][2 nf], b1 [4 nf], w2 [4 nf][4 nf], b2 [4 nf] (nn.Linear layout),
+ * all float32 device pointers; workspace >= B * 6 nf floats. */
+int32_t diffsep_time_embedding(const float* t, const float* fourier_w, const float* w1, const float* b1, const float* w2,
+                               const float* b2, float* temb, int32_t B, int32_t nf, void* workspace,
+                               int64_t workspace_bytes, void* stream);
+
 /* upfirdn2d with the [1,3,3,1] FIR, factor 2: upsample_2d / downsample_2d
  * (models/ncsnpp_utils/up_or_down_sampling.py:206-273; native op op/upfirdn2d.cpp:12-23,
  * op/upfirdn2d_kernel.cu:107-207).  up!=0: [B,H,W,C] -> [B,2H,2W,C]; else -> [B,H/2,W/2,C]. */

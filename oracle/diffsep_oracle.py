@@ -174,6 +174,14 @@ def _attn_block(p, pre, x):
     return (x + o) / math.sqrt(2.0)
 
 
+def time_embedding(p, t):
+    """ncsnpp.py:324-343 + layerspp.py:37-47: GaussianFourierProjection(log t) -> Linear -> SiLU -> Linear; [B] -> [B, 4 nf]."""
+    xp = torch.log(t)[:, None] * p["all_modules.0.W"][None, :] * 2 * np.pi
+    temb = torch.cat([torch.sin(xp), torch.cos(xp)], dim=-1)
+    temb = F.linear(temb, p["all_modules.1.weight"], p["all_modules.1.bias"])
+    return F.linear(F.silu(temb), p["all_modules.2.weight"], p["all_modules.2.bias"])
+
+
 def ncsnpp_forward(p, cfg, x, t):
     """NCSNpp.forward  ncsnpp.py:319-478 for the default (biggan / fir / output_skip / input_skip /
     sum / fourier / scale_by_sigma / not centered) configuration.  x [B,2S+2,H,W], t [B]."""

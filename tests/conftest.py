@@ -31,3 +31,10 @@ def golden2():
     """round-2 vectors (tests/golden/gen_golden_r2.py): SDE surface, nf = 128, three sources"""
     import numpy as np
     return dict(np.load(os.path.join(GOLDEN_DIR, "golden_ref2.npz")))
+
+
+@pytest.fixture(scope="session")
+def golden3():
+    """round-4 vectors (tests/golden/gen_golden_r4.py): the time embedding in isolation"""
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN_DIR, "golden_ref3.npz")))

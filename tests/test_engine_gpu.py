@@ -257,6 +257,17 @@ def test_full_size_sampler_nf64_N30_parity_with_oracle():
     d, r = diff_rms(out, ref), rel_rms(out, ref)
     print(f"\n[parity nf64 N30] out rms {rms(ref):.4f}  diff rms {d:.3e}  rel {r:.3e}")
     assert d < 1e-3, f"waveform RMS difference {d:.3e} exceeds the 1e-3 bar"
+    # The SHIPPED default at this width (dtype "auto" = f16 for nf <= 64) against the CPU oracle directly, on the same injected
+    # noise: inside the 1e-3 absolute bar AND bench.py's parity-grade bar of 1 % relative RMS (round 3 gated it against the
+    # fp32 engine only).  Measured 5e-5 absolute / 3.5e-3 relative.
+    engh, _ = engine(64, 2, _lib.F16)
+    seph, nfeh = engh.pc_sample(mix_norm, SDE, N=N, corrector_steps=1, snr=0.5, eps=0.03, denoise=True,
+                                noise=torch.stack(draws).to(DEV))
+    outh = ops.scale_output(mix.to(DEV), seph)
+    dh, rh = diff_rms(outh, ref), rel_rms(outh, ref)
+    print(f"[parity nf64 N30, f16 engine vs the CPU oracle, injected noise] diff rms {dh:.3e}  rel {rh:.3e}")
+    assert nfeh == 60 and torch.isfinite(outh).all()
+    assert dh < 1e-3 and rh < 1e-2, f"f16 default: {dh:.3e} abs / {rh:.3e} rel RMS from the oracle"
     # bf16 engine: gated on SI-SDR agreement with the fp32 result.  Which way 60 NFE of bf16 rounding push ONE utterance
     # depends on the summation order of every kernel (the same utterance measured 26.5 - 32.7 dB across kernel revisions),
     # so the gate is on 8 utterances against the fp32 ENGINE's output (itself 6e-8 from the oracle, asserted above):

@@ -228,3 +228,18 @@ def test_nf128_split_sampler_parity_with_oracle():
     d = rms(out - ref)
     print(f"\n[nf128 split N30 vs oracle] out rms {rms(ref):.4f} diff rms {d:.3e} rel {rel_rms(out, ref):.3e}")
     assert nfe == nfe2 == 60 and d < 1e-3
+    # The SHIPPED default at this width (dtype "auto" = hybrid for nf > 64: a split engine for the first HYBRID_HEAD_STEPS
+    # reverse steps, the f16 engine after) against the same oracle result on the same injected noise: 1e-3 absolute AND
+    # 1 % relative RMS.  f16 alone is printed beside it (36 dB at this width: why "auto" does not pick it).
+    from diffsep_amd.pl_model import HYBRID_HEAD_STEPS
+    eng16, _ = engine(128, 2, _lib.F16, spec_factor=0.15)
+    head, _ = engine(128, 2, _lib.F32_SPLIT, spec_factor=0.15, lib_kind="f16")
+    kw = dict(N=N, corrector_steps=1, snr=0.5, eps=0.03, denoise=True, noise=torch.stack(draws).to(DEV))
+    seph, nfeh = eng16.pc_sample(mn, SDE2, tail=head, head_steps=HYBRID_HEAD_STEPS, **kw)
+    outh = ops.scale_output(mix.to(DEV), seph).cpu()
+    dh, rh = rms(outh - ref), rel_rms(outh, ref)
+    out16 = ops.scale_output(mix.to(DEV), eng16.pc_sample(mn, SDE2, **kw)[0]).cpu()
+    print(f"[nf128 hybrid (the default) N30 vs oracle, injected noise] diff rms {dh:.3e} rel {rh:.3e}; "
+          f"f16 alone {rms(out16 - ref):.3e} / {rel_rms(out16, ref):.3e}")
+    assert nfeh == 60 and torch.isfinite(outh).all()
+    assert dh < 1e-3 and rh < 1e-2, f"hybrid default: {dh:.3e} abs / {rh:.3e} rel RMS from the oracle"

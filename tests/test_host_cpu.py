@@ -212,6 +212,9 @@ def test_bench_multi_rank_sequencing_gloo(tmp_path):
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "weak" and "roofline" in res
     assert res["config"]["sharding"] == "utterances/2" and res["value"] > 0
     assert res["ranks_seen"] == [[0, 0], [1, 1]]
+    # weak mode carries every rank's own time, their imbalance and the per-rank engine / memory situation too
+    assert len(res["rank_elapsed_s_per_step"]) == 2 and res["imbalance_max_over_mean"] >= 1.0
+    assert res["hbm"]["engines_per_rank"] == [4, 4]
 
 
 def test_bench_self_launches_its_ranks_gloo():
@@ -223,7 +226,7 @@ def test_bench_self_launches_its_ranks_gloo():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["DIFFSEP_BENCH_DRYRUN"] = "1"
-    for extra in ([], ["--scaling", "strong", "--utterances", "7"]):
+    for extra in ([], ["--scaling", "strong", "--utterances", "7"], ["--in-flight", "1"]):
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                               "--batch", "2", "--samples", "800"] + extra, env=env, cwd=root, capture_output=True,
                              text=True, timeout=240)
@@ -232,6 +235,9 @@ def test_bench_self_launches_its_ranks_gloo():
         assert len(lines) == 1, out.stdout[-500:]
         res = json.loads(lines[0])
         assert res["n_gpus"] == 2 and res["value"] > 0 and res["ranks_seen"] == [[0, 0], [1, 1]]
+        assert res["scaling"] == ("strong" if "strong" in extra else "weak") and res["imbalance_max_over_mean"] >= 1.0
+        if "--in-flight" in extra:
+            assert res["config"]["batches_in_flight"] == 1 and res["hbm"]["engines_per_rank"] == [1, 1]
 
 
 def test_bench_strong_scaling_sequencing_gloo():

@@ -1,6 +1,7 @@
 """Pin the CPU oracle (oracle/diffsep_oracle.py) against outputs of the reference itself
 (tests/golden/golden_ref.npz, produced by tests/golden/gen_golden.py).  CPU only."""
 import numpy as np
+import pytest
 import torch
 
 import diffsep_oracle as O
@@ -296,3 +297,15 @@ def test_separation_metrics_restatement():
     # two identical references (singular Gram matrix): finite
     r2 = r.copy(); r2[0, 2] = r2[0, 1]
     assert all(np.isfinite(v).all() for v in O.si_bss_eval_sources(r2, est)[:3])
+
+
+@pytest.mark.parametrize("nf", [16, 64])
+def test_time_embedding_in_isolation(golden3, nf):
+    # GaussianFourierProjection(log t) -> Linear -> SiLU -> Linear (ncsnpp.py:324-343) against the
+    # reference backbone's own modules
+    cfg = O.default_config(nf, 2)
+    p = O.to_torch(synth.synth_state_dict(O.param_table(cfg), 7))
+    t = torch.tensor([1.0, 0.53, 0.2, 0.03])
+    out = O.time_embedding(p, t)
+    assert out.shape == (4, 4 * nf)
+    assert rel_rms(out, golden3[f"g16_temb_nf{nf}"]) < 2e-5

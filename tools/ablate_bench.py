@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--nf", type=int, default=64)
     ap.add_argument("--masks", default="0,1,2,4,8,16,32,64,128,7,31,0")
+    ap.add_argument("--options", default="", help="engine options for every run, e.g. kc64=1,no_rw128=1")
     args = ap.parse_args()
     from diffsep_amd import _lib, ops, synth
     from diffsep_amd.engine import Engine, pack_state_dict, param_table
@@ -36,6 +37,9 @@ def main():
     cfg = _lib.model_config(nf=args.nf, num_sources=S, dtype=_lib.F16)
     blob = pack_state_dict(cfg, synth.synth_state_dict([(n, s) for n, s, _ in param_table(cfg)], 7))
     engs = [Engine(cfg, blob) for _ in range(K)]
+    for kv in [v for v in args.options.split(",") if v]:
+        for e in engs:
+            e.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     streams = [torch.cuda.Stream() for _ in range(K)]
     mix = torch.from_numpy(synth.synth_batch(B, T=T)[0]).cuda()
     sde = dict(ndim=S, d_lambda=2.0, sigma_min=0.05, sigma_max=0.5)

@@ -4,8 +4,8 @@
 set -e
 cd $(dirname $0)/../diffusion-separation_amd/csrc
 mkdir -p ../abl
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC -DCONV_TIMING -c conv_mfma.hip -o /tmp/conv_timing.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../abl/lib_timing.so /tmp/conv_timing.o build/conv3x3_ws.o build/conv3x3_small.o build/norm.o build/stft.o build/sde.o build/engine.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC -DCONV_TIMING $CONV_EXTRA -c conv_mfma.hip -o /tmp/conv_timing.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../abl/lib_timing.so /tmp/conv_timing.o build/conv3x3_rw.o build/conv3x3_ws.o build/conv3x3_small.o build/norm.o build/stft.o build/sde.o build/engine.o
 cd ../..
 DIFFSEP_LIB=$PWD/diffusion-separation_amd/abl/lib_timing.so python - <<'PY'
 import ctypes, sys, os, torch
@@ -13,7 +13,12 @@ sys.path.insert(0, "diffusion-separation_amd")
 from diffsep_amd import ops, _lib
 l = ctypes.CDLL(os.environ["DIFFSEP_LIB"])
 names = ["setup (offsets, descriptors)", "issue first loads", "wait first loads", "activation of chunk 0", "barrier+LDS store+barrier", "issue next loads", "MFMA loop (+activation of next)", "acc dump+barriers+residual loads", "epilogue LDS read+math", "epilogue global stores", "statistics reduce", "-"]
-for (k, ci, co, H, W) in [(3, 128, 64, 256, 256), (3, 128, 128, 64, 64), (3, 256, 128, 32, 32)]:
+# CONV_CASES="k,cin,cout,H,W;..."; CONV_OPTS="name=1,..." (process options, e.g. no_rw=1,kc64=1)
+CASES = [tuple(int(v) for v in c.split(",")) for c in os.environ["CONV_CASES"].split(";")] if os.environ.get("CONV_CASES") else \
+    [(3, 128, 64, 256, 256), (3, 128, 128, 64, 64), (3, 256, 128, 32, 32)]
+for kv in [v for v in os.environ.get("CONV_OPTS", "").split(",") if v]:
+    _lib.check(_lib.lib().diffsep_set_option(kv.split("=")[0].encode(), int(kv.split("=")[1])))
+for (k, ci, co, H, W) in CASES:
     B = 16
     x = torch.randn(B, H, W, ci, device="cuda").to(torch.bfloat16)
     w = (torch.randn(co, k * k, ci, device="cuda") / (k * k * ci) ** 0.5).to(torch.bfloat16)

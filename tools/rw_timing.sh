@@ -3,7 +3,7 @@
 set -e
 cd $(dirname $0)/../diffusion-separation_amd/csrc
 mkdir -p ../abl
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC -DRW_TIMING $RW_EXTRA -c conv3x3_rw.hip -o /tmp/rw_timing.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=1000000 -DRW_TIMING $RW_EXTRA -c conv3x3_rw.hip -o /tmp/rw_timing.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../abl/lib_rwtiming.so /tmp/rw_timing.o build/conv_mfma.o build/conv3x3_ws.o build/conv3x3_small.o build/norm.o build/stft.o build/sde.o build/engine.o
 cd ../..
 DIFFSEP_LIB=$PWD/diffusion-separation_amd/abl/lib_rwtiming.so python - <<'PY'
@@ -14,8 +14,13 @@ l = ctypes.CDLL(os.environ["DIFFSEP_LIB"])
 names = ["prologue: staging of the first chunk", "barrier wait", "3x3 chunk phases", "skip chunk phases", "epilogue", "tail (statistics)", "prologue: tables + descriptors", "prologue: first loads + weight fragments issued, barrier"]
 import os
 BS = [int(v) for v in os.environ.get('RW_B', '16').split(',')]
-for (ci, H, W, fused, B) in [(c, hh, ww, f, bb) for bb in BS for (c, hh, ww, f) in [(64, 256, 256, 2), (64, 256, 256, 1), (64, 256, 256, 0), (128, 256, 256, 1), (128, 256, 256, 0), (64, 128, 128, 1)]]:
-    co, k = 64, 3
+# RW_CASES="cin,cout,H,W,fused;..." (default: the 64-cout shapes of the large levels)
+CASES = [tuple(int(v) for v in c.split(",")) for c in os.environ["RW_CASES"].split(";")] if os.environ.get("RW_CASES") else \
+    [(64, 64, 256, 256, 2), (64, 64, 256, 256, 1), (64, 64, 256, 256, 0), (128, 64, 256, 256, 1), (128, 64, 256, 256, 0), (64, 64, 128, 128, 1)]
+from diffsep_amd import _lib
+_lib.lib().diffsep_set_option(b"rw_small", 1)
+for (ci, co, H, W, fused, B) in [(c, o, hh, ww, f, bb) for bb in BS for (c, o, hh, ww, f) in CASES]:
+    k = 3
     x = torch.randn(B, H, W, ci, device="cuda").to(torch.bfloat16)
     w = (torch.randn(co, 9, ci, device="cuda") / (9 * ci) ** 0.5).to(torch.bfloat16)
     b = torch.randn(co, device="cuda")
@@ -41,7 +46,7 @@ for (ci, H, W, fused, B) in [(c, hh, ww, f, bb) for bb in BS for (c, hh, ww, f) 
     nb = out[15]; tot = sum(out[i] for i in range(8))
     if nb == 0:
         continue  # (this launch did not run on the register-weight kernel)
-    print(f"B={B} {ci}->64 {H}x{W} {['plain', 'GN+SiLU+stats', 'GN+SiLU+stats+residual'][fused]}: {e0.elapsed_time(e1)/5*1e3:.1f} us/launch, {tot/nb:.0f} ticks/block (wave 0), {nb//5} blocks -> {tot/nb/(e0.elapsed_time(e1)/5*1e3)/1e3:.2f} ticks/ns")
+    print(f"B={B} {ci}->{co} {H}x{W} {['plain', 'GN+SiLU+stats', 'GN+SiLU+stats+residual'][fused]}: {e0.elapsed_time(e1)/5*1e3:.1f} us/launch, {tot/nb:.0f} ticks/block (wave 0), {nb//5} blocks -> {tot/nb/(e0.elapsed_time(e1)/5*1e3)/1e3:.2f} ticks/ns")
     for i in range(8):
         print(f"    {names[i]:36s} {out[i]/nb:9.0f}  {100*out[i]/tot:5.1f} %")
 PY
