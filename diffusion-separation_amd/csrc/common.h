@@ -265,14 +265,15 @@ bool ds_conv_small_eligible(const ConvArgs& a);  // conv3x3_small.hip: <= 16-row
 int ds_launch_conv_small(const ConvArgs& a, hipStream_t st);
 
 // attn_fused.hip: AttnBlockpp as one kernel (16-bit storage, 128 channels, <= 256 pixels per sample).  Weights in the
-// fragment-major order of ds_rw_frag_index(row, 0, column, 1, 128): wq / wv / wo = NIN_0 / 2 / 3 as [out][in], wkt = NIN_1 as
-// [in][out]; x: [B][L][ldx]; GroupNorm of x from its producer's accumulators (gn_acc) or from scale / shift arrays [B][C].
+// fragment-major order of ds_rw_frag_index(row, 0, column, 1, 128): wv / wo = NIN_2 / NIN_3 as [out][in], wqk = Wk^T Wq (the
+// query and key projections folded: rows = key-side input channel, columns = query-side input channel), bqk = Wk^T b_q;
+// x: [B][L][ldx]; GroupNorm of x from its producer's accumulators (gn_acc) or from scale / shift arrays [B][C].
 struct AttnFusedArgs {
   const void* x; long x_bs; int ldx;
   const long long* gn_acc; const float* gn_gamma; const float* gn_beta; int gn_groups; float gn_inv_count; float gn_eps;
   const float* gn_scale; const float* gn_shift;
-  const void* wq; const void* wkt; const void* wv; const void* wo;
-  const float* bq; const float* bv; const float* bo;
+  const void* wqk; const void* wv; const void* wo;
+  const float* bqk; const float* bv; const float* bo;
   void* y; long y_bs; int ldy;
   long long* stats;  // [B][C][2] accumulators of the output (nullable)
   int B, L, C;

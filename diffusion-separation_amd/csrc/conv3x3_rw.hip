@@ -236,6 +236,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   }
   const int ldi0 = (HW_ + 1 + ixp) * AROW + slot * 16;  // tile pixel (0, ixp): piece k < NI is HW_ pixels (one halo row) further
 
+  RT_MARK(6)
   const int M = p.H * p.W;
   const __amdgpu_buffer_rsrc_t rx1 = rsrc(p.x + (long)b * p.x_bs, (unsigned)M * p.ldx * 2u);
   const __amdgpu_buffer_rsrc_t rx2 = p.x2 ? rsrc(p.x2 + (long)b * p.x2_bs, (unsigned)M * p.ldx2 * 2u) : rx1;
@@ -675,6 +676,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     load_weights();
     build_tables();
     sync_lds();  // tables (and the LDS-resident weight fragments) visible
+    RT_MARK(7)
     if constexpr (REL_REGS) {
 #pragma unroll
       for (int k = 0; k < NB; ++k) relreg[k] = sDesc[k * NT + tid];

@@ -51,7 +51,10 @@ struct Module {
   // second copies of Conv_0 / Conv_1 / Conv_2 in the register-weight kernel's fragment-major order (16-bit engines, the shapes
   // that kernel takes: ds_rw_frag_shape), -1 = none
   long pf0 = -1, pf1 = -1, pf2 = -1;
-  long pf_nin[4] = {-1, -1, -1, -1};  // attention projections in fragment-major order (attn_fused.hip; 128 channels only)
+  // attention block, fused kernel (attn_fused.hip; 128 channels only): fragment-major copies [0] = Wk^T Wq (query and key
+  // projections folded at engine creation), [2] = Wv, [3] = Wo; ab_off = this block's Wk^T b_q in the engine's d_attn_b
+  long pf_nin[4] = {-1, -1, -1, -1};
+  long ab_off = -1;
 };
 
 struct Arch {
@@ -62,6 +65,7 @@ struct Arch {
   long total = 0;       // floats in the blob
   long pack_total = 0;  // elements in the packed weight buffer
   int dense_total = 0;  // sum of out_ch over residual blocks
+  long attn_bias_total = 0;  // floats of folded attention biases (Module::ab_off)
   int chan_in = 0, chan_out = 0, cpad_in = 0, cpad_out = 0;
 };
 
@@ -154,8 +158,9 @@ struct ArchBuilder {
       m.nin_w[i] = add(p + "NIN_" + std::to_string(i) + ".W", {c, c});
       m.nin_b[i] = add(p + "NIN_" + std::to_string(i) + ".b", {c});
       m.pk_nin[i] = pack(c, 1, c);
-      if (c == 128) m.pf_nin[i] = pack(c, 1, c);
+      if (c == 128 && i != 1) m.pf_nin[i] = pack(c, 1, c);
     }
+    if (c == 128) { m.ab_off = A.attn_bias_total; A.attn_bias_total += c; }
     A.mods.push_back(m);
   }
   void combine(int d1, int d2) {
@@ -306,6 +311,23 @@ __global__ __launch_bounds__(256) void repack_frag_kernel(const float* __restric
     dst[ds_rw_frag_index(o, tap, i, taps, O)] = f2h(src[o * so + i * si + tap * st]);
   }
 }
+// Fused attention block: M[c'][k] = sum_c Wk[c'][c] Wq[k][c] (NIN.W is [in][out]: Wq^T applied to h gives q) in fragment-major
+// order, and b'[c'] = sum_c Wk[c'][c] b_q[c] — fp32 sums, one rounding to the storage type (attn_fused.hip)
+__global__ __launch_bounds__(256) void attn_fold_qk_kernel(const float* __restrict__ wq, const float* __restrict__ wk,
+                                                           const float* __restrict__ bq, bf16_t* __restrict__ m_frag,
+                                                           float* __restrict__ b_fold, int Cc) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Cc * Cc) return;
+  const int cp = idx / Cc, k = idx % Cc;
+  float a = 0.f;
+  for (int c = 0; c < Cc; ++c) a = fmaf(wk[(long)cp * Cc + c], wq[(long)k * Cc + c], a);
+  m_frag[ds_rw_frag_index(cp, 0, k, 1, Cc)] = f2h(a);
+  if (k == 0) {
+    float bb = 0.f;
+    for (int c = 0; c < Cc; ++c) bb = fmaf(wk[(long)cp * Cc + c], bq[c], bb);
+    b_fold[cp] = bb;
+  }
+}
 // Which weights the engine keeps chunk-major: every conv whose input channels are a multiple of 64 and whose concat
 // split (c1 channels from the first source, 0 = no concat) falls on a chunk boundary
 static int weight_chunk(int taps, int cin, int c1, int dtype) {
@@ -386,6 +408,7 @@ struct diffsep_engine {
   char* d_pack = nullptr;
   float* d_dense_w = nullptr;
   float* d_dense_b = nullptr;
+  float* d_attn_b = nullptr;  // folded query / key biases of the fused attention blocks
   float* d_tab = nullptr;
   // arena
   char* arena = nullptr;
@@ -712,8 +735,8 @@ static int attn_block(diffsep_engine* e, const Module& m, const Tn& x, int B, Tn
     a.x = x.p; a.x_bs = (long)L * x.ld; a.ldx = x.ld;
     a.gn_acc = x.sa; a.gn_scale = ga.scale; a.gn_shift = ga.shift; a.gn_gamma = P(e, m.gn0_w); a.gn_beta = P(e, m.gn0_b);
     a.gn_groups = (C / 4 < 32) ? C / 4 : 32; a.gn_inv_count = (float)(1.0 / ((double)L * (C / a.gn_groups))); a.gn_eps = 1e-6f;
-    a.wq = PKF(e, m.pf_nin[0]); a.wkt = PKF(e, m.pf_nin[1]); a.wv = PKF(e, m.pf_nin[2]); a.wo = PKF(e, m.pf_nin[3]);
-    a.bq = P(e, m.nin_b[0]); a.bv = P(e, m.nin_b[2]); a.bo = P(e, m.nin_b[3]);
+    a.wqk = PKF(e, m.pf_nin[0]); a.wv = PKF(e, m.pf_nin[2]); a.wo = PKF(e, m.pf_nin[3]);
+    a.bqk = e->d_attn_b + m.ab_off; a.bv = P(e, m.nin_b[2]); a.bo = P(e, m.nin_b[3]);
     a.y = out.p; a.y_bs = (long)L * out.ld; a.ldy = out.ld;
     a.stats = out.sa;
     a.B = B; a.L = L; a.C = C;
@@ -1019,10 +1042,15 @@ static int repack_module(diffsep_engine* e, const Module& m) {
       // (the V projection is the A operand of its GEMM: it stays row-major)
       for (int i = 0; i < 4; ++i)
         rc |= repack_weight(e, m.nin_w[i], m.pk_nin[i], m.in_ch, m.in_ch, 1, 1, m.in_ch, 0, i != 2);
-      // fused attention kernel: NIN.W is [in][out]; rows of the fragment-major copy = outputs ([out][in]) for NIN_0 / 2 / 3,
-      // = inputs ([in][out]) for NIN_1 (the key projection applied to the query side: attn_fused.hip)
-      for (int i = 0; i < 4; ++i)
-        rc |= repack_frag(e, m.nin_w[i], m.pf_nin[i], m.in_ch, m.in_ch, 1, i == 1 ? m.in_ch : 1, i == 1 ? 1 : m.in_ch, 0);
+      // fused attention kernel: NIN.W is [in][out]; rows of the fragment-major copies of Wv / Wo = outputs ([out][in]); the
+      // query and key projections are folded into one matrix and one bias vector
+      for (int i = 2; i < 4; ++i) rc |= repack_frag(e, m.nin_w[i], m.pf_nin[i], m.in_ch, m.in_ch, 1, 1, m.in_ch, 0);
+      if (m.pf_nin[0] >= 0 && e->cfg.dtype == DS_BF16 && e->d_attn_b) {
+        hipLaunchKernelGGL(attn_fold_qk_kernel, dim3(cdiv((long)m.in_ch * m.in_ch, 256)), dim3(256), 0, 0, e->d_blob + m.nin_w[0].off,
+                           e->d_blob + m.nin_w[1].off, e->d_blob + m.nin_b[0].off, (bf16_t*)(e->d_pack) + m.pf_nin[0],
+                           e->d_attn_b + m.ab_off, m.in_ch);
+        DS_LAUNCH_CHECK();
+      }
       break;
     default: break;
   }
@@ -1052,6 +1080,7 @@ extern "C" int32_t diffsep_engine_create(const diffsep_model_config* cfg, const 
   DS_HIP(hipMemset(e->d_pack, 0, (size_t)A.pack_total * e->esz + 256));
   DS_HIP(hipMalloc((void**)&e->d_dense_w, (size_t)A.dense_total * 4 * cfg->nf * 4));
   DS_HIP(hipMalloc((void**)&e->d_dense_b, (size_t)A.dense_total * 4));
+  if (A.attn_bias_total) DS_HIP(hipMalloc((void**)&e->d_attn_b, (size_t)A.attn_bias_total * 4));
   e->weight_bytes = (int64_t)A.total * 4 + (int64_t)A.pack_total * e->esz + (int64_t)A.dense_total * (4 * cfg->nf + 1) * 4;
   if (ds_build_stft_table(cfg->n_fft, &e->d_tab)) { delete e; return 1; }
   if (const char* sv = getenv("DIFFSEP_DBG_ALLOC")) e->dbg_alloc = atoi(sv) != 0;  // (read once, at creation)
@@ -1071,6 +1100,7 @@ extern "C" void diffsep_engine_destroy(diffsep_engine* e) {
   if (!e) return;
   drop_graph(e);
   hipFree(e->d_blob); hipFree(e->d_pack); hipFree(e->d_dense_w); hipFree(e->d_dense_b); hipFree(e->d_tab);
+  if (e->d_attn_b) hipFree(e->d_attn_b);
   if (e->arena) hipFree(e->arena);
   if (e->own) hipStreamDestroy(e->own);
   if (e->ts_ev) hipEventDestroy(e->ts_ev);
@@ -1607,6 +1637,7 @@ static int mini_engine_init(MiniEngine& me, int dtype, int temb_dim, const float
   DS_HIP(hipMemset(e->d_pack, 0, (size_t)A.pack_total * e->esz + 256));
   DS_HIP(hipMalloc((void**)&e->d_dense_w, (size_t)(A.dense_total + 1) * (temb_dim + 1) * 4));
   DS_HIP(hipMalloc((void**)&e->d_dense_b, (size_t)(A.dense_total + 1) * 4));
+  if (A.attn_bias_total) DS_HIP(hipMalloc((void**)&e->d_attn_b, (size_t)A.attn_bias_total * 4));
   for (const Module& m : A.mods)
     if (repack_module(e, m)) return 1;
   DS_HIP(hipDeviceSynchronize());

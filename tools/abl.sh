@@ -7,7 +7,7 @@ C=diffusion-separation_amd/csrc
 for v in NOMFMA NOACT NOLOAD NOLDSW NOEPI; do
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DABL_$v -c $C/conv_mfma.hip -o /tmp/abl_$v.o 2>/dev/null &&
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DABL_$v -c $C/conv3x3_ws.hip -o /tmp/ablws_$v.o 2>/dev/null &&
-    hipcc --offload-arch=gfx950 -shared -fPIC -o diffusion-separation_amd/abl/lib_$v.so /tmp/abl_$v.o /tmp/ablws_$v.o $C/build/conv3x3_small.o $C/build/norm.o $C/build/stft.o $C/build/sde.o $C/build/engine.o ) &
+    hipcc --offload-arch=gfx950 -shared -fPIC -o diffusion-separation_amd/abl/lib_$v.so /tmp/abl_$v.o /tmp/ablws_$v.o $(ls $C/build/*.o | grep -Ev '/(conv_mfma\.o|conv3x3_ws\.o)$') ) &
 done
 wait
 for v in "" NOMFMA NOACT NOLOAD NOLDSW NOEPI; do

@@ -5,7 +5,7 @@ set -e
 cd $(dirname $0)/../diffusion-separation_amd/csrc
 mkdir -p ../abl
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC -DCONV_TIMING $CONV_EXTRA -c conv_mfma.hip -o /tmp/conv_timing.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../abl/lib_timing.so /tmp/conv_timing.o build/conv3x3_rw.o build/conv3x3_ws.o build/conv3x3_small.o build/norm.o build/stft.o build/sde.o build/engine.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../abl/lib_timing.so /tmp/conv_timing.o $(ls build/*.o | grep -Ev '/(conv_mfma\.o)$')
 cd ../..
 DIFFSEP_LIB=$PWD/diffusion-separation_amd/abl/lib_timing.so python - <<'PY'
 import ctypes, sys, os, torch

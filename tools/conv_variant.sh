@@ -8,7 +8,7 @@ i=0
 for f in "$@"; do
   i=$((i+1))
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $f -c $C/conv_mfma.hip -o /tmp/cv$i.o &&
-    hipcc --offload-arch=gfx950 -shared -fPIC -o diffusion-separation_amd/abl/lib_cv$i.so /tmp/cv$i.o $C/build/conv3x3_ws.o $C/build/conv3x3_small.o $C/build/norm.o $C/build/stft.o $C/build/sde.o $C/build/engine.o ) &
+    hipcc --offload-arch=gfx950 -shared -fPIC -o diffusion-separation_amd/abl/lib_cv$i.so /tmp/cv$i.o $(ls $C/build/*.o | grep -Ev '/(conv_mfma\.o)$') ) &
 done
 wait
 for rep in 1 2; do

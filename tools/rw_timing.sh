@@ -4,7 +4,7 @@ set -e
 cd $(dirname $0)/../diffusion-separation_amd/csrc
 mkdir -p ../abl
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=1000000 -DRW_TIMING $RW_EXTRA -c conv3x3_rw.hip -o /tmp/rw_timing.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../abl/lib_rwtiming.so /tmp/rw_timing.o build/conv_mfma.o build/conv3x3_ws.o build/conv3x3_small.o build/norm.o build/stft.o build/sde.o build/engine.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../abl/lib_rwtiming.so /tmp/rw_timing.o $(ls build/*.o | grep -Ev '/(conv3x3_rw\.o)$')
 cd ../..
 DIFFSEP_LIB=$PWD/diffusion-separation_amd/abl/lib_rwtiming.so python - <<'PY'
 import ctypes, sys, os, torch
@@ -23,17 +23,22 @@ for (ci, co, H, W, fused, B) in [(c, o, hh, ww, f, bb) for bb in BS for (c, o, h
     k = 3
     x = torch.randn(B, H, W, ci, device="cuda").to(torch.bfloat16)
     w = (torch.randn(co, 9, ci, device="cuda") / (9 * ci) ** 0.5).to(torch.bfloat16)
+    kc = 32 if os.environ.get("RW_CHUNKED", "1") == "1" else 0  # chunk-major [Cin/32][9][Cout][32] like the engine's weights
+    wkw = {}
+    if kc:
+        w = w.reshape(co, 9, ci // kc, kc).permute(2, 1, 0, 3).contiguous()
+        wkw = dict(w_chunk=kc)
     b = torch.randn(co, device="cuda")
     sc = torch.rand(B, ci, device="cuda") + 0.5; sh = torch.randn(B, ci, device="cuda") * 0.1
     res = torch.randn(B, H, W, co, device="cuda").to(torch.bfloat16)
     y = torch.zeros(B, H, W, co, device="cuda", dtype=torch.bfloat16)
-    _, st = ops.conv2d_fused(x, w, b, co, k, out=y, stats=True)
+    _, st = ops.conv2d_fused(x, w, b, co, k, out=y, stats=True, **wkw)
     if fused == 2:    # Conv_1 of a plain block: GroupNorm + SiLU, bias, residual, 1/sqrt(2), statistics
-        run = lambda: ops.conv2d_fused(x, w, b, co, k, gn=(sc, sh), gn_act=1, res=res, out_scale=0.7071, out=y, stats=st)
+        run = lambda: ops.conv2d_fused(x, w, b, co, k, gn=(sc, sh), gn_act=1, res=res, out_scale=0.7071, out=y, stats=st, **wkw)
     elif fused == 1:  # Conv_0: GroupNorm + SiLU, bias, statistics
-        run = lambda: ops.conv2d_fused(x, w, b, co, k, gn=(sc, sh), gn_act=1, out=y, stats=st)
+        run = lambda: ops.conv2d_fused(x, w, b, co, k, gn=(sc, sh), gn_act=1, out=y, stats=st, **wkw)
     else:
-        run = lambda: ops.conv2d_fused(x, w, b, co, k, out=y)
+        run = lambda: ops.conv2d_fused(x, w, b, co, k, out=y, **wkw)
     for _ in range(2): run()
     torch.cuda.synchronize()
     out = (ctypes.c_ulonglong * 16)()

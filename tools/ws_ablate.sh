@@ -6,7 +6,7 @@ C=diffusion-separation_amd/csrc
 mkdir -p diffusion-separation_amd/abl
 for v in NOLOAD NOACT NOLDSW NOMFMA NOEPI; do
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DABL2_$v -c $C/conv3x3_ws.hip -o /tmp/wsa_$v.o 2>/dev/null &&
-    hipcc --offload-arch=gfx950 -shared -fPIC -o diffusion-separation_amd/abl/lib_wsa_$v.so /tmp/wsa_$v.o $C/build/conv_mfma.o $C/build/conv3x3_small.o $C/build/norm.o $C/build/stft.o $C/build/sde.o $C/build/engine.o ) &
+    hipcc --offload-arch=gfx950 -shared -fPIC -o diffusion-separation_amd/abl/lib_wsa_$v.so /tmp/wsa_$v.o $(ls $C/build/*.o | grep -Ev '/(conv3x3_ws\.o)$') ) &
 done
 wait
 echo "== BASE"; timeout 60 python tools/bench_conv.py bf16 20 0 2>&1 | grep "^k"

@@ -4,7 +4,7 @@ set -e
 cd $(dirname $0)/../diffusion-separation_amd/csrc
 mkdir -p ../abl
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -fPIC -DWS_TIMING -c conv3x3_ws.hip -o /tmp/ws_timing.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../abl/lib_wstiming.so /tmp/ws_timing.o build/conv_mfma.o build/conv3x3_small.o build/norm.o build/stft.o build/sde.o build/engine.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../abl/lib_wstiming.so /tmp/ws_timing.o $(ls build/*.o | grep -Ev '/(conv3x3_ws\.o)$')
 cd ../..
 DIFFSEP_LIB=$PWD/diffusion-separation_amd/abl/lib_wstiming.so python - <<'PY'
 import ctypes, sys, os, torch
