@@ -240,15 +240,12 @@ def test_full_size_score_nf64_fp32_and_bf16_vs_oracle():
     assert torch.isfinite(out16).all()
 
 
-def test_full_size_sampler_nf64_N30_parity_with_oracle():
-    # THE parity gate: 4 s / 8 kHz / 2 speakers / N=30 + 1 corrector step = 60 NFE, identical noise.
-    cfg = O.default_config(64, 2)
-    T, B, N = 32000, 1, 30
+def test_full_size_sampler_nf64_N30_parity_with_oracle(oracle_fullsize_nf64):
+    # THE parity gate: 4 s / 8 kHz / 2 speakers / N=30 + 1 corrector step = 60 NFE, identical noise (the oracle's result is
+    # computed once per session: conftest.oracle_fullsize_nf64)
+    fs = oracle_fullsize_nf64
+    T, B, N, mix, draws, ref, nfe = fs["T"], fs["B"], fs["N"], fs["mix"], fs["draws"], fs["ref"], fs["nfe"]
     eng, sd = engine(64, 2, _lib.F32)
-    p = O.to_torch(sd)
-    mix = torch.from_numpy(synth.synth_batch(B, T=T)[0])
-    draws = [rnd(f"fs.z{i}", (B, 2, T)) for i in range(1 + 2 * N)]
-    ref, nfe = O.separate(p, cfg, mix, draws, N=N, corrector_steps=1, snr=0.5, eps=0.03, denoise=True)
     mix_norm, _, _ = ops.normalize_batch(mix.to(DEV))
     sep, nfe2 = eng.pc_sample(mix_norm, SDE, N=N, corrector_steps=1, snr=0.5, eps=0.03, denoise=True,
                               noise=torch.stack(draws).to(DEV))

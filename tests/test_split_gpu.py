@@ -70,16 +70,13 @@ def test_split_engine_matches_reference_golden(golden):
     assert diff_rms(sep, g["g9_sep"]) < 1e-3 and rel_rms(sep, g["g9_sep"]) < 3e-4
 
 
-def test_split_full_size_sampler_nf64_N30_parity_with_oracle():
+def test_split_full_size_sampler_nf64_N30_parity_with_oracle(oracle_fullsize_nf64):
     # the parity gate of the fp32 engine (test_engine_gpu.py) for the split engine: 4 s / 8 kHz / 2 speakers / 60 NFE,
-    # identical noise, against the CPU oracle; and against the exact fp32 engine (SI-SDR: what a listener could tell)
-    cfg = O.default_config(64, 2)
-    T, B, N = 32000, 1, 30
+    # identical noise, against the CPU oracle (one oracle run per session: conftest.oracle_fullsize_nf64); and against the
+    # exact fp32 engine (SI-SDR: what a listener could tell)
+    fs = oracle_fullsize_nf64
+    T, B, N, mix, draws, ref, nfe = fs["T"], fs["B"], fs["N"], fs["mix"], fs["draws"], fs["ref"], fs["nfe"]
     eng, sd = engine(64, 2, _lib.F32_SPLIT)
-    p = O.to_torch(sd)
-    mix = torch.from_numpy(synth.synth_batch(B, T=T)[0])
-    draws = [rnd(f"fs.z{i}", (B, 2, T)) for i in range(1 + 2 * N)]
-    ref, nfe = O.separate(p, cfg, mix, draws, N=N, corrector_steps=1, snr=0.5, eps=0.03, denoise=True)
     mix_norm, _, _ = ops.normalize_batch(mix.to(DEV))
     kw = dict(N=N, corrector_steps=1, snr=0.5, eps=0.03, denoise=True, noise=torch.stack(draws).to(DEV))
     sep, nfe2 = eng.pc_sample(mix_norm, SDE, **kw)
