@@ -433,18 +433,23 @@ def main():
             ent = pj.get("by_instantiation", {}).get(kname) if pj.get("dtype") == args.dtype and args.nf == 64 and B == 16 else None
             if ent:
                 traffic = ent["hbm_bytes_per_launch_guide_formula"]
-                traffic_source = ("profiles/pmc_conv3x3.json: rocprofv3 --pmc passes of tools/pmc_traffic.sh (FETCH_SIZE and WRITE_SIZE in "
-                                  "separate runs, guide correction 2*FETCH + WRITE, average over the %d launches of this instantiation in a "
-                                  "4-step sampler), measured at commit %s - NOT collected in this run" % (ent["launches"], pj.get("commit")))
+                traffic_source = ("profiles/pmc_conv3x3.json = output of `COMMIT=%s bash tools/pmc_traffic.sh` (rocprofv3 --kernel-trace --pmc "
+                                  "FETCH_SIZE / --pmc WRITE_SIZE in separate passes around `python bench.py --steps 1 --warmup 0 -N 4 --in-flight 1 "
+                                  "--no-graph`, guide correction 2*FETCH + WRITE, average over the %d launches of this instantiation; the "
+                                  "profiler cannot wrap the N = 30 run of this line: rocprofv3 --pmc crashes on it, so the counters come from "
+                                  "that separate, committed run of the same kernels and launch mix)" % (pj.get("commit"), ent["launches"]))
         except Exception:
             traffic = traffic_source = None
         try:
-            pu = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_mfma_util.json")))
+            pu = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_mfma_util.json")))
             for k_, v_ in pu.get("kernels", {}).items():
                 if k_.split(" grid ")[0] == kname and pu.get("dtype") == args.dtype:
                     pmc_util = {"mfma_util_per_shader_cycle": v_.get("mfma_util"), "shader_clock_ghz": v_.get("shader_clock_ghz"),
                                 "valu_per_mfma": v_.get("valu_per_mfma"), "lds_per_mfma": v_.get("lds_per_mfma"),
-                                "source": "profiles/r03_pmc_mfma_util.json (tools/pmc_r03.sh, commit %s) - NOT collected in this run" % pu.get("commit")}
+                                "lds_bank_conflict_cycles_per_lds_inst": v_.get("lds_bank_conflict_cycles_per_lds_inst"),
+                                "source": "profiles/r04_pmc_mfma_util.json = output of `COMMIT=%s bash tools/pmc_r03.sh` (two rocprofv3 "
+                                          "--kernel-trace --pmc passes around the N = 4, one-in-flight, eager variant of this command; a "
+                                          "separate, committed run)" % pu.get("commit")}
         except Exception:
             pmc_util = None
         if hbm_floor_us > mfma_floor_us:

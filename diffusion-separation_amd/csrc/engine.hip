@@ -466,7 +466,7 @@ struct diffsep_engine {
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
 };
-#define DS_NCLS 9
+#define DS_NCLS 10
 static hipEvent_t prof_event(diffsep_engine* e) {
   if (!e->ev_pool.empty()) { hipEvent_t v = e->ev_pool.back(); e->ev_pool.pop_back(); return v; }
   hipEvent_t v = nullptr;
@@ -740,7 +740,19 @@ static int attn_block(diffsep_engine* e, const Module& m, const Tn& x, int B, Tn
     a.y = out.p; a.y_bs = (long)L * out.ld; a.ldy = out.ld;
     a.stats = out.sa;
     a.B = B; a.L = L; a.C = C;
-    return ds_launch_attn_fused(a, st);
+    if (!e->prof) return ds_launch_attn_fused(a, st);
+    diffsep_engine::ProfRec r;  // (per-launch timing like the convolutions: class 9)
+    r.a = prof_event(e); r.b = prof_event(e);
+    // V^T, Q' and the output projection (2 L C^2 each), scores and P V (2 L^2 C each); input + output + three matrices once
+    r.flops = (double)B * (6.0 * L * C * C + 4.0 * (double)L * L * C);
+    r.bytes = (double)e->esz * (2.0 * B * L * C + 3.0 * C * C);
+    r.cls = 9; r.B = B; r.H = x.H; r.W = x.W; r.Cin = C; r.Cout = C; r.taps = 1; r.sCin = 0; r.res = 1; r.ms = 0.f;
+    r.kernel = "attn_fused_kernel";
+    hipEventRecord(r.a, st);
+    const int rc = ds_launch_attn_fused(a, st);
+    hipEventRecord(r.b, st);
+    e->prof_recs.push_back(r);
+    return rc;
   }
   GnAff a0;
   if (gn_stats(e, x, P(e, m.gn0_w), P(e, m.gn0_b), B, a0, st)) return 1;
@@ -1168,7 +1180,7 @@ extern "C" int64_t diffsep_engine_get_option(const diffsep_engine* e, const char
 
 // Per-launch timing of the MFMA contraction kernels inside the real launch sequence: between
 // profile_begin and profile_end every conv/GEMM launch is bracketed by HIP events on its stream
-// (graph replay is bypassed meanwhile).  Arrays have 9 entries: 3x3 {8x32xBN64, 8x32xBN32, 8x8xBN64},
+// (graph replay is bypassed meanwhile).  Arrays have 10 entries (the last: the fused attention block): 3x3 {8x32xBN64, 8x32xBN32, 8x8xBN64},
 // then the same three tiles for 1x1/GEMM, the weight-stationary 64 -> 64 3x3 kernel, the small-image 3x3 kernel, the
 // register-weight 3x3 kernel.  flops = algorithmic 2*taps*Cin*Cout*H*W*B (unpadded).
 extern "C" int32_t diffsep_engine_profile_begin(diffsep_engine* e) {
