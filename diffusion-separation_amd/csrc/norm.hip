@@ -350,6 +350,114 @@ __global__ __launch_bounds__(256) void gn_resample2x2_kernel(const T* __restrict
   }
 }
 
+
+// FIR x2 DOWN for the large levels (16-bit tensors): the 2 x 2-block kernel above walks 36 input vectors per thread (each input
+// element activated 2.25 times, rows re-read by the vertical neighbours) with little memory-level parallelism: 98 us at 256^2
+// against ~40 us of HBM time.  Here a thread owns TWO adjacent output columns x 8 channels and walks DOWN a strip of RS output
+// rows: an input row is 6 vectors (its 4-tap windows overlap by 2: 3 activations per output pixel and row instead of 4), loaded
+// one row ahead, filtered horizontally into the two columns, and added into the two output rows it belongs to (taps 1/8, 3/8
+// into the newer, 3/8, 1/8 into the older, which is then complete and stored) — every input row of the strip is read once.
+// Same arithmetic as the kernels above up to fp32 summation order (horizontal taps first, then vertical; zeros outside).
+template <int RS>
+__global__ __launch_bounds__(256) void gn_fir_down_strip_kernel(const bf16_t* __restrict__ x, int ldx,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int C,
+                                                                bf16_t* __restrict__ y, int ldy, bf16_t* __restrict__ xr,
+                                                                int ldxr, int B, int H, int W, int act) {
+  const int Ho = H / 2, Wo = W / 2, ncg = C >> 3, ntx = Wo / 2, nst = (Ho + RS - 1) / RS;
+  const long total = (long)B * nst * ntx * ncg;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cg = (int)(i % ncg);
+  long r = i / ncg;
+  const int tx = (int)(r % ntx);
+  r /= ntx;
+  const int st = (int)(r % nst), b = (int)(r / nst);
+  float sc[8], sf[8];
+  {
+    const float4 s0 = *reinterpret_cast<const float4*>(scale + (long)b * C + cg * 8), s1 = *reinterpret_cast<const float4*>(scale + (long)b * C + cg * 8 + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(shift + (long)b * C + cg * 8), h1 = *reinterpret_cast<const float4*>(shift + (long)b * C + cg * 8 + 4);
+    sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+    sf[0] = h0.x; sf[1] = h0.y; sf[2] = h0.z; sf[3] = h0.w; sf[4] = h1.x; sf[5] = h1.y; sf[6] = h1.z; sf[7] = h1.w;
+  }
+  const bf16_t* xb = x + (long)b * H * W * ldx + cg * 8;
+  const int ix0 = 4 * tx - 1, oy0 = st * RS, iy0 = 2 * oy0 - 1;
+  bool cok[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) cok[c] = ix0 + c >= 0 && ix0 + c < W;
+  auto load_row = [&](int iy, uint4 (&raw)[6]) __attribute__((always_inline)) {
+    const bool rok = iy >= 0 && iy < H;
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+      raw[c] = (rok && cok[c]) ? *reinterpret_cast<const uint4*>(xb + ((long)iy * W + ix0 + c) * ldx) : make_uint4(0, 0, 0, 0);
+  };
+  // horizontally filtered row for the two output columns: ha (activated) / hx (raw)
+  auto hrow = [&](int iy, const uint4 (&raw)[6], float (&ha)[2][8], float (&hx)[2][8]) __attribute__((always_inline)) {
+    const bool rok = iy >= 0 && iy < H;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ha[q][j] = 0.f; hx[q][j] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      float f[8];
+      f[0] = h_lo(raw[c].x); f[1] = h_hi(raw[c].x); f[2] = h_lo(raw[c].y); f[3] = h_hi(raw[c].y);
+      f[4] = h_lo(raw[c].z); f[5] = h_hi(raw[c].z); f[6] = h_lo(raw[c].w); f[7] = h_hi(raw[c].w);
+      const bool ok = rok && cok[c];  // zero padding: the ACTIVATED value of a pixel outside the image is 0 too
+      const float w0 = c == 0 || c == 3 ? 0.125f : (c == 1 || c == 2 ? 0.375f : 0.f);  // tap of column c for output column 0
+      const float w1 = c == 2 || c == 5 ? 0.125f : (c == 3 || c == 4 ? 0.375f : 0.f);  // ... for output column 1
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = fmaf(f[j], sc[j], sf[j]);
+        v = act ? silu_t<bf16_t>(v) : v;
+        v = ok ? v : 0.f;
+        if (w0 != 0.f) { ha[0][j] = fmaf(w0, v, ha[0][j]); hx[0][j] = fmaf(w0, f[j], hx[0][j]); }
+        if (w1 != 0.f) { ha[1][j] = fmaf(w1, v, ha[1][j]); hx[1][j] = fmaf(w1, f[j], hx[1][j]); }
+      }
+    }
+  };
+  float pa[2][8], px[2][8], qa[2][8], qx[2][8];  // P: the older output row (gets taps 2, 3), Q: the newer (taps 0, 1)
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { pa[q][j] = 0.f; px[q][j] = 0.f; qa[q][j] = 0.f; qx[q][j] = 0.f; }
+  uint4 cur[6], nxt[6];
+  load_row(iy0, cur);
+#pragma unroll
+  for (int k = 0; k < 2 * RS + 2; ++k) {
+    if (k + 1 < 2 * RS + 2) load_row(iy0 + k + 1, nxt);
+    float ha[2][8], hx[2][8];
+    hrow(iy0 + k, cur, ha, hx);
+    const float wq = (k & 1) ? 0.375f : 0.125f, wp = (k & 1) ? 0.125f : 0.375f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        qa[q][j] = (k & 1) ? fmaf(wq, ha[q][j], qa[q][j]) : wq * ha[q][j];
+        qx[q][j] = (k & 1) ? fmaf(wq, hx[q][j], qx[q][j]) : wq * hx[q][j];
+        pa[q][j] = fmaf(wp, ha[q][j], pa[q][j]);
+        px[q][j] = fmaf(wp, hx[q][j], px[q][j]);
+      }
+    if (k & 1) {  // the older row is complete
+      const int oy = oy0 + (k >> 1) - 1;
+      if (k >= 3 && oy < Ho) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const long opix = ((long)b * Ho + oy) * Wo + 2 * tx + q;
+          store8<bf16_t>(y + opix * ldy + cg * 8, pa[q]);
+          if (xr) store8<bf16_t>(xr + opix * ldxr + cg * 8, px[q]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pa[q][j] = qa[q][j]; px[q][j] = qx[q][j]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) cur[c] = nxt[c];
+  }
+}
+
 // Tiled FIR x2 UP for the large levels: the 2 x 2-block kernel above evaluates SiLU(GN(.)) 9 times per input element in
 // its up mode, which makes it VALU-bound (91 us at 256^2 output against 60 us of HBM time).  Here a block stages one input
 // tile — 8 channel groups x (4 + 2) x (8 + 2) pixels — in LDS ONCE: the activated value as fp32 and the raw value in the
@@ -492,6 +600,17 @@ static int gn_apply_typed(const void* x, int ldx, const float* scale, const floa
                        (const T*)x, ldx, scale, shift, C, (T*)y, ldy, (T*)xr, ldxr, B, H, W, act, tw, th);
     DS_LAUNCH_CHECK();
     return 0;
+  }
+  if constexpr (sizeof(T) == 2) {
+    // large levels, FIR down, 16-bit tensors: column pairs walking down strips of 8 output rows (every input row read once)
+    if (aff && mode == 2 && H % 2 == 0 && W % 4 == 0 && tot2 >= 131072) {
+      constexpr int RS = 8;
+      const long tot3 = (long)B * cdiv(H / 2, RS) * (W / 4) * (C >> 3);
+      hipLaunchKernelGGL((gn_fir_down_strip_kernel<RS>), dim3((unsigned)cdiv(tot3, 256)), dim3(256), 0, st, (const bf16_t*)x, ldx, scale,
+                         shift, C, (bf16_t*)y, ldy, (bf16_t*)xr, ldxr, B, H, W, act);
+      DS_LAUNCH_CHECK();
+      return 0;
+    }
   }
   if (aff && (mode == 1 || (mode == 2 && H % 4 == 0 && W % 4 == 0 && tot2 >= 131072))) {
     long nb2 = (tot2 + 255) / 256;

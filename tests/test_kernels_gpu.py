@@ -105,9 +105,11 @@ def test_conv_f32_is_exact_fmaf_chain_on_integers():
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
 @pytest.mark.parametrize("C,H,W,resample", [(64, 32, 64, 0), (128, 16, 16, 0), (192, 8, 24, 0), (256, 4, 4, 0),
                                             (64, 16, 32, 1), (128, 16, 32, 2), (16, 8, 12, 1), (16, 8, 12, 2),
-                                            # large levels: the LDS-tiled FIR-up kernel (whole and ragged tiles) and
-                                            # the 2 x 2-block FIR-down kernel
-                                            (64, 100, 172, 1), (128, 256, 520, 2), (64, 128, 128, 1), (64, 256, 256, 2)])
+                                            # large levels: the LDS-tiled FIR-up kernel (whole and ragged tiles) and the
+                                            # 2 x 2-block FIR-down kernel (fp32) / the strip FIR-down kernel (16-bit: whole and
+                                            # ragged strips of 8 output rows, odd numbers of column pairs)
+                                            (64, 100, 172, 1), (128, 256, 520, 2), (64, 128, 128, 1), (64, 256, 256, 2),
+                                            (256, 44, 1032, 2)])
 def test_groupnorm_silu_resample(dtype, tol, C, H, W, resample):
     B = 2
     x = rnd(f"gn.x{C}{H}{resample}", (B, C, H, W), 1.5) + 0.3
