@@ -165,16 +165,23 @@ template <int GW, int PC, int NS, int ESZ>
 struct SmGeom {
   static constexpr int THT = SmTile<GW>::THT, NT = SmTile<GW>::NT;
   static constexpr int HWS = GW + 2, HP = (THT + 2) * HWS;  // halo columns / pixels
+  // LDS geometry of the halo tile: rows of HWSP pixels (HWS padded), PSTR bytes per pixel.  A fragment read of the
+  // 16 x 16 x 32 MFMA is lane = (pixel l16 of the 16-pixel group, k-quarter q) -> (row * HWSP + column) * PSTR + 16 q, and
+  // ds_read_b128 serves lanes {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... in one pass each: 16 distinct 16-byte bank
+  // slots per pass need PSTR / 16 = 2 (mod 4) and, where a group spans several tile rows (GW = 8: 2 rows, GW = 4: 4 rows), a
+  // halo row of 16 / 12 pixels (exhaustive search over pitches and row lengths; rounds 2 - 3 had PSTR / 16 = 1 (mod 4) and
+  // unpadded rows: 4.3 - 4.5 conflict cycles per LDS instruction in the counters).
+  static constexpr int HWSP = GW == 16 ? HWS : (GW == 8 ? 16 : 12);
   static constexpr int KVE = 16 / ESZ;                       // elements per 16-byte vector
   static constexpr int NVEC = PC / KVE;                      // 16-byte vectors per pixel / weight row
   static constexpr int RPS = NT / NVEC;                      // rows staged by one pass of the block
-  static constexpr int PSTR = PC * ESZ + 16;                 // LDS pitch of a halo pixel / of a (tap, cout) weight row
+  static constexpr int PSTR = PC * ESZ + 32;                 // LDS pitch of a halo pixel / of a (tap, cout) weight row
   static constexpr int NA = (HP + RPS - 1) / RPS;            // input vectors per thread and phase
   static constexpr int NWV = (9 * NS + RPS - 1) / RPS;       // weight vectors per thread and phase
   static constexpr int NGRP = THT * GW / 16;                 // 16-pixel groups of the tile (one per wave)
   static constexpr int NSK = (NS + RPS - 1) / RPS;           // staging passes of the folded skip convolution's weights
   static_assert(NGRP <= NT / 64 && NSK <= NWV && RPS % NS == 0, "one MFMA group per wave; a staging pass covers whole taps");
-  static constexpr int LDS_IN = HP * PSTR, LDS_W = 9 * NS * PSTR;
+  static constexpr int LDS_IN = (THT + 2) * HWSP * PSTR, LDS_W = 9 * NS * PSTR;
   static constexpr int LDS = LDS_IN + LDS_W + 2 * GN_MAX * 4;
   static_assert(LDS_IN + LDS_W >= 2 * GN_MAX * 8, "the GroupNorm table is built in the staging area");
 };
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
   constexpr bool SPLIT = ESZ == 4;
   constexpr int NSK = G::NSK, NH = NS / 16;
   constexpr int THT = G::THT, NT = G::NT, NWAVES = NT / 64;
-  constexpr int HWS = G::HWS, HP = G::HP, NVEC = G::NVEC, RPS = G::RPS, PSTR = G::PSTR, NA = G::NA, NWV = G::NWV,
+  constexpr int HWS = G::HWS, HWSP = G::HWSP, HP = G::HP, NVEC = G::NVEC, RPS = G::RPS, PSTR = G::PSTR, NA = G::NA, NWV = G::NWV,
                 NGRP = G::NGRP;
   ST_DECL
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -207,6 +214,7 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
   // ---- staging geometry: vector i = tid + NT k is 16 bytes (8 channels, slot tid % NVEC) of halo pixel i / NVEC
   const int cv = tid % NVEC, row0 = tid / NVEC;
   int pixi[NA];    // linear pixel index in the image, or -1 (outside the image or past the halo)
+  int ldsa[NA];    // LDS byte offset of the vector (halo rows are HWSP pixels long there)
   bool inner[NA];  // the pixel belongs to the tile proper (all the folded 1x1 convolution needs)
 #pragma unroll
   for (int k = 0; k < NA; ++k) {
@@ -216,6 +224,7 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
     const bool ok = pix < HP && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
     pixi[k] = ok ? gy * p.W + gx : -1;
     inner[k] = ok && hy >= 1 && hy <= THT && hx >= 1 && hx <= GW;
+    ldsa[k] = (hy * HWSP + hx) * PSTR + cv * (SPLIT ? 8 : 16);
   }
   const int lds0 = row0 * PSTR + cv * (SPLIT ? 8 : 16);  // + RPS k PSTR (split: 8 bytes in each of the two planes)
 
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
   auto write = [&](Stage& S) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < NA; ++k)
-      if (row0 + RPS * k < HP) put(sIn + lds0 + RPS * k * PSTR, S.pa[k]);
+      if (row0 + RPS * k < HP) put(sIn + ldsa[k], S.pa[k]);
     if (S.raw) {
 #pragma unroll
       for (int k = 0; k < NSK; ++k)
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
 #pragma unroll
   for (int h = 0; h < NH; ++h) { acc[h][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[h][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const int woff = l16 * PSTR + q * 16;
-  const int aoff = (ty * HWS + tx) * PSTR + q * 16;
+  const int aoff = (ty * HWSP + tx) * PSTR + q * 16;
   // fragment reads run one tap ahead of the MFMAs (two register sets): the LDS latency is paid once per phase
   auto mma = [&](bool raw) __attribute__((always_inline)) {
     if (!mma_wave) return;
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
           xf[set][pl_][kb] =
-              *reinterpret_cast<const uint4*>(sIn + ((tap / 3) * HWS + tap % 3) * PSTR + aoff + pl_ * PC * 2 + kb * 64);
+              *reinterpret_cast<const uint4*>(sIn + ((tap / 3) * HWSP + tap % 3) * PSTR + aoff + pl_ * PC * 2 + kb * 64);
 #pragma unroll
           for (int h = 0; h < NH; ++h)
             wf[set][pl_][h][kb] = *reinterpret_cast<const uint4*>(sW + (tap * NS + 16 * h) * PSTR + woff + pl_ * PC * 2 + kb * 64);

@@ -674,7 +674,11 @@ struct ThinOutK {
   int Cout;
   int H, W, G, tiles_x, tiles_per_img;
 };
-constexpr int TO_PROW = 64 * 2 + 16;              // LDS pitch of a halo pixel (64 channels) / of a (tap, cout) weight row
+// LDS pitch of a halo pixel (64 channels) / of a (tap, cout) weight row: 160 B.  A 16 x 16 x 32 fragment read is lane = (row l16,
+// k-quarter q) -> row * pitch + 16 q; ds_read_b128 serves lanes {0-3, 12-15, 20-27} (rows 0-3, 12-15 at q, rows 4-11 at q + 1)
+// etc. in one pass, and those 16 addresses fall into 16 distinct 16-byte bank slots iff pitch / 16 = 2 (mod 4): with the 144 B
+// of rounds 2 - 3 (right for the 32 x 32 x 16 layout of the other kernels) the counters showed 3.4 conflict cycles per read.
+constexpr int TO_PROW = 64 * 2 + 32;
 constexpr int TO_LDS_X = HP * TO_PROW;            // 48,960
 constexpr int TO_LDS_W = 9 * 16 * TO_PROW;        // 20,736
 constexpr int TO_LDS = TO_LDS_X + TO_LDS_W + 2 * 64 * 4;

@@ -168,6 +168,12 @@ struct ConvGeom {
   static constexpr int KV = 16 / (int)sizeof(T);
   static constexpr int R = (TAPS == 9) ? 1 : 0;
   static constexpr int HW_ = TW + 2 * R, HH_ = TH + 2 * R, HP = HW_ * HH_;
+  // LDS row length of the halo tile (pixels).  A wave's 32 fragment pixels are one tile row when TW = 32, two when TW = 16,
+  // four when TW = 8; ds_read_b128 serves lanes {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... in one pass each, and with the
+  // 80 / 144-byte pitch those 16 rows fall into 16 distinct 16-byte bank slots only if the tile rows start 32 (TW = 16) / 24
+  // (TW = 8) LDS rows apart (exhaustive search; unpadded, the half-width tile of the 32^2 level had 2 of 16 lanes conflicting
+  // in every pass: 2.8 conflict cycles per LDS instruction in round 3's counters)
+  static constexpr int HWP = (TAPS == 9 && TW == 16) ? 32 : ((TAPS == 9 && TW == 8) ? 24 : HW_);
   static constexpr int BM = TH * TW;
   static constexpr int ROWB = KC * (int)sizeof(T) + 16;
   static constexpr int NVEC = KC / KV;
@@ -175,7 +181,8 @@ struct ConvGeom {
   static constexpr int NA = (HP * NVEC + NT - 1) / NT;
   static constexpr int NB = (TAPS * BN * NVEC + NT - 1) / NT;
   static constexpr int OROW = BN * 4 + 16;  // fp32 output staging row pitch
-  static constexpr int LDS_STAGE = HP * ROWB + TAPS * BN * ROWB;
+  static constexpr int LDS_A = HH_ * HWP * ROWB;   // the halo tile
+  static constexpr int LDS_STAGE = LDS_A + TAPS * BN * ROWB;
   static constexpr int LDS_OUT = (BM / EP) * OROW;  // the epilogue streams the tile out in EP passes
   static constexpr int LDS = LDS_STAGE > LDS_OUT ? LDS_STAGE : LDS_OUT;
   // fused 1x1 skip convolution: needs one weight staging pass per tap (256 / NVEC rows per pass == BN)
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(NT, OCC) void conv_mfma_kernel(ConvK p) {
   using G = ConvGeom<T, TAPS, TH, TW, BN, KC, EP, NT>;
   static_assert(EP == 1 || (WM % EP == 0), "epilogue passes split the wave's M blocks");
   static_assert(SP == 0 || (sizeof(T) == 4 && KC % 16 == 0), "split mode: fp32 storage, whole 16-channel k-blocks");
-  constexpr int KV = G::KV, R = G::R, HW_ = G::HW_, HP = G::HP, BM = G::BM, ROWB = G::ROWB, NVEC = G::NVEC,
+  constexpr int KV = G::KV, R = G::R, HW_ = G::HW_, HWP = G::HWP, HP = G::HP, BM = G::BM, ROWB = G::ROWB, NVEC = G::NVEC,
                 NKB = SP ? KC / 16 : G::NKB, NA = G::NA, NB = G::NB, OROW = G::OROW;
   constexpr int ESZ = (int)sizeof(T);
   constexpr int WAVES_N = BN / (32 * WN);
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(NT, OCC) void conv_mfma_kernel(ConvK p) {
   CT_DECL
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
-  char* sB = smem + HP * ROWB;
+  char* sB = smem + G::LDS_A;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -270,6 +277,7 @@ __global__ __launch_bounds__(NT, OCC) void conv_mfma_kernel(ConvK p) {
   // pixel index of the thread's halo vectors (-1: outside the image).  The byte offset in a source is
   // (pixi * ld + vch) * ESZ; for pixi = -1 that is negative = far beyond num_records as unsigned: reads zero.
   int pixi_[NA];
+  int ldsa_[NA];  // LDS byte offset of the thread's halo vectors (tile rows are HWP pixels apart there)
   bool aval[NA];
   bool ain[NA];  // the vector belongs to the tile proper (not its halo): all the fused 1x1 skip conv needs
 #pragma unroll
@@ -287,6 +295,11 @@ __global__ __launch_bounds__(NT, OCC) void conv_mfma_kernel(ConvK p) {
     }
     aval[k] = pixi >= 0;
     pixi_[k] = pixi;
+    {
+      const int pix = row0 + k * RPS;
+      const int hy = TAPS == 9 ? pix / HW_ : 0, hx = TAPS == 9 ? pix - hy * HW_ : pix;
+      ldsa_[k] = (hy * HWP + hx) * ROWB;
+    }
     {
       const int pix = row0 + k * RPS;
       const int hy = pix / HW_, hx = pix - hy * HW_;
@@ -328,7 +341,7 @@ __global__ __launch_bounds__(NT, OCC) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
     const int pp = (wm * WM + i) * 32 + l32;
-    const int row = (TAPS == 9) ? ((pp / TW) * HW_ + (pp % TW)) : pp;
+    const int row = (TAPS == 9) ? ((pp / TW) * HWP + (pp % TW)) : pp;
     aoff[i] = row * ROWB + h * 16;
   }
 #pragma unroll
@@ -478,7 +491,7 @@ __global__ __launch_bounds__(NT, OCC) void conv_mfma_kernel(ConvK p) {
 #endif
 #pragma unroll
     for (int k = 0; k < NA; ++k)
-      if (a_in(k)) put(sA + ldsw0 + k * RPS * ROWB, pa[k]);
+      if (a_in(k)) put(sA + ldsa_[k] + ldsw0 - row0 * ROWB, pa[k]);
     if (skip) {  // only the centre tap's weight rows exist (and only they are read)
 #pragma unroll
       for (int q = 0; q < QS; ++q) put(sB + ldsw0 + (KSKIP + q) * RPS * ROWB, pb[KSKIP + q]);
@@ -512,7 +525,7 @@ __global__ __launch_bounds__(NT, OCC) void conv_mfma_kernel(ConvK p) {
       constexpr bool SKIP = decltype(SKIP_)::value;  // fused skip convolution: the centre tap only
 #pragma unroll
       for (int tap = (SKIP ? 4 : 0); tap < (SKIP ? 5 : TAPS); ++tap) {
-        const int toff = (TAPS == 9) ? ((tap / 3) * HW_ + (tap % 3)) * ROWB : 0;
+        const int toff = (TAPS == 9) ? ((tap / 3) * HWP + (tap % 3)) * ROWB : 0;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
           uint4 af[WM], bfr[WN];
