@@ -51,6 +51,9 @@ struct Module {
   // second copies of Conv_0 / Conv_1 / Conv_2 in the register-weight kernel's fragment-major order (16-bit engines, the shapes
   // that kernel takes: ds_rw_frag_shape), -1 = none
   long pf0 = -1, pf1 = -1, pf2 = -1;
+  // cat(128, 128) -> 128 blocks whose convolutions run as two 128-channel launches (res_block): fragment-major copies of the
+  // two halves of Conv_0, of the first half of Conv_2, and the second half of Conv_2 packed for a stand-alone 1x1 launch
+  long pf0a = -1, pf0b = -1, pf2a = -1, pk2b = -1;
   // attention block, fused kernel (attn_fused.hip; 128 channels only): fragment-major copies [0] = Wk^T Wq (query and key
   // projections folded at engine creation), [2] = Wv, [3] = Wo; ab_off = this block's Wk^T b_q in the engine's d_attn_b
   long pf_nin[4] = {-1, -1, -1, -1};
@@ -145,6 +148,9 @@ struct ArchBuilder {
     if (ds_rw_frag_shape(9, in, out)) m.pf0 = pack(out, 9, in);
     if (ds_rw_frag_shape(9, out, out)) m.pf1 = pack(out, 9, out);
     if (m.has_conv2 && ds_rw_frag_shape(1, in, out)) m.pf2 = pack(out, 1, in);
+    if (in == 256 && in_c1 == 128 && out == 128 && !up && !down) {
+      m.pf0a = pack(out, 9, 128); m.pf0b = pack(out, 9, 128); m.pf2a = pack(out, 1, 128); m.pk2b = pack(out, 1, 128);
+    }
     m.temb_off = A.dense_total;
     A.dense_total += out;
     A.mods.push_back(m);
@@ -369,7 +375,8 @@ static int opt_bit(const char* name, unsigned* bit) {
   static const struct { const char* n; unsigned b; } tab[] = {
       {"no_rw", DS_OPT_NO_RW}, {"no_rw128", DS_OPT_NO_RW128}, {"rw_small", DS_OPT_RW_SMALL}, {"no_rw_res", DS_OPT_NO_RW_RES},
       {"no_wfrag", DS_OPT_NO_WFRAG},
-      {"no_attn_fused", DS_OPT_NO_ATTN_FUSED}};
+      {"no_attn_fused", DS_OPT_NO_ATTN_FUSED},
+      {"no_split256", DS_OPT_NO_SPLIT256}};
   for (const auto& t : tab)
     if (!strcmp(name, t.n)) { *bit = t.b; return 0; }
   return 1;
@@ -653,6 +660,38 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
   const int Ho = m.up ? 2 * x.H : (m.down ? x.H / 2 : x.H);
   const int Wo = m.up ? 2 * x.W : (m.down ? x.W / 2 : x.W);
   GnAff a0, a1;
+  // cat(128, 128) -> 128 on a level with at least one 4 x 32 tile per CU (nf = 128 at 256^2 / 128^2), 16-bit: no register-weight
+  // kernel holds 256 input channels (section 8 of DESIGN.md), but conv(cat(a, b)) = conv_a(a) + conv_b(b) and no GroupNorm group
+  // straddles the seam (256 / 32 = 8 channels per group): each convolution runs as TWO 128 -> 128 register-weight launches, the
+  // second taking the first's result as its residual (one more storage rounding of a partial sum).  Conv_0: 850 -> 593 us at
+  // 256^2; Conv_1 + the 256-channel 1x1 skip: the first half of the skip folded as before, the second as a 1x1 launch.
+  if (e->cfg.dtype == DS_BF16 && mode == 0 && x.p2 && m.pf0a >= 0 && x.C1 == 128 && x.sa && x.sa2 && x.W % 32 == 0 && x.H % 8 == 0 &&
+      x.H >= 32 && (long)B * (x.H / 4) * (x.W / 32) >= ds_num_cus() &&
+      !(e->opts & (DS_OPT_NO_RW | DS_OPT_NO_RW128 | DS_OPT_NO_SPLIT256 | DS_OPT_NO_WFRAG))) {
+    Tn xa = x, xb = x;
+    xa.C = 128; xa.p2 = nullptr; xa.C1 = 0; xa.ld2 = 0; xa.sa2 = nullptr;
+    xb.p = x.p2; xb.ld = x.ld2; xb.C = 128; xb.p2 = nullptr; xb.C1 = 0; xb.ld2 = 0; xb.sa = x.sa2; xb.sa2 = nullptr;
+    GnAff ga, gb;
+    ga.acc1 = xa.sa; ga.gamma = P(e, m.gn0_w); ga.beta = P(e, m.gn0_b); ga.groups = 16;
+    ga.inv_count = (float)(1.0 / ((double)x.H * x.W * 8));
+    gb = ga; gb.acc1 = xb.sa; gb.gamma = ga.gamma + 128; gb.beta = ga.beta + 128;
+    Tn h1p = e_tensor(e, B, Ho, Wo, m.out_ch), h1 = e_tensor(e, B, Ho, Wo, m.out_ch);
+    const long half0 = 4L * 9 * m.out_ch * 32;  // chunk-major [Cin / 32][9][Cout][32]: the first source = the first 4 chunks
+    if (conv(e, xa, PK(e, m.pk0), P(e, m.conv0_b), temb_proj + m.temb_off, e->arch.dense_total, nullptr, 1.f, h1p, m.out_ch, 9, B,
+             nullptr, st, &ga, 1, false, nullptr, PKF(e, m.pf0a)))
+      return 1;
+    if (conv(e, xb, PK(e, m.pk0 + half0), nullptr, nullptr, 0, &h1p, 1.f, h1, m.out_ch, 9, B, nullptr, st, &gb, 1, true, nullptr,
+             PKF(e, m.pf0b)))
+      return 1;
+    if (gn_stats(e, h1, P(e, m.gn1_w), P(e, m.gn1_b), B, a1, st, true)) return 1;
+    Tn outp = e_tensor(e, B, Ho, Wo, m.out_ch);
+    out = e_tensor(e, B, Ho, Wo, m.out_ch);
+    const SkipConv sk = {&xa, PK(e, m.pk2), weight_chunk(9, 128, 0, e->cfg.dtype), PKF(e, m.pf2a)};
+    if (conv(e, h1, PK(e, m.pk1), P(e, m.conv1_b), P(e, m.conv2_b), 0, nullptr, 1.f, outp, m.out_ch, 9, B, nullptr, st, &a1, 1,
+             false, &sk, PKF(e, m.pf1)))
+      return 1;
+    return conv(e, xb, PK(e, m.pk2b), nullptr, nullptr, 0, &outp, kInvSqrt2, out, m.out_ch, 1, B, nullptr, st, nullptr, 0, true);
+  }
   if (gn_stats(e, x, P(e, m.gn0_w), P(e, m.gn0_b), B, a0, st, mode == 0)) return 1;  // resampling needs the arrays
   Tn h1 = e_tensor(e, B, Ho, Wo, m.out_ch);
   Tn xr = x, h0m;
@@ -1043,6 +1082,15 @@ static int repack_module(diffsep_engine* e, const Module& m) {
       rc |= repack_frag(e, m.conv0_w, m.pf0, m.out_ch, m.in_ch, 9, (long)m.in_ch * 9, 9, 1);
       rc |= repack_frag(e, m.conv1_w, m.pf1, m.out_ch, m.out_ch, 9, (long)m.out_ch * 9, 9, 1);
       if (m.has_conv2) rc |= repack_frag(e, m.conv2_w, m.pf2, m.out_ch, m.in_ch, 1, m.in_ch, 1, 0);
+      if (m.pf0a >= 0) {  // the halves of a cat(128, 128) block (channel offset 128 in the second)
+        PRef w0b = m.conv0_w, w2b = m.conv2_w;
+        w0b.off += 128L * 9;
+        w2b.off += 128;
+        rc |= repack_frag(e, m.conv0_w, m.pf0a, m.out_ch, 128, 9, (long)m.in_ch * 9, 9, 1);
+        rc |= repack_frag(e, w0b, m.pf0b, m.out_ch, 128, 9, (long)m.in_ch * 9, 9, 1);
+        rc |= repack_frag(e, m.conv2_w, m.pf2a, m.out_ch, 128, 1, m.in_ch, 1, 0);
+        rc |= repack_weight(e, w2b, m.pk2b, m.out_ch, 128, 1, m.in_ch, 1, 0);
+      }
       // Dense_0.weight [out][temb dim] -> columns [temb_off, temb_off + out) of the transposed concatenation
       // [temb dim][dense_total] (ds_launch_linear_t)
       rc |= ds_launch_dense_transpose(e->d_blob + m.dense_w.off, e->d_dense_w, m.out_ch, (int)(m.dense_w.numel / m.out_ch),
