@@ -682,7 +682,12 @@ constexpr int TO_PROW = 64 * 2 + 32;
 constexpr int TO_LDS_X = HP * TO_PROW;            // 48,960
 constexpr int TO_LDS_W = 9 * 16 * TO_PROW;        // 20,736
 constexpr int TO_LDS = TO_LDS_X + TO_LDS_W + 2 * 64 * 4;
-__global__ __launch_bounds__(512, 2) void conv3x3_thin_out_kernel(ThinOutK p) {
+// WPE = waves per SIMD the register allocation is held to: 4 = 128 VGPRs, TWO blocks per CU, so that one block's loads / activation
+// / LDS writes overlap the other's MFMA phase (64 -> 6 at 256^2: 73.7 -> 58.8 us; at 134 VGPRs only one block fitted); 2 for
+// launches with a single tile per block, where the few spilled registers of the tight allocation cost more than they buy
+// (128 -> 6 at 64^2: 11.9 vs 13.1 us)
+template <int WPE>
+__global__ __launch_bounds__(512, WPE) void conv3x3_thin_out_kernel(ThinOutK p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sX = smem;
   char* sWt = smem + TO_LDS_X;
@@ -946,8 +951,13 @@ int ds_launch_conv_thin_out(const ConvArgs& a, hipStream_t st) {
   k.H = a.H; k.W = a.W; k.G = ws_blocks_per_image(a) * 2;  // two blocks per CU
   if (k.G > tiles) k.G = tiles;
   k.tiles_x = a.W / TW; k.tiles_per_img = tiles;
-  DS_FUNC_LDS_ONCE(conv3x3_thin_out_kernel, TO_LDS);
-  hipLaunchKernelGGL(conv3x3_thin_out_kernel, dim3(a.B * k.G), dim3(512), TO_LDS, st, k);
+  if (tiles >= 2 * k.G) {
+    DS_FUNC_LDS_ONCE(conv3x3_thin_out_kernel<4>, TO_LDS);
+    hipLaunchKernelGGL(conv3x3_thin_out_kernel<4>, dim3(a.B * k.G), dim3(512), TO_LDS, st, k);
+  } else {
+    DS_FUNC_LDS_ONCE(conv3x3_thin_out_kernel<2>, TO_LDS);
+    hipLaunchKernelGGL(conv3x3_thin_out_kernel<2>, dim3(a.B * k.G), dim3(512), TO_LDS, st, k);
+  }
   ds_set_last_conv_kernel("conv3x3_thin_out_kernel");
   DS_LAUNCH_CHECK();
   return 0;
