@@ -277,7 +277,10 @@ __global__ __launch_bounds__(NT, OCC) void conv_mfma_kernel(ConvK p) {
   // pixel index of the thread's halo vectors (-1: outside the image).  The byte offset in a source is
   // (pixi * ld + vch) * ESZ; for pixi = -1 that is negative = far beyond num_records as unsigned: reads zero.
   int pixi_[NA];
-  int ldsa_[NA];  // LDS byte offset of the thread's halo vectors (tile rows are HWP pixels apart there)
+  // LDS byte offset of the thread's halo vectors (tile rows are HWP pixels apart there); linear in k — a compile-time
+  // immediate, no registers — when the LDS rows carry no padding (TW = 32, 1x1)
+  constexpr bool LDSA_LIN = TAPS != 9 || HWP == HW_;
+  int ldsa_[LDSA_LIN ? 1 : NA];
   bool aval[NA];
   bool ain[NA];  // the vector belongs to the tile proper (not its halo): all the fused 1x1 skip conv needs
 #pragma unroll
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(NT, OCC) void conv_mfma_kernel(ConvK p) {
     }
     aval[k] = pixi >= 0;
     pixi_[k] = pixi;
-    {
+    if constexpr (!LDSA_LIN) {
       const int pix = row0 + k * RPS;
       const int hy = TAPS == 9 ? pix / HW_ : 0, hx = TAPS == 9 ? pix - hy * HW_ : pix;
       ldsa_[k] = (hy * HWP + hx) * ROWB;
@@ -307,9 +310,25 @@ __global__ __launch_bounds__(NT, OCC) void conv_mfma_kernel(ConvK p) {
     }
   }
   auto voa = [&](int k, int ld) __attribute__((always_inline)) { return (unsigned)((pixi_[k] * ld + vch) * ESZ); };
-  unsigned vob[NB];  // byte offsets of the thread's weight vectors (row = cout, tap): DS_OOB past Cout
+  // byte offsets of the thread's weight vectors (row = cout, tap): DS_OOB past Cout.  When a pass of the block covers whole
+  // taps the offsets are base + k * step (one register + a scalar instead of NB registers: the 8 x 32 x 64 tile sat at 256
+  // VGPRs with 5 of them in scratch memory, and a scratch reload next to in-flight loads is a full vmcnt(0))
+  constexpr bool VOB_LIN = B_TAPSTEP;
+  unsigned vob[VOB_LIN ? 1 : NB];
+  unsigned vob_step = 0;
+  int vtap0 = 0;
+  bool vcol_ok = false;
+  if constexpr (VOB_LIN) {
+    const int col = row0 % BN;
+    vtap0 = row0 / BN;
+    vcol_ok = n0 + col < p.Cout;
+    vob[0] = p.w_chunked ? (unsigned)((((vch >> p.w_shift) * TAPS + vtap0) * p.Cout + n0 + col) * p.w_chunked +
+                                      (vch & (p.w_chunked - 1))) * ESZ
+                         : (unsigned)(((n0 + col) * TAPS + vtap0) * p.Cin + vch) * ESZ;
+    vob_step = (unsigned)(RPS / BN) * (p.w_chunked ? (unsigned)(p.Cout * p.w_chunked) : (unsigned)p.Cin) * ESZ;
+  }
 #pragma unroll
-  for (int k = 0; k < NB; ++k) {
+  for (int k = 0; k < (VOB_LIN ? 0 : NB); ++k) {
     int col, tap;
     if (B_TAPSTEP) {  // a pass covers whole taps
       col = row0 % BN;
@@ -327,6 +346,10 @@ __global__ __launch_bounds__(NT, OCC) void conv_mfma_kernel(ConvK p) {
                                             (vch & (p.w_chunked - 1))) * ESZ
                                : (unsigned)(((n0 + col) * TAPS + tap) * p.Cin + vch) * ESZ;
   }
+  auto vobk = [&](int k) __attribute__((always_inline)) {
+    if constexpr (VOB_LIN) return (vcol_ok && vtap0 + k * (RPS / BN) < TAPS) ? vob[0] + (unsigned)k * vob_step : DS_OOB;
+    else return vob[k];
+  };
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -411,7 +434,7 @@ __global__ __launch_bounds__(NT, OCC) void conv_mfma_kernel(ConvK p) {
         for (int k = 0; k < NA; ++k) pa[k] = buf_load16a(rx2, voa(k, ld_), so);
       }
 #pragma unroll
-      for (int k = 0; k < NB; ++k) pb[k] = buf_load16(rw, vob[k], sw);
+      for (int k = 0; k < NB; ++k) pb[k] = buf_load16(rw, vobk(k), sw);
     } else {  // channel tail of a source: lanes past the end read zeros
       if (!second) {
 #pragma unroll
@@ -421,7 +444,7 @@ __global__ __launch_bounds__(NT, OCC) void conv_mfma_kernel(ConvK p) {
         for (int k = 0; k < NA; ++k) pa[k] = buf_load16(rx2, ch_ok ? voa(k, ld_) : DS_OOB, so);
       }
 #pragma unroll
-      for (int k = 0; k < NB; ++k) pb[k] = buf_load16(rw, ch_ok ? vob[k] : DS_OOB, sw);
+      for (int k = 0; k < NB; ++k) pb[k] = buf_load16(rw, ch_ok ? vobk(k) : DS_OOB, sw);
     }
   };
   auto load_gn = [&](int c) __attribute__((always_inline)) {  // scale / shift of this thread's KV channels of chunk c
@@ -491,7 +514,7 @@ __global__ __launch_bounds__(NT, OCC) void conv_mfma_kernel(ConvK p) {
 #endif
 #pragma unroll
     for (int k = 0; k < NA; ++k)
-      if (a_in(k)) put(sA + ldsa_[k] + ldsw0 - row0 * ROWB, pa[k]);
+      if (a_in(k)) put(LDSA_LIN ? sA + ldsw0 + k * RPS * ROWB : sA + ldsa_[LDSA_LIN ? 0 : k] + ldsw0 - row0 * ROWB, pa[k]);
     if (skip) {  // only the centre tap's weight rows exist (and only they are read)
 #pragma unroll
       for (int q = 0; q < QS; ++q) put(sB + ldsw0 + (KSKIP + q) * RPS * ROWB, pb[KSKIP + q]);
