@@ -1211,9 +1211,12 @@ extern "C" int32_t diffsep_engine_set_option(diffsep_engine* e, const char* name
     ds_set_error(std::string("engine_set_option: unknown option '") + name + "'");
     return 1;
   }
-  // the captured graphs froze the old launch decisions (and the cache may now be over its cap): forget them all
+  // the captured graphs froze the old launch decisions (and the cache may now be over its cap): forget them all — and the plan:
+  // a dispatch switch may change what a forward allocates (tensors, GroupNorm accumulators), so the next call sizes it again
   DS_HIP(hipDeviceSynchronize());
   drop_graph(e);
+  e->planB = -1;
+  e->planT = -1;
   return 0;
 }
 extern "C" int64_t diffsep_engine_get_option(const diffsep_engine* e, const char* name) {
