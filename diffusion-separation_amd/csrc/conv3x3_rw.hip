@@ -823,7 +823,8 @@ bool ds_conv_rw_eligible(const ConvArgs& a) {
   if (gn && !a.gn_act) return false;  // (affine without SiLU does not occur in front of a 3x3 convolution)
   if (a.gn_acc1 && !(a.gn_groups > 0 && a.Cin % a.gn_groups == 0 && a.Cin / a.gn_groups <= 8 && (!a.x2 || a.gn_acc2))) return false;
   if (a.sx) {
-    if (!(a.sw && !a.res && (a.sCin == 64 || a.sCin == 128) && a.ldsx % 8 == 0 &&
+    // (192 skip channels = the cat(64, 128) block of the 128^2 up path: 36 + 12 fragments fill 192 of the 256 weight registers)
+    if (!(a.sw && !a.res && (a.sCin == 64 || a.sCin == 128 || (a.sCin == 192 && CO == 64 && a.Cin == 64)) && a.ldsx % 8 == 0 &&
           (!a.sx2 || (a.sC1 % KC == 0 && a.sC1 > 0 && a.sC1 < a.sCin && a.ldsx2 % 8 == 0)) &&
           (a.sw_chunked == 0 || ((a.sw_chunked & (a.sw_chunked - 1)) == 0 && a.sw_chunked >= 16))))
       return false;
@@ -889,6 +890,7 @@ int ds_launch_conv_rw(const ConvArgs& a, hipStream_t st) {
   if (a.Cin == 128) RW_GO(2, 0);
   if (nsk == 0) RW_GO(1, 0);
   if (nsk == 1) RW_GO(1, 1);
-  RW_GO(1, 2);
+  if (nsk == 2) RW_GO(1, 2);
+  RW_GO(1, 3);
 #undef RW_GO
 }

@@ -604,10 +604,21 @@ static int gn_apply_typed(const void* x, int ldx, const float* scale, const floa
   if constexpr (sizeof(T) == 2) {
     // large levels, FIR down, 16-bit tensors: column pairs walking down strips of 8 output rows (every input row read once)
     if (aff && mode == 2 && H % 2 == 0 && W % 4 == 0 && tot2 >= 131072) {
-      constexpr int RS = 8;
-      const long tot3 = (long)B * cdiv(H / 2, RS) * (W / 4) * (C >> 3);
-      hipLaunchKernelGGL((gn_fir_down_strip_kernel<RS>), dim3((unsigned)cdiv(tot3, 256)), dim3(256), 0, st, (const bf16_t*)x, ldx, scale,
-                         shift, C, (bf16_t*)y, ldy, (bf16_t*)xr, ldxr, B, H, W, act);
+      const long per_row = (long)B * (W / 4) * (C >> 3);
+      // strips of 8 output rows where that still gives every CU two blocks (256^2: 131072 threads); strips of 4 below (nf = 64 at
+      // 128^2: 32768 threads of 8-row strips were 128 blocks, 63 us with the statistics passes; 4-row strips 50, 2-row 53, the
+      // 2 x 2-block kernel 55)
+      if (per_row * cdiv(H / 2, 8) >= 131072) {
+        constexpr int RS = 8;
+        const long tot3 = per_row * cdiv(H / 2, RS);
+        hipLaunchKernelGGL((gn_fir_down_strip_kernel<RS>), dim3((unsigned)cdiv(tot3, 256)), dim3(256), 0, st, (const bf16_t*)x, ldx, scale,
+                           shift, C, (bf16_t*)y, ldy, (bf16_t*)xr, ldxr, B, H, W, act);
+      } else {
+        constexpr int RS = 4;
+        const long tot3 = per_row * cdiv(H / 2, RS);
+        hipLaunchKernelGGL((gn_fir_down_strip_kernel<RS>), dim3((unsigned)cdiv(tot3, 256)), dim3(256), 0, st, (const bf16_t*)x, ldx, scale,
+                           shift, C, (bf16_t*)y, ldy, (bf16_t*)xr, ldxr, B, H, W, act);
+      }
       DS_LAUNCH_CHECK();
       return 0;
     }

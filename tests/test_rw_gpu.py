@@ -182,10 +182,12 @@ def test_rw128_resblock_vs_oracle(cin, B, H, W, up, down):
 
 @pytest.mark.parametrize("cin,B,H,W,up,down", [(128, 3, 32, 64, False, False), (128, 2, 40, 32, False, False),
                                                (64, 3, 32, 32, True, False), (64, 2, 64, 128, False, True),
-                                               (128, 70, 64, 64, False, False), (64, 2, 24, 32, True, False)])
+                                               (128, 70, 64, 64, False, False), (64, 2, 24, 32, True, False),
+                                               (192, 2, 32, 64, False, False), (192, 33, 32, 32, False, False)])
 def test_rw_resblock_with_folded_skip_vs_oracle(cin, B, H, W, up, down):
     # 64-cout residual blocks whose Conv_0 (cat(64, 64) -> 64, GroupNorm + SiLU on the concat) and Conv_1 + folded Conv_2
-    # (64 or 128 raw channels through the centre tap) run on the register-weight kernel: 16-row and 8-row tiles, one and
+    # (64, 128 or — the cat(64, 128) block of the 128^2 up path — 192 raw channels through the centre tap) run on the
+    # register-weight kernel: 16-row and 8-row tiles, one and
     # several tiles per block, FIR up / down in front (raw-input mode of Conv_0)
     cout = 64
     shp = dict(cin=(cin,), cout=(cout,), w0=(cout, cin, 3, 3), w1=(cout, cout, 3, 3), w2=(cout, cin, 1, 1), d=(cout, 64))
