@@ -261,7 +261,7 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
         const unsigned vo = p.sw_chunked
                                 ? (unsigned)((((wb >> p.sw_shift) * p.Cout + co0 + co) * p.sw_chunked + (wb & (p.sw_chunked - 1))) * ESZ)
                                 : (unsigned)(((co0 + co) * p.sCin + wb) * ESZ);
-        S.pw[k] = ld16(rsw, co < NS ? vo : OOB, 0);
+        S.pw[k] = ld16(rsw, (co < NS && co0 + co < p.Cout) ? vo : OOB, 0);
       }
       S.raw = true;
       return;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
                     : (unsigned)((((co0 + co) * 9 + tap0) * p.Cin + wb) * ESZ);
     const unsigned vstep = (unsigned)((RPS / NS) * (p.w_chunked ? p.Cout * p.w_chunked : p.Cin) * ESZ);
 #pragma unroll
-    for (int k = 0; k < NWV; ++k) S.pw[k] = ld16(rw, row0 + RPS * k < 9 * NS ? vo0 + k * vstep : OOB, 0);
+    for (int k = 0; k < NWV; ++k) S.pw[k] = ld16(rw, (row0 + RPS * k < 9 * NS && co0 + co < p.Cout) ? vo0 + k * vstep : OOB, 0);  // (couts past Cout — the <= 8-cout heads — multiply zeros)
     S.raw = false;
   };
   // GroupNorm scale / shift of the thread's 8 channels of conv phase ph (from the LDS table or the materialised arrays)
@@ -447,10 +447,11 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
   const __amdgpu_buffer_rsrc_t ry = rsrc((char*)p.y + (long)b * p.y_bs * ESZ, (unsigned)M * p.ldy * (unsigned)ESZ);
   const int gy = y0 + ty, gx = x0 + tx;
   const int mo = (mma_wave && gy < p.H && gx < p.W) ? gy * p.W + gx : -1;
+  const int cpad = (p.Cout + 7) & ~7;  // the output's (and residual's) channels incl. padding: quads past it are neither read nor written
   uint4 rres[NH];  // 4 couts: 8 bytes of bf16 or 16 bytes of fp32
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
-    const unsigned ro = mo >= 0 ? (unsigned)((mo * p.ldr + co0 + 16 * h + 4 * q) * ESZ) : OOB;
+    const unsigned ro = (mo >= 0 && co0 + 16 * h + 4 * q < cpad) ? (unsigned)((mo * p.ldr + co0 + 16 * h + 4 * q) * ESZ) : OOB;
     if constexpr (SPLIT) {
       rres[h] = ld16(rr, ro, 0);
     } else {
@@ -486,10 +487,10 @@ __global__ __launch_bounds__(SmTile<GW>::NT, 2) void conv3x3_small_kernel(SmK p)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = co0 + 16 * h + 4 * q + i;
-      const float bs = ((p.bias ? p.bias[c] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + c] : 0.f)) * osc;
+      const float bs = c < p.Cout ? ((p.bias ? p.bias[c] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + c] : 0.f)) * osc : 0.f;
       v[h][i] = fmaf(acc[h][0][i] + acc[h][1][i], osc, bs);
     }
-    const unsigned yo = mo >= 0 ? (unsigned)((mo * p.ldy + co0 + 16 * h + 4 * q) * ESZ) : OOB;
+    const unsigned yo = (mo >= 0 && co0 + 16 * h + 4 * q < cpad) ? (unsigned)((mo * p.ldy + co0 + 16 * h + 4 * q) * ESZ) : OOB;
     if constexpr (SPLIT) {
       v[h][0] = fmaf(__uint_as_float(rres[h].x), osc, v[h][0]);
       v[h][1] = fmaf(__uint_as_float(rres[h].y), osc, v[h][1]);
@@ -547,7 +548,7 @@ template <int GW, int PC, int NS, int MODE, int ESZ>
 int launch_small(const SmK& k, const ConvArgs& a, hipStream_t st) {
   constexpr int LDS = SmGeom<GW, PC, NS, ESZ>::LDS;
   DS_FUNC_LDS_ONCE((conv3x3_small_kernel<GW, PC, NS, MODE, ESZ>), LDS);
-  dim3 grid(k.tiles_x * cdiv(a.H, SmTile<GW>::THT), a.Cout / NS, a.B);
+  dim3 grid(k.tiles_x * cdiv(a.H, SmTile<GW>::THT), cdiv(a.Cout, NS), a.B);
   hipLaunchKernelGGL((conv3x3_small_kernel<GW, PC, NS, MODE, ESZ>), grid, dim3(SmTile<GW>::NT), LDS, st, k);
   {
     static char name[64] = {0};
@@ -587,7 +588,10 @@ bool ds_conv_small_eligible(const ConvArgs& a) {
   // bf16, or fp32 tensors in split mode (the exact fp32 engine keeps the generic kernel's fp32 MFMAs)
   if (!(a.dtype == DS_BF16 || (a.dtype == DS_F32 && a.split)) || a.taps != 9 || a.w_bs != 0 || a.bias_mode != 0 || a.div_b) return false;
   if (!(a.W < 32 || a.H < 8) || a.H > 16) return false;
-  if (a.Cout % 16 != 0 || !small_sources_multiple_of(a, 64)) return false;
+  // whole 16-cout slabs, or the <= 8-cout heads of the output pyramid (one slab, couts past Cout masked: 14 - 17 us on the generic
+  // 8 x 8 tile; no statistics, no folded skip there)
+  const bool head = a.Cout <= 8 && !a.stats_acc && !a.sx && a.ldy >= 8 && (!a.res || a.ldr >= 8) && a.dtype == DS_BF16;
+  if ((a.Cout % 16 != 0 && !head) || !small_sources_multiple_of(a, 64)) return false;
   if (a.ldx % 8 != 0 || (a.x2 && a.ldx2 % 8 != 0)) return false;
   if ((a.w_chunked & (a.w_chunked - 1)) || (a.w_chunked && a.w_chunked < 8)) return false;
   if (a.dtype == DS_F32 && ((a.w_chunked && a.w_chunked < 4) || (a.sx && a.sw_chunked && a.sw_chunked < 4))) return false;

@@ -494,6 +494,32 @@ def test_small_image_conv3x3(C1, C2, Cout, H, W, act, lazy):
     assert rel_rms(y2.float().cpu(), ref2) < 4e-3
 
 
+@pytest.mark.parametrize("C,Cout,H,W", [(128, 6, 4, 4), (128, 6, 8, 8), (128, 6, 16, 16), (128, 8, 16, 12), (256, 4, 8, 6)])
+@pytest.mark.parametrize("chunk", [0, 32])
+def test_small_image_pyramid_head_conv3x3(C, Cout, H, W, chunk):
+    # the output-pyramid heads of the <= 16-row levels (<= 8 couts, GroupNorm + SiLU on the input, + the upsampled pyramid) on the
+    # small-image kernel: one 16-cout slab whose couts past Cout multiply zeros and whose channel quads past the padded output
+    # are neither read nor written; the padding channels of the output stay zero
+    dt = torch.bfloat16
+    B, cp = 3, 8
+    tag = f"{C}.{Cout}.{H}.{W}"
+    x = (rnd("hd.x" + tag, (B, H, W, C), 1.1) + 0.1).to(DEV).to(dt)
+    w = rnd("hd.w" + tag, (Cout, C, 3, 3), (9 * C) ** -0.5)
+    bias = rnd(f"hd.b{Cout}", (Cout,), 0.1).to(DEV)
+    res = torch.zeros(B, H, W, cp)
+    res[..., :Cout] = rnd("hd.r" + tag, (B, H, W, Cout))
+    res = res.to(DEV).to(dt)
+    sc, sh = (1.0 + rnd(f"hd.sc{C}", (B, C), 0.2)).to(DEV), rnd(f"hd.sh{C}", (B, C), 0.2).to(DEV)
+    hn = F.silu(x.float().cpu() * sc.cpu()[:, None, None, :] + sh.cpu()[:, None, None, :]).to(dt).float()
+    ref = F.conv2d(hn.permute(0, 3, 1, 2), w.to(dt).float(), bias.cpu(), padding=1).permute(0, 2, 3, 1) + res.float().cpu()[..., :Cout]
+    wp = ops.pack_conv_weight(w, dt, chunk=chunk).to(DEV)
+    y = torch.full((B, H, W, cp), 7.0, device=DEV, dtype=dt)
+    y[..., Cout:] = 0  # (the engine's arena is zeroed: padding channels are never written)
+    ops.conv2d_fused(x, wp, bias, Cout, 3, gn=(sc, sh), gn_act=1, res=res, cout_pad=cp, out=y, w_chunk=chunk)
+    assert rel_rms(y[..., :Cout].float().cpu(), ref) < 4e-3
+    assert Cout == cp or float(y[..., Cout:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("B,H,W,cin", [(2, 16, 32, 6), (16, 64, 64, 6), (3, 8, 96, 8), (64, 24, 32, 4)])
 def test_first_layer_conv3x3_8_to_64(B, H, W, cin):
     # the network's first layer (<= 8 input channels, padded to 8) on its own persistent kernel in bf16
