@@ -665,8 +665,10 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
   // straddles the seam (256 / 32 = 8 channels per group): each convolution runs as TWO 128 -> 128 register-weight launches, the
   // second taking the first's result as its residual (one more storage rounding of a partial sum).  Conv_0: 850 -> 593 us at
   // 256^2; Conv_1 + the 256-channel 1x1 skip: the first half of the skip folded as before, the second as a 1x1 launch.
+  // Only from 128 rows up: at 64^2 (where nf = 64 has these blocks) the register-weight launches carry their weight prologue for
+  // two tiles per block and the pair is SLOWER than the generic tile (61.5 + 50.0 against 49.3 + 42.6 us per block in the graph).
   if (e->cfg.dtype == DS_BF16 && mode == 0 && x.p2 && m.pf0a >= 0 && x.C1 == 128 && x.sa && x.sa2 && x.W % 32 == 0 && x.H % 8 == 0 &&
-      x.H >= 32 && (long)B * (x.H / 4) * (x.W / 32) >= ds_num_cus() &&
+      x.H >= 128 && (long)B * (x.H / 4) * (x.W / 32) >= ds_num_cus() &&
       !(e->opts & (DS_OPT_NO_RW | DS_OPT_NO_RW128 | DS_OPT_NO_SPLIT256 | DS_OPT_NO_WFRAG))) {
     Tn xa = x, xb = x;
     xa.C = 128; xa.p2 = nullptr; xa.C1 = 0; xa.ld2 = 0; xa.sa2 = nullptr;
