@@ -153,6 +153,16 @@ def run_strong(args, engs, ops, on_stream, sync, fence, dist, world, rank, dev, 
         elapsed = max(float(q[0]) for q in parts)
         busy_all = [float(q[1]) for q in parts]
     ranks_seen = seen_ranks(dist, world, rank, int(os.environ.get("LOCAL_RANK", "0")), dev) if world > 1 else [[0, 0]]
+    # which utterance sits in which row of the gathered blocks (untimed bookkeeping: every utterance must arrive exactly once)
+    rows = [i for g, _, _ in staged for i in g]
+    idx = torch.full((nloc_max,), -1, dtype=torch.int64, device=dev)
+    if rows:
+        idx[:len(rows)] = torch.tensor(rows, dtype=torch.int64, device=dev)
+    idx_all = [idx]
+    if world > 1:
+        idx_all = [torch.empty_like(idx) for _ in range(world)]
+        dist.all_gather(idx_all, idx)
+    got = [int(v) for q in idx_all for v in q.tolist() if int(v) >= 0]
     if rank == 0:
         value = n * args.steps / elapsed
         secs = sum(lengths) / 8000.0
@@ -170,6 +180,7 @@ def run_strong(args, engs, ops, on_stream, sync, fence, dist, world, rank, dev, 
             "realtime_factor": round(secs * args.steps / elapsed, 2),
             "rank_busy_s_per_step": [round(b / args.steps, 4) for b in busy_all],
             "imbalance_max_over_mean": round(max(busy_all) / (sum(busy_all) / len(busy_all)), 4),
+            "gathered_utterances": len(got), "gathered_unique": len(set(got)),
             "engine_calls_rank0_per_step": len(staged), "nfe_per_call": int(nfe), "finite": finite,
             "ranks_seen": ranks_seen}), flush=True)
 
@@ -401,11 +412,11 @@ def main():
         # instantiation (real template arguments) with the most GPU time names the roofline object
         by_shape, by_kernel = {}, {}
         for r in recs:
+            if r["cls"] < 0:
+                continue
             key = (r["kernel"], r["taps"], r["Cin"], r["Cout"], r["H"], r["W"], r["skip_cin"], r["has_res"])
             a = by_shape.setdefault(key, [0, 0.0, 0.0, 0.0])
             a[0] += 1; a[1] += r["ms"]; a[2] += r["flops"]; a[3] += r["bytes"]
-            b_ = by_kernel.setdefault(r["kernel"], [0, 0.0, 0.0, 0.0])
-            b_[0] += 1; b_[1] += r["ms"]; b_[2] += r["flops"]; b_[3] += r["bytes"]
         per_shape = []
         for (kn, taps, ci, co, H_, W_, sk, hr), (n_, ms_, fl_, by_) in sorted(by_shape.items(), key=lambda kv: -kv[1][1]):
             if ms_ <= 0 or H_ * W_ < 128 * 128:
@@ -418,6 +429,26 @@ def main():
                               # the roof that bounds THIS shape = the higher of its two floors (64-cout layers at 256^2
                               # sit at the machine balance: their HBM floor is the higher one)
                               "bound": "hbm" if by_ / HBM_PEAK_BPS > fl_ / (peak * 1e12) else "mfma"})
+        # SURVEY 8(d), second half: the HBM-bound launches of the step against the HBM roof, one entry per (kernel, shape):
+        # algorithmic bytes (inputs read once, outputs written once) over the summed HIP-event durations of the same pass
+        hbm_shape = {}
+        for r in recs:
+            if r["cls"] >= 0:
+                continue
+            a = hbm_shape.setdefault((r["kernel"], r["Cin"], r["H"], r["W"]), [0, 0.0, 0.0])
+            a[0] += 1; a[1] += r["ms"]; a[2] += r["bytes"]
+        hbm_kernels = [{"kernel": kn, "shape": "C=%d @%dx%d" % (c_, H_, W_), "launches": n_, "avg_us": round(ms_ / n_ * 1e3, 2),
+                        "algorithmic_bytes_per_launch": by_ / n_, "gb_per_s": round(by_ / (ms_ * 1e-3) / 1e9, 1),
+                        "frac_hbm": round(by_ / (ms_ * 1e-3) / HBM_PEAK_BPS, 4), "total_ms": round(ms_, 3)}
+                       for (kn, c_, H_, W_), (n_, ms_, by_) in sorted(hbm_shape.items(), key=lambda kv: -kv[1][1]) if ms_ > 0]
+        recs = [r for r in recs if r["cls"] >= 0]
+        by_shape, by_kernel = {}, {}
+        for r in recs:
+            key = (r["kernel"], r["taps"], r["Cin"], r["Cout"], r["H"], r["W"], r["skip_cin"], r["has_res"])
+            a = by_shape.setdefault(key, [0, 0.0, 0.0, 0.0])
+            a[0] += 1; a[1] += r["ms"]; a[2] += r["flops"]; a[3] += r["bytes"]
+            b_ = by_kernel.setdefault(r["kernel"], [0, 0.0, 0.0, 0.0])
+            b_[0] += 1; b_[1] += r["ms"]; b_[2] += r["flops"]; b_[3] += r["bytes"]
         dom_k = max(by_kernel, key=lambda k: by_kernel[k][1]) if by_kernel else None
         kname = dom_k or dom
         if dom_k:  # the roofline object describes this one instantiation
@@ -465,6 +496,8 @@ def main():
                 "achieved_tflops": round(ach, 2),
                 "gpu_time_share_of_mfma_kernels": round(ms / tot_ms, 4) if tot_ms > 0 else None,
                 "per_shape": per_shape[:24],
+                "hbm_kernels": hbm_kernels[:24],
+                "hbm_kernels_total_ms": round(sum(h_["total_ms"] for h_ in hbm_kernels), 2),
                 "per_instantiation_ms": {k: round(v[1], 2) for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][1])[:16]},
                 "per_kernel_ms": {k: round(v[1], 2) for k, v in prof.items() if v[2]},
                 # every MFMA kernel class of the step against both roofs (algorithmic flops / bytes over its summed time)
@@ -512,6 +545,8 @@ def main():
             es[0].profile_end()
             by_k = {}
             for r in es[0].profile_records():
+                if r["cls"] < 0:
+                    continue
                 a_ = by_k.setdefault(r["kernel"], [0, 0.0, 0.0])
                 a_[0] += 1; a_[1] += r["ms"]; a_[2] += r["flops"]
             k_ = max(by_k, key=lambda k: by_k[k][1])
@@ -597,7 +632,10 @@ def main():
             e.close()
         if args.nf != 128 and not args.no_nf128:
             # ---- the published model width (icassp-separation.yaml:14-18, nr.yaml): nf = 128 in the main dtype
-            cfg128 = _lib.model_config(nf=128, num_sources=S, dtype=dt_flag)
+            # (spec_factor 0.15 as published — icassp-separation.yaml:17 — not the 0.33 of the nf = 64 default: the smaller
+            # spectrogram scale is what makes 16-bit rounding cost more at this width, tests/test_fullsize_gpu.py)
+            SF128 = 0.15
+            cfg128 = _lib.model_config(nf=128, num_sources=S, dtype=dt_flag, spec_factor=SF128)
             sd128 = synth.synth_state_dict([(n, s_) for n, s_, _ in param_table(cfg128)], 7)
             blob128 = pack_state_dict(cfg128, sd128)
             e128 = [Engine(cfg128, blob128) for _ in range(K2)]
@@ -609,7 +647,7 @@ def main():
             alone128 = (time.perf_counter() - t3) * 1e3
             k128, (n128, ms128, fl128) = dominant(e128)
             extra_json["nf128"] = {"utt_per_s": round(u128, 3), "batches_in_flight": K2, "one_batch_alone_ms": round(alone128, 1),
-                                   "realtime_factor": round(u128 * T / 8000.0, 1), "dtype": args.dtype,
+                                   "realtime_factor": round(u128 * T / 8000.0, 1), "dtype": args.dtype, "spec_factor": SF128,
                                    "dominant_kernel": k128, "launches": n128, "avg_launch_us": round(ms128 / n128 * 1e3, 1),
                                    "frac_mfma": round(fl128 / (ms128 * 1e-3) / 1e12 / PEAK_TFLOPS[args.dtype], 4),
                                    "model_tflops": round(u128 * nfe * GFLOP_PER_NFE[128] * (T / 32000.0) / 1e3, 1)}
@@ -618,7 +656,7 @@ def main():
                 # HYBRID_HEAD_STEPS reverse steps, the f16 engine after — throughput on the same clock and the agreement of
                 # both modes with the exact fp32 engine on the same noise
                 from diffsep_amd.pl_model import HYBRID_HEAD_STEPS
-                h128 = [Engine(_lib.model_config(nf=128, num_sources=S, dtype=_lib.F32_SPLIT), blob128, lib_kind="f16") for _ in range(K2)]
+                h128 = [Engine(_lib.model_config(nf=128, num_sources=S, dtype=_lib.F32_SPLIT, spec_factor=SF128), blob128, lib_kind="f16") for _ in range(K2)]
 
                 def run_h128(i, w):
                     with on_stream(w):
@@ -635,7 +673,7 @@ def main():
                     run_h128(i, i % K2)
                 sync()
                 uh128 = B * 4 / (time.perf_counter() - t5)
-                f128 = Engine(_lib.model_config(nf=128, num_sources=S, dtype=_lib.F32), blob128)
+                f128 = Engine(_lib.model_config(nf=128, num_sources=S, dtype=_lib.F32, spec_factor=SF128), blob128)
                 Bq = min(B, 4)  # (the exact fp32 engine at this width: a few utterances are enough for the agreement figures)
                 mq, mnq = mix[:Bq].contiguous(), mix_norm0[:Bq].contiguous()
                 r32 = ops.scale_output(mq, f128.pc_sample(mnq, sde, **kw)[0])
@@ -683,7 +721,7 @@ def main():
                                    "flight per GPU" % (args.N, args.corrector_steps, B, T / 8000.0, args.nf, nfe, K),
                        "batch_per_gpu": B, "samples": T, "N": args.N, "corrector_steps": args.corrector_steps,
                        "nf": args.nf, "sharding": "utterances/%d" % world, "graph": not args.no_graph,
-                       "batches_in_flight": K},
+                       "batches_in_flight": K, "one_batch_alone_ms": round(alone_ms, 2)},
             "one_batch_alone_ms": round(alone_ms, 2),
             "utt_per_s_per_gpu_one_batch_at_a_time": round(B / (alone_ms * 1e-3), 2),
             "in_flight_bit_identical": same_bits,

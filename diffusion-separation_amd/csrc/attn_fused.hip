@@ -397,7 +397,10 @@ int ds_launch_attn_fused(const AttnFusedArgs& a, hipStream_t st) {
   DS_CHECK(ds_attn_fused_eligible(DS_BF16, a.C, a.L), "attn_fused: unsupported shape");
   DS_CHECK(a.x && a.y && a.wqk && a.wv && a.wo && a.bqk && a.bv && a.bo, "attn_fused: null pointer");
   DS_CHECK(a.gn_acc || (a.gn_scale && a.gn_shift), "attn_fused: no GroupNorm statistics");
-  DS_CHECK(a.ldx % 8 == 0 && a.ldy % 4 == 0 && a.ldx >= C && a.ldy >= C, "attn_fused: bad pixel stride");
+  // (x is read and y written with 16-byte vector accesses at pixel * ld + 8 k elements: strides in multiples of 8 elements,
+  // 16-byte aligned bases)
+  DS_CHECK(a.ldx % 8 == 0 && a.ldy % 8 == 0 && a.ldx >= C && a.ldy >= C, "attn_fused: bad pixel stride");
+  DS_CHECK(((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.y & 15) == 0 && (a.x_bs % 8) == 0 && (a.y_bs % 8) == 0, "attn_fused: x / y must be 16-byte aligned");
   AttnK k;
   k.x = reinterpret_cast<const bf16_t*>(a.x); k.x_bs = a.x_bs; k.ldx = a.ldx;
   k.gn_acc = a.gn_acc; k.gn_gamma = a.gn_gamma; k.gn_beta = a.gn_beta; k.gn_groups = a.gn_groups; k.gn_inv_count = a.gn_inv_count;

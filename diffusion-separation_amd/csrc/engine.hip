@@ -346,7 +346,7 @@ static bool fuse_skip(const Module& m) { return m.has_conv2 && m.out_ch > 32; }
 // ------------------------------------------------------------------ process-wide options, device properties
 // Defaults of the dispatch switches: the environment is read ONCE, here (never inside a launch decision); diffsep_set_option
 // changes them for engines created later and for the unit entry points.
-static unsigned g_opts = 0;
+static std::atomic<unsigned> g_opts{0};  // (read by every thread that creates an engine or calls a unit entry point)
 static std::once_flag g_opts_once;
 unsigned ds_default_opts() {
   std::call_once(g_opts_once, [] {
@@ -386,7 +386,7 @@ extern "C" int32_t diffsep_set_option(const char* name, int64_t value) {
   unsigned bit = 0;
   if (opt_bit(name, &bit)) { ds_set_error(std::string("set_option: unknown option '") + name + "'"); return 1; }
   ds_default_opts();
-  g_opts = value ? (g_opts | bit) : (g_opts & ~bit);
+  if (value) g_opts.fetch_or(bit); else g_opts.fetch_and(~bit);
   return 0;
 }
 
@@ -498,6 +498,24 @@ static int conv_launch_prof(diffsep_engine* e, const ConvArgs& a, hipStream_t st
   const int rc = ds_launch_conv(a, st);
   hipEventRecord(r.b, st);
   r.kernel = ds_last_conv_kernel();
+  e->prof_recs.push_back(r);
+  return rc;
+}
+
+// The HBM-bound launches of the path (GroupNorm apply / FIR resampling, STFT / iSTFT, SDE updates, RNG) in the same profile span:
+// records with cls = -1 (not a member of the per-class arrays of profile_end), flops = 0, bytes = the ALGORITHMIC HBM bytes of the
+// launch (every input read once, every output written once), kernel = a static name.  `body` issues the launch (or launch
+// sequence: the STFT is frame + DFT + pack) on st.
+template <typename F>
+static int hbm_launch_prof(diffsep_engine* e, hipStream_t st, const char* name, double bytes, int B, int H, int W, int C, F&& body) {
+  if (!e->prof) return body();
+  diffsep_engine::ProfRec r;
+  r.a = prof_event(e); r.b = prof_event(e);
+  r.flops = 0.0; r.bytes = bytes; r.cls = -1; r.kernel = name;
+  r.B = B; r.H = H; r.W = W; r.Cin = C; r.Cout = 0; r.taps = 0; r.sCin = 0; r.res = 0; r.ms = 0.f;
+  hipEventRecord(r.a, st);
+  const int rc = body();
+  hipEventRecord(r.b, st);
   e->prof_recs.push_back(r);
   return rc;
 }
@@ -644,9 +662,18 @@ static int gn_stats(diffsep_engine* e, const Tn& x, const float* gamma, const fl
 static int gn_apply(diffsep_engine* e, const Tn& x, const GnAff* aff, const Tn* y, const Tn* xr, int B, int act,
                     int mode, hipStream_t st) {
   if (e->dry || (e->ablate & 8u)) return 0;
-  return ds_launch_gn_apply(x.p, x.ld, aff ? aff->scale : nullptr, aff ? aff->shift : nullptr, x.C, y ? y->p : nullptr,
-                            y ? y->ld : 0, xr ? xr->p : nullptr, xr ? xr->ld : 0, B, x.H, x.W, act, mode, e->cfg.dtype,
-                            st);
+  // algorithmic bytes: x read once; each output (act(GN(x)) and / or raw x, resampled: x 4 up, / 4 down) written once
+  const double esz = e->cfg.dtype == DS_F32 ? 4.0 : 2.0, nin = (double)B * x.H * x.W * x.C;
+  const double fo = mode == 1 ? 4.0 : (mode == 2 ? 0.25 : 1.0);
+  const double bytes = esz * nin * (1.0 + fo * ((y ? 1 : 0) + (xr ? 1 : 0)));
+  const char* name = mode == 1 ? (aff ? "gn_fir_up (GroupNorm + SiLU + FIR x2 up of act and raw)" : "fir_up (pyramid)")
+                               : (mode == 2 ? (aff ? "gn_fir_down (GroupNorm + SiLU + FIR x2 down of act and raw)" : "fir_down (pyramid)")
+                                            : "gn_apply (GroupNorm affine + SiLU)");
+  return hbm_launch_prof(e, st, name, bytes, B, x.H, x.W, x.C, [&]() {
+    return ds_launch_gn_apply(x.p, x.ld, aff ? aff->scale : nullptr, aff ? aff->shift : nullptr, x.C, y ? y->p : nullptr,
+                              y ? y->ld : 0, xr ? xr->p : nullptr, xr ? xr->ld : 0, B, x.H, x.W, act, mode, e->cfg.dtype,
+                              st);
+  });
 }
 
 static const float kInvSqrt2 = 0.70710678118654752440f;
@@ -955,15 +982,22 @@ static int score_forward_impl(diffsep_engine* e, const float* xt, const float* t
   const int dft_split = e->split || c.dtype == DS_BF16;
   float* ws_f = (float*)e_alloc(e, (size_t)ds_stft_workspace_bytes(B, S, T, c.n_fft, c.hop));
   float* frames = (float*)e_alloc(e, (size_t)ds_istft_workspace_bytes(B, S, T, c.n_fft, c.hop));
+  const double esz_t = c.dtype == DS_F32 ? 4.0 : 2.0;
   if (!e->dry && !(e->ablate & 128u))
-    if (ds_launch_stft_pack(xt, mix, x0.p, B, S, T, c.n_fft, c.hop, c.spec_abs_exponent, c.spec_factor, W,
-                            e->arch.cpad_in, 1, c.dtype, e->d_tab, ws_f, st, dft_split))
+    if (hbm_launch_prof(e, st, "stft (frame + real-DFT GEMM + compress / pack)",
+                        4.0 * B * (S + 1) * (double)T + esz_t * B * H * (double)W * e->arch.cpad_in, B, H, W, e->arch.cpad_in, [&]() {
+          return ds_launch_stft_pack(xt, mix, x0.p, B, S, T, c.n_fft, c.hop, c.spec_abs_exponent, c.spec_factor, W,
+                                     e->arch.cpad_in, 1, c.dtype, e->d_tab, ws_f, st, dft_split);
+        }))
       return 1;
   Tn pyr;
   if (net_forward(e, x0, t, y, B, st, &pyr)) return 1;
   if (!e->dry && !(e->ablate & 128u))
-    if (ds_launch_istft(pyr.p, out, B, S, T, c.n_fft, c.hop, c.spec_abs_exponent, c.spec_factor, W, pyr.ld, c.dtype,
-                        e->d_tab, frames, st, dft_split, P(e, e->arch.out_w), P(e, e->arch.out_b), t, e->arch.chan_in))
+    if (hbm_launch_prof(e, st, "istft (unpack / decompress + inverse-DFT GEMM + overlap-add)",
+                        esz_t * B * H * (double)W * pyr.ld + 4.0 * B * S * (double)T, B, H, W, pyr.ld, [&]() {
+          return ds_launch_istft(pyr.p, out, B, S, T, c.n_fft, c.hop, c.spec_abs_exponent, c.spec_factor, W, pyr.ld, c.dtype,
+                                 e->d_tab, frames, st, dft_split, P(e, e->arch.out_w), P(e, e->arch.out_b), t, e->arch.chan_in);
+        }))
       return 1;
   return 0;
 }
@@ -1242,21 +1276,31 @@ extern "C" int32_t diffsep_engine_profile_begin(diffsep_engine* e) {
   e->prof_recs.clear();
   return 0;
 }
+static_assert(DS_NCLS == DIFFSEP_NUM_KERNEL_CLASSES, "header and engine agree on the number of kernel classes");
+extern "C" int32_t diffsep_num_kernel_classes(void) { return DS_NCLS; }
 extern "C" int32_t diffsep_engine_profile_end(diffsep_engine* e, double* flops, double* ms, int64_t* launches,
                                                double* bytes) {
-  DS_CHECK(e && flops && ms && launches, "profile_end: null argument");
+  return diffsep_engine_profile_end_n(e, DS_NCLS, flops, ms, launches, bytes, nullptr);
+}
+extern "C" int32_t diffsep_engine_profile_end_n(diffsep_engine* e, int32_t n_classes, double* flops, double* ms,
+                                                 int64_t* launches, double* bytes, int32_t* n_written) {
+  DS_CHECK(e && flops && ms && launches && n_classes >= 0, "profile_end: null argument");
   DS_HIP(hipDeviceSynchronize());
-  for (int i = 0; i < DS_NCLS; ++i) { flops[i] = 0; ms[i] = 0; launches[i] = 0; if (bytes) bytes[i] = 0; }
+  const int ncls = n_classes < DS_NCLS ? n_classes : DS_NCLS;
+  if (n_written) *n_written = ncls;
+  for (int i = 0; i < ncls; ++i) { flops[i] = 0; ms[i] = 0; launches[i] = 0; if (bytes) bytes[i] = 0; }
   e->prof_done.clear();
   for (auto& r : e->prof_recs) {
     float t = 0.f;
     hipEventElapsedTime(&t, r.a, r.b);
     r.ms = t;
     e->prof_done.push_back(r);
-    flops[r.cls] += r.flops;
-    if (bytes) bytes[r.cls] += r.bytes;
-    ms[r.cls] += t;
-    launches[r.cls] += 1;
+    if (r.cls >= 0 && r.cls < ncls) {  // (cls -1: the HBM-bound launches, reported through profile_records only)
+      flops[r.cls] += r.flops;
+      if (bytes) bytes[r.cls] += r.bytes;
+      ms[r.cls] += t;
+      launches[r.cls] += 1;
+    }
     e->ev_pool.push_back(r.a);
     e->ev_pool.push_back(r.b);
   }
@@ -1346,8 +1390,9 @@ static int run_nfe(diffsep_engine* e, int B, long T, hipStream_t st) {
         DS_HIP(hipGraphInstantiate(&e->gexec, e->graph, nullptr, nullptr, 0));
         e->graph_ok = true;
         if ((int)e->graphs.size() >= e->graph_cap) {  // evict the least recently used plan's graph
-          // (its last replay may still be running on this stream: wait before destroying the executable)
-          DS_HIP(hipStreamSynchronize(st));
+          // (its last replay may still be running — on this stream or, if the engine was driven from another stream in an
+          // earlier call, on that one: eviction is rare, wait for the device before destroying the executable)
+          DS_HIP(hipDeviceSynchronize());
           while ((int)e->graphs.size() >= e->graph_cap) {
             auto lru = e->graphs.begin();
             for (auto it = e->graphs.begin(); it != e->graphs.end(); ++it)
@@ -1488,9 +1533,13 @@ extern "C" int32_t diffsep_pc_sample_ex(diffsep_engine* e, const diffsep_sde_con
     if (noise) { *z = noise + (size_t)draw * nst; }
     else {
       if (batch_rng) {
-        if (ds_launch_randn_batch(e->st_noise, B, S, T, (const uint64_t*)e->st_seeds, e->st_lens, (uint64_t)draw, st))
+        if (hbm_launch_prof(e, st, "randn (Philox4x32-10 + Box-Muller)", 4.0 * nst, B, 1, (int)T, S, [&]() {
+              return ds_launch_randn_batch(e->st_noise, B, S, T, (const uint64_t*)e->st_seeds, e->st_lens, (uint64_t)draw, st);
+            }))
           return 1;
-      } else if (ds_launch_randn(e->st_noise, (long)nst, seed, (uint64_t)draw, st)) {
+      } else if (hbm_launch_prof(e, st, "randn (Philox4x32-10 + Box-Muller)", 4.0 * nst, B, 1, (int)T, S, [&]() {
+                   return ds_launch_randn(e->st_noise, (long)nst, seed, (uint64_t)draw, st);
+                 })) {
         return 1;
       }
       *z = e->st_noise;
@@ -1535,8 +1584,10 @@ extern "C" int32_t diffsep_pc_sample_ex(diffsep_engine* e, const diffsep_sde_con
       if (smp->corrector == DIFFSEP_CORR_LANGEVIN) {
         if (ds_launch_langevin(smp->snr, e->st_x, score, z, e->st_x, e->st_xm, B, (long)S * T, e->st_lang, st))
           return 1;
-      } else if (ds_launch_sde_corrector(sp, smp->snr, e->st_x, e->st_t, score, z, e->st_x, e->st_xm, B, S, T,
-                                         smix, smp->corrector == DIFFSEP_CORR_ALD ? 1 : 0, st, lens)) {
+      } else if (hbm_launch_prof(e, st, "sde_corrector (ald2 update)", 4.0 * nst * 5.0, B, 1, (int)T, S, [&]() {  // x, score, z in; x, x_mean out
+                   return ds_launch_sde_corrector(sp, smp->snr, e->st_x, e->st_t, score, z, e->st_x, e->st_xm, B, S, T,
+                                                  smix, smp->corrector == DIFFSEP_CORR_ALD ? 1 : 0, st, lens);
+                 })) {
         return 1;
       }
     }
@@ -1546,7 +1597,9 @@ extern "C" int32_t diffsep_pc_sample_ex(diffsep_engine* e, const diffsep_sde_con
       if (eval_score(i)) return 1;
       ++nfe;
       if (next_noise(&z)) return 1;
-      if (ds_launch_sde_predictor(sp, N, e->st_x, e->st_t, score, z, e->st_x, e->st_xm, B, S, T, smix, 0, st, lens))
+      if (hbm_launch_prof(e, st, "sde_predictor (reverse-diffusion update)", 4.0 * nst * 5.0, B, 1, (int)T, S, [&]() {
+            return ds_launch_sde_predictor(sp, N, e->st_x, e->st_t, score, z, e->st_x, e->st_xm, B, S, T, smix, 0, st, lens);
+          }))
         return 1;
     } else {
       DS_HIP(hipMemcpyAsync(e->st_xm, e->st_x, nst * 4, hipMemcpyDeviceToDevice, st));

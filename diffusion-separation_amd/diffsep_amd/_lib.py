@@ -79,6 +79,9 @@ _SIGS = {
     "diffsep_engine_profile_begin": (_I, [_P]),
     "diffsep_engine_profile_end": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L),
                                         C.POINTER(C.c_double)]),
+    "diffsep_engine_profile_end_n": (_I, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_L),
+                                          C.POINTER(C.c_double), C.POINTER(_I)]),
+    "diffsep_num_kernel_classes": (_I, []),
     "diffsep_engine_profile_records": (_I, [_P, C.POINTER(ProfRecord), _I, C.POINTER(_I)]),
     "diffsep_time_embedding": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _L, _P]),
     "diffsep_upfirdn2d": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -128,8 +128,9 @@ class Engine:
         profile_begin."""
         nc = len(self.CONV_CLASSES)
         fl, ms, n, by = (C.c_double * nc)(), (C.c_double * nc)(), (C.c_int64 * nc)(), (C.c_double * nc)()
-        check(self._L.diffsep_engine_profile_end(self._h, fl, ms, n, by), self._L)
-        return {k: (fl[i], ms[i], int(n[i]), by[i]) for i, k in enumerate(self.CONV_CLASSES)}
+        nw = C.c_int32(0)
+        check(self._L.diffsep_engine_profile_end_n(self._h, nc, fl, ms, n, by, C.byref(nw)), self._L)
+        return {k: (fl[i], ms[i], int(n[i]), by[i]) for i, k in enumerate(self.CONV_CLASSES[:nw.value])}
 
     def profile_records(self):
         """The launches of the last profile_begin .. profile_end span, one dict per launch: kernel instantiation (real

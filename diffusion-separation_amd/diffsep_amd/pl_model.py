@@ -140,15 +140,28 @@ class DiffSepModel:
                 if tuple(v.shape) != tuple(state[n].shape):
                     raise ValueError(f"EMA shadow parameter for '{n}' has shape {tuple(v.shape)}")
                 state[n] = v
-        model.score_model.load_state_dict(state)
-        if model.tail_model is not None:
-            model.tail_model.load_state_dict(state)
+        model.load_state_dict(state)
         return model
 
     def to(self, device):
         self.score_model.to(device)
         if self.tail_model is not None:
             self.tail_model.to(device)
+        # (the fallback's score model is the tail model or a twin that follows score_model's device and weights)
+        return self
+
+    def has_fallback(self):
+        """Whether this mode has an overflow fallback at all — from the mode alone, without constructing it."""
+        return self.dtype in ("f16", "fp16", "hybrid")
+
+    def load_state_dict(self, state, strict=True):
+        """Weights in the reference's score_model key layout ('backbone.all_modules....'), into every engine of the model.
+        The overflow fallback follows: a split twin re-reads its parent's weights (ScoreModelNCSNpp.twin), and the cached
+        fallback object is dropped."""
+        self.score_model.load_state_dict(state, strict=strict)
+        if self.tail_model is not None:
+            self.tail_model.load_state_dict(state, strict=strict)
+        self._fallback = None
         return self
 
     def fallback_model(self):
@@ -157,7 +170,7 @@ class DiffSepModel:
         half precision ends at 65504 where bfloat16 and fp32 do not; an overflow anywhere in the network reaches the output as
         inf / NaN (residual trunk), which is what rerun_if_nonfinite looks for.  None for the modes without a range limit
         (bf16, f32, split).  (Round 3 fell back to bf16: finite, but 13 - 19 dB from the fp32 result at nf = 128.)"""
-        if self.dtype in ("bf16", "f32", "split"):
+        if not self.has_fallback():
             return None
         if getattr(self, "_fallback", None) is None:
             fb = object.__new__(DiffSepModel)
@@ -220,7 +233,7 @@ class DiffSepModel:
 
         def make(y_part):
             inner = make_on(self, y_part)
-            if not check_finite or self.fallback_model() is None:
+            if not check_finite or not self.has_fallback():  # (decided from the mode: the fallback is BUILT at the first overflow)
                 return inner
             return lambda: self.rerun_if_nonfinite(inner(), lambda fb: make_on(fb, y_part)())
 

@@ -53,18 +53,31 @@ class ScoreModelNCSNpp:
         self.device = device
         self.lib_kind = lib_kind  # (Engine: which build of the library; None = by dtype)
         self._engine = None
+        self._parent, self._version, self._built_version = None, 0, 0  # (twin(): weights / device follow the parent)
         # random init like the reference constructor (no checkpoint yet): synthetic variance-scaling weights
         self._state = synth.synth_state_dict([(n, s) for n, s, _ in param_table(self.cfg)], init_seed)
 
     def twin(self, dtype, lib_kind=None):
-        """The same model (same weights, shared host copy) in another precision mode; its engine is created on first use."""
-        import ctypes as C
+        """The same model in another precision mode; its engine is created on first use.  The twin FOLLOWS this model: it
+        reads the weights and the device of its parent whenever it (re)creates its engine, and a later load_state_dict() /
+        to() on the parent drops the twin's engine (a twin built once from a copy of __dict__ kept the weights and device
+        of the moment it was made: an overflow fallback on stale weights returns finite but wrong samples)."""
         t = object.__new__(ScoreModelNCSNpp)
         t.__dict__.update(self.__dict__)
         t.cfg = _lib.ModelConfig.from_buffer_copy(self.cfg)
         t.cfg.dtype = {"bf16": _lib.BF16, "f16": _lib.F16, "f32": _lib.F32, "split": _lib.F32_SPLIT}[dtype]
-        t.lib_kind, t._engine = lib_kind, None
+        t.lib_kind, t._engine, t._parent, t._built_version = lib_kind, None, self, -1
         return t
+
+    def _sync_with_parent(self):
+        """twin only: adopt the parent's current weights / device; drop an engine built from older ones"""
+        par = self._parent
+        if par is None or self._built_version == par._version:
+            return
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+        self._state, self.device, self._built_version = par._state, par.device, par._version
 
     # ---- weights ---------------------------------------------------------------------------
     def param_names(self):
@@ -86,6 +99,8 @@ class ScoreModelNCSNpp:
                 raise ValueError(f"size mismatch for '{k}': {tuple(v.shape)} vs {shape}")
             new[n] = v
         self._state = new
+        self._version += 1
+        self._parent = None  # (a twin that gets its own weights stops following its parent)
         if self._engine is not None:
             self._engine.close()
             self._engine = None
@@ -95,7 +110,12 @@ class ScoreModelNCSNpp:
         return {"backbone." + n: torch.from_numpy(np.array(v)) for n, v in self._state.items()}
 
     def to(self, device):
-        self.device = device
+        if device != self.device:
+            self.device = device
+            self._version += 1
+            if self._engine is not None:  # (the engine is bound to one device: re-created there on next use)
+                self._engine.close()
+                self._engine = None
         return self
 
     def eval(self):
@@ -103,6 +123,7 @@ class ScoreModelNCSNpp:
 
     def engine(self):
         """The device-resident engine (created lazily on the current / configured device)."""
+        self._sync_with_parent()
         if self._engine is None:
             self._engine = Engine(self.cfg, pack_state_dict(self.cfg, self._state), device=self.device, lib_kind=self.lib_kind)
         return self._engine

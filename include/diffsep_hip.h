@@ -204,10 +204,21 @@ int64_t diffsep_engine_get_option(const diffsep_engine* e, const char* name);
  * tiles for 1x1 / GEMM, the weight-stationary 64 -> 64 3x3 kernel, the small-image 3x3 kernel, the register-weight
  * 3x3 kernel (conv3x3_rw.hip), the fused attention block (attn_fused.hip) — TEN entries: summed algorithmic flops, summed milliseconds, launch counts and (bytes, nullable)
  * summed algorithmic HBM bytes = every operand read once + the output written once. */
+#define DIFFSEP_NUM_KERNEL_CLASSES 10
 int32_t diffsep_engine_profile_begin(diffsep_engine* e);
+/* Writes DIFFSEP_NUM_KERNEL_CLASSES entries per array — the caller's buffers must hold that many (ABI note: the count was 9
+ * until round 3; a caller compiled against an older header must use the _n form below or be rebuilt). */
 int32_t diffsep_engine_profile_end(diffsep_engine* e, double* flops, double* ms, int64_t* launches, double* bytes);
+/* The same with the capacity of the caller's arrays stated: writes min(n_classes, DIFFSEP_NUM_KERNEL_CLASSES) entries per
+ * array and never more; *n_written (nullable) receives that number. */
+int32_t diffsep_engine_profile_end_n(diffsep_engine* e, int32_t n_classes, double* flops, double* ms, int64_t* launches,
+                                     double* bytes, int32_t* n_written);
+int32_t diffsep_num_kernel_classes(void);
 /* The launches of that span one by one (call after profile_end; out may be NULL to query *n): the kernel instantiation
- * with its template arguments, the problem shape, algorithmic flops / bytes and the measured duration. */
+ * with its template arguments, the problem shape, algorithmic flops / bytes and the measured duration.  Round 5: the
+ * HBM-bound launches of the path (GroupNorm apply / FIR x2 resampling, STFT, iSTFT, SDE updates, RNG) are bracketed too and
+ * appear here with cls = -1, flops = 0, Cin = channels, bytes = algorithmic HBM bytes (inputs read once, outputs written once);
+ * they are not part of the per-class arrays of profile_end. */
 typedef struct diffsep_prof_record {
   char kernel[128];
   int32_t B, H, W, Cin, Cout, taps, skip_cin, has_res, cls, _pad;

@@ -338,3 +338,68 @@ def test_plan_batches_buckets_by_padded_width():
     assert got == [[5], [3], [4, 0, 7], [1], [2, 6]]          # ascending width, longest first, <= 3 per call
     assert all(len({width(lengths[i]) for i in g}) == 1 for g in got)
     assert sorted(i for g in got for i in g) == list(range(len(lengths)))
+
+
+def test_overflow_fallback_follows_weights_and_device():
+    # the split fallback of an f16 model must never run on the weights / device of the moment it was made.
+    # (i) whether a fallback exists is decided from the mode, nothing is constructed by get_pc_sampler's wrapper;
+    # (ii) a twin re-reads its parent's weights and device when the parent changed after the twin was made.
+    m = DiffSepModel(default_config(nf=16), dtype="f16")
+    assert m.has_fallback() and not DiffSepModel(default_config(nf=16), dtype="bf16").has_fallback()
+    assert not DiffSepModel(default_config(nf=16), dtype="split").has_fallback()
+    assert getattr(m, "_fallback", None) is None
+    fb = m.fallback_model()
+    tw = fb.score_model
+    assert tw._parent is m.score_model and tw.cfg.dtype != m.score_model.cfg.dtype
+    tw._sync_with_parent()
+    assert tw._state is m.score_model._state
+    # new weights on the parent (directly on the score model, as a user of the reference API would): the twin follows
+    sd = {k: v + 1.0 for k, v in m.score_model.state_dict().items()}
+    m.score_model.load_state_dict(sd)
+    assert tw._state is not m.score_model._state          # (not yet: adopted when the twin next builds its engine)
+    tw._sync_with_parent()
+    assert tw._state is m.score_model._state and tw._built_version == m.score_model._version
+    k0 = next(iter(tw._state))
+    np.testing.assert_array_equal(tw._state[k0], sd["backbone." + k0].numpy())
+    # ... and the device
+    m.to("cuda:1")
+    tw._sync_with_parent()
+    assert tw.device == "cuda:1"
+    # DiffSepModel.load_state_dict drops the cached fallback object as well
+    m.load_state_dict(sd)
+    assert m._fallback is None and m.fallback_model().score_model._parent is m.score_model
+    # a hybrid model's fallback is its own split head engine, loaded by DiffSepModel.load_state_dict
+    h = DiffSepModel(default_config(nf=16), dtype="hybrid")
+    sdh = {k: v * 0.5 for k, v in h.score_model.state_dict().items()}
+    h.load_state_dict(sdh)
+    assert h.fallback_model().score_model is h.tail_model
+    np.testing.assert_array_equal(h.tail_model._state[k0], sdh["backbone." + k0].numpy())
+
+
+def test_bench_eight_ranks_weak_and_strong_gloo():
+    # the 8-rank shape of the driver's scaling run, as a gloo dry run (stand-in engine): every
+    # rank takes part (ranks_seen has 8 entries), weak mode keeps 16-per-rank semantics, strong mode deals a fixed set with
+    # a remainder (19 utterances on 8 ranks) and gathers every utterance exactly once.
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["DIFFSEP_BENCH_DRYRUN"] = "1"
+    env["OMP_NUM_THREADS"] = "1"
+    for extra in ([], ["--scaling", "strong", "--utterances", "19"]):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1",
+                              "--batch", "2", "--samples", "800", "--in-flight", "1"] + extra, env=env, cwd=root,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-800:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout[-500:]
+        res = json.loads(lines[0])
+        assert res["n_gpus"] == 8 and res["ranks_seen"] == [[r, r] for r in range(8)] and res["value"] > 0
+        if extra:
+            assert res["scaling"] == "strong" and res["config"]["utterances"] == 19
+            assert len(res["rank_busy_s_per_step"]) == 8
+            assert res["gathered_utterances"] == 19 and res["gathered_unique"] == 19
+        else:
+            assert res["scaling"] == "weak" and res["config"]["sharding"] == "utterances/8"
+            assert len(res["rank_elapsed_s_per_step"]) == 8
