@@ -94,6 +94,7 @@ __device__ inline f32x4_acc mfma_bf16(const uint4& a, const uint4& b, const f32x
 #ifdef DS_HALF_F16
 #define DS_HALF_NAME "f16"
 #define DS_MFMA_H32_ASM "v_mfma_f32_32x32x16_f16"
+#define DS_CVT_PK_H_ASM "v_cvt_pk_f16_f32"
 #define DS_H_ONE 0x3c00u   // 1.0
 __host__ __device__ inline float h2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
 __host__ __device__ inline bf16_t f2h(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
@@ -112,6 +113,7 @@ __device__ inline f32x4_acc mfma_h16(const uint4& a, const uint4& b, const f32x4
 #else
 #define DS_HALF_NAME "bf16"
 #define DS_MFMA_H32_ASM "v_mfma_f32_32x32x16_bf16"
+#define DS_CVT_PK_H_ASM "v_cvt_pk_bf16_f32"
 #define DS_H_ONE 0x3f80u   // 1.0
 __host__ __device__ inline float h2f(bf16_t v) { return bf2f(v); }
 __host__ __device__ inline bf16_t f2h(float f) { return f2bf(f); }

@@ -346,116 +346,42 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   // every input of the launch is activated (no raw skip / residual chunk shares the accumulators): the activation may
   // leave a constant factor to the epilogue
   constexpr bool FOLD = MODE == 2 && NSK == 0;
-  // Round 5.  (i) RW_ACT_PK (half-precision build): GroupNorm affine + SiLU in PACKED half precision — per dword (two channels)
-  // v_pk_fma_f16, 2 x v_exp_f16, v_pk_add_f16, 2 x v_rcp_f16, v_pk_mul_f16 = 7 instructions (8 without FOLD) instead of 11
-  // (2 fma_mix, 2 exp, 2 add, 2 rcp, 2 mul, cvt_pk); the upper halves go through SDWA forms of the transcendentals, no
-  // unpack / pack.  What it costs in rounding is gated by tests/test_engine_gpu.py against the CPU oracle (-DRW_ACT_F32
-  // restores the fp32 arithmetic for the A/B).  (ii) RW_PIPE: a unit runs in THREE stages, one unit apart (affine + exp |
-  // 1 + e, rcp | multiply, write, re-issue): the single in-order wave no longer issues a transcendental's consumer straight
-  // behind it (a k-step carries 0.6 units: inside one unit every instruction depends on the previous one).
-#if defined(DS_HALF_F16) && !defined(RW_ACT_F32)
-  constexpr bool ACT_PK = true;
-#else
-  constexpr bool ACT_PK = false;
-#endif
-#ifdef RW_NO_PIPE
-  constexpr int PIPE_LAG = 0;
-#else
-  constexpr int PIPE_LAG = 2;
-#endif
-  float gsc[ACT_PK ? 1 : 8], gsh[ACT_PK ? 1 : 8];
-  unsigned psc[ACT_PK ? 4 : 1], psh[ACT_PK ? 4 : 1];
+  float gsc[8], gsh[8];
   auto act_tab = [&](int c) __attribute__((always_inline)) {  // scale / shift of this thread's 8 channels of chunk c
     if constexpr (MODE != 0) {
       const float4* ts = reinterpret_cast<const float4*>(sTab + c * KC + slot * 8);
       const float4* th = reinterpret_cast<const float4*>(sTab + CIN + c * KC + slot * 8);
       const float4 s0 = ts[0], s1 = ts[1], h0 = th[0], h1 = th[1];
-      float a[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, b_[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+      gsc[0] = s0.x; gsc[1] = s0.y; gsc[2] = s0.z; gsc[3] = s0.w; gsc[4] = s1.x; gsc[5] = s1.y; gsc[6] = s1.z; gsc[7] = s1.w;
+      gsh[0] = h0.x; gsh[1] = h0.y; gsh[2] = h0.z; gsh[3] = h0.w; gsh[4] = h1.x; gsh[5] = h1.y; gsh[6] = h1.z; gsh[7] = h1.w;
       if constexpr (FOLD) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { a[j] *= -1.4426950408889634f; b_[j] *= -1.4426950408889634f; }
-      }
-      if constexpr (ACT_PK) {
-#pragma unroll
-        for (int d = 0; d < 4; ++d) { psc[d] = pack_h2(a[2 * d], a[2 * d + 1]); psh[d] = pack_h2(b_[2 * d], b_[2 * d + 1]); }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { gsc[j] = a[j]; gsh[j] = b_[j]; }
+        for (int j = 0; j < 8; ++j) { gsc[j] *= -1.4426950408889634f; gsh[j] *= -1.4426950408889634f; }
       }
     }
   };
   // Staging runs in UNITS of one dword (two channels) so that its VALU work spreads evenly over the k-steps of a phase:
   // unit u = dword u & 3 of piece u >> 2.  The piece's last unit writes it to the ring and re-issues its registers as
-  // the load of the chunk after next.  Stage registers of the units in flight: ring of 3 by unit index (compile time).
+  // the load of the chunk after next.
   u32x4_t so;  // the piece being assembled
-  float uz[3][2], ut[3][2];
-  unsigned uzp[3], utp[3], uxp[3], udp[3], urp[3];
-  // stages 0 (unit u0: affine, exp2 of both channels) and 1 (unit u1: 1 + e, reciprocal) of two DIFFERENT units, emitted
-  // interleaved: an SDWA transcendental that completes a register (upper half, the lower one preserved) straight behind the
-  // instruction that wrote the lower half costs a wait state (s_nop) — the other unit's instruction sits between them.
-  // u0 / u1 < 0: that stage has nothing to do in this step.
-  auto unit_s01 = [&](auto P1_, int u0, int u1) __attribute__((always_inline)) {
+  auto unit = [&](auto P1_, auto P2_, const TileG& g1, const TileG& g2, int sl, int u, int rel) __attribute__((always_inline)) {
     constexpr int P1 = decltype(P1_)::value;
+    const int k = u >> 2, d = u & 3;
+    const unsigned w = pa[k][d];
     if constexpr (P1 < NCH && MODE != 0) {
-      const int q0 = u0 >= 0 ? u0 % 3 : 0, q1 = u1 >= 0 ? u1 % 3 : 0;
-      if constexpr (ACT_PK) {
-        unsigned z = 0, x = 0, e = 0, dd = 0, r = 0;
-        if (u0 >= 0) {
-          asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(z) : "v"(pa[u0 >> 2][u0 & 3]), "v"(psc[u0 & 3]), "v"(psh[u0 & 3]));
-          x = z;
-          if constexpr (MODE == 2 && !FOLD) asm("v_pk_mul_f16 %0, %1, %2" : "=v"(x) : "v"(z), "s"(0xbdc5bdc5u));  // -log2(e) in both halves
-        }
-        if constexpr (MODE == 2) {
-          if (u1 >= 0) asm("v_pk_add_f16 %0, %1, %2" : "=v"(dd) : "v"(utp[q1]), "s"(0x3c003c00u));
-          if (u0 >= 0) asm("v_exp_f16 %0, %1" : "=v"(e) : "v"(x));
-          if (u1 >= 0) asm("v_rcp_f16 %0, %1" : "=v"(r) : "v"(dd));
-          if (u0 >= 0) asm("v_exp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(e) : "v"(x));
-          if (u1 >= 0) asm("v_rcp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(r) : "v"(dd));
-          if (u1 >= 0) urp[q1] = r;
-          if (u0 >= 0) utp[q0] = e;
-        }
-        if (u0 >= 0) uzp[q0] = z;
-      } else {
-        if (u1 >= 0 && MODE == 2) {
-          ut[q1][0] = __builtin_amdgcn_rcpf(1.0f + ut[q1][0]);
-          ut[q1][1] = __builtin_amdgcn_rcpf(1.0f + ut[q1][1]);
-        }
-        if (u0 >= 0) {
-          const unsigned w = pa[u0 >> 2][u0 & 3];
-          const int d = u0 & 3;
-          const float lo = h_lo(w), hi = h_hi(w);
-          const float z0 = fmaf(lo, gsc[2 * d], gsh[2 * d]), z1 = fmaf(hi, gsc[2 * d + 1], gsh[2 * d + 1]);
-          uz[q0][0] = z0; uz[q0][1] = z1;
-          if (MODE == 2) {
-            // FOLD: the affine carries the factor -log2(e), z IS the exponent of the sigmoid's exp2 and the staged value is
-            // silu(GN(x)) / -ln 2; the epilogue multiplies the accumulators back (exact in fp32, one multiply per element less)
-            ut[q0][0] = __builtin_amdgcn_exp2f(FOLD ? z0 : z0 * -1.4426950408889634f);
-            ut[q0][1] = __builtin_amdgcn_exp2f(FOLD ? z1 : z1 * -1.4426950408889634f);
-          }
-        }
+      const float lo = h_lo(w), hi = h_hi(w);
+      float z0 = fmaf(lo, gsc[2 * d], gsh[2 * d]), z1 = fmaf(hi, gsc[2 * d + 1], gsh[2 * d + 1]);
+      if (MODE == 2) {
+        // FOLD: the affine carries the factor -log2(e), z IS the exponent of the sigmoid's exp2 and the staged value is
+        // silu(GN(x)) / -ln 2; the epilogue multiplies the accumulators back (exact in fp32, one multiply per element less)
+        const float e0 = __builtin_amdgcn_exp2f(FOLD ? z0 : z0 * -1.4426950408889634f);
+        const float e1 = __builtin_amdgcn_exp2f(FOLD ? z1 : z1 * -1.4426950408889634f);
+        z0 *= __builtin_amdgcn_rcpf(1.0f + e0);
+        z1 *= __builtin_amdgcn_rcpf(1.0f + e1);
       }
-    }
-  };
-  // stage 2: z * sigmoid, the dword into the piece (unit_s2); the piece's last unit writes it and re-issues its registers
-  // (unit_fin: that part alone, for the hand-placed stream whose multiply sits in an earlier lump)
-  auto unit_s2x = [&](auto P1_, auto P2_, auto FIN_, const TileG& g1, const TileG& g2, int sl, int u, int rel) __attribute__((always_inline)) {
-    constexpr int P1 = decltype(P1_)::value;
-    constexpr bool FIN_ONLY = decltype(FIN_)::value;
-    const int k = u >> 2, d = u & 3, q = u % 3;
-    if constexpr (!FIN_ONLY) {
-    if constexpr (P1 < NCH && MODE != 0) {
-      if constexpr (ACT_PK) {
-        unsigned v = uzp[q];
-        if constexpr (MODE == 2) asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(v) : "v"(uzp[q]), "v"(urp[q]));
-        so[d] = v;
-      } else {
-        float z0 = uz[q][0], z1 = uz[q][1];
-        if (MODE == 2) { z0 *= ut[q][0]; z1 *= ut[q][1]; }
-        so[d] = pack_h2(z0, z1);
-      }
+      so[d] = pack_h2(z0, z1);
     } else {
-      so[d] = pa[k][d];
-    }
+      so[d] = w;
     }
     if (d == 3) {
       if (P1 < NCH && MODE != 0 && k >= NI) {  // zero padding stays zero (silu(GN(0)) != 0): border pieces only
@@ -477,18 +403,6 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
       issue_one(P2_, g2, k, rel);
 #endif
     }
-  };
-  auto unit_s2 = [&](auto P1_, auto P2_, const TileG& g1, const TileG& g2, int sl, int u, int rel) __attribute__((always_inline)) {
-    unit_s2x(P1_, P2_, std::false_type{}, g1, g2, sl, u, rel);
-  };
-  auto unit_fin = [&](auto P1_, auto P2_, const TileG& g1, const TileG& g2, int sl, int u, int rel) __attribute__((always_inline)) {
-    unit_s2x(P1_, P2_, std::true_type{}, g1, g2, sl, u, rel);
-  };
-  // a whole unit at once (the prologue)
-  auto unit = [&](auto P1_, auto P2_, const TileG& g1, const TileG& g2, int sl, int u, int rel) __attribute__((always_inline)) {
-    unit_s01(P1_, u, -1);
-    unit_s01(P1_, -1, u);
-    unit_s2(P1_, P2_, g1, g2, sl, u, rel);
   };
 
   f32x16 acc[RPW];
@@ -581,25 +495,15 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   };
 
   // ---- one HALF of a phase: the MFMAs of chunk (phase P, ring slot P & 1) for the wave's rows [HF * RH, HF * RH + RH),
-  // interleaved with (i) its share of the staging of the next phase's chunk and of the loads of the chunk after that,
-  // (ii) EPI: the epilogue of the OTHER half's rows — rows [RH, RPW) of the previous tile during the first half of phase
-  // 0, rows [0, RH) of this tile during the second half of the last phase.  The epilogue of one half of the accumulators
-  // thus always runs under the MFMAs of the other half: no second accumulator set, no phase in which all waves of the
-  // chip store at once.
-  //
-  // Round 5: the stream is HAND-PLACED.  A single in-order wave hides at most ~5 other instructions under one 32-cycle
-  // MFMA, and only if they sit in the gap behind it; the compiler's placement (sched_group_barrier sees neither the
-  // inline-asm MFMAs nor inline-asm VALU) put two MFMAs back to back and the k-step's VALU behind them.  Now every
-  // MFMA is followed by its GAP: the fragment read scheduled there, then the LUMPS (<= 4 - 5 instructions each, volatile
-  // inline asm in the order written) that a compile-time schedule assigns to it:
-  //   * unit lumps: virtual staging step v = {stage 0 of unit v, stage 1 of unit v - 1 | stage 2 of unit v - 2} in two
-  //     lumps; spread evenly over the phase's gaps, a gap of an epilogue half counting W_E / W_N of another one;
-  //   * epilogue lumps (EPI halves): per row 20 lumps — per half row (j) 4 x {2 fma + pack | the pair's statistics}, the
-  //     permlane32 swap; then the permlane16 regrouping and the two stores — spread evenly over the half's gaps.
+  // interleaved k-step by k-step with (i) its share of the staging of the next phase's chunk and of the loads of the
+  // chunk after that, (ii) EPI: the epilogue of the OTHER half's rows — rows [RH, RPW) of the previous tile during the
+  // first half of phase 0, rows [0, RH) of this tile during the second half of the last phase.  The epilogue of one half
+  // of the accumulators thus always runs under the MFMAs of the other half: no second accumulator set, no phase in
+  // which all waves of the chip store at once.
   constexpr int RH = RPW / 2;
-  constexpr int W_E = 2, W_N = 5;  // capacity of a gap for unit lumps: epilogue half / other half
-  float et[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // the two cout pairs in flight through the epilogue lumps
-  u32x4_t osa = {0, 0, 0, 0}, osb = {0, 0, 0, 0};  // the row's two store pieces after the regrouping
+#ifdef RW_NO_ROWREUSE
+  constexpr int DEPTH = RH >= 4 ? 2 : 4;  // pixel fragments are read DEPTH k-steps (>= 8 MFMAs) ahead of their use
+#endif
   auto half = [&](auto P_, auto HF_, auto EPI_, int slot_r, const TileG& ge, const TileG& g1, const TileG& g2) __attribute__((always_inline)) {
     constexpr int P = decltype(P_)::value, HF = decltype(HF_)::value;
     constexpr bool EPI = decltype(EPI_)::value;
@@ -608,15 +512,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     constexpr int NK = CONV ? KSC : NKB;
     constexpr int W0 = CONV ? C * KSC : NCH * KSC + (C - NCH) * NKB;
     constexpr int C1 = G::chunk_of((P + 1) % NPH), C2 = G::chunk_of((P + 2) % NPH);
-    constexpr int NU = NL * 4;
-    constexpr bool ACT1 = C1 < NCH && MODE != 0;
-    // virtual unit index v: stage 0 of unit v, stage 1 of unit v - 1, stage 2 of unit v - LAG (LAG = 0: the whole unit at v)
-    constexpr int LAG = ACT1 ? PIPE_LAG : 0, NUV = NU + LAG, NLU = 2 * NUV;
-    constexpr int NGH = NK * RH;  // gaps (MFMAs) of this half
-    constexpr int w0 = (P == 0) ? W_E : W_N, w1 = (P == NPH - 1) ? W_E : W_N, CAP = NGH * (w0 + w1);
-    // first unit lump of phase gap GP in [0, 2 NGH]
-    auto lub = [](int GP) constexpr { return NLU * (GP <= NGH ? GP * w0 : NGH * w0 + (GP - NGH) * w1) / CAP; };
-    constexpr int NLE = RH * 22;  // epilogue lumps of an EPI half
+    constexpr int NU = NL * 4, NE = RH * 2;
     constexpr int R0 = HF * RH, ER0 = HF ? 0 : RH;
     const char* fb = sA + slot_r * LDS_A + fbase + R0 * HW_ * AROW;
 #ifndef RW_BUILTIN_MFMA
@@ -626,6 +522,22 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     }
 #endif
     if constexpr (HF == 0 && C1 < NCH) act_tab(C1);
+#ifdef RW_NO_ROWREUSE  // (A/B: every k-step reads its own RH fragments, DEPTH k-steps ahead)
+    auto ldb = [&](int ks, int r) __attribute__((always_inline)) {
+      const int tap = CONV ? ks / NKB : 4, kb = ks % NKB;
+      const int dy = tap / 3, dx = tap % 3;
+      return *reinterpret_cast<const u32x4_t*>(fb + ((r + dy) * HW_ + dx) * AROW + kb * 32);
+    };
+    u32x4_t bf[DEPTH][RH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+      for (int r = 0; r < RH; ++r)
+        if (d < NK) bf[d][r] = ldb(d, r);
+    auto widx = [](int ks) { return ks; };
+#define RW_FRAG(ks, r) bf[(ks) % DEPTH][r]
+#define RW_FRAG_LAST(ks) bf[(ks) % DEPTH][RH - 1]
+#else
     // K order inside a 3x3 chunk: (kx, 16-channel block) groups outside, ky inside.  The RH rows of this half use the
     // pixel fragments of input rows R0 .. R0 + RH + 1 at the group's (kx, block): each is read ONCE per group and serves up
     // to three k-steps (ky) — RH + 2 fragment reads per 3 RH MFMAs instead of 3 RH, and one wait per group.  (A skip
@@ -647,134 +559,48 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     };
 #define RW_FRAG(ks, r) rf[((ks) / SUB) & 1][(r) + (CONV ? (ks) % SUB : 0)]
 #define RW_FRAG_LAST(ks) rf[((ks) / SUB) & 1][RFN - 1]
+#endif
     // weight fragment of k-step ks: a register, or (the last NWL fragments) an LDS read issued one k-step ahead
     u32x4_t wl = {0, 0, 0, 0}, wln = {0, 0, 0, 0};
     if constexpr (W0 + widx(0) >= NWR) wl = *reinterpret_cast<const u32x4_t*>(sWl + (W0 + widx(0) - NWR) * G::WL_STEP);
-    // relative pixel index of the border pieces that complete in a k-step, read (registers or LDS table) one k-step ahead
     int rels[2][NL];
-    auto fetch_rels = [&](int ks, int par) __attribute__((always_inline)) {  // for the unit lumps of k-step ks of this half
-      const int gp0 = HF * NGH + ks * RH;
+    float4 eb[2][NE][2];
+    {  // (the first k-step's operands: the one exposed round trip of the half)
+      const int s0 = HF * NK, ua = s0 * NU / (2 * NK), ub = (s0 + 1) * NU / (2 * NK);
 #pragma unroll
-      for (int L = lub(gp0); L < lub(gp0 + RH); ++L) {
-        const int u = (L >> 1) - LAG;
-        if ((L & 1) && u >= 0 && u < NU && (u & 3) == 3 && (u >> 2) >= NI)
-          rels[par][u >> 2] = REL_REGS ? relreg[(u >> 2) - NI] : sDesc[((u >> 2) - NI) * NT + tid];
-      }
-    };
-    fetch_rels(0, 0);  // (the first k-step's operands: the one exposed round trip of the half)
-
-    // ---- lumps.  (An inline-asm instruction that reads a register written by one of the two instructions in front of it
-    // gets a wait state from the compiler, which cannot see whether the producer was a transcendental: the orders below
-    // keep every consumer three instructions behind its producer.)
-    auto unit_lump = [&](int L, int par) __attribute__((always_inline)) {
-      const int v = L >> 1;
-      const int u0 = v < NU ? v : -1, u1 = LAG ? ((v >= 1 && v - 1 < NU) ? v - 1 : -1) : v, u2 = v - LAG;
-      const bool s2 = u2 >= 0 && u2 < NU;
-      if ((L & 1) == 0) {
-        if constexpr (ACT1 && ACT_PK) {
-          // affine of unit u0 | 1 + e of unit u1 | z * sigmoid of unit u2 | exp2 (lower half) of u0 | reciprocal (lower half) of u1
-          if (u0 >= 0) {
-            asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(uzp[u0 % 3]) : "v"(pa[u0 >> 2][u0 & 3]), "v"(psc[u0 & 3]), "v"(psh[u0 & 3]));
-            if constexpr (MODE == 2 && !FOLD) asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(uxp[u0 % 3]) : "v"(uzp[u0 % 3]), "s"(0xbdc5bdc5u));  // x -log2(e)
-          }
-          if constexpr (MODE == 2) {
-            if (u1 >= 0) asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(udp[u1 % 3]) : "v"(utp[u1 % 3]), "s"(0x3c003c00u));
-            if (s2) asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(so[u2 & 3]) : "v"(uzp[u2 % 3]), "v"(urp[u2 % 3]));
-            if (u0 >= 0) asm volatile("v_exp_f16 %0, %1" : "=v"(utp[u0 % 3]) : "v"(FOLD ? uzp[u0 % 3] : uxp[u0 % 3]));
-            if (u1 >= 0) asm volatile("v_rcp_f16 %0, %1" : "=v"(urp[u1 % 3]) : "v"(udp[u1 % 3]));
-          } else {
-            if (s2) so[u2 & 3] = uzp[u2 % 3];
-          }
-        } else if constexpr (ACT1) {
-          if (u0 >= 0) unit_s01(std::integral_constant<int, C1>{}, u0, -1);
-        }
-      } else {
-        if constexpr (ACT1 && ACT_PK) {
-          if constexpr (MODE == 2) {
-            if (u0 >= 0) asm volatile("v_exp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(utp[u0 % 3]) : "v"(FOLD ? uzp[u0 % 3] : uxp[u0 % 3]));
-            if (u1 >= 0) asm volatile("v_rcp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(urp[u1 % 3]) : "v"(udp[u1 % 3]));
-          }
-        } else if constexpr (ACT1) {
-          if (u1 >= 0) unit_s01(std::integral_constant<int, C1>{}, -1, u1);
-        }
-#ifndef RW_ABL_NOSTAGE
-        if (s2) {
-          const int rel = ((u2 & 3) == 3 && (u2 >> 2) >= NI) ? rels[par][u2 >> 2] : 0;
-          if constexpr (ACT1 && ACT_PK) unit_fin(std::integral_constant<int, C1>{}, std::integral_constant<int, C2>{}, g1, g2, slot_r ^ 1, u2, rel);
-          else unit_s2(std::integral_constant<int, C1>{}, std::integral_constant<int, C2>{}, g1, g2, slot_r ^ 1, u2, rel);
-        }
-#endif
-      }
-    };
-    // epilogue lumps of row rr, 22 per row: per half row j the pairs p = 0 .. 3 of the lane's 8 couts as a two-deep
-    // pipeline — A(p) = {v = acc * scale + bias of pair p; pack pair p - 1}, B(p) = {statistics of pair p} in the order
-    // A0 A1 B0 A2 B1 A3 B2 A4 B3 — then the permlane32 swap; x = 20: permlane16 regrouping; x = 21: the stores
-    auto epi_lump = [&](int LE) __attribute__((always_inline)) {
-      const int rr = ER0 + LE / 22, x = LE % 22;
-      if (x < 20) {
-        const int j = x / 10, y = x % 10;
-        // y: 0 A0, 1 A1, 2 B0, 3 A2, 4 B1, 5 A3, 6 B2, 7 A4, 8 B3, 9 swap
-        const bool isA = y == 0 || y == 1 || y == 3 || y == 5 || y == 7;
-        const int pr = y == 0 ? 0 : (y == 1 ? 1 : (y == 2 ? 0 : (y == 3 ? 2 : (y == 4 ? 1 : (y == 5 ? 3 : (y == 6 ? 2 : (y == 7 ? 4 : 3)))))));
-        if (y == 9) {
-          // lane (pixel l32, half h): couts 16 j + 8 h .. + 7
-          if (j == 0) {
-            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(osa[0]), "+v"(osa[2]));
-            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(osa[1]), "+v"(osa[3]));
-          } else {
-            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(osb[0]), "+v"(osb[2]));
-            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(osb[1]), "+v"(osb[3]));
-          }
-        } else if (isA) {
-          if (pr < 4) {
-            const int e0 = 8 * j + 2 * pr;
-            const float b0 = pr == 0 ? breg[j][0].x : (pr == 1 ? breg[j][0].z : (pr == 2 ? breg[j][1].x : breg[j][1].z));
-            const float b1 = pr == 0 ? breg[j][0].y : (pr == 1 ? breg[j][0].w : (pr == 2 ? breg[j][1].y : breg[j][1].w));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(et[pr & 1][0]) : "v"(acc[rr][e0]), "s"(osc), "v"(b0));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(et[pr & 1][1]) : "v"(acc[rr][e0 + 1]), "s"(osc), "v"(b1));
-          }
-          if (pr >= 1) {
-            const int q = pr - 1;
-            if (j == 0) asm volatile(DS_CVT_PK_H_ASM " %0, %1, %2" : "=v"(osa[q]) : "v"(et[q & 1][0]), "v"(et[q & 1][1]));
-            else asm volatile(DS_CVT_PK_H_ASM " %0, %1, %2" : "=v"(osb[q]) : "v"(et[q & 1][0]), "v"(et[q & 1][1]));
-          }
-        } else {
-#ifndef RW_ABL_NOSTATS
-          const int e0 = 8 * j + 2 * pr;
-          asm volatile("v_add_f32 %0, %0, %1" : "+v"(ssum[e0]) : "v"(et[pr & 1][0]));
-          asm volatile("v_add_f32 %0, %0, %1" : "+v"(ssum[e0 + 1]) : "v"(et[pr & 1][1]));
-          asm volatile("v_fma_f32 %0, %1, %1, %0" : "+v"(ssq[e0]) : "v"(et[pr & 1][0]));
-          asm volatile("v_fma_f32 %0, %1, %1, %0" : "+v"(ssq[e0 + 1]) : "v"(et[pr & 1][1]));
-#endif
-        }
-      } else if (x == 20) {
+      for (int u = ua; u < ub; ++u)
+        if ((u & 3) == 3 && (u >> 2) >= NI) rels[0][u >> 2] = REL_REGS ? relreg[(u >> 2) - NI] : sDesc[((u >> 2) - NI) * NT + tid];
+      if (EPI) {
 #pragma unroll
-        for (int d = 0; d < 4; ++d) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(osa[d]), "+v"(osb[d]));
-      } else {
-        const int pix = ge.pix0 + (pg * RPW + rr) * p.W + (lane & 15);
-        const unsigned o = __umul24((unsigned)pix, (unsigned)p.ldy * 2u) + spiece;
-#ifdef RW_TIMING
-        const unsigned o1 = (p.dbg & 1) ? OOB : o, o2 = (p.dbg & 1) ? OOB : o + 16u * (unsigned)p.ldy * 2u;
-#else
-        const unsigned o1 = o, o2 = o + 16u * (unsigned)p.ldy * 2u;
-#endif
-#ifdef RW_ABL_NOSTORE
-        asm volatile("" :: "v"(osa), "v"(osb), "v"(o1), "v"(o2));
-#else
-        __builtin_amdgcn_raw_buffer_store_b128(osa, ry, o1, 0, 0);   // pixels 0 .. 15 of the row
-        __builtin_amdgcn_raw_buffer_store_b128(osb, ry, o2, 0, 0);   // pixels 16 .. 31
-#endif
+        for (int e = 0; e < NE / NK + (NE % NK ? 1 : 0); ++e)
+          if (e < (1 * NE) / NK) epi_bias(e & 1, eb[0][e][0], eb[0][e][1]);
       }
-    };
-
+    }
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
-      if (ks + 1 < NK) fetch_rels(ks + 1, (ks + 1) & 1);
+      const int sl = HF * NK + ks;  // slot of this k-step in the phase's staging schedule
+      const int u0 = sl * NU / (2 * NK), u1 = (sl + 1) * NU / (2 * NK);
+      const int e0 = EPI ? ks * NE / NK : 0, e1 = EPI ? (ks + 1) * NE / NK : 0;
+      // LDS operands of the NEXT k-step's staging / epilogue units, read a whole k-step ahead of their use (a read
+      // issued and consumed inside one k-step waits for the LDS round trip behind the fragment reads already queued):
+      // relative pixel indices of the pieces that complete, bias of the epilogue units
+      if (ks + 1 < NK) {
+        const int sn = sl + 1, un0 = sn * NU / (2 * NK), un1 = (sn + 1) * NU / (2 * NK);
+#pragma unroll
+        for (int u = un0; u < un1; ++u)
+          if ((u & 3) == 3 && (u >> 2) >= NI) rels[(ks + 1) & 1][u >> 2] = REL_REGS ? relreg[(u >> 2) - NI] : sDesc[((u >> 2) - NI) * NT + tid];
+        if (EPI) {
+          const int en0 = (ks + 1) * NE / NK, en1 = (ks + 2) * NE / NK;
+#pragma unroll
+          for (int e = en0; e < en1; ++e) epi_bias(e & 1, eb[(ks + 1) & 1][e - en0][0], eb[(ks + 1) & 1][e - en0][1]);
+        }
+      }
       const int wi = W0 + widx(ks), win = W0 + widx(ks + 1 < NK ? ks + 1 : ks);
       if (win >= NWR && ks + 1 < NK) wln = *reinterpret_cast<const u32x4_t*>(sWl + (win - NWR) * G::WL_STEP);
       const u32x4_t wk = wi < NWR ? wf[wi < NWR ? wi : 0] : wl;
       // RW_DEP: the k-step's LAST pixel fragment rides along as an unused operand of every MFMA of the k-step: the
-      // compiler then waits ONCE per k-step (for the newest fragment) instead of once per MFMA
+      // compiler then waits ONCE per k-step (for the newest fragment) instead of once per MFMA — one s_waitcnt less per
+      // MFMA in a stream whose issue slots are the bottleneck (the fragments were read DEPTH k-steps ago)
 #ifdef RW_NO_DEP
 #define RW_DEP
 #else
@@ -782,10 +608,12 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
 #endif
 #pragma unroll
       for (int r = 0; r < RH; ++r) {
+#ifndef RW_BUILTIN_MFMA
         // Inline asm: the register-resident weight fragment is pinned to the accumulator half of the register file ("a")
         // and feeds the MFMA from there; accumulators, pixel fragments and everything the VALU touches live in the
-        // architectural half.  What the compiler does not know about an asm MFMA: the 12 wait states between its result and
-        // a VALU read — the guard at the start of every half.
+        // architectural half.  (With the builtin hipcc kept the weights in VGPRs and shuttled accumulators, statistics
+        // and staged pieces through AGPRs: 200 v_accvgpr moves per tile.)  What the compiler does not know about an asm
+        // MFMA: the 12 wait states between its result and a VALU read — the guard at the start of every half.
         if (wi < NWR) {
           if (P == 0 && ks == 0) asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, 0" : "=v"(acc[R0 + r]) : "a"(wk), "v"(RW_FRAG(ks, r)) RW_DEP);
           else asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, %0" : "+v"(acc[R0 + r]) : "a"(wk), "v"(RW_FRAG(ks, r)) RW_DEP);
@@ -793,22 +621,45 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
           if (P == 0 && ks == 0) asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, 0" : "=v"(acc[R0 + r]) : "v"(wk), "v"(RW_FRAG(ks, r)) RW_DEP);
           else asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, %0" : "+v"(acc[R0 + r]) : "v"(wk), "v"(RW_FRAG(ks, r)) RW_DEP);
         }
-        // ---- the gap behind this MFMA
+#else
+        if (P == 0 && ks == 0) {  // a tile's first MFMA of a row starts from zero (the row's epilogue has run)
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[R0 + r] = mfma_h32(__builtin_bit_cast(uint4, wk), __builtin_bit_cast(uint4, RW_FRAG(ks, r)), zero);
+        } else {
+          acc[R0 + r] = mfma_h32(__builtin_bit_cast(uint4, wk), __builtin_bit_cast(uint4, RW_FRAG(ks, r)), acc[R0 + r]);
+        }
+#endif
+#ifdef RW_NO_ROWREUSE
+        if (ks + DEPTH < NK) bf[ks % DEPTH][r] = ldb(ks + DEPTH, r);
+#else
         {  // the next group's fragments, one per MFMA slot of this group
           const int g = ks / SUB, q = (ks % SUB) * RH + r;
           if (q < RFN && g + 1 < NG) rf[(g + 1) & 1][q] = ldg(g + 1, q);
         }
-        const int gh = ks * RH + r, gp = HF * NGH + gh;
-#pragma unroll
-        for (int L = lub(gp); L < lub(gp + 1); ++L) unit_lump(L, ks & 1);
-#ifndef RW_ABL_NOEPI
-        if constexpr (EPI) {
-#pragma unroll
-          for (int LE = gh * NLE / NGH; LE < (gh + 1) * NLE / NGH; ++LE) epi_lump(LE);
-        }
 #endif
       }
       wl = wln;
+#ifndef RW_ABL_NOSTAGE
+#pragma unroll
+      for (int u = u0; u < u1; ++u)
+        unit(std::integral_constant<int, C1>{}, std::integral_constant<int, C2>{}, g1, g2, slot_r ^ 1, u, (u & 3) == 3 ? rels[ks & 1][u >> 2] : 0);
+#endif
+#ifndef RW_ABL_NOEPI
+#pragma unroll
+      for (int e = e0; e < e1; ++e) epi_unit(ge, ER0 + (e >> 1), e & 1, eb[ks & 1][e - e0][0], eb[ks & 1][e - e0][1]);
+#endif
+      // the k-step's instruction mix, spread evenly: every MFMA (32 cycles on the matrix pipe) is followed by its share
+      // of the VALU work and one fragment read, so that neither pipe waits for the other
+      {
+        constexpr int VPU = (C1 < NCH && MODE == 2) ? 17 : 1;   // VALU per staging unit
+        constexpr int NV = (NU * VPU + NL * 10 + 2 * NK - 1) / (2 * NK) + 4 + (EPI ? (NE * 36 + NK - 1) / NK : 0);  // VALU of an average k-step
+#pragma unroll
+        for (int r = 0; r < RH; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, (NV + RH - 1) / RH, 0);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
