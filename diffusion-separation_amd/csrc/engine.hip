@@ -376,6 +376,7 @@ static int opt_bit(const char* name, unsigned* bit) {
       {"no_rw", DS_OPT_NO_RW}, {"no_rw128", DS_OPT_NO_RW128}, {"rw_small", DS_OPT_RW_SMALL}, {"no_rw_res", DS_OPT_NO_RW_RES},
       {"no_wfrag", DS_OPT_NO_WFRAG},
       {"no_attn_fused", DS_OPT_NO_ATTN_FUSED},
+      {"no_stft_fused", DS_OPT_NO_STFT_FUSED},
       {"no_split256", DS_OPT_NO_SPLIT256}};
   for (const auto& t : tab)
     if (!strcmp(name, t.n)) { *bit = t.b; return 0; }
@@ -464,6 +465,11 @@ struct diffsep_engine {
   int ts_B = 0;
   bool had_arena = false;
   bool dbg_alloc = false;  // DIFFSEP_DBG_ALLOC=1: log every arena allocation (offset, bytes) to stderr
+  // option "track_tensors": every activation tensor of a forward is recorded so that diffsep_engine_debug_absmax can scan them
+  // (the range margin of half-precision storage: tests/test_round5_gpu.py); off by default, eager forwards only
+  bool track_tensors = false;
+  struct Tracked { void* p; long n; int H, W, C; };
+  std::vector<Tracked> tracked;
   // DIFFSEP_F32_SPLIT: fp32 tensors, every MFMA product as 3 bf16 MFMAs on hi / lo halves (cfg.dtype stays DS_F32)
   int split = 0;
   // optional per-launch timing of the MFMA kernels (HIP events on the launch stream)
@@ -569,6 +575,7 @@ static Tn e_tensor(diffsep_engine* e, int B, int H, int W, int C) {
   Tn t;
   t.C = C; t.ld = C; t.H = H; t.W = W;
   t.p = e_alloc(e, (size_t)B * H * W * C * e->esz);
+  if (e->track_tensors && !e->dry) e->tracked.push_back({t.p, (long)B * H * W * C, H, W, C});
   return t;
 }
 static float* e_f32(diffsep_engine* e, size_t n) { return (float*)e_alloc(e, n * 4); }
@@ -974,6 +981,7 @@ static int score_forward_impl(diffsep_engine* e, const float* xt, const float* t
   const diffsep_model_config& c = e->cfg;
   const int W = diffsep_padded_frames(&c, T), H = c.n_fft / 2 + 1, S = c.num_sources;
   e->top = e->fwd_base;
+  e->tracked.clear();
   if (stats_begin(e, st)) return 1;
   Tn x0 = e_tensor(e, B, H, W, e->arch.cpad_in);
   Tn y = e_tensor(e, B, H, W, e->arch.cpad_out);
@@ -1217,6 +1225,43 @@ extern "C" int32_t diffsep_engine_reserve(diffsep_engine* e, int32_t B, int64_t 
   DS_HIP(hipStreamSynchronize(st));  // the workspace is zeroed before any other stream may use the plan
   return 0;
 }
+// Largest finite |value| and number of non-finite values of every activation tensor of the LAST eager forward (option
+// "track_tensors" on): out[i] = {max |v|, non-finite count, H, C} for tensor i in allocation order.  Debug / test aid.
+__global__ __launch_bounds__(256) void absmax_kernel(const void* __restrict__ p, long n, int f32, unsigned* __restrict__ out) {
+  float m = 0.f;
+  unsigned bad = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = f32 ? reinterpret_cast<const float*>(p)[i] : h2f(reinterpret_cast<const bf16_t*>(p)[i]);
+    if (v != v || fabsf(v) > 3.0e38f) ++bad; else m = fmaxf(m, fabsf(v));
+  }
+  atomicMax(out, __float_as_uint(m));
+  if (bad) atomicAdd(out + 1, bad);
+}
+extern "C" int32_t diffsep_engine_debug_absmax(diffsep_engine* e, double* out, int32_t cap, int32_t* n) {
+  DS_CHECK(e && n, "debug_absmax: null argument");
+  *n = (int32_t)e->tracked.size();
+  if (!out || cap <= 0) return 0;
+  const int cnt = *n < cap ? *n : cap;
+  unsigned* d = nullptr;
+  DS_HIP(hipMalloc(&d, (size_t)cnt * 8 + 8));
+  DS_HIP(hipMemset(d, 0, (size_t)cnt * 8 + 8));
+  for (int i = 0; i < cnt; ++i) {
+    const auto& t = e->tracked[i];
+    long nb = (t.n + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)nb), dim3(256), 0, nullptr, t.p, t.n, e->cfg.dtype == DS_F32 ? 1 : 0, d + 2 * i);
+  }
+  std::vector<unsigned> hbuf((size_t)cnt * 2);
+  DS_HIP(hipDeviceSynchronize());
+  DS_HIP(hipMemcpy(hbuf.data(), d, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+  hipFree(d);
+  for (int i = 0; i < cnt; ++i) {
+    float m;
+    memcpy(&m, &hbuf[2 * i], 4);
+    out[4 * i] = m; out[4 * i + 1] = hbuf[2 * i + 1]; out[4 * i + 2] = e->tracked[i].H; out[4 * i + 3] = e->tracked[i].C;
+  }
+  return 0;
+}
 extern "C" int32_t diffsep_engine_debug_arena(const diffsep_engine* e, void** base, int64_t* bytes, int64_t* fwd_base) {
   DS_CHECK(e && base && bytes && fwd_base, "debug_arena: null argument");
   *base = e->arena; *bytes = (int64_t)e->cap; *fwd_base = (int64_t)e->fwd_base;
@@ -1240,6 +1285,9 @@ extern "C" int32_t diffsep_engine_set_option(diffsep_engine* e, const char* name
     e->ablate = (unsigned)value;
   } else if (!strcmp(name, "dbg_alloc")) {
     e->dbg_alloc = value != 0;
+  } else if (!strcmp(name, "track_tensors")) {
+    e->track_tensors = value != 0;
+    e->tracked.clear();
     return 0;
   } else if (!opt_bit(name, &bit)) {
     e->opts = value ? (e->opts | bit) : (e->opts & ~bit);

@@ -458,6 +458,134 @@ __global__ __launch_bounds__(256) void gn_fir_down_strip_kernel(const bf16_t* __
   }
 }
 
+#ifdef DS_HALF_F16
+// FIR x2 DOWN, round 5 (half-precision build): row tiles through LDS, every input element loaded and activated ONCE.
+// The strip kernel above is VALU-bound: a thread re-activates the two columns it shares with each neighbour (48 SiLU per
+// 32 new elements) in fp32 arithmetic and keeps 6 + 6 vectors in flight with most waves spilling — 80 us at 256^2 for
+// 201 MB (0.31 of the HBM roof), 32 us at 128^2 (0.20).  Here a block of 256 threads walks DOWN a strip of RS output rows
+// of a tile of 16 output columns x 64 channels:
+//   phase 1 (per input row): thread (column c < 32, channel octet cg) loads its 16 bytes (one row ahead), applies
+//     GroupNorm + SiLU (fp32, one rounding to the storage type) and
+//     writes the activated and the raw vector to the row's LDS buffer (34 columns: threads 0 .. 15 also take the halo
+//     columns -1 and 32); zeros outside the image for BOTH tensors;
+//   phase 2: threads 0 .. 127 filter the activated tensor, 128 .. 255 the raw one: thread (output column m < 16, octet cg)
+//     reads the 4 taps (ds_read_b128), filters horizontally in fp32 (v_fma_mix) and adds the row into its two running
+//     output rows (taps 1/8, 3/8 into the newer, 3/8, 1/8 into the older, which is then complete: one 16-byte store).
+// One barrier per input row (two row buffers).  Same arithmetic as the kernels above up to one storage rounding of the
+// activated value in front of the filter and fp32 summation order.
+template <int RS>
+__global__ __launch_bounds__(256) void gn_fir_down_tiled_kernel(const bf16_t* __restrict__ x, int ldx,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int C,
+                                                                bf16_t* __restrict__ y, int ldy, bf16_t* __restrict__ xr,
+                                                                int ldxr, int B, int H, int W, int act, int tiles_x, int strips) {
+  constexpr int CP = 144, NCOL = 34, TB = NCOL * CP;  // column pitch (bytes), staged columns, bytes per tensor and row
+  __shared__ __attribute__((aligned(16))) char sm[2][2][TB];
+  const int tid = threadIdx.x, cg = tid & 7, col = tid >> 3;
+  const int ncgb = C >> 6;
+  int bid = blockIdx.x;
+  const int cgb = bid % ncgb; bid /= ncgb;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int st = bid % strips;
+  const int b = bid / strips;
+  const int ch0 = cgb * 64 + cg * 8;
+  const int Ho = H >> 1, Wo = W >> 1;
+  float sc[8], sf[8];
+  {
+    const float4 s0 = *reinterpret_cast<const float4*>(scale + (long)b * C + ch0), s1 = *reinterpret_cast<const float4*>(scale + (long)b * C + ch0 + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(shift + (long)b * C + ch0), h1 = *reinterpret_cast<const float4*>(shift + (long)b * C + ch0 + 4);
+    sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+    sf[0] = h0.x; sf[1] = h0.y; sf[2] = h0.z; sf[3] = h0.w; sf[4] = h1.x; sf[5] = h1.y; sf[6] = h1.z; sf[7] = h1.w;
+  }
+  const bf16_t* xb = x + (long)b * H * W * ldx + ch0;
+  const int ix = 32 * tx + col;                       // this thread's input column (always inside the image: W % 32 == 0)
+  const bool halo = tid < 16;                         // threads 0 .. 7: column -1 of the tile, 8 .. 15: column 32
+  const int hix = 32 * tx + (tid < 8 ? -1 : 32);
+  const bool hok = halo && hix >= 0 && hix < W;
+  const int iy0 = 2 * st * RS - 1;
+  constexpr int NR = 2 * RS + 2;
+  auto load_row = [&](int iy, uint4& v, uint4& hv) __attribute__((always_inline)) {
+    const bool rok = iy >= 0 && iy < H;
+    v = rok ? *reinterpret_cast<const uint4*>(xb + ((long)iy * W + ix) * ldx) : make_uint4(0, 0, 0, 0);
+    hv = (rok && hok) ? *reinterpret_cast<const uint4*>(xb + ((long)iy * W + hix) * ldx) : make_uint4(0, 0, 0, 0);
+  };
+  // GroupNorm + SiLU in fp32, ONE rounding to the storage type on the way to LDS.  (A first version ran the activation in
+  // packed half precision like the register-weight convolution does: 65 -> 63 us, but the sampler's agreement with the fp32
+  // engine fell from 3.3e-3 to 4.3e-3 relative RMS — profiles/experiments/README.md round 5; behind a 16-tap average the
+  // activation's rounding is not hidden by a following storage rounding of the same size, it adds to it.)
+  auto silu2 = [&](unsigned w, int d) __attribute__((always_inline)) {
+    float z0 = fmaf(h_lo(w), sc[2 * d], sf[2 * d]), z1 = fmaf(h_hi(w), sc[2 * d + 1], sf[2 * d + 1]);
+    if (act) { z0 = silu_t<bf16_t>(z0); z1 = silu_t<bf16_t>(z1); }
+    return pack_h2(z0, z1);
+  };
+  auto activate = [&](const uint4& v, bool ok) __attribute__((always_inline)) {  // zero padding: the activated value outside the image is 0 too
+    uint4 a;
+    a.x = silu2(v.x, 0); a.y = silu2(v.y, 1); a.z = silu2(v.z, 2); a.w = silu2(v.w, 3);
+    if (!ok) a = make_uint4(0, 0, 0, 0);
+    return a;
+  };
+  // phase-2 role
+  const int tensor = tid >> 7, ocol = (tid >> 3) & 15;
+  bf16_t* const out = tensor ? xr : y;
+  const int ldo = tensor ? ldxr : ldy;
+  float P[8], Q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { P[j] = 0.f; Q[j] = 0.f; }
+  uint4 cur, hcur, nxt = make_uint4(0, 0, 0, 0), hnxt = make_uint4(0, 0, 0, 0);
+  load_row(iy0, cur, hcur);
+#pragma unroll 2
+  for (int k = 0; k < NR; ++k) {
+    const int iy = iy0 + k;
+    if (k + 1 < NR) load_row(iy + 1, nxt, hnxt);
+    const bool rok = iy >= 0 && iy < H;
+    char* rowb = &sm[k & 1][0][0];
+    {
+      const uint4 a = activate(cur, rok);
+      *reinterpret_cast<uint4*>(rowb + (col + 1) * CP + cg * 16) = a;
+      *reinterpret_cast<uint4*>(rowb + TB + (col + 1) * CP + cg * 16) = cur;
+      if (halo) {
+        const uint4 ha = activate(hcur, rok && hok);
+        const int hc = tid < 8 ? 0 : NCOL - 1;
+        *reinterpret_cast<uint4*>(rowb + hc * CP + cg * 16) = ha;
+        *reinterpret_cast<uint4*>(rowb + TB + hc * CP + cg * 16) = hcur;
+      }
+    }
+    __syncthreads();
+    {
+      const char* src = rowb + tensor * TB + (2 * ocol) * CP + cg * 16;
+      float hsum[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hsum[j] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint4 v = *reinterpret_cast<const uint4*>(src + t * CP);
+        const float w = (t == 0 || t == 3) ? 0.125f : 0.375f;
+        hsum[0] = fmaf(w, h_lo(v.x), hsum[0]); hsum[1] = fmaf(w, h_hi(v.x), hsum[1]);
+        hsum[2] = fmaf(w, h_lo(v.y), hsum[2]); hsum[3] = fmaf(w, h_hi(v.y), hsum[3]);
+        hsum[4] = fmaf(w, h_lo(v.z), hsum[4]); hsum[5] = fmaf(w, h_hi(v.z), hsum[5]);
+        hsum[6] = fmaf(w, h_lo(v.w), hsum[6]); hsum[7] = fmaf(w, h_hi(v.w), hsum[7]);
+      }
+      const float wq = (k & 1) ? 0.375f : 0.125f, wp = (k & 1) ? 0.125f : 0.375f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        Q[j] = (k & 1) ? fmaf(wq, hsum[j], Q[j]) : wq * hsum[j];
+        P[j] = fmaf(wp, hsum[j], P[j]);
+      }
+      if (k & 1) {  // the older row is complete
+        const int oy = st * RS + (k >> 1) - 1;
+        if (k >= 3 && oy < Ho && out) {
+          const long opix = ((long)b * Ho + oy) * Wo + 16 * tx + ocol;
+          store8<bf16_t>(out + opix * ldo + ch0, P);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) P[j] = Q[j];
+      }
+    }
+    cur = nxt; hcur = hnxt;
+  }
+}
+#endif
+
 // Tiled FIR x2 UP for the large levels: the 2 x 2-block kernel above evaluates SiLU(GN(.)) 9 times per input element in
 // its up mode, which makes it VALU-bound (91 us at 256^2 output against 60 us of HBM time).  Here a block stages one input
 // tile — 8 channel groups x (4 + 2) x (8 + 2) pixels — in LDS ONCE: the activated value as fp32 and the raw value in the
@@ -603,6 +731,24 @@ static int gn_apply_typed(const void* x, int ldx, const float* scale, const floa
   }
   if constexpr (sizeof(T) == 2) {
     // large levels, FIR down, 16-bit tensors: column pairs walking down strips of 8 output rows (every input row read once)
+#if defined(DS_HALF_F16) && !defined(DS_NO_FIR_TILED)
+    // (half-precision build) row tiles through LDS: one activation per input element, 16 output columns x 64 channels per block
+    if (aff && mode == 2 && H % 2 == 0 && W % 32 == 0 && C % 64 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && (!xr || ldxr % 8 == 0) &&
+        (long)B * H * W * C >= (1l << 21)) {
+      const int Ho_ = H / 2, tiles_x = W / 32, ncgb = C / 64;
+      // strips of RS output rows: as long as the strips still give every CU ~2 blocks
+      int rs = 16;
+      while (rs > 4 && (long)B * tiles_x * cdiv(Ho_, rs) * ncgb < 2 * ds_num_cus()) rs >>= 1;
+      const int strips = cdiv(Ho_, rs);
+      const unsigned nblk = (unsigned)((long)B * tiles_x * strips * ncgb);
+#define FD(RS_) hipLaunchKernelGGL((gn_fir_down_tiled_kernel<RS_>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)x, ldx, scale, shift, C, \
+                                   (bf16_t*)y, ldy, (bf16_t*)xr, ldxr, B, H, W, act, tiles_x, strips)
+      if (rs == 16) FD(16); else if (rs == 8) FD(8); else FD(4);
+#undef FD
+      DS_LAUNCH_CHECK();
+      return 0;
+    }
+#endif
     if (aff && mode == 2 && H % 2 == 0 && W % 4 == 0 && tot2 >= 131072) {
       const long per_row = (long)B * (W / 4) * (C >> 3);
       // strips of 8 output rows where that still gives every CU two blocks (256^2: 131072 threads); strips of 4 below (nf = 64 at

@@ -28,10 +28,16 @@
 //                       c_0 = c_Nyq = 1 (their imaginary parts are ignored like c2r does), c_j = 2 otherwise.
 long ds_stft_fwd_offset(int n_fft) { return ((long)3 * n_fft + 63) & ~63L; }
 long ds_stft_inv_offset(int n_fft) { return ds_stft_fwd_offset(n_fft) + 512L * 512L; }
+// round 5: MFMA-fragment-major copy of the forward DFT with the Hann window folded in, as hi / lo halves of the build's 16-bit
+// type (the fused STFT kernel below): [part hi | lo][row tile 16][k-step 32][lane 64][8] — 2 x 512 KB, in float units
+long ds_stft_ffrag_offset(int n_fft) { return ds_stft_inv_offset(n_fft) + 512L * 512L; }
+constexpr long DS_STFT_FFRAG_FLOATS = 2L * 16 * 32 * 64 * 8 / 2;
+// ... and of the inverse DFT (window, 1 / n_fft and the one-sided weights folded in): [part][column tile 16 (taps n)][k-step 32][lane][8]
+long ds_stft_ifrag_offset(int n_fft) { return ds_stft_ffrag_offset(n_fft) + DS_STFT_FFRAG_FLOATS; }
 int ds_build_stft_table(int n_fft, float** dev_tab) {
   if (n_fft > 510 || n_fft % 2) { ds_set_error("stft: n_fft must be even and <= 510"); return 1; }
   const int bins = n_fft / 2 + 1;
-  std::vector<float> t((size_t)ds_stft_inv_offset(n_fft) + 512 * 512, 0.f);
+  std::vector<float> t((size_t)ds_stft_ifrag_offset(n_fft) + DS_STFT_FFRAG_FLOATS, 0.f);
   for (int n = 0; n < n_fft; ++n) {
     const double a = 2.0 * M_PI * (double)n / (double)n_fft;
     t[n] = (float)cos(a);
@@ -50,6 +56,41 @@ int ds_build_stft_table(int n_fft, float** dev_tab) {
       iv[(size_t)n * 512 + k] = (float)(wn * cj * cos(a));
       iv[(size_t)n * 512 + 256 + k] = (k == 0 || k == bins - 1) ? 0.f : (float)(-wn * cj * sin(a));
     }
+  {  // DFT rows interleaved (row 2 k = Re bin k, 2 k + 1 = Im bin k): a lane's accumulator quad holds two whole complex bins
+    bf16_t* fr = reinterpret_cast<bf16_t*>(t.data() + ds_stft_ffrag_offset(n_fft));
+    const size_t part = (size_t)16 * 32 * 64 * 8;
+    for (int rt = 0; rt < 16; ++rt)
+      for (int ks = 0; ks < 32; ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int r = rt * 32 + (lane & 31), kb = r >> 1, im = r & 1, n = 16 * ks + 8 * (lane >> 5) + j;
+            float v = 0.f;
+            if (n < n_fft && kb < bins) {
+              const double a = 2.0 * M_PI * (double)(((long)kb * n) % n_fft) / (double)n_fft;
+              const double wn = 0.5 * (1.0 - cos(2.0 * M_PI * (double)n / (double)n_fft));
+              v = (float)(wn * (im ? -sin(a) : cos(a)));
+            }
+            const bf16_t hi = f2h(v);
+            const size_t o = (((size_t)rt * 32 + ks) * 64 + lane) * 8 + j;
+            fr[o] = hi;
+            fr[part + o] = f2h(v - h2f(hi));
+          }
+  }
+  {  // inverse: B operand of frames[r][n] = sum_K U[r][K] dft_inv[n][K]: lane = tap n of the column tile, 8 consecutive K
+    bf16_t* fr = reinterpret_cast<bf16_t*>(t.data() + ds_stft_ifrag_offset(n_fft));
+    const size_t part = (size_t)16 * 32 * 64 * 8;
+    for (int ct = 0; ct < 16; ++ct)
+      for (int ks = 0; ks < 32; ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int n = ct * 32 + (lane & 31), K = 16 * ks + 8 * (lane >> 5) + j;
+            const float v = iv[(size_t)n * 512 + K];
+            const bf16_t hi = f2h(v);
+            const size_t o = (((size_t)ct * 32 + ks) * 64 + lane) * 8 + j;
+            fr[o] = hi;
+            fr[part + o] = f2h(v - h2f(hi));
+          }
+  }
   float* d = nullptr;
   DS_HIP(hipMalloc(&d, t.size() * sizeof(float)));
   DS_HIP(hipMemcpy(d, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -129,6 +170,134 @@ __global__ __launch_bounds__(256) void stft_pack_kernel(const float* __restrict_
   for (int c0 = 0; c0 < Cpad; c0 += 8) store8<T>(dst + c0, o + c0);
 }
 
+// ---- round 5: the forward transform as ONE kernel for the 16-bit engines (n_fft = 510, hop = 128).
+// The three launches above move 25 MB of fp32 frames and 25 MB of fp32 spectra through HBM and run the DFT on the generic
+// GEMM tile (18 + 42 + 14 us per evaluation at B = 16, T = 32000).  Here a block owns 32 consecutive frames of one utterance
+// and one half of the DFT rows:
+//   * the 32 * 128 + 382 samples its frames cover go to LDS ONCE per channel, as hi / lo halves of the build's 16-bit type (the
+//     split keeps 16 - 22 significand bits), 128 samples per 272-byte row: frame r, tap n is sample 128 r + n, so the frame
+//     matrix is never formed — a B fragment (32 frames x 16 taps) is one conflict-free ds_read_b128 per lane;
+//   * the A operand is the DFT matrix with the window folded in, fragment-major (ds_build_stft_table), hi / lo as well; three
+//     MFMAs per product (hi hi + lo hi + hi lo); rows interleaved Re / Im: a lane's accumulator quad = two whole complex bins of
+//     ONE frame for every channel, i.e. exactly the 16 bytes of two output pixels' channel vectors;
+//   * epilogue in the accumulator layout: |z|^e e^{j angle} * factor, (2x - 1), channel pack, frame padding — 16-byte stores
+//     that run 512 bytes contiguous along the frame axis.
+constexpr int SF_PITCH = 272, SF_ROWS = 35, SF_CH = SF_ROWS * SF_PITCH, SF_NS = 32 * 128 + 382;
+template <int NC>
+__global__ __launch_bounds__(256) void stft_fused_kernel(const float* __restrict__ xt, const float* __restrict__ mix,
+                                                         bf16_t* __restrict__ y, long Tlen, int F, int W, float expo,
+                                                         float factor, int shift, const uint4* __restrict__ dfrag) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];  // [part][channel][SF_CH]
+  constexpr int S = NC - 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
+  const int ntile = W >> 5;
+  const int rh = blockIdx.x & 1, ft = (blockIdx.x >> 1) % ntile, b = (blockIdx.x >> 1) / ntile;
+  const int f0 = ft * 32;
+  const float pv = shift ? -1.f : 0.f;
+  if (f0 >= F) {  // a tile of padding frames only (score_models.py:83-91): the pad value, no transform
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = j < 2 * NC ? pv : 0.f;
+    for (int i = tid; i < 128 * 32; i += 256) {
+      const int kb = rh * 128 + (i >> 5), f = f0 + (i & 31);
+      store8<bf16_t>(y + (((long)b * 256 + kb) * W + f) * 8, o);
+    }
+    return;
+  }
+  // ---- the samples of the tile's frames: sample j of the tile = original sample 128 f0 - 255 + j (zeros outside [0, T))
+  const long g0 = 128L * f0 - 255;
+  for (int idx = tid; idx < NC * (SF_NS / 2); idx += 256) {
+    const int c = idx / (SF_NS / 2), j = 2 * (idx - c * (SF_NS / 2));
+    const float* src = c < S ? xt + ((long)b * S + c) * Tlen : mix + (long)b * Tlen;
+    const long t0 = g0 + j;
+    const float v0 = (t0 >= 0 && t0 < Tlen) ? src[t0] : 0.f, v1 = (t0 + 1 >= 0 && t0 + 1 < Tlen) ? src[t0 + 1] : 0.f;
+    const bf16_t h0 = f2h(v0), h1 = f2h(v1);
+    const bf16_t l0 = f2h(v0 - h2f(h0)), l1 = f2h(v1 - h2f(h1));
+    const int addr = 2 * j + 16 * (j >> 7);
+    *reinterpret_cast<unsigned*>(sm + c * SF_CH + addr) = (unsigned)h0 | ((unsigned)h1 << 16);
+    *reinterpret_cast<unsigned*>(sm + (NC + c) * SF_CH + addr) = (unsigned)l0 | ((unsigned)l1 << 16);
+  }
+  __syncthreads();
+  // ---- 32 frames x 64 DFT rows per wave (row tiles rt0, rt0 + 1), NC channels
+  f32x16 acc[2][NC];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][c][e] = 0.f;
+  const int rt0 = rh * 8 + 2 * wave;
+  const uint4* ahi = dfrag + ((size_t)rt0 * 32 * 64 + lane);
+  const uint4* alo = ahi + (size_t)16 * 32 * 64;
+  constexpr int DEPTH = 3;  // A fragments in flight: DEPTH k-steps (L2 latency ~ 2 k-steps of 18 MFMAs)
+  uint4 a[DEPTH][2][2];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { a[d][t][0] = ahi[((size_t)t * 32 + d) * 64]; a[d][t][1] = alo[((size_t)t * 32 + d) * 64]; }
+  const char* bbase = sm + SF_PITCH * l32 + 16 * h;
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) {
+    const int n = 16 * ks;  // (+ 8 h: the lane's half of the k-step, in bbase)
+    const int boff = 2 * n + 16 * (n >> 7);  // (16 ks + 8 h stays inside one 128-sample row: the row's pad is the same for both halves)
+    uint4 bh[NC], bl[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      bh[c] = *reinterpret_cast<const uint4*>(bbase + c * SF_CH + boff);
+      bl[c] = *reinterpret_cast<const uint4*>(bbase + (NC + c) * SF_CH + boff);
+    }
+    uint4 ah[2], al[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { ah[t] = a[ks % DEPTH][t][0]; al[t] = a[ks % DEPTH][t][1]; }
+    if (ks + DEPTH < 32) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[ks % DEPTH][t][0] = ahi[((size_t)t * 32 + ks + DEPTH) * 64];
+        a[ks % DEPTH][t][1] = alo[((size_t)t * 32 + ks + DEPTH) * 64];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        acc[t][c] = mfma_h32(ah[t], bh[c], acc[t][c]);
+        acc[t][c] = mfma_h32(al[t], bh[c], acc[t][c]);
+        acc[t][c] = mfma_h32(ah[t], bl[c], acc[t][c]);
+      }
+  }
+  // ---- epilogue: lane (frame l32, half h) holds rows 8 q + 4 h + i of each row tile = bins 16 rt + 4 q + 2 h + {0, 1}, Re / Im
+  const int f = f0 + l32;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int kb = 16 * (rt0 + t) + 4 * q + 2 * h + kk;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const float re = acc[t][c][4 * q + 2 * kk], im = acc[t][c][4 * q + 2 * kk + 1];
+          // |z|^e e^{j angle(z)} * factor == z * |z|^(e-1) * factor (0 at z = 0); then 2x - 1
+          const float mag = sqrtf(re * re + im * im);
+          float sc = 0.f;
+          if (mag > 0.f) sc = (expo == 0.5f) ? (1.0f / sqrtf(mag)) : ((expo == 1.0f) ? 1.0f : powf(mag, expo - 1.0f));
+          sc *= factor;
+          float vr = re * sc, vi = im * sc;
+          if (shift) { vr = 2.f * vr - 1.f; vi = 2.f * vi - 1.f; }
+          o[c] = vr;
+          o[NC + c] = vi;
+        }
+        if (f >= F) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = j < 2 * NC ? pv : 0.f;
+        }
+        store8<bf16_t>(y + (((long)b * 256 + kb) * W + f) * 8, o);
+      }
+}
+
 long ds_stft_workspace_bytes(int B, int S, long T, int n_fft, int hop) {
   const long F = 1 + (T + n_fft - hop) / hop;
   const long rows = (long)B * (S + 1) * F;
@@ -144,6 +313,20 @@ int ds_launch_stft_pack(const float* xt, const float* mix, void* y, int B, int S
   const int F = 1 + (int)((T + n_fft - hop) / hop);
   DS_CHECK(W >= F, "stft: padded width smaller than the frame count");
   const int bins = n_fft / 2 + 1;
+  if (dtype == DS_BF16 && n_fft == 510 && hop == 128 && Cpad == 8 && W % 32 == 0 && !(ds_default_opts() & DS_OPT_NO_STFT_FUSED)) {
+    const uint4* dfrag = reinterpret_cast<const uint4*>(tab + ds_stft_ffrag_offset(n_fft));
+    const unsigned nblk = (unsigned)(2 * (W / 32) * B);
+#define SFK(NC_)                                                                                                           \
+  {                                                                                                                          \
+    constexpr int LDS_ = 2 * NC_ * SF_CH;                                                                                    \
+    DS_FUNC_LDS_ONCE((stft_fused_kernel<NC_>), LDS_);                                                                        \
+    hipLaunchKernelGGL((stft_fused_kernel<NC_>), dim3(nblk), dim3(256), LDS_, st, xt, mix, (bf16_t*)y, T, F, W, exponent, factor, shift, dfrag); \
+  }
+    if (S == 1) SFK(2) else if (S == 2) SFK(3) else SFK(4)
+#undef SFK
+    DS_LAUNCH_CHECK();
+    return 0;
+  }
   const long rows = (long)B * (S + 1) * F;
   const long rows_p = (rows + 7) & ~7L;  // pixel stride of specT (16-byte aligned vector stores)
   float* frames = ws;
@@ -252,6 +435,136 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
   out[bs * Tlen + t] = v;
 }
 
+// ---- round 5: the inverse transform as ONE kernel for the 16-bit engines (n_fft = 510, hop = 128): output layer + decompress,
+// inverse DFT, overlap-add and envelope division.  The three launches above write and re-read 2 x 12 MB of fp32 rows (26 + 36 +
+// 8 us per evaluation).  A block owns one source of one utterance and 29 hops (3712 samples) of its output: the 32 frames
+// g0 - 1 .. g0 + 30 are all that touch those samples, so the overlap-add is local to the block.
+//   * prologue: the 32 x 256 pixels of the frames' columns -> `h = pyramid / t; output_layer(h)` for the source's two channels
+//     (ncsnpp.py:472-477) -> z / |factor|, |z|^(1/e) e^{j angle} -> U[frame][Re 256 | Im 256] in LDS as hi / lo halves;
+//   * frames = U dft_inv^T on the matrix cores, three MFMAs per product, U as the A operand (frames = rows), the fragment-major
+//     inverse table as the B operand: a lane holds ONE tap n of 16 frames;
+//   * overlap-add: frame r, tap n lands on sample 128 r + n - 383 of the block's segment: LDS float atomics, the lanes of an
+//     instruction on consecutive addresses; then every sample is divided by its window envelope and written once.
+constexpr int SI_PITCH = 1040, SI_U = 32 * SI_PITCH, SI_SEG = 29 * 128;
+__global__ __launch_bounds__(256, 2) void istft_fused_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int S,
+                                                             long Tlen, int F, int W, int ld, float expo, float factor,
+                                                             const float* __restrict__ ow, const float* __restrict__ ob,
+                                                             const float* __restrict__ tdiv, int ow_cin,
+                                                             const uint4* __restrict__ dfrag, const float* __restrict__ tab,
+                                                             int nseg) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];  // U hi [32][SI_PITCH] | U lo | ola [SI_SEG] fp32
+  float* ola = reinterpret_cast<float*>(sm + 2 * SI_U);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
+  const int seg = blockIdx.x % nseg, s = (blockIdx.x / nseg) % S, b = blockIdx.x / (nseg * S);
+  const int g0 = 29 * seg, fA = g0 - 1;  // frame r of the block = frame fA + r
+  for (int i = tid; i < SI_SEG; i += 256) ola[i] = 0.f;
+  // ---- U: thread -> (frame r fastest: 32 x 16 B contiguous per bin, then the bin)
+  {
+    const float inv_fac = 1.0f / fabsf(factor);
+    float wre[8], wim[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      wre[k] = (ow && k < ow_cin) ? ow[s * ow_cin + k] : (k == s ? 1.f : 0.f);
+      wim[k] = (ow && k < ow_cin) ? ow[(S + s) * ow_cin + k] : (k == S + s ? 1.f : 0.f);
+    }
+    const float td = ow ? tdiv[b] : 1.f, bre = ow ? ob[s] : 0.f, bim = ow ? ob[S + s] : 0.f;
+    for (int i = tid; i < 32 * 256; i += 256) {
+      const int r = i & 31, kb = i >> 5, f = fA + r;
+      float re = 0.f, im = 0.f;
+      if (f >= 0 && f < F) {
+        float v[8];
+        load8<bf16_t>(x + (((long)b * 256 + kb) * W + f) * ld, v);
+        float ar = 0.f, ai = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ar = fmaf(wre[k], v[k], ar); ai = fmaf(wim[k], v[k], ai); }
+        if (ow) { ar = ar / td + bre; ai = ai / td + bim; }
+        const float vr = ar * inv_fac, vi = ai * inv_fac;
+        const float mag = sqrtf(vr * vr + vi * vi);
+        float sc = 0.f;
+        if (mag > 0.f) sc = (expo == 0.5f) ? mag : ((expo == 1.0f) ? 1.0f : powf(mag, 1.0f / expo - 1.0f));
+        re = vr * sc;
+        im = vi * sc;
+      }
+      const bf16_t rh_ = f2h(re), ih_ = f2h(im);
+      char* u = sm + r * SI_PITCH;
+      *reinterpret_cast<bf16_t*>(u + 2 * kb) = rh_;
+      *reinterpret_cast<bf16_t*>(u + 2 * (256 + kb)) = ih_;
+      *reinterpret_cast<bf16_t*>(u + SI_U + 2 * kb) = f2h(re - h2f(rh_));
+      *reinterpret_cast<bf16_t*>(u + SI_U + 2 * (256 + kb)) = f2h(im - h2f(ih_));
+    }
+  }
+  __syncthreads();
+  // ---- frames[r][n]: 32 frames x 128 taps per wave (column tiles 4 wave .. + 3)
+  f32x16 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
+  const uint4* bhi = dfrag + ((size_t)(4 * wave) * 32 * 64 + lane);
+  const uint4* blo = bhi + (size_t)16 * 32 * 64;
+  constexpr int DEPTH = 3;
+  uint4 bf[DEPTH][4][2];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { bf[d][c][0] = bhi[((size_t)c * 32 + d) * 64]; bf[d][c][1] = blo[((size_t)c * 32 + d) * 64]; }
+  const char* abase = sm + SI_PITCH * l32 + 16 * h;
+#pragma unroll
+  for (int ks = 0; ks < 32; ++ks) {
+    const uint4 ah = *reinterpret_cast<const uint4*>(abase + 32 * ks);
+    const uint4 al = *reinterpret_cast<const uint4*>(abase + SI_U + 32 * ks);
+    uint4 bh_[4], bl_[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { bh_[c] = bf[ks % DEPTH][c][0]; bl_[c] = bf[ks % DEPTH][c][1]; }
+    if (ks + DEPTH < 32) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bf[ks % DEPTH][c][0] = bhi[((size_t)c * 32 + ks + DEPTH) * 64];
+        bf[ks % DEPTH][c][1] = blo[((size_t)c * 32 + ks + DEPTH) * 64];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc[c] = mfma_h32(ah, bh_[c], acc[c]);
+      acc[c] = mfma_h32(al, bh_[c], acc[c]);
+      acc[c] = mfma_h32(ah, bl_[c], acc[c]);
+    }
+  }
+  // ---- overlap-add: lane (tap n = 32 (4 wave + c) + l32, half h) holds frames r = 8 q + 4 h + i
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int n = 32 * (4 * wave + c) + l32;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = 8 * (e >> 2) + 4 * h + (e & 3);
+      const int p = 128 * r + n - 383;
+      if (n < 510 && p >= 0 && p < SI_SEG) atomicAdd(ola + p, acc[c][e]);  // (frames outside [0, F) contributed zeros)
+    }
+  }
+  __syncthreads();
+  // ---- out[b, s, t] = ola / sum_f w^2[t + 255 - 128 f]   (torch.istft, center = True; zeros beyond 128 (F - 1): adjust_length)
+  const float* win = tab + 2 * 510;
+  for (int i = tid; i < SI_SEG; i += 256) {
+    const long t = 128L * g0 + i;
+    if (t >= Tlen) break;
+    float v = 0.f;
+    if (t < 128L * (F - 1)) {
+      const long q = t + 255;
+      long f_hi = q / 128;
+      if (f_hi > F - 1) f_hi = F - 1;
+      long f_lo = (q - 509 + 127) / 128;
+      if (q - 509 <= 0) f_lo = 0;
+      float den = 0.f;
+      for (long f = f_lo; f <= f_hi; ++f) {
+        const float w = win[(int)(q - f * 128)];
+        den = fmaf(w, w, den);
+      }
+      v = ola[i] / den;
+    }
+    out[((long)b * S + s) * Tlen + t] = v;
+  }
+}
+
 long ds_istft_workspace_bytes(int B, int S, long T, int n_fft, int hop) {
   const long F = 1 + (T + n_fft - hop) / hop;
   return 2 * ((long)B * S * F * 512 * 4 + 256);
@@ -266,6 +579,16 @@ int ds_launch_istft(const void* x, float* out, int B, int S, long T, int n_fft, 
   const int F = 1 + (int)((T + n_fft - hop) / hop);
   DS_CHECK(W >= F, "istft: padded width smaller than the frame count");
   const int bins = n_fft / 2 + 1;
+  if (dtype == DS_BF16 && n_fft == 510 && hop == 128 && Cpad % 8 == 0 && (!ow || ow_cin <= 8) && !(ds_default_opts() & DS_OPT_NO_STFT_FUSED)) {
+    const uint4* dfrag = reinterpret_cast<const uint4*>(tab + ds_stft_ifrag_offset(n_fft));
+    const int nseg = (int)cdiv(T, (long)SI_SEG);
+    constexpr int LDS_ = 2 * SI_U + SI_SEG * 4;
+    DS_FUNC_LDS_ONCE(istft_fused_kernel, LDS_);
+    hipLaunchKernelGGL(istft_fused_kernel, dim3((unsigned)(B * S * nseg)), dim3(256), LDS_, st, (const bf16_t*)x, out, S, T, F, W, Cpad,
+                       exponent, factor, ow, ob, tdiv, ow_cin, dfrag, tab, nseg);
+    DS_LAUNCH_CHECK();
+    return 0;
+  }
   const long rows = (long)B * S * F;
   float* U = ws;
   float* frames = ws + ((rows * 512 + 63) & ~63L);

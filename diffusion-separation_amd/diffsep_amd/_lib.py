@@ -63,6 +63,7 @@ _SIGS = {
     "diffsep_engine_destroy": (None, [_P]),
     "diffsep_engine_device_bytes": (_L, [_P]),
     "diffsep_engine_reserve": (_I, [_P, _I, _L, _P]),
+    "diffsep_engine_debug_absmax": (_I, [_P, C.POINTER(C.c_double), _I, C.POINTER(_I)]),
     "diffsep_engine_debug_arena": (_I, [_P, C.POINTER(_P), C.POINTER(_L), C.POINTER(_L)]),
     "diffsep_num_frames": (_I, [C.POINTER(ModelConfig), _L]),
     "diffsep_padded_frames": (_I, [C.POINTER(ModelConfig), _L]),

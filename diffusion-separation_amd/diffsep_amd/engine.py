@@ -173,6 +173,15 @@ class Engine:
         with torch.cuda.device(self.device):
             check(self._L.diffsep_engine_reserve(self._h, int(B), int(T), _stream_ptr(self.device)), self._L)
 
+    def debug_absmax(self):
+        """[(max finite |value|, non-finite count, rows H, channels C)] of every activation tensor of the last eager forward
+        (set_option("track_tensors", 1) first; score() is an eager forward).  Debug / test aid."""
+        n = C.c_int32(0)
+        check(self._L.diffsep_engine_debug_absmax(self._h, None, 0, C.byref(n)), self._L)
+        buf = (C.c_double * (4 * max(1, n.value)))()
+        check(self._L.diffsep_engine_debug_absmax(self._h, buf, n.value, C.byref(n)), self._L)
+        return [(buf[4 * i], int(buf[4 * i + 1]), int(buf[4 * i + 2]), int(buf[4 * i + 3])) for i in range(n.value)]
+
     def debug_arena(self):
         """(uint8 view of the workspace arena, offset of the forward region): every intermediate tensor of the last
         forward, in launch order.  Debug / test aid."""

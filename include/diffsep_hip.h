@@ -123,6 +123,10 @@ int32_t diffsep_engine_reserve(diffsep_engine* e, int32_t B, int64_t T, void* st
 /* Debug aid: the engine's workspace arena (sampler state, then one forward's activations in launch order from
  * fwd_base).  Lets a test snapshot every intermediate tensor of a forward; no reference counterpart. */
 int32_t diffsep_engine_debug_arena(const diffsep_engine* e, void** base, int64_t* bytes, int64_t* fwd_base);
+/* Debug / test aid (engine option "track_tensors" = 1, eager forwards: diffsep_score_forward): for every activation tensor of the
+ * last forward, in allocation order, out[4 i ..] = {largest finite |value|, number of non-finite values, rows H, channels C};
+ * *n = number of tensors (out may be NULL to query).  How far the half-precision engines are from 65504. */
+int32_t diffsep_engine_debug_absmax(diffsep_engine* e, double* out, int32_t cap, int32_t* n);
 /* frames F = 1 + (T + n_fft - hop)/hop and padded width W = 64*ceil(F/64) for T samples
  * (score_models.py:83-91,107-112). Pure host arithmetic. */
 int32_t diffsep_num_frames(const diffsep_model_config* cfg, int64_t T);

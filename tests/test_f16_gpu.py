@@ -98,6 +98,27 @@ def test_f16_elementwise_kernels():
             assert rel_rms(ops.to_nchw(xr).float(), xx) < 1.5e-3
 
 
+@pytest.mark.parametrize("C,H,W", [(64, 64, 256), (128, 40, 256), (64, 256, 256), (128, 6, 1376), (192, 32, 192)])
+def test_f16_fir_down_row_tiles(C, H, W):
+    # round 5: the LDS row-tile FIR-down kernel of the half-precision build (W % 32 == 0, C % 64 == 0, >= 2^21 elements): whole
+    # and ragged strips of 16 / 8 / 4 output rows, one / two / three 64-channel blocks, against torch fp32 on the CPU.  The
+    # activation runs in packed half precision: same 1.5e-3 bar as the other half-precision elementwise kernels.
+    B = 2
+    groups = min(C // 4, 32)
+    x = (rnd(f"h.fd{C}{H}", (B, H, W, C), 1.5) + 0.3).to(DEV, H16)
+    g, be = (1.0 + rnd(f"h.fdg{C}", (C,), 0.2)).to(DEV), rnd(f"h.fdb{C}", (C,), 0.1).to(DEV)
+    y, xr = ops.groupnorm_act(x, g, be, groups, 1e-6, act=1, resample=2, want_xr=True)
+    xx = x.float().cpu().permute(0, 3, 1, 2)
+    hn = O.fir_down2(F.silu(F.group_norm(xx, groups, g.cpu(), be.cpu(), eps=1e-6)))
+    assert y.shape == (B, H // 2, W // 2, C) and xr.shape == y.shape
+    assert rel_rms(ops.to_nchw(y).float(), hn) < 1.5e-3
+    assert rel_rms(ops.to_nchw(xr).float(), O.fir_down2(xx)) < 1e-3
+    # image borders: the first / last output rows and columns see the zero padding of BOTH tensors
+    yb, hb = ops.to_nchw(y).float(), hn
+    for sl in ((..., 0, slice(None)), (..., -1, slice(None)), (..., slice(None), 0), (..., slice(None), -1)):
+        assert rel_rms(yb[sl], hb[sl]) < 2e-3
+
+
 def test_f16_full_size_score_and_sampler():
     # one score evaluation at BASELINE's size against the CPU oracle, then the 60-NFE sampler against the fp32 engine
     T, N = 32000, 30

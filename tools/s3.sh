@@ -11,3 +11,5 @@ for fl in "-DRW_ABL_NOEPI" "-DRW_ABL_NOSTAGE" "-DRW_ABL_NOSTAGE -DRW_ABL_NOEPI";
   RW_EXTRA="$fl" timeout 600 bash tools/rw_timing16.sh 2>&1 | grep -v amdgpu
 done >> gpurun_out/rw_timing_s3.txt 2>&1
 tail -30 gpurun_out/rw_timing_s3.txt
+timeout 600 python -m pytest tests/test_f16_gpu.py -m gpu -x -q -k "fir_down or elementwise" > gpurun_out/pytest_s3.txt 2>&1; echo "pytest fir rc=$?"; tail -4 gpurun_out/pytest_s3.txt
+RW_DT=f16 timeout 300 python tools/bench_resample.py > gpurun_out/resample_s3.txt 2>&1; cat gpurun_out/resample_s3.txt | grep -v amdgpu
