@@ -472,15 +472,17 @@ def main():
         except Exception:
             traffic = traffic_source = None
         try:
-            pu = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_mfma_util.json")))
+            pmc_file = "r05_pmc_mfma_util.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_pmc_mfma_util.json")) else "r04_pmc_mfma_util.json"
+            pu = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             for k_, v_ in pu.get("kernels", {}).items():
                 if k_.split(" grid ")[0] == kname and pu.get("dtype") == args.dtype:
                     pmc_util = {"mfma_util_per_shader_cycle": v_.get("mfma_util"), "shader_clock_ghz": v_.get("shader_clock_ghz"),
+                                "mfma_busy_per_wave_cycle": v_.get("mfma_busy_per_wave_cycle"),
                                 "valu_per_mfma": v_.get("valu_per_mfma"), "lds_per_mfma": v_.get("lds_per_mfma"),
                                 "lds_bank_conflict_cycles_per_lds_inst": v_.get("lds_bank_conflict_cycles_per_lds_inst"),
-                                "source": "profiles/r04_pmc_mfma_util.json = output of `COMMIT=%s bash tools/pmc_r03.sh` (two rocprofv3 "
+                                "source": "profiles/%s = output of `COMMIT=%s bash tools/pmc_r05.sh` (two rocprofv3 "
                                           "--kernel-trace --pmc passes around the N = 4, one-in-flight, eager variant of this command; a "
-                                          "separate, committed run)" % pu.get("commit")}
+                                          "separate, committed run)" % (pmc_file, pu.get("commit"))}
         except Exception:
             pmc_util = None
         if hbm_floor_us > mfma_floor_us:

@@ -28,8 +28,9 @@
 //                       c_0 = c_Nyq = 1 (their imaginary parts are ignored like c2r does), c_j = 2 otherwise.
 long ds_stft_fwd_offset(int n_fft) { return ((long)3 * n_fft + 63) & ~63L; }
 long ds_stft_inv_offset(int n_fft) { return ds_stft_fwd_offset(n_fft) + 512L * 512L; }
-// round 5: MFMA-fragment-major copy of the forward DFT with the Hann window folded in, as hi / lo halves of the build's 16-bit
-// type (the fused STFT kernel below): [part hi | lo][row tile 16][k-step 32][lane 64][8] — 2 x 512 KB, in float units
+// round 5: MFMA-fragment-major copy of the forward DFT with the Hann window folded in, as hi / lo BFLOAT16 halves in both builds
+// (like the split mode's planes: the decompressed spectrum |z|^2 of the inverse transform reaches 1e6 at t = 0.03 — past the range
+// of IEEE half precision, whose hi half became inf and lo half NaN in a first version) (the fused STFT kernel below): [part hi | lo][row tile 16][k-step 32][lane 64][8] — 2 x 512 KB, in float units
 long ds_stft_ffrag_offset(int n_fft) { return ds_stft_inv_offset(n_fft) + 512L * 512L; }
 constexpr long DS_STFT_FFRAG_FLOATS = 2L * 16 * 32 * 64 * 8 / 2;
 // ... and of the inverse DFT (window, 1 / n_fft and the one-sided weights folded in): [part][column tile 16 (taps n)][k-step 32][lane][8]
@@ -70,10 +71,10 @@ int ds_build_stft_table(int n_fft, float** dev_tab) {
               const double wn = 0.5 * (1.0 - cos(2.0 * M_PI * (double)n / (double)n_fft));
               v = (float)(wn * (im ? -sin(a) : cos(a)));
             }
-            const bf16_t hi = f2h(v);
+            const bf16_t hi = f2bf(v);
             const size_t o = (((size_t)rt * 32 + ks) * 64 + lane) * 8 + j;
             fr[o] = hi;
-            fr[part + o] = f2h(v - h2f(hi));
+            fr[part + o] = f2bf(v - bf2f(hi));
           }
   }
   {  // inverse: B operand of frames[r][n] = sum_K U[r][K] dft_inv[n][K]: lane = tap n of the column tile, 8 consecutive K
@@ -85,10 +86,10 @@ int ds_build_stft_table(int n_fft, float** dev_tab) {
           for (int j = 0; j < 8; ++j) {
             const int n = ct * 32 + (lane & 31), K = 16 * ks + 8 * (lane >> 5) + j;
             const float v = iv[(size_t)n * 512 + K];
-            const bf16_t hi = f2h(v);
+            const bf16_t hi = f2bf(v);
             const size_t o = (((size_t)ct * 32 + ks) * 64 + lane) * 8 + j;
             fr[o] = hi;
-            fr[part + o] = f2h(v - h2f(hi));
+            fr[part + o] = f2bf(v - bf2f(hi));
           }
   }
   float* d = nullptr;
@@ -174,8 +175,8 @@ __global__ __launch_bounds__(256) void stft_pack_kernel(const float* __restrict_
 // The three launches above move 25 MB of fp32 frames and 25 MB of fp32 spectra through HBM and run the DFT on the generic
 // GEMM tile (18 + 42 + 14 us per evaluation at B = 16, T = 32000).  Here a block owns 32 consecutive frames of one utterance
 // and one half of the DFT rows:
-//   * the 32 * 128 + 382 samples its frames cover go to LDS ONCE per channel, as hi / lo halves of the build's 16-bit type (the
-//     split keeps 16 - 22 significand bits), 128 samples per 272-byte row: frame r, tap n is sample 128 r + n, so the frame
+//   * the 32 * 128 + 382 samples its frames cover go to LDS ONCE per channel, as hi / lo bfloat16 halves (16 significand bits, the
+//     range of fp32), 128 samples per 272-byte row: frame r, tap n is sample 128 r + n, so the frame
 //     matrix is never formed — a B fragment (32 frames x 16 taps) is one conflict-free ds_read_b128 per lane;
 //   * the A operand is the DFT matrix with the window folded in, fragment-major (ds_build_stft_table), hi / lo as well; three
 //     MFMAs per product (hi hi + lo hi + hi lo); rows interleaved Re / Im: a lane's accumulator quad = two whole complex bins of
@@ -206,13 +207,16 @@ __global__ __launch_bounds__(256) void stft_fused_kernel(const float* __restrict
   }
   // ---- the samples of the tile's frames: sample j of the tile = original sample 128 f0 - 255 + j (zeros outside [0, T))
   const long g0 = 128L * f0 - 255;
-  for (int idx = tid; idx < NC * (SF_NS / 2); idx += 256) {
-    const int c = idx / (SF_NS / 2), j = 2 * (idx - c * (SF_NS / 2));
+  // (SF_NSP = SF_NS rounded up to whole fragments: taps 510 and 511 of the last frame meet zero DFT columns, but they must be
+  // FINITE — uninitialised LDS there turned into NaN x 0 for one utterance of a batch)
+  constexpr int SF_NSP = (SF_NS + 7) & ~7;
+  for (int idx = tid; idx < NC * (SF_NSP / 2); idx += 256) {
+    const int c = idx / (SF_NSP / 2), j = 2 * (idx - c * (SF_NSP / 2));
     const float* src = c < S ? xt + ((long)b * S + c) * Tlen : mix + (long)b * Tlen;
     const long t0 = g0 + j;
     const float v0 = (t0 >= 0 && t0 < Tlen) ? src[t0] : 0.f, v1 = (t0 + 1 >= 0 && t0 + 1 < Tlen) ? src[t0 + 1] : 0.f;
-    const bf16_t h0 = f2h(v0), h1 = f2h(v1);
-    const bf16_t l0 = f2h(v0 - h2f(h0)), l1 = f2h(v1 - h2f(h1));
+    const bf16_t h0 = f2bf(v0), h1 = f2bf(v1);
+    const bf16_t l0 = f2bf(v0 - bf2f(h0)), l1 = f2bf(v1 - bf2f(h1));
     const int addr = 2 * j + 16 * (j >> 7);
     *reinterpret_cast<unsigned*>(sm + c * SF_CH + addr) = (unsigned)h0 | ((unsigned)h1 << 16);
     *reinterpret_cast<unsigned*>(sm + (NC + c) * SF_CH + addr) = (unsigned)l0 | ((unsigned)l1 << 16);
@@ -260,9 +264,9 @@ __global__ __launch_bounds__(256) void stft_fused_kernel(const float* __restrict
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        acc[t][c] = mfma_h32(ah[t], bh[c], acc[t][c]);
-        acc[t][c] = mfma_h32(al[t], bh[c], acc[t][c]);
-        acc[t][c] = mfma_h32(ah[t], bl[c], acc[t][c]);
+        acc[t][c] = mfma_bf32(ah[t], bh[c], acc[t][c]);
+        acc[t][c] = mfma_bf32(al[t], bh[c], acc[t][c]);
+        acc[t][c] = mfma_bf32(ah[t], bl[c], acc[t][c]);
       }
   }
   // ---- epilogue: lane (frame l32, half h) holds rows 8 q + 4 h + i of each row tile = bins 16 rt + 4 q + 2 h + {0, 1}, Re / Im
@@ -443,8 +447,8 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
 //     (ncsnpp.py:472-477) -> z / |factor|, |z|^(1/e) e^{j angle} -> U[frame][Re 256 | Im 256] in LDS as hi / lo halves;
 //   * frames = U dft_inv^T on the matrix cores, three MFMAs per product, U as the A operand (frames = rows), the fragment-major
 //     inverse table as the B operand: a lane holds ONE tap n of 16 frames;
-//   * overlap-add: frame r, tap n lands on sample 128 r + n - 383 of the block's segment: LDS float atomics, the lanes of an
-//     instruction on consecutive addresses; then every sample is divided by its window envelope and written once.
+//   * overlap-add: frame r, tap n lands on sample 128 r + n - 383 of the block's segment: one contribution per wave, written to
+//     per-wave copies of the segment and summed in a fixed order; then every sample is divided by its window envelope and written once.
 constexpr int SI_PITCH = 1040, SI_U = 32 * SI_PITCH, SI_SEG = 29 * 128;
 __global__ __launch_bounds__(256, 2) void istft_fused_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int S,
                                                              long Tlen, int F, int W, int ld, float expo, float factor,
@@ -452,12 +456,11 @@ __global__ __launch_bounds__(256, 2) void istft_fused_kernel(const bf16_t* __res
                                                              const float* __restrict__ tdiv, int ow_cin,
                                                              const uint4* __restrict__ dfrag, const float* __restrict__ tab,
                                                              int nseg) {
-  extern __shared__ __attribute__((aligned(16))) char sm[];  // U hi [32][SI_PITCH] | U lo | ola [SI_SEG] fp32
-  float* ola = reinterpret_cast<float*>(sm + 2 * SI_U);
+  extern __shared__ __attribute__((aligned(16))) char sm[];  // U hi [32][SI_PITCH] | U lo; after the products: 4 x ola [SI_SEG] fp32
+  float* ola = reinterpret_cast<float*>(sm);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
   const int seg = blockIdx.x % nseg, s = (blockIdx.x / nseg) % S, b = blockIdx.x / (nseg * S);
   const int g0 = 29 * seg, fA = g0 - 1;  // frame r of the block = frame fA + r
-  for (int i = tid; i < SI_SEG; i += 256) ola[i] = 0.f;
   // ---- U: thread -> (frame r fastest: 32 x 16 B contiguous per bin, then the bin)
   {
     const float inv_fac = 1.0f / fabsf(factor);
@@ -485,12 +488,12 @@ __global__ __launch_bounds__(256, 2) void istft_fused_kernel(const bf16_t* __res
         re = vr * sc;
         im = vi * sc;
       }
-      const bf16_t rh_ = f2h(re), ih_ = f2h(im);
+      const bf16_t rh_ = f2bf(re), ih_ = f2bf(im);
       char* u = sm + r * SI_PITCH;
       *reinterpret_cast<bf16_t*>(u + 2 * kb) = rh_;
       *reinterpret_cast<bf16_t*>(u + 2 * (256 + kb)) = ih_;
-      *reinterpret_cast<bf16_t*>(u + SI_U + 2 * kb) = f2h(re - h2f(rh_));
-      *reinterpret_cast<bf16_t*>(u + SI_U + 2 * (256 + kb)) = f2h(im - h2f(ih_));
+      *reinterpret_cast<bf16_t*>(u + SI_U + 2 * kb) = f2bf(re - bf2f(rh_));
+      *reinterpret_cast<bf16_t*>(u + SI_U + 2 * (256 + kb)) = f2bf(im - bf2f(ih_));
     }
   }
   __syncthreads();
@@ -525,12 +528,18 @@ __global__ __launch_bounds__(256, 2) void istft_fused_kernel(const bf16_t* __res
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      acc[c] = mfma_h32(ah, bh_[c], acc[c]);
-      acc[c] = mfma_h32(al, bh_[c], acc[c]);
-      acc[c] = mfma_h32(ah, bl_[c], acc[c]);
+      acc[c] = mfma_bf32(ah, bh_[c], acc[c]);
+      acc[c] = mfma_bf32(al, bh_[c], acc[c]);
+      acc[c] = mfma_bf32(ah, bl_[c], acc[c]);
     }
   }
-  // ---- overlap-add: lane (tap n = 32 (4 wave + c) + l32, half h) holds frames r = 8 q + 4 h + i
+  // ---- overlap-add: lane (tap n = 32 (4 wave + c) + l32, half h) holds frames r = 8 q + 4 h + i.  Sample p of the segment
+  // receives frame r's tap n = p + 383 - 128 r: consecutive frames' taps are 128 apart, i.e. ONE contribution per wave — every wave
+  // writes its own copy of the segment with plain stores (no atomics: float atomics would make the sum's order, and with it the
+  // result's last bit, depend on the timing of the waves — tests/test_engine_gpu.py::test_concurrent_streams_are_bit_identical...),
+  // over the U planes, which nobody reads any more
+  __syncthreads();
+  float* mine = ola + wave * SI_SEG;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int n = 32 * (4 * wave + c) + l32;
@@ -538,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void istft_fused_kernel(const bf16_t* __res
     for (int e = 0; e < 16; ++e) {
       const int r = 8 * (e >> 2) + 4 * h + (e & 3);
       const int p = 128 * r + n - 383;
-      if (n < 510 && p >= 0 && p < SI_SEG) atomicAdd(ola + p, acc[c][e]);  // (frames outside [0, F) contributed zeros)
+      if (n < 510 && p >= 0 && p < SI_SEG) mine[p] = acc[c][e];  // (frames outside [0, F) contributed zeros)
     }
   }
   __syncthreads();
@@ -559,7 +568,13 @@ __global__ __launch_bounds__(256, 2) void istft_fused_kernel(const bf16_t* __res
         const float w = win[(int)(q - f * 128)];
         den = fmaf(w, w, den);
       }
-      v = ola[i] / den;
+      float num = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {  // wave w's contribution: tap n = 128 w + ((i + 383) & 127) of frame r = (i + 383 - n) / 128
+        const int n = 128 * w + ((i + 383) & 127), r = (i + 383 - n) >> 7;
+        if (n < 510 && r >= 0 && r < 32) num += ola[w * SI_SEG + i];
+      }
+      v = num / den;
     }
     out[((long)b * S + s) * Tlen + t] = v;
   }
@@ -582,7 +597,8 @@ int ds_launch_istft(const void* x, float* out, int B, int S, long T, int n_fft, 
   if (dtype == DS_BF16 && n_fft == 510 && hop == 128 && Cpad % 8 == 0 && (!ow || ow_cin <= 8) && !(ds_default_opts() & DS_OPT_NO_STFT_FUSED)) {
     const uint4* dfrag = reinterpret_cast<const uint4*>(tab + ds_stft_ifrag_offset(n_fft));
     const int nseg = (int)cdiv(T, (long)SI_SEG);
-    constexpr int LDS_ = 2 * SI_U + SI_SEG * 4;
+    constexpr int LDS_ = 2 * SI_U;
+    static_assert(4 * SI_SEG * 4 <= LDS_, "the four per-wave copies of the segment fit the U planes");
     DS_FUNC_LDS_ONCE(istft_fused_kernel, LDS_);
     hipLaunchKernelGGL(istft_fused_kernel, dim3((unsigned)(B * S * nseg)), dim3(256), LDS_, st, (const bf16_t*)x, out, S, T, F, W, Cpad,
                        exponent, factor, ow, ob, tdiv, ow_cin, dfrag, tab, nseg);
