@@ -531,14 +531,12 @@ __global__ __launch_bounds__(256) void gn_fir_down_tiled_kernel(const bf16_t* __
   float P[8], Q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { P[j] = 0.f; Q[j] = 0.f; }
-  uint4 cur, hcur, nxt = make_uint4(0, 0, 0, 0), hnxt = make_uint4(0, 0, 0, 0);
-  load_row(iy0, cur, hcur);
-#pragma unroll 2
-  for (int k = 0; k < NR; ++k) {
+  // input rows in flight: three rows ahead of the one being filtered (a row's phases take ~500 cycles, an HBM load under load
+  // more: one row ahead left every row waiting for its data).  Four named register sets, four rows per trip of the loop.
+  auto do_row = [&](int k, const uint4& cur, const uint4& hcur, bool odd) __attribute__((always_inline)) {
     const int iy = iy0 + k;
-    if (k + 1 < NR) load_row(iy + 1, nxt, hnxt);
     const bool rok = iy >= 0 && iy < H;
-    char* rowb = &sm[k & 1][0][0];
+    char* rowb = &sm[odd][0][0];
     {
       const uint4 a = activate(cur, rok);
       *reinterpret_cast<uint4*>(rowb + (col + 1) * CP + cg * 16) = a;
@@ -565,13 +563,13 @@ __global__ __launch_bounds__(256) void gn_fir_down_tiled_kernel(const bf16_t* __
         hsum[4] = fmaf(w, h_lo(v.z), hsum[4]); hsum[5] = fmaf(w, h_hi(v.z), hsum[5]);
         hsum[6] = fmaf(w, h_lo(v.w), hsum[6]); hsum[7] = fmaf(w, h_hi(v.w), hsum[7]);
       }
-      const float wq = (k & 1) ? 0.375f : 0.125f, wp = (k & 1) ? 0.125f : 0.375f;
+      const float wq = odd ? 0.375f : 0.125f, wp = odd ? 0.125f : 0.375f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        Q[j] = (k & 1) ? fmaf(wq, hsum[j], Q[j]) : wq * hsum[j];
+        Q[j] = odd ? fmaf(wq, hsum[j], Q[j]) : wq * hsum[j];
         P[j] = fmaf(wp, hsum[j], P[j]);
       }
-      if (k & 1) {  // the older row is complete
+      if (odd) {  // the older row is complete
         const int oy = st * RS + (k >> 1) - 1;
         if (k >= 3 && oy < Ho && out) {
           const long opix = ((long)b * Ho + oy) * Wo + 16 * tx + ocol;
@@ -581,7 +579,23 @@ __global__ __launch_bounds__(256) void gn_fir_down_tiled_kernel(const bf16_t* __
         for (int j = 0; j < 8; ++j) P[j] = Q[j];
       }
     }
-    cur = nxt; hcur = hnxt;
+  };
+  uint4 r0, r1, r2, r3, h0, h1, h2, h3;
+  load_row(iy0, r0, h0);
+  load_row(iy0 + 1, r1, h1);
+  load_row(iy0 + 2, r2, h2);
+  for (int k = 0; k < NR; k += 4) {
+    if (k + 3 < NR) load_row(iy0 + k + 3, r3, h3);
+    do_row(k, r0, h0, false);
+    if (k + 1 >= NR) break;
+    if (k + 4 < NR) load_row(iy0 + k + 4, r0, h0);
+    do_row(k + 1, r1, h1, true);
+    if (k + 2 >= NR) break;
+    if (k + 5 < NR) load_row(iy0 + k + 5, r1, h1);
+    do_row(k + 2, r2, h2, false);
+    if (k + 3 >= NR) break;
+    if (k + 6 < NR) load_row(iy0 + k + 6, r2, h2);
+    do_row(k + 3, r3, h3, true);
   }
 }
 #endif

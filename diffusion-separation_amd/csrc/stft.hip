@@ -16,6 +16,7 @@
 
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -30,10 +31,10 @@ long ds_stft_fwd_offset(int n_fft) { return ((long)3 * n_fft + 63) & ~63L; }
 long ds_stft_inv_offset(int n_fft) { return ds_stft_fwd_offset(n_fft) + 512L * 512L; }
 // round 5: MFMA-fragment-major copy of the forward DFT with the Hann window folded in, as hi / lo BFLOAT16 halves in both builds
 // (like the split mode's planes: the decompressed spectrum |z|^2 of the inverse transform reaches 1e6 at t = 0.03 — past the range
-// of IEEE half precision, whose hi half became inf and lo half NaN in a first version) (the fused STFT kernel below): [part hi | lo][row tile 16][k-step 32][lane 64][8] — 2 x 512 KB, in float units
+// of IEEE half precision, whose hi half became inf and lo half NaN in a first version) (the fused STFT kernel below): [part hi | lo][k-step 32][row tile 16][lane 64][8] — 2 x 512 KB, in float units
 long ds_stft_ffrag_offset(int n_fft) { return ds_stft_inv_offset(n_fft) + 512L * 512L; }
 constexpr long DS_STFT_FFRAG_FLOATS = 2L * 16 * 32 * 64 * 8 / 2;
-// ... and of the inverse DFT (window, 1 / n_fft and the one-sided weights folded in): [part][column tile 16 (taps n)][k-step 32][lane][8]
+// ... and of the inverse DFT (window, 1 / n_fft and the one-sided weights folded in): [part][k-step 32][column tile 16 (taps n)][lane][8]
 long ds_stft_ifrag_offset(int n_fft) { return ds_stft_ffrag_offset(n_fft) + DS_STFT_FFRAG_FLOATS; }
 int ds_build_stft_table(int n_fft, float** dev_tab) {
   if (n_fft > 510 || n_fft % 2) { ds_set_error("stft: n_fft must be even and <= 510"); return 1; }
@@ -72,7 +73,7 @@ int ds_build_stft_table(int n_fft, float** dev_tab) {
               v = (float)(wn * (im ? -sin(a) : cos(a)));
             }
             const bf16_t hi = f2bf(v);
-            const size_t o = (((size_t)rt * 32 + ks) * 64 + lane) * 8 + j;
+            const size_t o = (((size_t)ks * 16 + rt) * 64 + lane) * 8 + j;
             fr[o] = hi;
             fr[part + o] = f2bf(v - bf2f(hi));
           }
@@ -87,7 +88,7 @@ int ds_build_stft_table(int n_fft, float** dev_tab) {
             const int n = ct * 32 + (lane & 31), K = 16 * ks + 8 * (lane >> 5) + j;
             const float v = iv[(size_t)n * 512 + K];
             const bf16_t hi = f2bf(v);
-            const size_t o = (((size_t)ct * 32 + ks) * 64 + lane) * 8 + j;
+            const size_t o = (((size_t)ks * 16 + ct) * 64 + lane) * 8 + j;
             fr[o] = hi;
             fr[part + o] = f2bf(v - bf2f(hi));
           }
@@ -183,6 +184,19 @@ __global__ __launch_bounds__(256) void stft_pack_kernel(const float* __restrict_
 //     ONE frame for every channel, i.e. exactly the 16 bytes of two output pixels' channel vectors;
 //   * epilogue in the accumulator layout: |z|^e e^{j angle} * factor, (2x - 1), channel pack, frame padding — 16-byte stores
 //     that run 512 bytes contiguous along the frame axis.
+#ifdef ST_TIMING  // profiling build only: phase ticks of wave 0 of every block (tools/stft_timing.sh)
+__device__ unsigned long long g_st_dbg[16];
+#define ST_DECL unsigned long long st_prev = __builtin_readcyclecounter();
+#define ST_MARK(i) { const unsigned long long st_now = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_st_dbg[i], st_now - st_prev); st_prev = st_now; }
+extern "C" int diffsep_st_debug_read(unsigned long long* out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_st_dbg), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_st_dbg), z, sizeof(z)); }
+  return 0;
+}
+#else
+#define ST_DECL
+#define ST_MARK(i)
+#endif
 constexpr int SF_PITCH = 272, SF_ROWS = 35, SF_CH = SF_ROWS * SF_PITCH, SF_NS = 32 * 128 + 382;
 template <int NC>
 __global__ __launch_bounds__(256) void stft_fused_kernel(const float* __restrict__ xt, const float* __restrict__ mix,
@@ -195,6 +209,7 @@ __global__ __launch_bounds__(256) void stft_fused_kernel(const float* __restrict
   const int rh = blockIdx.x & 1, ft = (blockIdx.x >> 1) % ntile, b = (blockIdx.x >> 1) / ntile;
   const int f0 = ft * 32;
   const float pv = shift ? -1.f : 0.f;
+  ST_DECL
   if (f0 >= F) {  // a tile of padding frames only (score_models.py:83-91): the pad value, no transform
     float o[8];
 #pragma unroll
@@ -210,18 +225,39 @@ __global__ __launch_bounds__(256) void stft_fused_kernel(const float* __restrict
   // (SF_NSP = SF_NS rounded up to whole fragments: taps 510 and 511 of the last frame meet zero DFT columns, but they must be
   // FINITE — uninitialised LDS there turned into NaN x 0 for one utterance of a batch)
   constexpr int SF_NSP = (SF_NS + 7) & ~7;
-  for (int idx = tid; idx < NC * (SF_NSP / 2); idx += 256) {
-    const int c = idx / (SF_NSP / 2), j = 2 * (idx - c * (SF_NSP / 2));
-    const float* src = c < S ? xt + ((long)b * S + c) * Tlen : mix + (long)b * Tlen;
-    const long t0 = g0 + j;
-    const float v0 = (t0 >= 0 && t0 < Tlen) ? src[t0] : 0.f, v1 = (t0 + 1 >= 0 && t0 + 1 < Tlen) ? src[t0 + 1] : 0.f;
-    const bf16_t h0 = f2bf(v0), h1 = f2bf(v1);
-    const bf16_t l0 = f2bf(v0 - bf2f(h0)), l1 = f2bf(v1 - bf2f(h1));
-    const int addr = 2 * j + 16 * (j >> 7);
-    *reinterpret_cast<unsigned*>(sm + c * SF_CH + addr) = (unsigned)h0 | ((unsigned)h1 << 16);
-    *reinterpret_cast<unsigned*>(sm + (NC + c) * SF_CH + addr) = (unsigned)l0 | ((unsigned)l1 << 16);
+  // (loads first, nine iterations at a time: one load -> convert -> LDS store per iteration is a chain of 27 memory latencies,
+  // 60 of the first version's 72 us)
+  constexpr int NPAIR = NC * (SF_NSP / 2), NIT = (NPAIR + 255) / 256, GRP = 9;
+#pragma unroll
+  for (int base = 0; base < NIT; base += GRP) {
+    float v0[GRP], v1[GRP];
+#pragma unroll
+    for (int u = 0; u < GRP; ++u) {
+      const int idx = tid + (base + u) * 256;
+      v0[u] = 0.f; v1[u] = 0.f;
+      if (base + u < NIT && idx < NPAIR) {
+        const int c = idx / (SF_NSP / 2), j = 2 * (idx - c * (SF_NSP / 2));
+        const float* src = c < S ? xt + ((long)b * S + c) * Tlen : mix + (long)b * Tlen;
+        const long t0 = g0 + j;
+        if (t0 >= 0 && t0 < Tlen) v0[u] = src[t0];
+        if (t0 + 1 >= 0 && t0 + 1 < Tlen) v1[u] = src[t0 + 1];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GRP; ++u) {
+      const int idx = tid + (base + u) * 256;
+      if (base + u < NIT && idx < NPAIR) {
+        const int c = idx / (SF_NSP / 2), j = 2 * (idx - c * (SF_NSP / 2));
+        const bf16_t h0 = f2bf(v0[u]), h1 = f2bf(v1[u]);
+        const bf16_t l0 = f2bf(v0[u] - bf2f(h0)), l1 = f2bf(v1[u] - bf2f(h1));
+        const int addr = 2 * j + 16 * (j >> 7);
+        *reinterpret_cast<unsigned*>(sm + c * SF_CH + addr) = (unsigned)h0 | ((unsigned)h1 << 16);
+        *reinterpret_cast<unsigned*>(sm + (NC + c) * SF_CH + addr) = (unsigned)l0 | ((unsigned)l1 << 16);
+      }
+    }
   }
   __syncthreads();
+  ST_MARK(0)
   // ---- 32 frames x 64 DFT rows per wave (row tiles rt0, rt0 + 1), NC channels
   f32x16 acc[2][NC];
 #pragma unroll
@@ -231,14 +267,16 @@ __global__ __launch_bounds__(256) void stft_fused_kernel(const float* __restrict
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[t][c][e] = 0.f;
   const int rt0 = rh * 8 + 2 * wave;
-  const uint4* ahi = dfrag + ((size_t)rt0 * 32 * 64 + lane);
+  // (k-step major: the 32 KB all waves of all blocks read for one k-step are CONTIGUOUS.  Tile-major, the same k-step of the 16
+  // tiles sat 32 KB apart — on a quarter of the L2 channels: 2.5k cycles per k-step for 768 cycles of MFMAs)
+  const uint4* ahi = dfrag + ((size_t)rt0 * 64 + lane);
   const uint4* alo = ahi + (size_t)16 * 32 * 64;
   constexpr int DEPTH = 3;  // A fragments in flight: DEPTH k-steps (L2 latency ~ 2 k-steps of 18 MFMAs)
   uint4 a[DEPTH][2][2];
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) { a[d][t][0] = ahi[((size_t)t * 32 + d) * 64]; a[d][t][1] = alo[((size_t)t * 32 + d) * 64]; }
+    for (int t = 0; t < 2; ++t) { a[d][t][0] = ahi[((size_t)d * 16 + t) * 64]; a[d][t][1] = alo[((size_t)d * 16 + t) * 64]; }
   const char* bbase = sm + SF_PITCH * l32 + 16 * h;
 #pragma unroll
   for (int ks = 0; ks < 32; ++ks) {
@@ -256,10 +294,12 @@ __global__ __launch_bounds__(256) void stft_fused_kernel(const float* __restrict
     if (ks + DEPTH < 32) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        a[ks % DEPTH][t][0] = ahi[((size_t)t * 32 + ks + DEPTH) * 64];
-        a[ks % DEPTH][t][1] = alo[((size_t)t * 32 + ks + DEPTH) * 64];
+        a[ks % DEPTH][t][0] = ahi[((size_t)(ks + DEPTH) * 16 + t) * 64];
+        a[ks % DEPTH][t][1] = alo[((size_t)(ks + DEPTH) * 16 + t) * 64];
       }
     }
+    // (product-major order — consecutive MFMAs on different accumulators — measured no faster here and slower in the inverse
+    // kernel: the phase waits for the fragment stream, not for accumulator dependencies)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -269,37 +309,50 @@ __global__ __launch_bounds__(256) void stft_fused_kernel(const float* __restrict
         acc[t][c] = mfma_bf32(ah[t], bl[c], acc[t][c]);
       }
   }
-  // ---- epilogue: lane (frame l32, half h) holds rows 8 q + 4 h + i of each row tile = bins 16 rt + 4 q + 2 h + {0, 1}, Re / Im
+  ST_MARK(1)
+  // ---- epilogue: lane (frame l32, half h) holds rows 8 q + 4 h + i of each row tile = bins 16 rt + 4 q + 2 h + {0, 1}, Re / Im.
+  // The exponent case is decided ONCE (uniform): with the three cases inside the loops every one of the 48 compressions carried
+  // an inlined powf and IEEE sqrt / divide sequences — 11k VALU instructions per lane, 60 of the first version's 72 us.  The
+  // 16-bit output (2^-9 / 2^-12 relative) does not see the 1-ulp hardware sqrt / rsq of the e = 0.5 path.
   const int f = f0 + l32;
+  auto epilogue = [&](auto MODE_) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(MODE_)::value;  // 0: e = 0.5, 1: e = 1, 2: general
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int kb = 16 * (rt0 + t) + 4 * q + 2 * h + kk;
-        float o[8];
+        for (int kk = 0; kk < 2; ++kk) {
+          const int kb = 16 * (rt0 + t) + 4 * q + 2 * h + kk;
+          float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = 0.f;
+          for (int j = 0; j < 8; ++j) o[j] = 0.f;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const float re = acc[t][c][4 * q + 2 * kk], im = acc[t][c][4 * q + 2 * kk + 1];
-          // |z|^e e^{j angle(z)} * factor == z * |z|^(e-1) * factor (0 at z = 0); then 2x - 1
-          const float mag = sqrtf(re * re + im * im);
-          float sc = 0.f;
-          if (mag > 0.f) sc = (expo == 0.5f) ? (1.0f / sqrtf(mag)) : ((expo == 1.0f) ? 1.0f : powf(mag, expo - 1.0f));
-          sc *= factor;
-          float vr = re * sc, vi = im * sc;
-          if (shift) { vr = 2.f * vr - 1.f; vi = 2.f * vi - 1.f; }
-          o[c] = vr;
-          o[NC + c] = vi;
+          for (int c = 0; c < NC; ++c) {
+            const float re = acc[t][c][4 * q + 2 * kk], im = acc[t][c][4 * q + 2 * kk + 1];
+            // |z|^e e^{j angle(z)} * factor == z * |z|^(e-1) * factor (0 at z = 0); then 2x - 1
+            const float m2 = fmaf(re, re, im * im);
+            float sc;
+            if constexpr (MODE == 0) sc = m2 > 0.f ? __builtin_amdgcn_rsqf(__builtin_amdgcn_sqrtf(m2)) : 0.f;  // |z|^-1/2
+            else if constexpr (MODE == 1) sc = 1.f;
+            else sc = m2 > 0.f ? powf(sqrtf(m2), expo - 1.0f) : 0.f;
+            sc *= factor;
+            float vr = re * sc, vi = im * sc;
+            if (shift) { vr = fmaf(2.f, vr, -1.f); vi = fmaf(2.f, vi, -1.f); }
+            o[c] = vr;
+            o[NC + c] = vi;
+          }
+          if (f >= F) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = j < 2 * NC ? pv : 0.f;
+          }
+          store8<bf16_t>(y + (((long)b * 256 + kb) * W + f) * 8, o);
         }
-        if (f >= F) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = j < 2 * NC ? pv : 0.f;
-        }
-        store8<bf16_t>(y + (((long)b * 256 + kb) * W + f) * 8, o);
-      }
+  };
+  if (expo == 0.5f) epilogue(std::integral_constant<int, 0>{});
+  else if (expo == 1.0f) epilogue(std::integral_constant<int, 1>{});
+  else epilogue(std::integral_constant<int, 2>{});
+  ST_MARK(2)
 }
 
 long ds_stft_workspace_bytes(int B, int S, long T, int n_fft, int hop) {
@@ -450,113 +503,163 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict_
 //   * overlap-add: frame r, tap n lands on sample 128 r + n - 383 of the block's segment: one contribution per wave, written to
 //     per-wave copies of the segment and summed in a fixed order; then every sample is divided by its window envelope and written once.
 constexpr int SI_PITCH = 1040, SI_U = 32 * SI_PITCH, SI_SEG = 29 * 128;
-__global__ __launch_bounds__(256, 2) void istft_fused_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int S,
+// NS sources per block (2 when S = 2: the fragment table — 1 MB per block out of L2, what the product phase waits for — then
+// serves both; 1 otherwise)
+// EM: 0 exponent 0.5, 1 exponent 1, 2 general — a TEMPLATE parameter: with a run-time case inside the pixel loop the compiler
+// speculated the inlined powf of the general case for every pixel (200 instead of ~60 instructions)
+template <int NS, int EM>
+__global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void istft_fused_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int S,
                                                              long Tlen, int F, int W, int ld, float expo, float factor,
                                                              const float* __restrict__ ow, const float* __restrict__ ob,
                                                              const float* __restrict__ tdiv, int ow_cin,
                                                              const uint4* __restrict__ dfrag, const float* __restrict__ tab,
                                                              int nseg) {
-  extern __shared__ __attribute__((aligned(16))) char sm[];  // U hi [32][SI_PITCH] | U lo; after the products: 4 x ola [SI_SEG] fp32
-  float* ola = reinterpret_cast<float*>(sm);
+  extern __shared__ __attribute__((aligned(16))) char sm[];  // per source: U hi [32][SI_PITCH] | U lo; after the products: 4 x ola [SI_SEG] fp32
+  constexpr int SRC = 2 * SI_U;  // bytes per source
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
-  const int seg = blockIdx.x % nseg, s = (blockIdx.x / nseg) % S, b = blockIdx.x / (nseg * S);
+  const int nsg = S / NS;
+  const int seg = blockIdx.x % nseg, s0 = ((blockIdx.x / nseg) % nsg) * NS, b = blockIdx.x / (nseg * nsg);
   const int g0 = 29 * seg, fA = g0 - 1;  // frame r of the block = frame fA + r
+  ST_DECL
   // ---- U: thread -> (frame r fastest: 32 x 16 B contiguous per bin, then the bin)
   {
     const float inv_fac = 1.0f / fabsf(factor);
-    float wre[8], wim[8];
+    float wre[NS][8], wim[NS][8], bre[NS], bim[NS];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      wre[k] = (ow && k < ow_cin) ? ow[s * ow_cin + k] : (k == s ? 1.f : 0.f);
-      wim[k] = (ow && k < ow_cin) ? ow[(S + s) * ow_cin + k] : (k == S + s ? 1.f : 0.f);
-    }
-    const float td = ow ? tdiv[b] : 1.f, bre = ow ? ob[s] : 0.f, bim = ow ? ob[S + s] : 0.f;
-    for (int i = tid; i < 32 * 256; i += 256) {
-      const int r = i & 31, kb = i >> 5, f = fA + r;
-      float re = 0.f, im = 0.f;
-      if (f >= 0 && f < F) {
-        float v[8];
-        load8<bf16_t>(x + (((long)b * 256 + kb) * W + f) * ld, v);
-        float ar = 0.f, ai = 0.f;
+    for (int ns = 0; ns < NS; ++ns) {
+      const int s = s0 + ns;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { ar = fmaf(wre[k], v[k], ar); ai = fmaf(wim[k], v[k], ai); }
-        if (ow) { ar = ar / td + bre; ai = ai / td + bim; }
-        const float vr = ar * inv_fac, vi = ai * inv_fac;
-        const float mag = sqrtf(vr * vr + vi * vi);
-        float sc = 0.f;
-        if (mag > 0.f) sc = (expo == 0.5f) ? mag : ((expo == 1.0f) ? 1.0f : powf(mag, 1.0f / expo - 1.0f));
-        re = vr * sc;
-        im = vi * sc;
+      for (int k = 0; k < 8; ++k) {
+        wre[ns][k] = (ow && k < ow_cin) ? ow[s * ow_cin + k] : (k == s ? 1.f : 0.f);
+        wim[ns][k] = (ow && k < ow_cin) ? ow[(S + s) * ow_cin + k] : (k == S + s ? 1.f : 0.f);
       }
-      const bf16_t rh_ = f2bf(re), ih_ = f2bf(im);
-      char* u = sm + r * SI_PITCH;
-      *reinterpret_cast<bf16_t*>(u + 2 * kb) = rh_;
-      *reinterpret_cast<bf16_t*>(u + 2 * (256 + kb)) = ih_;
-      *reinterpret_cast<bf16_t*>(u + SI_U + 2 * kb) = f2bf(re - bf2f(rh_));
-      *reinterpret_cast<bf16_t*>(u + SI_U + 2 * (256 + kb)) = f2bf(im - bf2f(ih_));
+      bre[ns] = ow ? ob[s] : 0.f;
+      bim[ns] = ow ? ob[S + s] : 0.f;
+    }
+    const float inv_td = ow ? 1.0f / tdiv[b] : 1.f;
+    // thread -> frame r = tid & 31 (fixed), bins (tid >> 5) + 8 it; eight loads in flight per pass (one load -> LDS store per
+    // iteration was a chain of 32 memory latencies)
+    const int r = tid & 31, f = fA + r;
+    const bool fok = f >= 0 && f < F;
+    char* u = sm + r * SI_PITCH;
+#pragma unroll
+    for (int base = 0; base < 32; base += 8) {
+      uint4 raw[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int kb = (tid >> 5) + 8 * (base + q);
+        raw[q] = fok ? *reinterpret_cast<const uint4*>(x + (((long)b * 256 + kb) * W + f) * ld) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int kb = (tid >> 5) + 8 * (base + q);
+        float v[8];
+        v[0] = h_lo(raw[q].x); v[1] = h_hi(raw[q].x); v[2] = h_lo(raw[q].y); v[3] = h_hi(raw[q].y);
+        v[4] = h_lo(raw[q].z); v[5] = h_hi(raw[q].z); v[6] = h_lo(raw[q].w); v[7] = h_hi(raw[q].w);
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) {
+          float re = 0.f, im = 0.f;
+          if (fok) {
+            float ar = 0.f, ai = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { ar = fmaf(wre[ns][k], v[k], ar); ai = fmaf(wim[ns][k], v[k], ai); }
+            if (ow) { ar = fmaf(ar, inv_td, bre[ns]); ai = fmaf(ai, inv_td, bim[ns]); }
+            const float vr = ar * inv_fac, vi = ai * inv_fac;
+            const float m2 = fmaf(vr, vr, vi * vi);
+            float sc;
+            if constexpr (EM == 0) sc = __builtin_amdgcn_sqrtf(m2);   // |z|^(1/e - 1) = |z| at e = 0.5 (0 at z = 0)
+            else if constexpr (EM == 1) sc = 1.f;
+            else sc = m2 > 0.f ? powf(sqrtf(m2), 1.0f / expo - 1.0f) : 0.f;
+            re = vr * sc;
+            im = vi * sc;
+          }
+          const bf16_t rh_ = f2bf(re), ih_ = f2bf(im);
+          char* un = u + ns * SRC;
+          *reinterpret_cast<bf16_t*>(un + 2 * kb) = rh_;
+          *reinterpret_cast<bf16_t*>(un + 2 * (256 + kb)) = ih_;
+          *reinterpret_cast<bf16_t*>(un + SI_U + 2 * kb) = f2bf(re - bf2f(rh_));
+          *reinterpret_cast<bf16_t*>(un + SI_U + 2 * (256 + kb)) = f2bf(im - bf2f(ih_));
+        }
+      }
     }
   }
   __syncthreads();
+  ST_MARK(4)
   // ---- frames[r][n]: 32 frames x 128 taps per wave (column tiles 4 wave .. + 3)
-  f32x16 acc[4];
+  f32x16 acc[NS][4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
-  const uint4* bhi = dfrag + ((size_t)(4 * wave) * 32 * 64 + lane);
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[ns][c][e] = 0.f;
+  const uint4* bhi = dfrag + ((size_t)(4 * wave) * 64 + lane);  // (k-step major, see stft_fused_kernel)
   const uint4* blo = bhi + (size_t)16 * 32 * 64;
   constexpr int DEPTH = 3;
   uint4 bf[DEPTH][4][2];
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { bf[d][c][0] = bhi[((size_t)c * 32 + d) * 64]; bf[d][c][1] = blo[((size_t)c * 32 + d) * 64]; }
+    for (int c = 0; c < 4; ++c) { bf[d][c][0] = bhi[((size_t)d * 16 + c) * 64]; bf[d][c][1] = blo[((size_t)d * 16 + c) * 64]; }
   const char* abase = sm + SI_PITCH * l32 + 16 * h;
 #pragma unroll
   for (int ks = 0; ks < 32; ++ks) {
-    const uint4 ah = *reinterpret_cast<const uint4*>(abase + 32 * ks);
-    const uint4 al = *reinterpret_cast<const uint4*>(abase + SI_U + 32 * ks);
+    uint4 ah[NS], al[NS];
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
+      ah[ns] = *reinterpret_cast<const uint4*>(abase + ns * SRC + 32 * ks);
+      al[ns] = *reinterpret_cast<const uint4*>(abase + ns * SRC + SI_U + 32 * ks);
+    }
     uint4 bh_[4], bl_[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) { bh_[c] = bf[ks % DEPTH][c][0]; bl_[c] = bf[ks % DEPTH][c][1]; }
     if (ks + DEPTH < 32) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        bf[ks % DEPTH][c][0] = bhi[((size_t)c * 32 + ks + DEPTH) * 64];
-        bf[ks % DEPTH][c][1] = blo[((size_t)c * 32 + ks + DEPTH) * 64];
+        bf[ks % DEPTH][c][0] = bhi[((size_t)(ks + DEPTH) * 16 + c) * 64];
+        bf[ks % DEPTH][c][1] = blo[((size_t)(ks + DEPTH) * 16 + c) * 64];
       }
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      acc[c] = mfma_bf32(ah, bh_[c], acc[c]);
-      acc[c] = mfma_bf32(al, bh_[c], acc[c]);
-      acc[c] = mfma_bf32(ah, bl_[c], acc[c]);
-    }
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) {
+        acc[ns][c] = mfma_bf32(ah[ns], bh_[c], acc[ns][c]);
+        acc[ns][c] = mfma_bf32(al[ns], bh_[c], acc[ns][c]);
+        acc[ns][c] = mfma_bf32(ah[ns], bl_[c], acc[ns][c]);
+      }
   }
+  ST_MARK(5)
   // ---- overlap-add: lane (tap n = 32 (4 wave + c) + l32, half h) holds frames r = 8 q + 4 h + i.  Sample p of the segment
   // receives frame r's tap n = p + 383 - 128 r: consecutive frames' taps are 128 apart, i.e. ONE contribution per wave — every wave
   // writes its own copy of the segment with plain stores (no atomics: float atomics would make the sum's order, and with it the
   // result's last bit, depend on the timing of the waves — tests/test_engine_gpu.py::test_concurrent_streams_are_bit_identical...),
   // over the U planes, which nobody reads any more
   __syncthreads();
-  float* mine = ola + wave * SI_SEG;
+  // (the squared window for the envelope, beside the four copies: the envelope loop below read it from global memory in a chain
+  // of 15 x 4 dependent loads per thread — most of the first version's 100 us)
+  float* w2 = reinterpret_cast<float*>(sm) + 4 * SI_SEG;
+  for (int i = tid; i < 512; i += 256) { const float w = i < 510 ? tab[2 * 510 + i] : 0.f; w2[i] = w * w; }
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int n = 32 * (4 * wave + c) + l32;
+  for (int ns = 0; ns < NS; ++ns) {
+    float* mine = reinterpret_cast<float*>(sm + ns * SRC) + wave * SI_SEG;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int r = 8 * (e >> 2) + 4 * h + (e & 3);
-      const int p = 128 * r + n - 383;
-      if (n < 510 && p >= 0 && p < SI_SEG) mine[p] = acc[c][e];  // (frames outside [0, F) contributed zeros)
+    for (int c = 0; c < 4; ++c) {
+      const int n = 32 * (4 * wave + c) + l32;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = 8 * (e >> 2) + 4 * h + (e & 3);
+        const int p = 128 * r + n - 383;
+        if (n < 510 && p >= 0 && p < SI_SEG) mine[p] = acc[ns][c][e];  // (frames outside [0, F) contributed zeros)
+      }
     }
   }
   __syncthreads();
+  ST_MARK(6)
   // ---- out[b, s, t] = ola / sum_f w^2[t + 255 - 128 f]   (torch.istft, center = True; zeros beyond 128 (F - 1): adjust_length)
-  const float* win = tab + 2 * 510;
   for (int i = tid; i < SI_SEG; i += 256) {
     const long t = 128L * g0 + i;
     if (t >= Tlen) break;
-    float v = 0.f;
     if (t < 128L * (F - 1)) {
       const long q = t + 255;
       long f_hi = q / 128;
@@ -564,20 +667,25 @@ __global__ __launch_bounds__(256, 2) void istft_fused_kernel(const bf16_t* __res
       long f_lo = (q - 509 + 127) / 128;
       if (q - 509 <= 0) f_lo = 0;
       float den = 0.f;
-      for (long f = f_lo; f <= f_hi; ++f) {
-        const float w = win[(int)(q - f * 128)];
-        den = fmaf(w, w, den);
-      }
-      float num = 0.f;
+      for (long f = f_lo; f <= f_hi; ++f) den += w2[(int)(q - f * 128)];
+      const float inv_den = 1.0f / den;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {  // wave w's contribution: tap n = 128 w + ((i + 383) & 127) of frame r = (i + 383 - n) / 128
-        const int n = 128 * w + ((i + 383) & 127), r = (i + 383 - n) >> 7;
-        if (n < 510 && r >= 0 && r < 32) num += ola[w * SI_SEG + i];
+      for (int ns = 0; ns < NS; ++ns) {
+        const float* ola = reinterpret_cast<const float*>(sm + ns * SRC);
+        float num = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {  // wave w's contribution: tap n = 128 w + ((i + 383) & 127) of frame r = (i + 383 - n) / 128
+          const int n = 128 * w + ((i + 383) & 127), r = (i + 383 - n) >> 7;
+          if (n < 510 && r >= 0 && r < 32) num += ola[w * SI_SEG + i];
+        }
+        out[((long)b * S + s0 + ns) * Tlen + t] = num * inv_den;
       }
-      v = num / den;
+    } else {
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) out[((long)b * S + s0 + ns) * Tlen + t] = 0.f;
     }
-    out[((long)b * S + s) * Tlen + t] = v;
   }
+  ST_MARK(7)
 }
 
 long ds_istft_workspace_bytes(int B, int S, long T, int n_fft, int hop) {
@@ -597,11 +705,18 @@ int ds_launch_istft(const void* x, float* out, int B, int S, long T, int n_fft, 
   if (dtype == DS_BF16 && n_fft == 510 && hop == 128 && Cpad % 8 == 0 && (!ow || ow_cin <= 8) && !(ds_default_opts() & DS_OPT_NO_STFT_FUSED)) {
     const uint4* dfrag = reinterpret_cast<const uint4*>(tab + ds_stft_ifrag_offset(n_fft));
     const int nseg = (int)cdiv(T, (long)SI_SEG);
-    constexpr int LDS_ = 2 * SI_U;
-    static_assert(4 * SI_SEG * 4 <= LDS_, "the four per-wave copies of the segment fit the U planes");
-    DS_FUNC_LDS_ONCE(istft_fused_kernel, LDS_);
-    hipLaunchKernelGGL(istft_fused_kernel, dim3((unsigned)(B * S * nseg)), dim3(256), LDS_, st, (const bf16_t*)x, out, S, T, F, W, Cpad,
-                       exponent, factor, ow, ob, tdiv, ow_cin, dfrag, tab, nseg);
+    constexpr int LDS1 = 2 * SI_U;
+    static_assert(4 * SI_SEG * 4 + 512 * 4 <= LDS1, "the four per-wave copies of the segment and the squared window fit the U planes");
+#define ISK(NS_, EM_)                                                                                                                     \
+  {                                                                                                                                          \
+    DS_FUNC_LDS_ONCE((istft_fused_kernel<NS_, EM_>), NS_ * LDS1);                                                                            \
+    hipLaunchKernelGGL((istft_fused_kernel<NS_, EM_>), dim3((unsigned)(B * (S / NS_) * nseg)), dim3(256), NS_ * LDS1, st, (const bf16_t*)x, out, \
+                       S, T, F, W, Cpad, exponent, factor, ow, ob, tdiv, ow_cin, dfrag, tab, nseg);                                       \
+  }
+    const int em = exponent == 0.5f ? 0 : (exponent == 1.0f ? 1 : 2);
+    if (S == 2) { if (em == 0) ISK(2, 0) else if (em == 1) ISK(2, 1) else ISK(2, 2) }
+    else { if (em == 0) ISK(1, 0) else if (em == 1) ISK(1, 1) else ISK(1, 2) }
+#undef ISK
     DS_LAUNCH_CHECK();
     return 0;
   }
