@@ -597,7 +597,11 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   //   * epilogue lumps (EPI halves): per row 20 lumps — per half row (j) 4 x {2 fma + pack | the pair's statistics}, the
   //     permlane32 swap; then the permlane16 regrouping and the two stores — spread evenly over the half's gaps.
   constexpr int RH = RPW / 2;
-  constexpr int W_E = 2, W_N = 5;  // capacity of a gap for unit lumps: epilogue half / other half
+#ifndef RW_W_E
+#define RW_W_E 2
+#define RW_W_N 5
+#endif
+  constexpr int W_E = RW_W_E, W_N = RW_W_N;  // capacity of a gap for unit lumps: epilogue half / other half (A/B: -DRW_W_E=.. -DRW_W_N=..)
   float et[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // the two cout pairs in flight through the epilogue lumps
   u32x4_t osa = {0, 0, 0, 0}, osb = {0, 0, 0, 0};  // the row's two store pieces after the regrouping
   auto half = [&](auto P_, auto HF_, auto EPI_, int slot_r, const TileG& ge, const TileG& g1, const TileG& g2) __attribute__((always_inline)) {
@@ -930,6 +934,9 @@ int rw_blocks_per_image(const ConvArgs& a, int tiles) {
 #ifdef RW_TIMING  // (profiling builds only: fewer, fatter blocks)
   if (getenv("DIFFSEP_RW_G")) g = atoi(getenv("DIFFSEP_RW_G"));
 #endif
+  // option rw_half (A/B, round 5): launches whose blocks would get <= 4 tiles (the 128-row level at B = 16: a 295 KB weight
+  // prologue per 4 tiles) run on HALF the CUs with twice the tiles per block — pays only if another stream's kernel takes the rest
+  if ((a.opts & DS_OPT_RW_HALF) && g >= 2 && tiles / g <= 4) g /= 2;
   if (g < 1) g = 1;
   if (g > tiles) g = tiles;
   return g;

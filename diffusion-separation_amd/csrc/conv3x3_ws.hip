@@ -131,6 +131,28 @@ struct WsK {
 // GN affine (+ SiLU) on 8 bf16 channels
 template <bool ACT>
 __device__ inline uint4 gn8(const uint4& u, const float* sc, const float* sh) {
+#if defined(DS_HALF_F16) && !defined(DS_GN8_F32)
+  // half-precision build, round 5: affine + SiLU in packed half precision, 8 instructions per dword (as the register-weight
+  // convolution: DESIGN.md section 2 for what it costs in agreement — in front of a convolution, nothing measurable)
+  if constexpr (ACT) {
+    auto one = [&](unsigned w, int d) __attribute__((always_inline)) {
+      const unsigned ps = pack_h2(sc[2 * d], sc[2 * d + 1]), pb = pack_h2(sh[2 * d], sh[2 * d + 1]);
+      unsigned z, xx, e, dd, r, o;
+      asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(z) : "v"(w), "v"(ps), "v"(pb));
+      asm("v_pk_mul_f16 %0, %1, %2" : "=v"(xx) : "v"(z), "s"(0xbdc5bdc5u));  // x -log2(e)
+      asm("v_exp_f16 %0, %1" : "=v"(e) : "v"(xx));
+      asm("v_exp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(e) : "v"(xx));
+      asm("v_pk_add_f16 %0, %1, %2" : "=v"(dd) : "v"(e), "s"(0x3c003c00u));
+      asm("v_rcp_f16 %0, %1" : "=v"(r) : "v"(dd));
+      asm("v_rcp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(r) : "v"(dd));
+      asm("v_pk_mul_f16 %0, %1, %2" : "=v"(o) : "v"(z), "v"(r));
+      return o;
+    };
+    uint4 o;
+    o.x = one(u.x, 0); o.y = one(u.y, 1); o.z = one(u.z, 2); o.w = one(u.w, 3);
+    return o;
+  }
+#endif
   float f[8];
   f[0] = h_lo(u.x); f[1] = h_hi(u.x);
   f[2] = h_lo(u.y); f[3] = h_hi(u.y);

@@ -355,6 +355,8 @@ unsigned ds_default_opts() {
     if (on("DIFFSEP_NO_RW128")) g_opts |= DS_OPT_NO_RW128;
     if (on("DIFFSEP_RW_SMALL")) g_opts |= DS_OPT_RW_SMALL;
     if (on("DIFFSEP_NO_RW_RES")) g_opts |= DS_OPT_NO_RW_RES;
+    if (on("DIFFSEP_RW_HALF")) g_opts |= DS_OPT_RW_HALF;
+    if (on("DIFFSEP_NO_STFT_FUSED")) g_opts |= DS_OPT_NO_STFT_FUSED;
   });
   return g_opts;
 }
@@ -377,6 +379,7 @@ static int opt_bit(const char* name, unsigned* bit) {
       {"no_wfrag", DS_OPT_NO_WFRAG},
       {"no_attn_fused", DS_OPT_NO_ATTN_FUSED},
       {"no_stft_fused", DS_OPT_NO_STFT_FUSED},
+      {"rw_half", DS_OPT_RW_HALF},
       {"no_split256", DS_OPT_NO_SPLIT256}};
   for (const auto& t : tab)
     if (!strcmp(name, t.n)) { *bit = t.b; return 0; }
