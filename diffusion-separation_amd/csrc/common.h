@@ -238,6 +238,8 @@ struct ConvArgs {
 #define DS_OPT_NO_ATTN_FUSED 64u  // attention blocks as the 11 separate launches of rounds 1 - 3 (A/B)
 #define DS_OPT_NO_SPLIT256 128u   // cat(128, 128) -> 128 blocks as ONE launch per convolution on the generic tile (A/B)
 #define DS_OPT_NO_STFT_FUSED 256u // (process default only) STFT / iSTFT as the launch sequences of rounds 1 - 4 instead of the fused kernels (A/B)
+#define DS_OPT_RW_QUARTER 1024u   // ... on a quarter of the CUs (A/B)
+#define DS_OPT_RW_BIG_HALF 2048u  // register-weight launches with > 4 tiles per block (the 256-row level) on half the CUs (A/B)
 #define DS_OPT_RW_HALF 512u       // register-weight launches with <= 4 tiles per block on half the CUs (A/B)
 #define DS_OPT_NO_WFRAG 32u   // the engine does not hand the fragment-major weight copies to the register-weight kernel (A/B)
 unsigned ds_default_opts();

@@ -937,6 +937,8 @@ int rw_blocks_per_image(const ConvArgs& a, int tiles) {
   // option rw_half (A/B, round 5): launches whose blocks would get <= 4 tiles (the 128-row level at B = 16: a 295 KB weight
   // prologue per 4 tiles) run on HALF the CUs with twice the tiles per block — pays only if another stream's kernel takes the rest
   if ((a.opts & DS_OPT_RW_HALF) && g >= 2 && tiles / g <= 4) g /= 2;
+  if ((a.opts & DS_OPT_RW_QUARTER) && g >= 4 && tiles / g <= 4) g /= 4;
+  if ((a.opts & DS_OPT_RW_BIG_HALF) && g >= 2 && tiles / g > 4) g /= 2;
   if (g < 1) g = 1;
   if (g > tiles) g = tiles;
   return g;

@@ -356,6 +356,8 @@ unsigned ds_default_opts() {
     if (on("DIFFSEP_RW_SMALL")) g_opts |= DS_OPT_RW_SMALL;
     if (on("DIFFSEP_NO_RW_RES")) g_opts |= DS_OPT_NO_RW_RES;
     if (on("DIFFSEP_RW_HALF")) g_opts |= DS_OPT_RW_HALF;
+    if (on("DIFFSEP_RW_QUARTER")) g_opts |= DS_OPT_RW_QUARTER;
+    if (on("DIFFSEP_RW_BIG_HALF")) g_opts |= DS_OPT_RW_BIG_HALF;
     if (on("DIFFSEP_NO_STFT_FUSED")) g_opts |= DS_OPT_NO_STFT_FUSED;
   });
   return g_opts;
@@ -380,6 +382,8 @@ static int opt_bit(const char* name, unsigned* bit) {
       {"no_attn_fused", DS_OPT_NO_ATTN_FUSED},
       {"no_stft_fused", DS_OPT_NO_STFT_FUSED},
       {"rw_half", DS_OPT_RW_HALF},
+      {"rw_quarter", DS_OPT_RW_QUARTER},
+      {"rw_big_half", DS_OPT_RW_BIG_HALF},
       {"no_split256", DS_OPT_NO_SPLIT256}};
   for (const auto& t : tab)
     if (!strcmp(name, t.n)) { *bit = t.b; return 0; }
