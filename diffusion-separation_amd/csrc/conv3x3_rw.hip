@@ -438,12 +438,13 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   };
   // stage 2: z * sigmoid, the dword into the piece (unit_s2); the piece's last unit writes it and re-issues its registers
   // (unit_fin: that part alone, for the hand-placed stream whose multiply sits in an earlier lump)
-  auto unit_s2x = [&](auto P1_, auto P2_, auto FIN_, const TileG& g1, const TileG& g2, int sl, int u, int rel) __attribute__((always_inline)) {
+  // (RAW: the chunk's registers already hold the ACTIVATED values — the pre-activation of round 5, see half())
+  auto unit_s2x = [&](auto P1_, auto P2_, auto FIN_, auto RAW_, const TileG& g1, const TileG& g2, int sl, int u, int rel) __attribute__((always_inline)) {
     constexpr int P1 = decltype(P1_)::value;
-    constexpr bool FIN_ONLY = decltype(FIN_)::value;
+    constexpr bool FIN_ONLY = decltype(FIN_)::value, RAW = decltype(RAW_)::value;
     const int k = u >> 2, d = u & 3, q = u % 3;
     if constexpr (!FIN_ONLY) {
-    if constexpr (P1 < NCH && MODE != 0) {
+    if constexpr (P1 < NCH && MODE != 0 && !RAW) {
       if constexpr (ACT_PK) {
         unsigned v = uzp[q];
         if constexpr (MODE == 2) asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(v) : "v"(uzp[q]), "v"(urp[q]));
@@ -479,10 +480,13 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
     }
   };
   auto unit_s2 = [&](auto P1_, auto P2_, const TileG& g1, const TileG& g2, int sl, int u, int rel) __attribute__((always_inline)) {
-    unit_s2x(P1_, P2_, std::false_type{}, g1, g2, sl, u, rel);
+    unit_s2x(P1_, P2_, std::false_type{}, std::false_type{}, g1, g2, sl, u, rel);
   };
   auto unit_fin = [&](auto P1_, auto P2_, const TileG& g1, const TileG& g2, int sl, int u, int rel) __attribute__((always_inline)) {
-    unit_s2x(P1_, P2_, std::true_type{}, g1, g2, sl, u, rel);
+    unit_s2x(P1_, P2_, std::true_type{}, std::false_type{}, g1, g2, sl, u, rel);
+  };
+  auto unit_raw = [&](auto P1_, auto P2_, const TileG& g1, const TileG& g2, int sl, int u, int rel) __attribute__((always_inline)) {
+    unit_s2x(P1_, P2_, std::false_type{}, std::true_type{}, g1, g2, sl, u, rel);
   };
   // a whole unit at once (the prologue)
   auto unit = [&](auto P1_, auto P2_, const TileG& g1, const TileG& g2, int sl, int u, int rel) __attribute__((always_inline)) {
@@ -604,22 +608,43 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
   constexpr int W_E = RW_W_E, W_N = RW_W_N;  // capacity of a gap for unit lumps: epilogue half / other half (A/B: -DRW_W_E=.. -DRW_W_N=..)
   float et[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // the two cout pairs in flight through the epilogue lumps
   u32x4_t osa = {0, 0, 0, 0}, osb = {0, 0, 0, 0};  // the row's two store pieces after the regrouping
-  auto half = [&](auto P_, auto HF_, auto EPI_, int slot_r, const TileG& ge, const TileG& g1, const TileG& g2) __attribute__((always_inline)) {
+  // PRE-ACTIVATION (round 5, the 64 -> 64 layers with ONE folded skip / residual chunk, fp16 build).  A tile of those layers is a
+  // SHORT phase (the skip chunk: 16 MFMAs per wave) and a long one (the 3x3 chunk: 144); the short phase staged the next 3x3 chunk,
+  // i.e. carried its whole activation under 16 MFMAs, VALU-bound.  The registers of that chunk are re-issued as loads DURING the
+  // long phase (as the raw skip pieces leave them): now the raw units are placed in the first third of the long phase and, from there
+  // on, the landed 3x3 pieces are activated IN PLACE (pa[k][d] <- silu(GN(pa[k][d])), same lumps, the multiply's destination is the
+  // register itself): the short phase only copies, zeroes the padding and writes.  The first tile of a block has no long phase in
+  // front of it and activates as before (PD_ = false).
+  // MEASURED, NOT SHIPPED (-DRW_PREACT builds it): same box, 64 -> 64 + residual @256^2 136.9 / 139.8 us with, 136.5 / 133.6 without —
+  // the short phase was not waiting for its activation VALU (its first half also carries the previous tile's 44 epilogue lumps).
+  constexpr bool PRE_CFG = NCH == 1 && NSK == 1 && MODE == 2 && NCG == 2 && ACT_PK && PIPE_LAG == 2
+#ifndef RW_PREACT
+                           && false
+#endif
+      ;
+  auto half = [&](auto P_, auto HF_, auto EPI_, auto PD_, int slot_r, const TileG& ge, const TileG& g1, const TileG& g2) __attribute__((always_inline)) {
     constexpr int P = decltype(P_)::value, HF = decltype(HF_)::value;
     constexpr bool EPI = decltype(EPI_)::value;
+    constexpr bool PREDONE = decltype(PD_)::value;      // the chunk this phase stages was activated in registers by the phase before
+    constexpr bool PRE = PRE_CFG && P == NPH - 1;       // this phase activates, in place, the chunk whose loads it issues
     constexpr int C = G::chunk_of(P);
     constexpr bool CONV = C < NCH;
     constexpr int NK = CONV ? KSC : NKB;
     constexpr int W0 = CONV ? C * KSC : NCH * KSC + (C - NCH) * NKB;
     constexpr int C1 = G::chunk_of((P + 1) % NPH), C2 = G::chunk_of((P + 2) % NPH);
     constexpr int NU = NL * 4;
-    constexpr bool ACT1 = C1 < NCH && MODE != 0;
+    constexpr bool ACT1 = C1 < NCH && MODE != 0 && !PREDONE;
     // virtual unit index v: stage 0 of unit v, stage 1 of unit v - 1, stage 2 of unit v - LAG (LAG = 0: the whole unit at v)
     constexpr int LAG = ACT1 ? PIPE_LAG : 0, NUV = NU + LAG, NLU = 2 * NUV;
     constexpr int NGH = NK * RH;  // gaps (MFMAs) of this half
     constexpr int w0 = (P == 0) ? W_E : W_N, w1 = (P == NPH - 1) ? W_E : W_N, CAP = NGH * (w0 + w1);
     // first unit lump of phase gap GP in [0, 2 NGH]
-    auto lub = [](int GP) constexpr { return NLU * (GP <= NGH ? GP * w0 : NGH * w0 + (GP - NGH) * w1) / CAP; };
+    // (PRE: the raw units of this phase in its first third, the in-place activation lumps in the rest)
+    constexpr int GPRE = 2 * NGH / 3, NLP = PRE ? 2 * (NU + 2) : 0;
+    auto lub = [](int GP) constexpr {
+      return PRE ? NLU * (GP < GPRE ? GP : GPRE) / GPRE : NLU * (GP <= NGH ? GP * w0 : NGH * w0 + (GP - NGH) * w1) / CAP;
+    };
+    auto lpb = [](int GP) constexpr { return GP <= GPRE ? 0 : NLP * (GP - GPRE) / (2 * NGH - GPRE); };
     constexpr int NLE = RH * 22;  // epilogue lumps of an EPI half
     constexpr int R0 = HF * RH, ER0 = HF ? 0 : RH;
     const char* fb = sA + slot_r * LDS_A + fbase + R0 * HW_ * AROW;
@@ -705,9 +730,32 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
         if (s2) {
           const int rel = ((u2 & 3) == 3 && (u2 >> 2) >= NI) ? rels[par][u2 >> 2] : 0;
           if constexpr (ACT1 && ACT_PK) unit_fin(std::integral_constant<int, C1>{}, std::integral_constant<int, C2>{}, g1, g2, slot_r ^ 1, u2, rel);
+          else if constexpr (PREDONE) unit_raw(std::integral_constant<int, C1>{}, std::integral_constant<int, C2>{}, g1, g2, slot_r ^ 1, u2, rel);
           else unit_s2(std::integral_constant<int, C1>{}, std::integral_constant<int, C2>{}, g1, g2, slot_r ^ 1, u2, rel);
         }
 #endif
+      }
+    };
+    // in-place activation lumps (PRE): virtual step v = {affine + exp of unit v, 1 + e and reciprocal of unit v - 1, multiply of unit
+    // v - 2 INTO ITS OWN REGISTER}; the chunk is C2 — its scale / shift table is the one in psc / psh (NCH = 1: one table)
+    auto pre_lump = [&](int L) __attribute__((always_inline)) {
+      if constexpr (PRE) {
+        const int v = L >> 1;
+        const int u0 = v < NU ? v : -1, u1 = (v >= 1 && v - 1 < NU) ? v - 1 : -1, u2 = v - 2;
+        const bool s2 = u2 >= 0 && u2 < NU;
+        if ((L & 1) == 0) {
+          if (u0 >= 0) {
+            asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(uzp[u0 % 3]) : "v"(pa[u0 >> 2][u0 & 3]), "v"(psc[u0 & 3]), "v"(psh[u0 & 3]));
+            if constexpr (!FOLD) asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(uxp[u0 % 3]) : "v"(uzp[u0 % 3]), "s"(0xbdc5bdc5u));
+          }
+          if (u1 >= 0) asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(udp[u1 % 3]) : "v"(utp[u1 % 3]), "s"(0x3c003c00u));
+          if (s2) asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(pa[u2 >> 2][u2 & 3]) : "v"(uzp[u2 % 3]), "v"(urp[u2 % 3]));
+          if (u0 >= 0) asm volatile("v_exp_f16 %0, %1" : "=v"(utp[u0 % 3]) : "v"(FOLD ? uzp[u0 % 3] : uxp[u0 % 3]));
+          if (u1 >= 0) asm volatile("v_rcp_f16 %0, %1" : "=v"(urp[u1 % 3]) : "v"(udp[u1 % 3]));
+        } else {
+          if (u0 >= 0) asm volatile("v_exp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(utp[u0 % 3]) : "v"(FOLD ? uzp[u0 % 3] : uxp[u0 % 3]));
+          if (u1 >= 0) asm volatile("v_rcp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(urp[u1 % 3]) : "v"(udp[u1 % 3]));
+        }
       }
     };
     // epilogue lumps of row rr, 22 per row: per half row j the pairs p = 0 .. 3 of the lane's 8 couts as a two-deep
@@ -805,6 +853,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
         const int gh = ks * RH + r, gp = HF * NGH + gh;
 #pragma unroll
         for (int L = lub(gp); L < lub(gp + 1); ++L) unit_lump(L, ks & 1);
+        if constexpr (PRE) {
+#pragma unroll
+          for (int L = lpb(gp); L < lpb(gp + 1); ++L) pre_lump(L);
+        }
 #ifndef RW_ABL_NOEPI
         if constexpr (EPI) {
 #pragma unroll
@@ -868,14 +920,24 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_rw_kernel(RwK p) {
 #endif
       RT_MARK(1)
       const int slot_r = ph & 1;
-      half(P_, std::integral_constant<int, 0>{}, std::integral_constant<bool, P == 0>{}, slot_r, gp, ((P + 1) / NPH == 0 ? gc : gn), ((P + 2) / NPH == 0 ? gc : ((P + 2) / NPH == 1 ? gn : gnn)));
+      if constexpr (P == 0 && PRE_CFG) {  // (the first tile's 3x3 chunk was not pre-activated)
+        if (i == 0) half(P_, std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{}, slot_r, gp, gc, gn);
+        else half(P_, std::integral_constant<int, 0>{}, std::true_type{}, std::true_type{}, slot_r, gp, gc, gn);
+      } else {
+        half(P_, std::integral_constant<int, 0>{}, std::integral_constant<bool, P == 0>{}, std::false_type{}, slot_r, gp, ((P + 1) / NPH == 0 ? gc : gn), ((P + 2) / NPH == 0 ? gc : ((P + 2) / NPH == 1 ? gn : gnn)));
+      }
       if constexpr (P == 0) {
         if (i == 0) {  // (the first tile has no predecessor: what that epilogue summed up was not an output)
 #pragma unroll
           for (int j = 0; j < 16; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
         }
       }
-      half(P_, std::integral_constant<int, 1>{}, std::integral_constant<bool, P == NPH - 1>{}, slot_r, gc, ((P + 1) / NPH == 0 ? gc : gn), ((P + 2) / NPH == 0 ? gc : ((P + 2) / NPH == 1 ? gn : gnn)));
+      if constexpr (P == 0 && PRE_CFG) {
+        if (i == 0) half(P_, std::integral_constant<int, 1>{}, std::false_type{}, std::false_type{}, slot_r, gc, gc, gn);
+        else half(P_, std::integral_constant<int, 1>{}, std::false_type{}, std::true_type{}, slot_r, gc, gc, gn);
+      } else {
+        half(P_, std::integral_constant<int, 1>{}, std::integral_constant<bool, P == NPH - 1>{}, std::false_type{}, slot_r, gc, ((P + 1) / NPH == 0 ? gc : gn), ((P + 2) / NPH == 0 ? gc : ((P + 2) / NPH == 1 ? gn : gnn)));
+      }
       ++ph;
       RT_MARK(G::chunk_of(P) < NCH ? 2 : 3)
       if constexpr (P + 1 < NPH) self(self, std::integral_constant<int, P + 1>{});
