@@ -241,6 +241,9 @@ struct ConvArgs {
 #define DS_OPT_RW_QUARTER 1024u   // ... on a quarter of the CUs (A/B)
 #define DS_OPT_RW_BIG_HALF 2048u  // register-weight launches with > 4 tiles per block (the 256-row level) on half the CUs (A/B)
 #define DS_OPT_RW_HALF 512u       // register-weight launches with <= 4 tiles per block on half the CUs (A/B)
+#define DS_OPT_NO_SW 4096u       // no streamed-weight 3x3 kernel (conv3x3_sw.hip): generic tile / two-launch cat route instead (A/B)
+#define DS_OPT_NO_SW_RW 8192u    // ... only for the launches the register-weight kernel does not take (A/B: by default it also takes the
+                                 // 128-cout launches with < 2 tiles of 8 x 32 per CU, where that kernel pays its weight prologue per tile)
 #define DS_OPT_NO_WFRAG 32u   // the engine does not hand the fragment-major weight copies to the register-weight kernel (A/B)
 unsigned ds_default_opts();
 int ds_num_cus();  // compute units of the current device (cached per device ordinal)
@@ -262,6 +265,11 @@ inline bool ds_rw_frag_shape(int taps, int Cin, int Cout) {  // the weight shape
 }
 bool ds_conv_rw_eligible(const ConvArgs& a);   // conv3x3_rw.hip: register-resident weights, 64 / 128 -> 64 bf16, >= 32-row images
 int ds_launch_conv_rw(const ConvArgs& a, hipStream_t st);
+// the weight shapes conv3x3_sw.hip streams (fragment-major copies of 3x3 weights and folded 1x1 skips)
+inline bool ds_sw_frag_shape(int taps, int Cin, int Cout) { return (Cout == 128 || Cout == 256) && Cin % 64 == 0 && Cin >= 64 && Cin <= 256; }
+bool ds_conv_sw_supported(const ConvArgs& a);  // conv3x3_sw.hip: streamed weights, 64 .. 256 -> 128 n couts, 16-bit
+bool ds_conv_sw_eligible(const ConvArgs& a);   // ... and dispatched there
+int ds_launch_conv_sw(const ConvArgs& a, hipStream_t st);
 bool ds_conv_ws_eligible(const ConvArgs& a);   // conv3x3_ws.hip: weight-stationary 64 -> 64 bf16 kernel
 int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st);
 bool ds_conv_thin_eligible(const ConvArgs& a);   // conv3x3_ws.hip: the 8 -> 64 first layer

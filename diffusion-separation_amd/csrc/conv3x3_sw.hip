@@ -1,0 +1,968 @@
+// conv3x3_sw.hip — 3x3 convolution with STREAMED weights for the 16-bit 128-cout layers whose weights no register file holds:
+// Cin = 192 / 256 (the cat(128, 64) / cat(128, 128) blocks: nf = 64 at 64^2, nf = 128 at 256^2 / 128^2), folded 1x1 skips on up to
+// 256 raw channels, and the 64 -> 128 / 128 -> 128 layers of levels with one or two tiles per compute unit, where the
+// register-weight kernel (conv3x3_rw.hip) pays a 295 KB weight prologue per block; gfx950, bfloat16 or (-DDS_HALF_F16) fp16 storage.
+// Reference: layers.py:141-156 (ddpm_conv3x3), layerspp.py:291-323 (ResnetBlockBigGANpp), ncsnpp.py:409-417 (the concat).
+//
+// The staging pipeline, the hand-placed MFMA gaps and the in-register epilogue are those of conv3x3_rw.hip (read its header first).
+// What differs:
+//   * one block of 4 waves per CU = 4 cout groups of 32 on ONE tile of 8 x 32 pixels: a wave has 8 accumulators (128 registers),
+//     and they live in the ACCUMULATOR half of the register file ("a" operands); the epilogue reads them back one value at a time;
+//   * NO weight is resident.  Every k-step's fragment (1 KB per wave, fragment-major copy of the weights: ds_rw_frag_index)
+//     is loaded straight from L2 into a ring of SW_D accumulator-file registers SW_D k-steps ahead of its 4 MFMAs
+//     (buffer_load_dwordx4 a[..]: the compiler counts vmcnt for the builtin loads, interleaved with the staging loads and
+//     the epilogue's stores, in program order); a half-phase (4 of the wave's 8 rows) walks the chunk's 36 k-steps, so a tile
+//     streams the layer's weights twice: 2 x 590 KB for Cin = 256, ~20 B / clk / CU against the ~60 the L2 delivers.
+//     The ring is primed at the top of every tile (a loop-carried ring would live in VGPRs across the back edge: the
+//     compiler keeps a loaded value that crosses a loop boundary in the architectural half and copies it over);
+//   * chunk order of a tile: first 3x3 chunk, the skip chunks, the other 3x3 chunks — the first and the last phase are
+//     long ones (each carries the epilogue of half a tile under its MFMAs).
+// Any number of 64-channel chunks (NCH <= 4 instantiated, NSK <= 4); the block's 128 couts may be one of several cout blocks
+// of a wider layer (Cout = 128 ncb: the fragment-major copy keeps the layer's Cout / 32 groups side by side).
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+#ifdef SW_TIMING  // profiling build only: per-phase cycle totals of wave 0
+__device__ unsigned long long g_sw_dbg[16];
+#define RT_DECL unsigned rt_prev = (unsigned)__builtin_readcyclecounter(), rt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RT_MARK(i) { unsigned rt_now = (unsigned)__builtin_readcyclecounter(); rt_acc[i] += rt_now - rt_prev; rt_prev = rt_now; }
+#define RT_FLUSH if (threadIdx.x == 0) { for (int q = 0; q < 8; ++q) atomicAdd(&g_sw_dbg[q], (unsigned long long)rt_acc[q]); atomicAdd(&g_sw_dbg[15], 1ull); }
+extern "C" int diffsep_sw_debug_read(unsigned long long* out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sw_dbg), sizeof(unsigned long long) * 16);
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sw_dbg), z, sizeof(z)); }
+  return 0;
+}
+#else
+#define RT_DECL
+#define RT_MARK(i)
+#define RT_FLUSH
+#endif
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ inline __amdgpu_buffer_rsrc_t rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ inline u32x4_t ld16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+// block barrier that orders LDS traffic only (a __syncthreads() would also drain the global prefetch)
+__device__ inline void sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int TW = 32, HW_ = TW + 2;  // tile width, halo row
+constexpr int KC = 64;                // channels per chunk: a pixel's chunk is ONE full 128-byte line of a 64-channel tensor
+constexpr int NKB = KC / 16;          // 16-channel k-blocks per tap
+constexpr int KSC = 9 * NKB;          // k-steps of a 3x3 chunk
+constexpr int AROW = KC * 2 + 16;     // 144 B: LDS pitch of a halo pixel (16 consecutive rows = 16 distinct bank slots)
+constexpr int PPL = KC / 8;           // 16-byte pieces (lanes) per pixel
+constexpr int NT = 256;
+
+struct SwK {
+  const bf16_t* x; long x_bs; int ldx; int C1;     // channels [0, C1) from x, [C1, Cin) from x2
+  const bf16_t* x2; long x2_bs; int ldx2;
+  const bf16_t* wfrag; const bf16_t* swfrag;       // fragment-major weights (ds_rw_frag_index): [k-step][Cout / 32][lane][8]
+  unsigned frag_step;                              // bytes of one k-step of the fragment-major copies: Cout / 32 KB
+  const float* gn_scale; const float* gn_shift;    // [B][Cin] or null
+  const long long* gn_acc1; const long long* gn_acc2; const float* gn_gamma; const float* gn_beta;
+  int gn_groups; float gn_inv_count; float gn_eps;
+  const float* bias; const float* bias_b; int bias_b_ld;
+  float out_scale;
+  bf16_t* y; long y_bs; int ldy;
+  long long* stats;
+  const bf16_t* sx; long sx_bs; int ldsx; int sC1;  // folded skip: raw channels [0, sC1) from sx, the rest from sx2
+  const bf16_t* sx2; long sx2_bs; int ldsx2;
+  int H, W, G, ncb, cout, tiles_x, tiles_per_img;   // G blocks per image and cout block; ncb cout blocks of 128; cout = 128 ncb
+  int dbg;  // profiling builds: bit 0 = stores fall outside the tensor, bit 1 = loads do
+};
+
+constexpr int RPW = 8, RH = RPW / 2, NCG = 4, CO = 32 * NCG;  // the wave's rows (= the tile's), rows per half-phase, cout groups
+#ifndef SW_D
+#define SW_D 16  // ring depth: k-steps between a fragment's load and its MFMAs (A/B: -DSW_D=..)
+#endif
+constexpr int RING = SW_D;
+
+template <int NCH, int NSK>
+struct SwGeom {
+  static constexpr int TH = RPW, HH_ = TH + 2, HP = HH_ * HW_;
+  // 16-byte staging pieces per thread and chunk: NI passes over the tile's own pixels (a pass = NT / PPL = 32 pixels = one
+  // tile row: always inside the image, no flags, no selects), then NB passes over the NBP pixels of the halo border
+  static constexpr int NI = TH * TW * PPL / NT, NBP = HP - TH * TW, NB = (NBP * PPL + NT - 1) / NT;
+  static constexpr int NL = NI + NB;
+  static_assert(NT / PPL == TW && TH * TW * PPL % NT == 0, "one staging pass = one tile row");
+  static constexpr int LDS_A = NL * (NT / PPL) * AROW;    // one ring slot (whole passes of the block: no predicated writes)
+  static constexpr int CIN = NCH * KC, SCIN = NSK * KC;
+  static constexpr int LDS_TAB = (2 * CIN + CO) * 4;      // GN scale, GN shift, (bias + temb bias) * out_scale
+  static constexpr int LDS_DESC = NB * NT * 4;            // relative pixel index of the border pieces
+  static_assert((NI + NB) * (NT / PPL) >= HP + NB * (NT / PPL) - NBP, "dummy pixels of the last border pass fit the slot");
+  static constexpr int NPH = NCH + NSK;                   // phases (chunks) per tile
+  static constexpr int NKS = NCH * KSC + NSK * NKB;       // k-steps of a tile's rows
+  static constexpr int OFF_TAB = 2 * LDS_A, OFF_DESC = OFF_TAB + ((LDS_TAB + 15) & ~15);
+  static constexpr int LDS_TOTAL = OFF_DESC + LDS_DESC;
+  // chunk of phase P: [0, NCH) = 3x3 chunk, NCH + s = skip chunk s.  Order: 3x3 chunk 0, the skip chunks, the other 3x3 chunks
+  // (NCH = 1 with a skip: the skip chunks first, as in conv3x3_rw.hip — the last phase has to be a long one)
+  static constexpr int chunk_of(int P) {
+    if (NCH == 1) return P < NSK ? NCH + P : P - NSK;
+    return P == 0 ? 0 : (P <= NSK ? NCH + P - 1 : P - NSK);
+  }
+  static constexpr int nk_of(int P) { return chunk_of(P) < NCH ? KSC : NKB; }
+  // ---- the weight stream of one tile: position s = (phase, half, k-step of the half) in program order
+  static constexpr int S = 2 * NKS;
+  static constexpr int pos0(int P) { int s = 0; for (int q = 0; q < P; ++q) s += 2 * nk_of(q); return s; }
+  // k-step ks of a 3x3 chunk in the loop's order ((kx, block) groups outside, ky inside) -> (tap, block) order of the copies
+  static constexpr int widx(bool conv, int ks) {
+    if (!conv) return ks;
+    const int g = ks / 3, dy = ks % 3, dx = g / NKB, kb = g % NKB;
+    return (dy * 3 + dx) * NKB + kb;
+  }
+  // fragment of stream position s: k-step index into wfrag (>= 0) or, for a skip chunk, -1 - index into swfrag
+  static constexpr int frag_of(int s) {
+    int P = 0;
+    while (s >= 2 * nk_of(P)) { s -= 2 * nk_of(P); ++P; }
+    const int nk = nk_of(P), ks = s % nk, c = chunk_of(P);
+    return c < NCH ? c * KSC + widx(true, ks) : -1 - ((c - NCH) * NKB + ks);
+  }
+  struct FragTab { int v[S]; };
+  static constexpr FragTab frag_tab() { FragTab t{}; for (int s = 0; s < S; ++s) t.v[s] = frag_of(s); return t; }
+  static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget of one CU");
+  static_assert(NT * 36 * 4 <= LDS_TOTAL, "the statistics reduce reuses the block's LDS");
+};
+
+// NCH: 64-channel chunks of the 3x3 input (one tensor or the in-place concat of two); NSK: 64-channel chunks of the folded
+// 1x1 skip; MODE: 0 raw input, 2 GroupNorm + SiLU
+template <int NCH, int NSK, int MODE>
+__global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
+  using G = SwGeom<NCH, NSK>;
+  constexpr int TH = G::TH, HP = G::HP, LDS_A = G::LDS_A, NL = G::NL, NPH = G::NPH, CIN = G::CIN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  float* sTab = reinterpret_cast<float*>(smem + G::OFF_TAB);
+  int* sDesc = reinterpret_cast<int*>(smem + G::OFF_DESC);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, h = lane >> 5;
+  const int cg = wave;
+  const int b = blockIdx.x / (p.G * p.ncb), cb = (blockIdx.x / p.G) % p.ncb, part = blockIdx.x % p.G;
+  const int t0 = (int)((long)part * p.tiles_per_img / p.G);
+  const int nt = (int)((long)(part + 1) * p.tiles_per_img / p.G) - t0;
+  RT_DECL
+
+  // ---- tables: GroupNorm scale / shift of image b, bias.  The operands are LOADED here, ahead of the first chunk's loads and
+  // the first weight fragments (loads return in order), and turned into the LDS tables after those have been issued
+  static_assert(CIN <= NT && CO <= NT, "one table entry per thread");
+  constexpr int CPG_MAX = 8;  // channels per GroupNorm group: min(C / 4, 32) groups -> 4 (C <= 128) or 8 (C = 256)
+  long long t_s[CPG_MAX], t_q[CPG_MAX];
+  float t_gam = 1.f, t_bet = 0.f, t_sc = 1.f, t_sh = 0.f, t_bias = 0.f;
+#pragma unroll
+  for (int j = 0; j < CPG_MAX; ++j) { t_s[j] = 0; t_q[j] = 0; }
+  if (tid < CIN) {
+    const int c = tid;
+    if (p.gn_acc1) {  // statistics straight from the producers' channel-sum accumulators
+      const int C1 = p.C1, C2 = CIN - C1;
+      const int cpg = CIN / p.gn_groups, g0 = (c / cpg) * cpg;
+#pragma unroll
+      for (int j = 0; j < CPG_MAX; ++j) {
+        if (j < cpg) {
+          const int cc = g0 + j;
+          const long long* src = cc < C1 ? p.gn_acc1 + ((long)b * C1 + cc) * 2 : p.gn_acc2 + ((long)b * C2 + (cc - C1)) * 2;
+          t_s[j] = src[0];
+          t_q[j] = src[1];
+        }
+      }
+      t_gam = p.gn_gamma ? p.gn_gamma[c] : 1.f;
+      t_bet = p.gn_beta ? p.gn_beta[c] : 0.f;
+    } else if (p.gn_scale) {
+      t_sc = p.gn_scale[(long)b * CIN + c];
+      t_sh = p.gn_shift[(long)b * CIN + c];
+    }
+  }
+  if (tid < CO) t_bias = (p.bias ? p.bias[cb * CO + tid] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + cb * CO + tid] : 0.f);
+  auto build_tables = [&]() __attribute__((always_inline)) {
+    if (tid < CIN) {
+      float sc = t_sc, sh = t_sh;
+      if (p.gn_acc1) {
+        long long t_ssum = 0, t_ssq = 0;
+#pragma unroll
+        for (int j = 0; j < CPG_MAX; ++j) { t_ssum += t_s[j]; t_ssq += t_q[j]; }
+        const double mean = (double)t_ssum * (1.0 / DS_STAT_SUM_SCALE) * (double)p.gn_inv_count;
+        double var = (double)t_ssq * (1.0 / DS_STAT_SQ_SCALE) * (double)p.gn_inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        sc = (float)(1.0 / sqrt(var + (double)p.gn_eps)) * t_gam;
+        sh = t_bet - (float)mean * sc;
+      }
+      sTab[tid] = sc;
+      sTab[CIN + tid] = sh;
+    }
+    if (tid < CO) sTab[2 * CIN + tid] = t_bias * p.out_scale;
+  };
+  const int slot = tid & (PPL - 1);
+  // staging pieces of this thread, 16-byte slot tid % PPL of a pixel: piece k < NI = pixel (row k, column tid / PPL) of the tile
+  // itself; piece NI + kb = border pixel tid / PPL + 32 kb of the halo line (top row, bottom row, left column, right column).
+  // Border pieces carry 5 flag bits (bits 0..3 = top / bottom / left / right halo line, bit 4 = past the last border
+  // pixel), their relative pixel index (LDS table or registers) and their LDS offset (registers).
+  constexpr int NI = G::NI, NB = G::NB, NBP = G::NBP;
+  const int ixp = tid / PPL;
+  unsigned fl = 0;
+  int dstb[NB];
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    const int bi = ixp + (NT / PPL) * kb;
+    int hy, hx;
+    if (bi < HW_) { hy = 0; hx = bi; }
+    else if (bi < 2 * HW_) { hy = G::HH_ - 1; hx = bi - HW_; }
+    else if (bi < 2 * HW_ + TH) { hy = 1 + bi - 2 * HW_; hx = 0; }
+    else { hy = 1 + bi - 2 * HW_ - TH; hx = HW_ - 1; }
+    const bool in = bi < NBP;
+    const unsigned flg = in ? (hy == 0 ? 1u : 0u) | (hy == G::HH_ - 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == HW_ - 1 ? 8u : 0u) : 16u;
+    sDesc[kb * NT + tid] = in ? (hy - 1) * p.W + (hx - 1) : 0;
+    dstb[kb] = (in ? hy * HW_ + hx : HP + (bi - NBP)) * AROW + slot * 16;  // (the pieces past the border: unused pixels of the slot)
+    fl |= flg << (5 * kb);
+  }
+  const int ldi0 = (HW_ + 1 + ixp) * AROW + slot * 16;  // tile pixel (0, ixp): piece k < NI is HW_ pixels (one halo row) further
+
+  RT_MARK(6)
+  const int M = p.H * p.W;
+  const __amdgpu_buffer_rsrc_t rx1 = rsrc(p.x + (long)b * p.x_bs, (unsigned)M * p.ldx * 2u);
+  const __amdgpu_buffer_rsrc_t rx2 = p.x2 ? rsrc(p.x2 + (long)b * p.x2_bs, (unsigned)M * p.ldx2 * 2u) : rx1;
+  const __amdgpu_buffer_rsrc_t rs1 = NSK ? rsrc(p.sx + (long)b * p.sx_bs, (unsigned)M * p.ldsx * 2u) : rx1;
+  const __amdgpu_buffer_rsrc_t rs2 = (NSK && p.sx2) ? rsrc(p.sx2 + (long)b * p.sx2_bs, (unsigned)M * p.ldsx2 * 2u) : rs1;
+  const __amdgpu_buffer_rsrc_t ry = rsrc(p.y + (long)b * p.y_bs, (unsigned)M * p.ldy * 2u);
+
+  // ---- the weight stream: fragment of stream position s (SwGeom::frag_of) -> ring[s % RING], loaded RING positions ahead.
+  // A wave's load = 1 KB of contiguous memory (lane L: 16 bytes at (cout group * 64 + L) * 16 of the k-step's Cout / 32 KB)
+  u32x4_t ring[RING];
+  const __amdgpu_buffer_rsrc_t rw = rsrc(p.wfrag, (unsigned)(NCH * KSC) * p.frag_step);
+  const __amdgpu_buffer_rsrc_t rsw = NSK ? rsrc(p.swfrag, (unsigned)(NSK * NKB) * p.frag_step) : rw;
+  const unsigned vfrag = (unsigned)(((cb * NCG + cg) * 64 + lane) * 16);
+  auto load_frag = [&](int s) __attribute__((always_inline)) {  // (s: compile time)
+    constexpr typename G::FragTab FT = G::frag_tab();  // (a constant table: the index is a constant once the K loop is unrolled)
+    const int f = FT.v[s];
+    if (f >= 0) ring[s % RING] = ld16(rw, vfrag, (unsigned)f * p.frag_step);
+    else ring[s % RING] = ld16(rsw, vfrag, (unsigned)(-1 - f) * p.frag_step);
+  };
+
+  // ---- staging state: pa[] holds the chunk AFTER the one in LDS (in flight or landed)
+  u32x4_t pa[NL];
+  // geometry of the tile a chunk belongs to (wave-uniform): first pixel, border mask (which halo lines lie outside
+  // the image); tiles past the block's range get a pixel index beyond every tensor (the hardware returns zeros)
+  struct TileG { int pix0; unsigned edge; };
+  auto geom_at = [&](int ty, int tx, bool valid) {
+    TileG g;
+    const int y0 = ty * TH, x0 = tx * TW;
+    g.edge = (y0 == 0 ? 1u : 0u) | (y0 + TH == p.H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + TW == p.W ? 8u : 0u);
+    g.pix0 = valid ? y0 * p.W + x0 : 0x3fffff;
+    return g;
+  };
+  auto tile_geom = [&](int i) {
+    const int t = t0 + i;
+    const int ty = t / p.tiles_x;
+    return geom_at(ty, t - ty * p.tiles_x, i < nt);
+  };
+  // piece k of a chunk of type P is valid (inside the image / an interior pixel for the skip chunks)
+  auto piece_ok = [&](auto P_, const TileG& g, int k) __attribute__((always_inline)) {
+    constexpr int P = decltype(P_)::value;
+    const unsigned em = (P < NCH ? (g.edge | 16u) : 31u) << (5 * (k - NI));  // (scalar; border pieces only)
+    return (fl & em) == 0u;
+  };
+  // source of chunk P (compile time): descriptor, pixel pitch in bytes, byte offset of this thread's 8 channels
+  auto issue_one = [&](auto P_, const TileG& g, int k, int rel) __attribute__((always_inline)) {
+    constexpr int P = decltype(P_)::value;
+    constexpr bool CONV = P < NCH;
+    constexpr int CB = (CONV ? P : P - NCH) * KC;
+    const int c1 = CONV ? p.C1 : p.sC1;
+    const bool second = CB >= c1;  // (wave-uniform)
+    const unsigned ld2 = (unsigned)(CONV ? (second ? p.ldx2 : p.ldx) : (second ? p.ldsx2 : p.ldsx)) * 2u;
+    const unsigned co2 = (unsigned)((second ? CB - c1 : CB) * 2) + (unsigned)slot * 16u;
+    const __amdgpu_buffer_rsrc_t r = CONV ? (second ? rx2 : rx1) : (second ? rs2 : rs1);
+    if constexpr (!CONV) {
+      if (k >= NI) return;  // (a skip chunk meets the centre tap only: its border pieces are never read)
+    }
+    if (k < NI) {  // a pixel of the tile itself: inside the image whenever the tile is (a tile past the block's range has a
+                   // pixel index beyond every tensor: the hardware returns zeros)
+      const unsigned off = __umul24((unsigned)(g.pix0 + k * p.W + ixp), ld2) + co2;
+      pa[k] = ld16(r, off, 0);
+      return;
+    }
+    const unsigned off = __umul24((unsigned)(rel + g.pix0), ld2) + co2;
+#ifdef SW_TIMING
+    pa[k] = ld16(r, (piece_ok(P_, g, k) && !(p.dbg & 2)) ? off : OOB, 0);
+#else
+    pa[k] = ld16(r, piece_ok(P_, g, k) ? off : OOB, 0);
+#endif
+  };
+  // every input of the launch is activated (no raw skip / residual chunk shares the accumulators): the activation may
+  // leave a constant factor to the epilogue
+  constexpr bool FOLD = MODE == 2 && NSK == 0;
+  // Round 5.  (i) RW_ACT_PK (half-precision build): GroupNorm affine + SiLU in PACKED half precision — per dword (two channels)
+  // v_pk_fma_f16, 2 x v_exp_f16, v_pk_add_f16, 2 x v_rcp_f16, v_pk_mul_f16 = 7 instructions (8 without FOLD) instead of 11
+  // (2 fma_mix, 2 exp, 2 add, 2 rcp, 2 mul, cvt_pk); the upper halves go through SDWA forms of the transcendentals, no
+  // unpack / pack.  What it costs in rounding is gated by tests/test_engine_gpu.py against the CPU oracle (-DRW_ACT_F32
+  // restores the fp32 arithmetic for the A/B).  (ii) RW_PIPE: a unit runs in THREE stages, one unit apart (affine + exp |
+  // 1 + e, rcp | multiply, write, re-issue): the single in-order wave no longer issues a transcendental's consumer straight
+  // behind it (a k-step carries 0.6 units: inside one unit every instruction depends on the previous one).
+#if defined(DS_HALF_F16) && !defined(RW_ACT_F32)
+  constexpr bool ACT_PK = true;
+#else
+  constexpr bool ACT_PK = false;
+#endif
+#ifdef RW_NO_PIPE
+  constexpr int PIPE_LAG = 0;
+#else
+  constexpr int PIPE_LAG = 2;
+#endif
+  float gsc[ACT_PK ? 1 : 8], gsh[ACT_PK ? 1 : 8];
+  unsigned psc[ACT_PK ? 4 : 1], psh[ACT_PK ? 4 : 1];
+  auto act_tab = [&](int c) __attribute__((always_inline)) {  // scale / shift of this thread's 8 channels of chunk c
+    if constexpr (MODE != 0) {
+      const float4* ts = reinterpret_cast<const float4*>(sTab + c * KC + slot * 8);
+      const float4* th = reinterpret_cast<const float4*>(sTab + CIN + c * KC + slot * 8);
+      const float4 s0 = ts[0], s1 = ts[1], h0 = th[0], h1 = th[1];
+      float a[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, b_[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+      if constexpr (FOLD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a[j] *= -1.4426950408889634f; b_[j] *= -1.4426950408889634f; }
+      }
+      if constexpr (ACT_PK) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { psc[d] = pack_h2(a[2 * d], a[2 * d + 1]); psh[d] = pack_h2(b_[2 * d], b_[2 * d + 1]); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { gsc[j] = a[j]; gsh[j] = b_[j]; }
+      }
+    }
+  };
+  // Staging runs in UNITS of one dword (two channels) so that its VALU work spreads evenly over the k-steps of a phase:
+  // unit u = dword u & 3 of piece u >> 2.  The piece's last unit writes it to the ring and re-issues its registers as
+  // the load of the chunk after next.  Stage registers of the units in flight: ring of 3 by unit index (compile time).
+  u32x4_t so;  // the piece being assembled
+  float uz[3][2], ut[3][2];
+  unsigned uzp[3], utp[3], uxp[3], udp[3], urp[3];
+  // stages 0 (unit u0: affine, exp2 of both channels) and 1 (unit u1: 1 + e, reciprocal) of two DIFFERENT units, emitted
+  // interleaved: an SDWA transcendental that completes a register (upper half, the lower one preserved) straight behind the
+  // instruction that wrote the lower half costs a wait state (s_nop) — the other unit's instruction sits between them.
+  // u0 / u1 < 0: that stage has nothing to do in this step.
+  auto unit_s01 = [&](auto P1_, int u0, int u1) __attribute__((always_inline)) {
+    constexpr int P1 = decltype(P1_)::value;
+    if constexpr (P1 < NCH && MODE != 0) {
+      const int q0 = u0 >= 0 ? u0 % 3 : 0, q1 = u1 >= 0 ? u1 % 3 : 0;
+      if constexpr (ACT_PK) {
+        unsigned z = 0, x = 0, e = 0, dd = 0, r = 0;
+        if (u0 >= 0) {
+          asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(z) : "v"(pa[u0 >> 2][u0 & 3]), "v"(psc[u0 & 3]), "v"(psh[u0 & 3]));
+          x = z;
+          if constexpr (MODE == 2 && !FOLD) asm("v_pk_mul_f16 %0, %1, %2" : "=v"(x) : "v"(z), "s"(0xbdc5bdc5u));  // -log2(e) in both halves
+        }
+        if constexpr (MODE == 2) {
+          if (u1 >= 0) asm("v_pk_add_f16 %0, %1, %2" : "=v"(dd) : "v"(utp[q1]), "s"(0x3c003c00u));
+          if (u0 >= 0) asm("v_exp_f16 %0, %1" : "=v"(e) : "v"(x));
+          if (u1 >= 0) asm("v_rcp_f16 %0, %1" : "=v"(r) : "v"(dd));
+          if (u0 >= 0) asm("v_exp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(e) : "v"(x));
+          if (u1 >= 0) asm("v_rcp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(r) : "v"(dd));
+          if (u1 >= 0) urp[q1] = r;
+          if (u0 >= 0) utp[q0] = e;
+        }
+        if (u0 >= 0) uzp[q0] = z;
+      } else {
+        if (u1 >= 0 && MODE == 2) {
+          ut[q1][0] = __builtin_amdgcn_rcpf(1.0f + ut[q1][0]);
+          ut[q1][1] = __builtin_amdgcn_rcpf(1.0f + ut[q1][1]);
+        }
+        if (u0 >= 0) {
+          const unsigned w = pa[u0 >> 2][u0 & 3];
+          const int d = u0 & 3;
+          const float lo = h_lo(w), hi = h_hi(w);
+          const float z0 = fmaf(lo, gsc[2 * d], gsh[2 * d]), z1 = fmaf(hi, gsc[2 * d + 1], gsh[2 * d + 1]);
+          uz[q0][0] = z0; uz[q0][1] = z1;
+          if (MODE == 2) {
+            // FOLD: the affine carries the factor -log2(e), z IS the exponent of the sigmoid's exp2 and the staged value is
+            // silu(GN(x)) / -ln 2; the epilogue multiplies the accumulators back (exact in fp32, one multiply per element less)
+            ut[q0][0] = __builtin_amdgcn_exp2f(FOLD ? z0 : z0 * -1.4426950408889634f);
+            ut[q0][1] = __builtin_amdgcn_exp2f(FOLD ? z1 : z1 * -1.4426950408889634f);
+          }
+        }
+      }
+    }
+  };
+  // stage 2: z * sigmoid, the dword into the piece (unit_s2); the piece's last unit writes it and re-issues its registers
+  // (unit_fin: that part alone, for the hand-placed stream whose multiply sits in an earlier lump)
+  auto unit_s2x = [&](auto P1_, auto P2_, auto FIN_, const TileG& g1, const TileG& g2, int sl, int u, int rel) __attribute__((always_inline)) {
+    constexpr int P1 = decltype(P1_)::value;
+    constexpr bool FIN_ONLY = decltype(FIN_)::value;
+    const int k = u >> 2, d = u & 3, q = u % 3;
+    if constexpr (!FIN_ONLY) {
+    if constexpr (P1 < NCH && MODE != 0) {
+      if constexpr (ACT_PK) {
+        unsigned v = uzp[q];
+        if constexpr (MODE == 2) asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(v) : "v"(uzp[q]), "v"(urp[q]));
+        so[d] = v;
+      } else {
+        float z0 = uz[q][0], z1 = uz[q][1];
+        if (MODE == 2) { z0 *= ut[q][0]; z1 *= ut[q][1]; }
+        so[d] = pack_h2(z0, z1);
+      }
+    } else {
+      so[d] = pa[k][d];
+    }
+    }
+    if (d == 3) {
+      if (P1 < NCH && MODE != 0 && k >= NI) {  // zero padding stays zero (silu(GN(0)) != 0): border pieces only
+        const bool ok = piece_ok(P1_, g1, k);
+        so.x = ok ? so.x : 0u;
+        so.y = ok ? so.y : 0u;
+        so.z = ok ? so.z : 0u;
+        so.w = ok ? so.w : 0u;
+      }
+#ifdef RW_ABL_NOLDSW
+      asm volatile("" :: "v"(so));
+#else
+      if (P1 < NCH || k < NI)  // (border pieces of a skip chunk: nothing was loaded, nothing is read)
+        *reinterpret_cast<u32x4_t*>(sA + sl * LDS_A + (k < NI ? ldi0 + k * HW_ * AROW : dstb[k < NI ? 0 : k - NI])) = so;
+#endif
+#ifdef RW_ABL_NOLOAD
+      pa[k][0] += rel;
+#else
+      issue_one(P2_, g2, k, rel);
+#endif
+    }
+  };
+  auto unit_s2 = [&](auto P1_, auto P2_, const TileG& g1, const TileG& g2, int sl, int u, int rel) __attribute__((always_inline)) {
+    unit_s2x(P1_, P2_, std::false_type{}, g1, g2, sl, u, rel);
+  };
+  auto unit_fin = [&](auto P1_, auto P2_, const TileG& g1, const TileG& g2, int sl, int u, int rel) __attribute__((always_inline)) {
+    unit_s2x(P1_, P2_, std::true_type{}, g1, g2, sl, u, rel);
+  };
+  // a whole unit at once (the prologue)
+  auto unit = [&](auto P1_, auto P2_, const TileG& g1, const TileG& g2, int sl, int u, int rel) __attribute__((always_inline)) {
+    unit_s01(P1_, u, -1);
+    unit_s01(P1_, -1, u);
+    unit_s2(P1_, P2_, g1, g2, sl, u, rel);
+  };
+
+  // the wave's 8 accumulators live in the accumulator half of the register file ("a" operands of the inline-asm MFMAs); they
+  // start UNDEFINED: the first tile's first half-phase runs the epilogue of "the tile before" on them (its stores fall outside
+  // every tensor, the statistics are reset behind it) and every half zeroes its rows with its first MFMA
+  f32x16 acc[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) asm volatile("" : "=a"(acc[r]));
+  float ssum[16], ssq[16];  // per lane: its 16 couts (8 q + 4 h + i), summed over its pixels
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+  const bool has_stats = p.stats != nullptr;
+  const float osc = FOLD ? p.out_scale * -0.6931471805599453f : p.out_scale;
+  // fragment base of this lane: pixel (row pg * RPW, column l32) of the halo tile, k-half h
+  const int fbase = l32 * AROW + h * 16;
+
+  // ---- epilogue of one tile, in the accumulator layout (no LDS): lane (pixel l32, half h) holds, per row, the cout
+  // quads 8 q + 4 h .. + 3 of the wave's 32 couts.  A 16-byte load / store of a lane covers couts 16 j + 8 h .. + 7 of its
+  // pixel; two v_permlane32_swap per 16 bytes turn that into the two quads (q = 2 j, 2 j + 1) of the lane and back.
+  auto swap_halves = [&](u32x4_t& v) __attribute__((always_inline)) {
+    auto r0 = __builtin_amdgcn_permlane32_swap(v.x, v.z, false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
+    v.x = r0[0]; v.z = r0[1]; v.y = r1[0]; v.w = r1[1];
+  };
+  // ---- epilogue work in UNITS of half a row (8 couts of the lane's pixel): bias, statistics, packing, one 16-byte
+  // store.  (There are no loads in the epilogue: a residual rides through the ring as two raw chunks that meet identity
+  // fragments — see the launcher.  vmcnt retires in order and counts stores: residual rows loaded between the stores
+  // were measured waiting for the acknowledgement of every earlier store, 1350 cycles per row on an idle chip.)
+  // The two units of a row leave together: v_permlane16_swap regroups their 16-byte pieces so that one store covers
+  // 16 pixels x 64 contiguous bytes (the wave's 32 couts) instead of 32 pixels x 32 bytes — half the write requests.
+  u32x4_t ov0;  // the row's first half, waiting for the second
+  const int srow = lane >> 4;  // after the regrouping lane L holds, of pixel L & 15 (+ 16 in the second store), the piece:
+  const unsigned spiece = (unsigned)((cb * NCG + cg) * 64 + (srow & 1) * 32 + (srow >> 1) * 16);  // byte offset in the pixel's Cout x 2 B
+  auto epi_unit = [&](const TileG& g, int r, int j, const float4& t0, const float4& t1) __attribute__((always_inline)) {
+    float v[8];
+    v[0] = fmaf(acc[r][8 * j + 0], osc, t0.x); v[1] = fmaf(acc[r][8 * j + 1], osc, t0.y);
+    v[2] = fmaf(acc[r][8 * j + 2], osc, t0.z); v[3] = fmaf(acc[r][8 * j + 3], osc, t0.w);
+    v[4] = fmaf(acc[r][8 * j + 4], osc, t1.x); v[5] = fmaf(acc[r][8 * j + 5], osc, t1.y);
+    v[6] = fmaf(acc[r][8 * j + 6], osc, t1.z); v[7] = fmaf(acc[r][8 * j + 7], osc, t1.w);
+    // (always taken: a branch here would cut the half-phase's instruction stream into separately scheduled pieces)
+#ifndef RW_ABL_NOSTATS
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ssum[8 * j + e] += v[e];
+      ssq[8 * j + e] = fmaf(v[e], v[e], ssq[8 * j + e]);
+    }
+#endif
+    u32x4_t ov = {pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7])};
+    swap_halves(ov);  // lane (pixel l32, half h): couts 16 j + 8 h .. + 7
+    if (j == 0) {
+      ov0 = ov;
+    } else {
+      u32x4_t a = ov0, b2 = ov;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        auto q = __builtin_amdgcn_permlane16_swap(a[d], b2[d], false, false);
+        a[d] = q[0]; b2[d] = q[1];
+      }
+      const int pix = g.pix0 + r * p.W + (lane & 15);
+      const unsigned o = __umul24((unsigned)pix, (unsigned)p.ldy * 2u) + spiece;
+#ifdef SW_TIMING
+      const unsigned o1 = (p.dbg & 1) ? OOB : o, o2 = (p.dbg & 1) ? OOB : o + 16u * (unsigned)p.ldy * 2u;
+#else
+      const unsigned o1 = o, o2 = o + 16u * (unsigned)p.ldy * 2u;
+#endif
+#ifdef RW_ABL_NOSTORE
+      asm volatile("" :: "v"(a), "v"(b2), "v"(o1), "v"(o2));
+#else
+      __builtin_amdgcn_raw_buffer_store_b128(a, ry, o1, 0, 0);    // pixels 0 .. 15 of the row
+      __builtin_amdgcn_raw_buffer_store_b128(b2, ry, o2, 0, 0);   // pixels 16 .. 31
+#endif
+    }
+  };
+  // (bias + temb bias) * out_scale of the unit's two cout quads: LDS broadcast reads, issued ahead of the k-step's MFMAs
+  // Where the register file has room (64-channel layers: 144 - 176 of the 256 accumulator registers hold weights) the
+  // lane's 16 values stay in registers for the whole launch: 8 LDS reads per half-phase less
+  // (64-channel layers and the 4-row tiles of the 128-cout variants have the VGPRs for both tables; the 128 -> 64 variant
+  // for the bias only)
+  constexpr bool REL_REGS = true;
+  constexpr bool BIAS_REGS = true;
+  float4 breg[2][2];
+  int relreg[G::NB];  // ... and so do the relative pixel indices of the thread's border pieces
+  auto epi_bias = [&](int j, float4& t0, float4& t1) __attribute__((always_inline)) {
+    if constexpr (BIAS_REGS) {
+      t0 = breg[j][0];
+      t1 = breg[j][1];
+    } else {
+      t0 = *reinterpret_cast<const float4*>(sTab + 2 * CIN + cg * 32 + 8 * (2 * j) + 4 * h);
+      t1 = *reinterpret_cast<const float4*>(sTab + 2 * CIN + cg * 32 + 8 * (2 * j + 1) + 4 * h);
+    }
+  };
+
+  // ---- one HALF of a phase: the MFMAs of chunk (phase P, ring slot P & 1) for the wave's rows [HF * RH, HF * RH + RH),
+  // interleaved with (i) its share of the staging of the next phase's chunk and of the loads of the chunk after that,
+  // (ii) EPI: the epilogue of the OTHER half's rows — rows [RH, RPW) of the previous tile during the first half of phase
+  // 0, rows [0, RH) of this tile during the second half of the last phase.  The epilogue of one half of the accumulators
+  // thus always runs under the MFMAs of the other half: no second accumulator set, no phase in which all waves of the
+  // chip store at once.
+  //
+  // Round 5: the stream is HAND-PLACED.  A single in-order wave hides at most ~5 other instructions under one 32-cycle
+  // MFMA, and only if they sit in the gap behind it; the compiler's placement (sched_group_barrier sees neither the
+  // inline-asm MFMAs nor inline-asm VALU) put two MFMAs back to back and the k-step's VALU behind them.  Now every
+  // MFMA is followed by its GAP: the fragment read scheduled there, then the LUMPS (<= 4 - 5 instructions each, volatile
+  // inline asm in the order written) that a compile-time schedule assigns to it:
+  //   * unit lumps: virtual staging step v = {stage 0 of unit v, stage 1 of unit v - 1 | stage 2 of unit v - 2} in two
+  //     lumps; spread evenly over the phase's gaps, a gap of an epilogue half counting W_E / W_N of another one;
+  //   * epilogue lumps (EPI halves): per row 20 lumps — per half row (j) 4 x {2 fma + pack | the pair's statistics}, the
+  //     permlane32 swap; then the permlane16 regrouping and the two stores — spread evenly over the half's gaps.
+#ifndef RW_W_E
+#define RW_W_E 2
+#define RW_W_N 5
+#endif
+  constexpr int W_E = RW_W_E, W_N = RW_W_N;  // capacity of a gap for unit lumps: epilogue half / other half (A/B: -DRW_W_E=.. -DRW_W_N=..)
+  float et[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // the two cout pairs in flight through the epilogue lumps
+  u32x4_t osa = {0, 0, 0, 0}, osb = {0, 0, 0, 0};  // the row's two store pieces after the regrouping
+  auto half = [&](auto P_, auto HF_, auto EPI_, int slot_r, const TileG& ge, const TileG& g1, const TileG& g2) __attribute__((always_inline)) {
+    constexpr int P = decltype(P_)::value, HF = decltype(HF_)::value;
+    constexpr bool EPI = decltype(EPI_)::value;
+    constexpr int C = G::chunk_of(P);
+    constexpr bool CONV = C < NCH;
+    constexpr int NK = CONV ? KSC : NKB;
+    constexpr int C1 = G::chunk_of((P + 1) % NPH), C2 = G::chunk_of((P + 2) % NPH);
+    constexpr int NU = NL * 4;
+    constexpr bool ACT1 = C1 < NCH && MODE != 0;
+    // virtual unit index v: stage 0 of unit v, stage 1 of unit v - 1, stage 2 of unit v - LAG (LAG = 0: the whole unit at v)
+    constexpr int LAG = ACT1 ? PIPE_LAG : 0, NUV = NU + LAG, NLU = 2 * NUV;
+    constexpr int NGH = NK * RH;  // gaps (MFMAs) of this half
+    constexpr int w0 = (P == 0) ? W_E : W_N, w1 = (P == NPH - 1) ? W_E : W_N, CAP = NGH * (w0 + w1);
+    // first unit lump of phase gap GP in [0, 2 NGH]
+    auto lub = [](int GP) constexpr { return NLU * (GP <= NGH ? GP * w0 : NGH * w0 + (GP - NGH) * w1) / CAP; };
+    constexpr int NLE = RH * 22;  // epilogue lumps of an EPI half
+    constexpr int R0 = HF * RH, ER0 = HF ? 0 : RH;
+    const char* fb = sA + slot_r * LDS_A + fbase + R0 * HW_ * AROW;
+    if constexpr (EPI) {  // the rows this half finishes were last written by asm MFMAs: 12 wait states before they are read
+      static_assert(RH == 4, "one guard for the half's four accumulators");
+      asm volatile("s_nop 11" : "+a"(acc[ER0]), "+a"(acc[ER0 + 1]), "+a"(acc[ER0 + 2]), "+a"(acc[ER0 + 3]));
+    }
+    if constexpr (HF == 0 && C1 < NCH) act_tab(C1);
+    // K order inside a 3x3 chunk: (kx, 16-channel block) groups outside, ky inside.  The RH rows of this half use the
+    // pixel fragments of input rows R0 .. R0 + RH + 1 at the group's (kx, block): each is read ONCE per group and serves up
+    // to three k-steps (ky) — RH + 2 fragment reads per 3 RH MFMAs instead of 3 RH, and one wait per group.  (A skip
+    // chunk has one k-step per group: the centre tap.)
+    constexpr int SUB = CONV ? 3 : 1, RFN = CONV ? RH + 2 : RH, NG = NK / SUB;
+    static_assert(SUB * RH >= RFN, "the next group's fragments are read in the MFMA slots of the current one");
+    auto ldg = [&](int g, int j) __attribute__((always_inline)) {  // fragment j of group g = kx * NKB + block
+      const int dx = CONV ? g / NKB : 1, kb = g % NKB, row = CONV ? j : j + 1;
+      return *reinterpret_cast<const u32x4_t*>(fb + (row * HW_ + dx) * AROW + kb * 32);
+    };
+    u32x4_t rf[2][RFN];
+#pragma unroll
+    for (int j = 0; j < RFN; ++j) rf[0][j] = ldg(0, j);
+#define RW_FRAG(ks, r) rf[((ks) / SUB) & 1][(r) + (CONV ? (ks) % SUB : 0)]
+#define RW_FRAG_LAST(ks) rf[((ks) / SUB) & 1][RFN - 1]
+    constexpr int SP0 = G::pos0(P) + HF * NK;  // stream position of this half's first k-step
+    // relative pixel index of the border pieces that complete in a k-step, read (registers or LDS table) one k-step ahead
+    int rels[2][NL];
+    auto fetch_rels = [&](int ks, int par) __attribute__((always_inline)) {  // for the unit lumps of k-step ks of this half
+      const int gp0 = HF * NGH + ks * RH;
+#pragma unroll
+      for (int L = lub(gp0); L < lub(gp0 + RH); ++L) {
+        const int u = (L >> 1) - LAG;
+        if ((L & 1) && u >= 0 && u < NU && (u & 3) == 3 && (u >> 2) >= NI)
+          rels[par][u >> 2] = REL_REGS ? relreg[(u >> 2) - NI] : sDesc[((u >> 2) - NI) * NT + tid];
+      }
+    };
+    fetch_rels(0, 0);  // (the first k-step's operands: the one exposed round trip of the half)
+
+    // ---- lumps.  (An inline-asm instruction that reads a register written by one of the two instructions in front of it
+    // gets a wait state from the compiler, which cannot see whether the producer was a transcendental: the orders below
+    // keep every consumer three instructions behind its producer.)
+    auto unit_lump = [&](int L, int par) __attribute__((always_inline)) {
+      const int v = L >> 1;
+      const int u0 = v < NU ? v : -1, u1 = LAG ? ((v >= 1 && v - 1 < NU) ? v - 1 : -1) : v, u2 = v - LAG;
+      const bool s2 = u2 >= 0 && u2 < NU;
+      if ((L & 1) == 0) {
+        if constexpr (ACT1 && ACT_PK) {
+          // affine of unit u0 | 1 + e of unit u1 | z * sigmoid of unit u2 | exp2 (lower half) of u0 | reciprocal (lower half) of u1
+          if (u0 >= 0) {
+            asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(uzp[u0 % 3]) : "v"(pa[u0 >> 2][u0 & 3]), "v"(psc[u0 & 3]), "v"(psh[u0 & 3]));
+            if constexpr (MODE == 2 && !FOLD) asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(uxp[u0 % 3]) : "v"(uzp[u0 % 3]), "s"(0xbdc5bdc5u));  // x -log2(e)
+          }
+          if constexpr (MODE == 2) {
+            if (u1 >= 0) asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(udp[u1 % 3]) : "v"(utp[u1 % 3]), "s"(0x3c003c00u));
+            if (s2) asm volatile("v_pk_mul_f16 %0, %1, %2" : "=v"(so[u2 & 3]) : "v"(uzp[u2 % 3]), "v"(urp[u2 % 3]));
+            if (u0 >= 0) asm volatile("v_exp_f16 %0, %1" : "=v"(utp[u0 % 3]) : "v"(FOLD ? uzp[u0 % 3] : uxp[u0 % 3]));
+            if (u1 >= 0) asm volatile("v_rcp_f16 %0, %1" : "=v"(urp[u1 % 3]) : "v"(udp[u1 % 3]));
+          } else {
+            if (s2) so[u2 & 3] = uzp[u2 % 3];
+          }
+        } else if constexpr (ACT1) {
+          if (u0 >= 0) unit_s01(std::integral_constant<int, C1>{}, u0, -1);
+        }
+      } else {
+        if constexpr (ACT1 && ACT_PK) {
+          if constexpr (MODE == 2) {
+            if (u0 >= 0) asm volatile("v_exp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(utp[u0 % 3]) : "v"(FOLD ? uzp[u0 % 3] : uxp[u0 % 3]));
+            if (u1 >= 0) asm volatile("v_rcp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1" : "+v"(urp[u1 % 3]) : "v"(udp[u1 % 3]));
+          }
+        } else if constexpr (ACT1) {
+          if (u1 >= 0) unit_s01(std::integral_constant<int, C1>{}, -1, u1);
+        }
+#ifndef RW_ABL_NOSTAGE
+        if (s2) {
+          const int rel = ((u2 & 3) == 3 && (u2 >> 2) >= NI) ? rels[par][u2 >> 2] : 0;
+          if constexpr (ACT1 && ACT_PK) unit_fin(std::integral_constant<int, C1>{}, std::integral_constant<int, C2>{}, g1, g2, slot_r ^ 1, u2, rel);
+          else unit_s2(std::integral_constant<int, C1>{}, std::integral_constant<int, C2>{}, g1, g2, slot_r ^ 1, u2, rel);
+        }
+#endif
+      }
+    };
+    // epilogue lumps of row rr, 22 per row: per half row j the pairs p = 0 .. 3 of the lane's 8 couts as a two-deep
+    // pipeline — A(p) = {v = acc * scale + bias of pair p; pack pair p - 1}, B(p) = {statistics of pair p} in the order
+    // A0 A1 B0 A2 B1 A3 B2 A4 B3 — then the permlane32 swap; x = 20: permlane16 regrouping; x = 21: the stores
+    auto epi_lump = [&](int LE) __attribute__((always_inline)) {
+      const int rr = ER0 + LE / 22, x = LE % 22;
+      if (x < 20) {
+        const int j = x / 10, y = x % 10;
+        // y: 0 A0, 1 A1, 2 B0, 3 A2, 4 B1, 5 A3, 6 B2, 7 A4, 8 B3, 9 swap
+        const bool isA = y == 0 || y == 1 || y == 3 || y == 5 || y == 7;
+        const int pr = y == 0 ? 0 : (y == 1 ? 1 : (y == 2 ? 0 : (y == 3 ? 2 : (y == 4 ? 1 : (y == 5 ? 3 : (y == 6 ? 2 : (y == 7 ? 4 : 3)))))));
+        if (y == 9) {
+          // lane (pixel l32, half h): couts 16 j + 8 h .. + 7
+          if (j == 0) {
+            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(osa[0]), "+v"(osa[2]));
+            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(osa[1]), "+v"(osa[3]));
+          } else {
+            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(osb[0]), "+v"(osb[2]));
+            asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(osb[1]), "+v"(osb[3]));
+          }
+        } else if (isA) {
+          if (pr < 4) {
+            const int e0 = 8 * j + 2 * pr;
+            const float b0 = pr == 0 ? breg[j][0].x : (pr == 1 ? breg[j][0].z : (pr == 2 ? breg[j][1].x : breg[j][1].z));
+            const float b1 = pr == 0 ? breg[j][0].y : (pr == 1 ? breg[j][0].w : (pr == 2 ? breg[j][1].y : breg[j][1].w));
+            // (the accumulators live in the accumulator file: the compiler reads the two values back — v_accvgpr_read_b32 —
+            // in front of the multiply-adds)
+            const float a0 = acc[rr][e0], a1 = acc[rr][e0 + 1];
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(et[pr & 1][0]) : "v"(a0), "s"(osc), "v"(b0));
+            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(et[pr & 1][1]) : "v"(a1), "s"(osc), "v"(b1));
+          }
+          if (pr >= 1) {
+            const int q = pr - 1;
+            if (j == 0) asm volatile(DS_CVT_PK_H_ASM " %0, %1, %2" : "=v"(osa[q]) : "v"(et[q & 1][0]), "v"(et[q & 1][1]));
+            else asm volatile(DS_CVT_PK_H_ASM " %0, %1, %2" : "=v"(osb[q]) : "v"(et[q & 1][0]), "v"(et[q & 1][1]));
+          }
+        } else {
+#ifndef RW_ABL_NOSTATS
+          const int e0 = 8 * j + 2 * pr;
+          asm volatile("v_add_f32 %0, %0, %1" : "+v"(ssum[e0]) : "v"(et[pr & 1][0]));
+          asm volatile("v_add_f32 %0, %0, %1" : "+v"(ssum[e0 + 1]) : "v"(et[pr & 1][1]));
+          asm volatile("v_fma_f32 %0, %1, %1, %0" : "+v"(ssq[e0]) : "v"(et[pr & 1][0]));
+          asm volatile("v_fma_f32 %0, %1, %1, %0" : "+v"(ssq[e0 + 1]) : "v"(et[pr & 1][1]));
+#endif
+        }
+      } else if (x == 20) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(osa[d]), "+v"(osb[d]));
+      } else {
+        const int pix = ge.pix0 + rr * p.W + (lane & 15);
+        const unsigned o = __umul24((unsigned)pix, (unsigned)p.ldy * 2u) + spiece;
+#ifdef SW_TIMING
+        const unsigned o1 = (p.dbg & 1) ? OOB : o, o2 = (p.dbg & 1) ? OOB : o + 16u * (unsigned)p.ldy * 2u;
+#else
+        const unsigned o1 = o, o2 = o + 16u * (unsigned)p.ldy * 2u;
+#endif
+#ifdef RW_ABL_NOSTORE
+        asm volatile("" :: "v"(osa), "v"(osb), "v"(o1), "v"(o2));
+#else
+        __builtin_amdgcn_raw_buffer_store_b128(osa, ry, o1, 0, 0);   // pixels 0 .. 15 of the row
+        __builtin_amdgcn_raw_buffer_store_b128(osb, ry, o2, 0, 0);   // pixels 16 .. 31
+#endif
+      }
+    };
+
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      if (ks + 1 < NK) fetch_rels(ks + 1, (ks + 1) & 1);
+      // RW_DEP: the k-step's LAST pixel fragment rides along as an unused operand of every MFMA of the k-step: the
+      // compiler then waits ONCE per k-step (for the newest fragment) instead of once per MFMA
+#ifdef RW_NO_DEP
+#define RW_DEP
+#else
+#define RW_DEP , "v"(RW_FRAG_LAST(ks))
+#endif
+#pragma unroll
+      for (int r = 0; r < RH; ++r) {
+        // Inline asm: the weight fragment (ring, loaded by the compiler's own buffer_load straight into the accumulator half
+        // of the register file) and the accumulators are "a" operands; pixel fragments and everything the VALU touches live
+        // in the architectural half.  What the compiler does not know about an asm MFMA: the 12 wait states between its
+        // result and a read of it — the guard at the start of every epilogue half.
+        if (P == 0 && ks == 0) asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, 0" : "=a"(acc[R0 + r]) : "a"(ring[(SP0 + ks) % RING]), "v"(RW_FRAG(ks, r)) RW_DEP);
+        else asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, %0" : "+a"(acc[R0 + r]) : "a"(ring[(SP0 + ks) % RING]), "v"(RW_FRAG(ks, r)) RW_DEP);
+        // ---- the gap behind this MFMA
+        {  // the next group's fragments, one per MFMA slot of this group
+          const int g = ks / SUB, q = (ks % SUB) * RH + r;
+          if (q < RFN && g + 1 < NG) rf[(g + 1) & 1][q] = ldg(g + 1, q);
+        }
+        const int gh = ks * RH + r, gp = HF * NGH + gh;
+#pragma unroll
+        for (int L = lub(gp); L < lub(gp + 1); ++L) unit_lump(L, ks & 1);
+#ifndef RW_ABL_NOEPI
+        if constexpr (EPI) {
+#pragma unroll
+          for (int LE = gh * NLE / NGH; LE < (gh + 1) * NLE / NGH; ++LE) epi_lump(LE);
+        }
+#endif
+      }
+      // this k-step's ring slot is free: the fragment RING positions ahead (the tile's last RING positions load nothing: the
+      // ring is primed again at the top of the next tile)
+#ifndef SW_ABL_NOSTREAM  // (ablation build: the ring keeps the tile's first fragments)
+      if (SP0 + ks + RING < G::S) load_frag(SP0 + ks + RING);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- prologue: the first phase's chunk into slot 0, the second phase's chunk in flight
+  TileG gc = tile_geom(0);
+  constexpr int CH0 = G::chunk_of(0), CH1 = G::chunk_of(1 % NPH);
+  const TileG g1st = NPH > 1 ? gc : tile_geom(1);  // the tile of the second phase
+  {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) issue_one(std::integral_constant<int, CH0>{}, gc, k, k < NI ? 0 : sDesc[(k < NI ? 0 : k - NI) * NT + tid]);
+    build_tables();
+    sync_lds();  // tables visible
+    RT_MARK(7)
+    if constexpr (REL_REGS) {
+#pragma unroll
+      for (int k = 0; k < NB; ++k) relreg[k] = sDesc[k * NT + tid];
+    }
+    if constexpr (BIAS_REGS) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        breg[j][0] = *reinterpret_cast<const float4*>(sTab + 2 * CIN + cg * 32 + 8 * (2 * j) + 4 * h);
+        breg[j][1] = *reinterpret_cast<const float4*>(sTab + 2 * CIN + cg * 32 + 8 * (2 * j + 1) + 4 * h);
+      }
+    }
+  }
+  TileG gp = tile_geom(nt);  // "previous tile" of the first one: no tile (its stores fall outside every tensor)
+  int ph = 0;                 // phases done: the chunk of phase ph sits in ring slot ph & 1
+  // tile i + 2 by increments (a division per tile and geometry is ~45 scalar instructions in a stream whose issue slots
+  // are the bottleneck)
+  TileG gnc = tile_geom(1);
+  int ty2 = (t0 + 2) / p.tiles_x, tx2 = (t0 + 2) - ty2 * p.tiles_x;
+  for (int i = 0; i < nt; ++i) {
+    const TileG gn = gnc, gnn = geom_at(ty2, tx2, i + 2 < nt);
+    // the tile's first RING weight fragments (the ring is not carried across the loop's back edge: see the header)
+#pragma unroll
+    for (int s = 0; s < RING && s < G::S; ++s) load_frag(s);
+    if (i == 0) {  // the block's first chunk: activated and written in one go, under the first fragments' flight
+      act_tab(CH0);
+      // (staging the first chunk re-issues every piece as the second one)
+#pragma unroll
+      for (int u = 0; u < NL * 4; ++u)
+        unit(std::integral_constant<int, CH0>{}, std::integral_constant<int, CH1>{}, gc, g1st, 0, u,
+             (u >> 2) < NI ? 0 : sDesc[((u >> 2) < NI ? 0 : (u >> 2) - NI) * NT + tid]);
+      RT_MARK(0)
+    }
+    // phase P stages the chunk of phase P + 1 and issues that of phase P + 2: both belong to the next tile once they wrap
+    auto run = [&](auto self, auto P_) __attribute__((always_inline)) {
+      constexpr int P = decltype(P_)::value;
+      sync_lds();
+#ifdef RW_SKEW
+      if (wave == 1) __builtin_amdgcn_s_sleep(RW_SKEW);
+      if (wave == 2) __builtin_amdgcn_s_sleep(2 * RW_SKEW);
+      if (wave == 3) __builtin_amdgcn_s_sleep(3 * RW_SKEW);
+#endif
+      RT_MARK(1)
+      const int slot_r = ph & 1;
+      half(P_, std::integral_constant<int, 0>{}, std::integral_constant<bool, P == 0>{}, slot_r, gp, ((P + 1) / NPH == 0 ? gc : gn), ((P + 2) / NPH == 0 ? gc : ((P + 2) / NPH == 1 ? gn : gnn)));
+      if constexpr (P == 0) {
+        if (i == 0) {  // (the first tile has no predecessor: what that epilogue summed up was not an output)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+        }
+      }
+      half(P_, std::integral_constant<int, 1>{}, std::integral_constant<bool, P == NPH - 1>{}, slot_r, gc, ((P + 1) / NPH == 0 ? gc : gn), ((P + 2) / NPH == 0 ? gc : ((P + 2) / NPH == 1 ? gn : gnn)));
+      ++ph;
+      RT_MARK(G::chunk_of(P) < NCH ? 2 : 3)
+      if constexpr (P + 1 < NPH) self(self, std::integral_constant<int, P + 1>{});
+    };
+    run(run, std::integral_constant<int, 0>{});
+    gp = gc;
+    gc = gn;
+    gnc = gnn;
+    if (++tx2 == p.tiles_x) { tx2 = 0; ++ty2; }
+  }
+  // the second half of the last tile's rows
+  asm volatile("s_nop 11" : "+a"(acc[RH]), "+a"(acc[RH + 1]), "+a"(acc[RH + 2]), "+a"(acc[RH + 3]));
+#pragma unroll
+  for (int e = 0; e < RH * 2; ++e) {
+    float4 t0, t1;
+    epi_bias(e & 1, t0, t1);
+    epi_unit(gp, RH + (e >> 1), e & 1, t0, t1);
+  }
+  RT_MARK(4)
+  if (has_stats) {
+    __syncthreads();
+    // per lane 16 couts (cg * 32 + 8 q + 4 h + i) of pixel column l32 of its rows: sum over the 32 columns and the two
+    // pixel groups
+    float* red = reinterpret_cast<float*>(smem);  // [256 threads][32 (+4 pad)]
+    constexpr int RED_ROW = 36;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<float4*>(red + tid * RED_ROW + 4 * q) = make_float4(ssum[4 * q], ssum[4 * q + 1], ssum[4 * q + 2], ssum[4 * q + 3]);
+      *reinterpret_cast<float4*>(red + tid * RED_ROW + 16 + 4 * q) = make_float4(ssq[4 * q], ssq[4 * q + 1], ssq[4 * q + 2], ssq[4 * q + 3]);
+    }
+    __syncthreads();
+    if (tid < 2 * CO) {
+      const int co = tid >> 1, st = tid & 1;
+      const int wcg = co >> 5, c32 = co & 31, q = c32 >> 3, hh = (c32 >> 2) & 1, i = c32 & 3;
+      double a = 0.0;
+      for (int l = 0; l < 32; ++l) {
+        const int t = wcg * 64 + hh * 32 + l;
+        a += (double)red[t * RED_ROW + st * 16 + 4 * q + i];
+      }
+      ds_stat_add(p.stats + ((long)b * p.cout + cb * CO + co) * 2 + st, (long long)llrint(a * (st ? DS_STAT_SQ_SCALE : DS_STAT_SUM_SCALE)));
+    }
+  }
+  RT_MARK(5)
+  RT_FLUSH
+}
+
+template <int NCH, int NSK, int MODE>
+int sw_launch(const SwK& k0, const ConvArgs& a, hipStream_t st) {
+  using G = SwGeom<NCH, NSK>;
+  SwK k = k0;
+  const int tiles = (a.H / G::TH) * (a.W / TW);
+  int g = ds_num_cus() / (a.B * k.ncb);
+#ifdef SW_TIMING  // (profiling builds only: fewer, fatter blocks)
+  if (getenv("DIFFSEP_SW_G")) g = atoi(getenv("DIFFSEP_SW_G"));
+#endif
+  if (g < 1) g = 1;
+  if (g > tiles) g = tiles;
+  k.G = g;
+  k.tiles_x = a.W / TW;
+  k.tiles_per_img = tiles;
+  auto kern = conv3x3_sw_kernel<NCH, NSK, MODE>;
+  DS_FUNC_LDS_ONCE(kern, G::LDS_TOTAL);
+  hipLaunchKernelGGL(kern, dim3(a.B * k.ncb * k.G), dim3(NT), G::LDS_TOTAL, st, k);
+  DS_LAUNCH_CHECK();
+  {
+    static char name[64] = {0};
+    if (!name[0]) snprintf(name, sizeof(name), "conv3x3_sw_kernel<%d,%d,%d>", NCH, NSK, MODE);
+    ds_set_last_conv_kernel(name);
+  }
+  return 0;
+}
+
+}  // namespace
+
+// The layers this kernel can take: 16-bit 3x3, Cout a multiple of 128, Cin = 64 .. 256 in 64-channel chunks (one tensor or the
+// in-place concat of two, split on a chunk boundary), input raw or GroupNorm + SiLU, optional folded 1x1 skip on 64 .. 256 raw
+// channels, whole 8 x 32 tiles, fragment-major weight copies at hand.  (A residual stays with the other kernels.)
+bool ds_conv_sw_supported(const ConvArgs& a) {
+  if (!(a.dtype == DS_BF16 && a.taps == 9 && a.Cout % CO == 0 && a.Cout <= 256 && a.Cin % KC == 0 && a.Cin >= KC && a.Cin <= 4 * KC &&
+        a.w_frag && a.w_bs == 0 && a.bias_mode == 0 && !a.div_b && !a.res && a.W % TW == 0 && a.H % RPW == 0 && a.H >= RPW &&
+        a.ldy >= a.Cout && a.ldy % 8 == 0))
+    return false;
+  if (a.x2 ? !(a.C1 % KC == 0 && a.C1 > 0 && a.C1 < a.Cin && a.ldx % 8 == 0 && a.ldx2 % 8 == 0) : a.ldx % 8 != 0) return false;
+  const bool gn = a.gn_scale || a.gn_acc1;
+  if (gn && !a.gn_act) return false;  // (affine without SiLU does not occur in front of a 3x3 convolution)
+  if (a.gn_acc1 && !(a.gn_groups > 0 && a.Cin % a.gn_groups == 0 && a.Cin / a.gn_groups <= 8 && (!a.x2 || a.gn_acc2))) return false;
+  if (a.sx) {
+    if (!(a.sw && a.sw_frag && a.sCin % KC == 0 && a.sCin >= KC && a.sCin <= 4 * KC && a.ldsx % 8 == 0 &&
+          (!a.sx2 || (a.sC1 % KC == 0 && a.sC1 > 0 && a.sC1 < a.sCin && a.ldsx2 % 8 == 0))))
+      return false;
+    if (!gn || a.Cin != 2 * KC) return false;  // (instantiated: the second convolution of a 128-channel block with its folded skip)
+  } else if (!gn && a.Cin > 2 * KC) {
+    return false;  // (instantiated raw: 64 / 128 input channels — the first convolution behind a resampling)
+  }
+  return true;
+}
+// ... and the launches it is given: what neither the register-weight kernel nor (small images) the small-image kernel holds, on
+// levels with at least one 8 x 32 tile per compute unit and cout block — and the register-weight kernel's own 128-cout launches
+// with fewer than two such tiles per unit, where its 295 KB weight prologue per block serves one or two tiles (nf = 64 at 64^2,
+// B = 16: 26.6 against 28.0 us, with a folded 64 / 128-channel skip 28.4 / 29.1 against 38 us; option no_sw_rw for the A/B)
+bool ds_conv_sw_eligible(const ConvArgs& a) {
+  if ((a.opts & DS_OPT_NO_SW) || !ds_conv_sw_supported(a)) return false;
+  const long tiles = (long)a.B * (a.H / RPW) * (a.W / TW) * (a.Cout / CO);
+  if (tiles < ds_num_cus() && !(a.opts & DS_OPT_RW_SMALL)) return false;
+  if (ds_conv_rw_eligible(a)) return !(a.opts & DS_OPT_NO_SW_RW) && tiles < 2L * ds_num_cus();
+  return true;
+}
+
+int ds_launch_conv_sw(const ConvArgs& a, hipStream_t st) {
+  SwK k;
+  k.x = reinterpret_cast<const bf16_t*>(a.x); k.x_bs = a.x_bs; k.ldx = a.ldx; k.C1 = a.x2 ? a.C1 : a.Cin;
+  k.x2 = reinterpret_cast<const bf16_t*>(a.x2); k.x2_bs = a.x2_bs; k.ldx2 = a.x2 ? a.ldx2 : a.ldx;
+  k.wfrag = reinterpret_cast<const bf16_t*>(a.w_frag);
+  k.swfrag = a.sx ? reinterpret_cast<const bf16_t*>(a.sw_frag) : nullptr;
+  k.frag_step = (unsigned)(a.Cout / 32) * 1024u;
+  k.gn_scale = a.gn_scale; k.gn_shift = a.gn_shift;
+  k.gn_acc1 = a.gn_acc1; k.gn_acc2 = a.gn_acc2; k.gn_gamma = a.gn_gamma; k.gn_beta = a.gn_beta;
+  k.gn_groups = a.gn_groups; k.gn_inv_count = a.gn_inv_count; k.gn_eps = a.gn_eps;
+  k.bias = a.bias; k.bias_b = a.bias_b; k.bias_b_ld = a.bias_b_ld;
+  k.out_scale = a.out_scale;
+  k.y = reinterpret_cast<bf16_t*>(a.y); k.y_bs = a.y_bs; k.ldy = a.ldy;
+  k.stats = a.stats_acc;
+  k.sx = reinterpret_cast<const bf16_t*>(a.sx); k.sx_bs = a.sx_bs; k.ldsx = a.ldsx; k.sC1 = a.sx2 ? a.sC1 : a.sCin;
+  k.sx2 = reinterpret_cast<const bf16_t*>(a.sx2); k.sx2_bs = a.sx2_bs; k.ldsx2 = a.sx2 ? a.ldsx2 : a.ldsx;
+  k.H = a.H; k.W = a.W; k.G = 0; k.ncb = a.Cout / CO; k.cout = a.Cout; k.tiles_x = 0; k.tiles_per_img = 0;
+#ifdef SW_TIMING  // (profiling builds only: stores / loads outside the tensors)
+  k.dbg = getenv("DIFFSEP_SW_DBG") ? atoi(getenv("DIFFSEP_SW_DBG")) : 0;
+#else
+  k.dbg = 0;
+#endif
+  const int mode = ((a.gn_scale || a.gn_acc1) && a.gn_act) ? 2 : 0;
+  const int nch = a.Cin / KC, nsk = a.sx ? a.sCin / KC : 0;
+  if (mode == 0) {
+    if (nch == 1) return sw_launch<1, 0, 0>(k, a, st);
+    return sw_launch<2, 0, 0>(k, a, st);
+  }
+  if (nsk == 0) {
+    if (nch == 1) return sw_launch<1, 0, 2>(k, a, st);
+    if (nch == 2) return sw_launch<2, 0, 2>(k, a, st);
+    if (nch == 3) return sw_launch<3, 0, 2>(k, a, st);
+    return sw_launch<4, 0, 2>(k, a, st);
+  }
+  if (nsk == 1) return sw_launch<2, 1, 2>(k, a, st);
+  if (nsk == 2) return sw_launch<2, 2, 2>(k, a, st);
+  if (nsk == 3) return sw_launch<2, 3, 2>(k, a, st);
+  return sw_launch<2, 4, 2>(k, a, st);
+}

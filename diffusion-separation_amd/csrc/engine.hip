@@ -145,9 +145,9 @@ struct ArchBuilder {
     }
     m.pk0 = pack(out, 9, in);
     m.pk1 = pack(out, 9, out);
-    if (ds_rw_frag_shape(9, in, out)) m.pf0 = pack(out, 9, in);
-    if (ds_rw_frag_shape(9, out, out)) m.pf1 = pack(out, 9, out);
-    if (m.has_conv2 && ds_rw_frag_shape(1, in, out)) m.pf2 = pack(out, 1, in);
+    if (ds_rw_frag_shape(9, in, out) || ds_sw_frag_shape(9, in, out)) m.pf0 = pack(out, 9, in);
+    if (ds_rw_frag_shape(9, out, out) || ds_sw_frag_shape(9, out, out)) m.pf1 = pack(out, 9, out);
+    if (m.has_conv2 && (ds_rw_frag_shape(1, in, out) || ds_sw_frag_shape(1, in, out))) m.pf2 = pack(out, 1, in);
     if (in == 256 && in_c1 == 128 && out == 128 && !up && !down) {
       m.pf0a = pack(out, 9, 128); m.pf0b = pack(out, 9, 128); m.pf2a = pack(out, 1, 128); m.pk2b = pack(out, 1, 128);
     }
@@ -359,6 +359,8 @@ unsigned ds_default_opts() {
     if (on("DIFFSEP_RW_QUARTER")) g_opts |= DS_OPT_RW_QUARTER;
     if (on("DIFFSEP_RW_BIG_HALF")) g_opts |= DS_OPT_RW_BIG_HALF;
     if (on("DIFFSEP_NO_STFT_FUSED")) g_opts |= DS_OPT_NO_STFT_FUSED;
+    if (on("DIFFSEP_NO_SW")) g_opts |= DS_OPT_NO_SW;
+    if (on("DIFFSEP_NO_SW_RW")) g_opts |= DS_OPT_NO_SW_RW;
   });
   return g_opts;
 }
@@ -384,7 +386,9 @@ static int opt_bit(const char* name, unsigned* bit) {
       {"rw_half", DS_OPT_RW_HALF},
       {"rw_quarter", DS_OPT_RW_QUARTER},
       {"rw_big_half", DS_OPT_RW_BIG_HALF},
-      {"no_split256", DS_OPT_NO_SPLIT256}};
+      {"no_split256", DS_OPT_NO_SPLIT256},
+      {"no_sw", DS_OPT_NO_SW},
+      {"no_sw_rw", DS_OPT_NO_SW_RW}};
   for (const auto& t : tab)
     if (!strcmp(name, t.n)) { *bit = t.b; return 0; }
   return 1;
@@ -710,6 +714,7 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
   // two tiles per block and the pair is SLOWER than the generic tile (61.5 + 50.0 against 49.3 + 42.6 us per block in the graph).
   if (e->cfg.dtype == DS_BF16 && mode == 0 && x.p2 && m.pf0a >= 0 && x.C1 == 128 && x.sa && x.sa2 && x.W % 32 == 0 && x.H % 8 == 0 &&
       x.H >= 128 && (long)B * (x.H / 4) * (x.W / 32) >= ds_num_cus() &&
+      (e->opts & DS_OPT_NO_SW) &&  // (round 5: the streamed-weight kernel takes these blocks whole; the route stays for the A/B)
       !(e->opts & (DS_OPT_NO_RW | DS_OPT_NO_RW128 | DS_OPT_NO_SPLIT256 | DS_OPT_NO_WFRAG))) {
     Tn xa = x, xb = x;
     xa.C = 128; xa.p2 = nullptr; xa.C1 = 0; xa.ld2 = 0; xa.sa2 = nullptr;
@@ -1769,6 +1774,47 @@ extern "C" int32_t diffsep_conv2d_fused(const void* x, const void* x2, int32_t C
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.taps = ksize == 3 ? 9 : 1;
   a.dtype = dtype == DS_F32_SPLIT ? DS_F32 : dtype; a.split = dtype == DS_F32_SPLIT;
   return ds_launch_conv(a, (hipStream_t)stream);
+}
+
+// Unit entry of the streamed-weight 3x3 kernel (conv3x3_sw.hip), whatever the dispatch would have chosen for the shape: dense
+// NHWC tensors, weights already in the fragment-major order of diffsep_frag_index (include/diffsep_hip.h).
+extern "C" int32_t diffsep_conv3x3_streamed(const void* x, const void* x2, int32_t C1, const float* gn_scale,
+                                            const float* gn_shift, const void* w_frag, const float* bias,
+                                            const float* bias_b, const void* sx, const void* sx2, int32_t sC1,
+                                            int32_t sCin, const void* sw_frag, void* y, int32_t B, int32_t H, int32_t W,
+                                            int32_t Cin, int32_t Cout, float out_scale, int32_t dtype, int64_t* stats,
+                                            void* stream) {
+  DS_CHECK(x && w_frag && y, "conv3x3_streamed: null pointer");
+  DS_CHECK(B > 0 && H > 0 && W > 0, "conv3x3_streamed: empty problem");
+  DS_CHECK(!x2 || (C1 > 0 && C1 < Cin), "conv3x3_streamed: bad concat split");
+  DS_CHECK(!sx || (sw_frag && sCin > 0 && (!sx2 || (sC1 > 0 && sC1 < sCin))), "conv3x3_streamed: bad skip operands");
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.opts = ds_default_opts();
+  a.stats_acc = (long long*)stats;
+  const int c1 = x2 ? C1 : Cin;
+  a.x = x; a.x_bs = (long)H * W * c1; a.ldx = c1;
+  a.x2 = x2; a.x2_bs = (long)H * W * (Cin - c1); a.ldx2 = Cin - c1; a.C1 = x2 ? C1 : 0;
+  a.gn_scale = gn_scale; a.gn_shift = gn_shift; a.gn_act = gn_scale ? 1 : 0;
+  a.w = w_frag; a.w_frag = w_frag; a.w_bs = 0;
+  a.bias = bias; a.bias_b = bias_b; a.bias_b_ld = Cout; a.bias_mode = 0;
+  if (sx) {
+    const int s1 = sx2 ? sC1 : sCin;
+    a.sx = sx; a.sx_bs = (long)H * W * s1; a.ldsx = s1;
+    a.sx2 = sx2; a.sx2_bs = (long)H * W * (sCin - s1); a.ldsx2 = sCin - s1; a.sC1 = sx2 ? sC1 : 0; a.sCin = sCin;
+    a.sw = sw_frag; a.sw_frag = sw_frag;
+  }
+  a.out_scale = out_scale;
+  a.y = y; a.y_bs = (long)H * W * Cout; a.ldy = Cout;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.taps = 9;
+  a.dtype = dtype;
+  DS_CHECK((long)H * W * (Cin > Cout ? Cin : Cout) * 2 < 2147483647L, "conv3x3_streamed: image too large for 32-bit buffer offsets");
+  DS_CHECK(ds_conv_sw_supported(a), "conv3x3_streamed: shape outside the kernel's instantiations (16-bit, Cout = 128 / 256, Cin = 64 .. 256 "
+                                    "by 64, W % 32 == 0, H % 8 == 0; a skip needs GroupNorm and Cin = 128; raw input: Cin <= 128)");
+  return ds_launch_conv_sw(a, (hipStream_t)stream);
+}
+extern "C" int64_t diffsep_frag_index(int32_t cout, int32_t tap, int32_t cin, int32_t taps, int32_t Cout) {
+  return ds_rw_frag_index(cout, tap, cin, taps, Cout);
 }
 
 extern "C" int32_t diffsep_conv2d_chunk(int32_t ksize, int32_t dtype) { return ds_conv_chunk(ksize == 3 ? 9 : 1, dtype); }

@@ -56,6 +56,41 @@ def pack_conv_weight(w, dtype, chunk=0):
     return wp.contiguous().to(dtype)
 
 
+def pack_frag_weight(w, dtype):
+    """OIHW float32 -> the fragment-major order of the register-weight / streamed-weight kernels (include/diffsep_hip.h,
+    diffsep_frag_index): element (o, tap, i) at ((((i // 64 * taps + tap) * 4 + i % 64 // 16) * (O // 32) + o // 32) * 64
+    + (i % 16 // 8) * 32 + o % 32) * 8 + i % 8.  I % 64 == 0, O % 32 == 0."""
+    O, I, kh, kw = w.shape
+    taps = kh * kw
+    assert I % 64 == 0 and O % 32 == 0
+    o, t, i = torch.meshgrid(torch.arange(O), torch.arange(taps), torch.arange(I), indexing="ij")
+    idx = ((((i // 64 * taps + t) * 4 + (i % 64) // 16) * (O // 32) + o // 32) * 64 + ((i % 16) // 8) * 32 + o % 32) * 8 + i % 8
+    out = torch.empty(O * taps * I, dtype=torch.float32)
+    out[idx.reshape(-1)] = w.permute(0, 2, 3, 1).reshape(-1).float()
+    return out.to(dtype)
+
+
+def conv3x3_streamed(x, w_frag, cout, x2=None, gn=None, bias=None, bias_b=None, skip=None, out_scale=1.0, stats=False, out=None):
+    """The streamed-weight 3x3 kernel as a unit (diffsep_conv3x3_streamed).  x [B,H,W,C1] (+ x2 [B,H,W,C2]) dense 16-bit;
+    gn = (scale, shift) [B,Cin] f32 -> SiLU(GroupNorm(.)) on the fly; skip = (sx, sx2 | None, sw_frag): folded 1x1 on raw channels."""
+    B, H, W, C1 = x.shape
+    Cin = C1 + (x2.shape[-1] if x2 is not None else 0)
+    y = torch.zeros((B, H, W, cout), dtype=x.dtype, device=x.device) if out is None else out
+    sc, sh = gn if gn is not None else (None, None)
+    st = None
+    if stats is True:
+        st = torch.zeros((B, cout, 2), dtype=torch.int64, device=x.device)
+    elif stats is not False:
+        st = stats  # (a tensor: the launch adds into it)
+    sx, sx2, swf = skip if skip is not None else (None, None, None)
+    sC1 = sx.shape[-1] if sx is not None else 0
+    sCin = sC1 + (sx2.shape[-1] if sx2 is not None else 0)
+    check(_L(x).diffsep_conv3x3_streamed(_ptr(x), _ptr(x2), C1, _ptr(sc), _ptr(sh), _ptr(w_frag), _ptr(bias), _ptr(bias_b),
+                                         _ptr(sx), _ptr(sx2), sC1, sCin, _ptr(swf), _ptr(y), B, H, W, Cin, cout, out_scale,
+                                         _dt(x), _ptr(st), _stream_ptr()), _L(x))
+    return (y, st) if stats is not False else y
+
+
 def conv2d_chunk(ksize, dtype):
     return lib().diffsep_conv2d_chunk(ksize, F32 if dtype == torch.float32 else BF16)  # (the same in both builds)
 

@@ -283,6 +283,19 @@ int32_t diffsep_conv2d_fused(const void* x, const void* x2, int32_t C1, const fl
  * [Cin_pad / kc][k*k][Cout][kc] (the layout the engine keeps its weights in: one K stage of the kernel is then
  * contiguous in memory and is fetched in full 128-byte lines). */
 int32_t diffsep_conv2d_chunk(int32_t ksize, int32_t dtype);
+/* The streamed-weight 3x3 kernel (csrc/conv3x3_sw.hip; the 128-cout layers with 192 / 256 input channels or a folded 1x1 skip
+ * on up to 256 raw channels: ncsnpp.py:409-417, layerspp.py:291-323) as a unit, whatever the dispatch would pick.  Dense NHWC
+ * 16-bit tensors: x [B][H][W][C1 or Cin], x2 (nullable) the other Cin - C1 channels; act(GroupNorm(.)) from per-(b, c)
+ * scale / shift when gn_scale != NULL (SiLU), raw input otherwise; optional folded skip y += sw * cat([sx, sx2]) on RAW channels;
+ * y [B][H][W][Cout] = (conv + bias + bias_b[b]) * out_scale; `stats` as in diffsep_conv2d_fused.  w_frag / sw_frag: the
+ * [Cout][3 x 3][Cin] / [Cout][sCin] weights in FRAGMENT-major order — element (cout, tap, cin) at diffsep_frag_index(cout, tap,
+ * cin, taps, Cout): one k-step (64-channel chunk, tap, 16-channel block) of all couts is contiguous, cout group by cout group,
+ * so that a wave's 1 KB load instruction is one MFMA B-operand. */
+int32_t diffsep_conv3x3_streamed(const void* x, const void* x2, int32_t C1, const float* gn_scale, const float* gn_shift,
+                                 const void* w_frag, const float* bias, const float* bias_b, const void* sx, const void* sx2,
+                                 int32_t sC1, int32_t sCin, const void* sw_frag, void* y, int32_t B, int32_t H, int32_t W,
+                                 int32_t Cin, int32_t Cout, float out_scale, int32_t dtype, int64_t* stats, void* stream);
+int64_t diffsep_frag_index(int32_t cout, int32_t tap, int32_t cin, int32_t taps, int32_t Cout);
 /* `stats` (nullable): channel-sum accumulators of the OUTPUT for the next GroupNorm, [B][Cout][2] int64 fixed point
  * (sum * 2^24, sum of squares * 2^16; exact to 6e-8 / 1.5e-5 per tile, no overflow while the per-image sum of
  * squares of a channel stays below 1.4e14).  Every block ADDS its tile's totals with integer atomics (associative:

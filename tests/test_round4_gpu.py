@@ -249,9 +249,10 @@ def test_fused_attention_block_matches_the_oracle(kind, dt, tol, B, H, W):
 
 # ------------------------------------------------------------------------------------------------ nf = 128: split cat(128, 128) blocks
 def test_nf128_cat_blocks_as_two_register_weight_launches_vs_oracle():
-    # the published width at full size: the cat(128, 128) -> 128 residual blocks of the 256^2 / 128^2 levels run each convolution
-    # as two 128-channel register-weight launches chained through the residual (engine.hip res_block); against the CPU oracle,
-    # and against the one-launch generic tile of rounds 1 - 3 (option no_split256) on the same operands
+    # the published width at full size: the cat(128, 128) -> 128 residual blocks of the 256^2 / 128^2 levels.  Round 4 ran each
+    # convolution as two 128-channel register-weight launches chained through the residual (engine.hip res_block); since round 5
+    # the streamed-weight kernel takes them whole (option no_sw restores the two-launch route, no_sw + no_split256 the one-launch
+    # generic tile of rounds 1 - 3).  All three against the CPU oracle on the same operands.
     cfg = O.default_config(128, 2, spec_factor=0.15)
     mcfg = _lib.model_config(nf=128, num_sources=2, dtype=_lib.F16, spec_factor=0.15)
     sd = synth.synth_state_dict([(n, s) for n, s, _ in param_table(mcfg)], 7)
@@ -262,10 +263,13 @@ def test_nf128_cat_blocks_as_two_register_weight_launches_vs_oracle():
     xt = O.prior_sampling(cfg, mixn, rnd("s256.z", (1, 2, T)))
     t = torch.tensor([0.4])
     ref = O.score_forward(O.to_torch(sd), cfg, xt, t, mixn)
+    c = eng.score(xt.to(DEV), t.to(DEV), mixn.to(DEV))
+    eng.set_option("no_sw", 1)
     a = eng.score(xt.to(DEV), t.to(DEV), mixn.to(DEV))
     eng.set_option("no_split256", 1)
     b = eng.score(xt.to(DEV), t.to(DEV), mixn.to(DEV))
     eng.set_option("no_split256", 0)
-    ra, rb = rel_rms(a, ref), rel_rms(b, ref)
-    print(f"\n[nf128 f16 score, T=32000 vs oracle] two launches per convolution {ra:.3e}, one launch {rb:.3e}")
-    assert ra < 8e-3 and rb < 8e-3 and not torch.equal(a, b)
+    eng.set_option("no_sw", 0)
+    ra, rb, rc = rel_rms(a, ref), rel_rms(b, ref), rel_rms(c, ref)
+    print(f"\n[nf128 f16 score, T=32000 vs oracle] streamed weights {rc:.3e}, two launches per convolution {ra:.3e}, one launch {rb:.3e}")
+    assert ra < 8e-3 and rb < 8e-3 and rc < 8e-3 and not torch.equal(a, b) and not torch.equal(a, c)

@@ -1,0 +1,114 @@
+"""GPU parity of the streamed-weight 3x3 kernel (conv3x3_sw.hip: 64 .. 256 -> 128 / 256 couts, optional folded 1x1 skip on up
+to 256 raw channels, 16-bit storage) through the C-ABI unit entry diffsep_conv3x3_streamed against torch fp32 on the CPU (same
+16-bit-rounded operands), and of the engine's dispatch to it (whole residual blocks against the CPU oracle).
+Tolerance: 4e-3 relative RMS per convolution (16-bit storage of the activated input and of the output; 6e-3 with bfloat16 weights
+and a 256-channel skip), 1.5e-2 per residual block.  Reference layers: layers.py:141-156, layerspp.py:291-323, ncsnpp.py:409-417."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from diffsep_amd import _lib, ops, synth
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = "cuda"
+
+
+def rel_rms(a, b):
+    a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
+    b = b.detach().double().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)) / (np.sqrt(np.mean(b ** 2)) + 1e-30))
+
+
+def rnd(tag, shape, scale=1.0):
+    return torch.from_numpy(synth.synth_noise(tag, shape)) * scale
+
+
+def test_frag_index_matches_the_library():
+    """ops.pack_frag_weight restates include/diffsep_hip.h's formula: check it against diffsep_frag_index (host function)."""
+    L = _lib.lib("f16")
+    for (O, I, taps) in [(128, 64, 9), (128, 256, 9), (256, 192, 1)]:
+        w = torch.arange(O * I * taps, dtype=torch.float32).reshape(O, I, 3 if taps == 9 else 1, 3 if taps == 9 else 1)
+        p = ops.pack_frag_weight(w, torch.float32)
+        for (o, t, i) in [(0, 0, 0), (5, taps - 1, 17), (O - 1, taps // 2, I - 1), (33, 0, 70 % I), (97, taps - 1, 63)]:
+            k = L.diffsep_frag_index(o, t, i, taps, O)
+            assert p[k] == w.reshape(O, I, taps)[o, i, t]
+
+
+# (B, H, W): one tile per block; several tiles per block and image borders inside a block's range; one row of tiles; wide
+SHAPES = [(2, 8, 32), (3, 64, 96), (40, 64, 64), (1, 128, 256), (5, 24, 32)]
+# (C1, C2, raw input?, skip channels (first, second), Cout)
+CASES = [
+    (64, 0, True, None, 128),        # 64 -> 128 behind a down-sampling (raw input)
+    (128, 0, True, None, 128),
+    (128, 0, False, None, 128),
+    (128, 64, False, None, 128),     # cat(128, 64) -> 128
+    (128, 128, False, None, 128),    # cat(128, 128) -> 128
+    (128, 0, False, (64, 0), 128),
+    (128, 0, False, (128, 0), 128),
+    (128, 0, False, (128, 64), 128),   # Conv_1 + folded skip on cat(128, 64)
+    (128, 0, False, (128, 128), 128),  # Conv_1 + folded skip on cat(128, 128)
+    (128, 128, False, None, 256),    # two cout blocks
+]
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W", SHAPES)
+@pytest.mark.parametrize("C1,C2,raw,skip,CO", CASES)
+def test_sw_conv3x3_matches_torch(dt, B, H, W, C1, C2, raw, skip, CO):
+    if dt == torch.bfloat16 and (B, H, W) not in ((2, 8, 32), (3, 64, 96)):
+        pytest.skip("bfloat16 build: two shapes")
+    if B * H * W > 200000 and (raw or CO == 256):
+        pytest.skip("large case covered by the GroupNorm variants")
+    C = C1 + C2
+    tag = f"{B}.{H}.{C1}.{C2}"
+    a = (rnd("sw.a" + tag, (B, H, W, C1), 1.2) + 0.1).to(DEV, dt)
+    bt = (rnd("sw.b" + tag, (B, H, W, C2), 0.9) - 0.2).to(DEV, dt) if C2 else None
+    w = rnd(f"sw.w{C}.{CO}", (CO, C, 3, 3), 1.0 / math.sqrt(9 * C))
+    bias, bb = rnd("sw.bias", (CO,), 0.1).to(DEV), rnd(f"sw.bb{B}", (B, CO), 0.1).to(DEV)
+    sc = (1.0 + rnd(f"sw.sc{B}{C}", (B, C), 0.2)).to(DEV)
+    sh = rnd(f"sw.sh{B}{C}", (B, C), 0.2).to(DEV)
+    xf = torch.cat([a.float(), bt.float()], -1) if C2 else a.float()
+    if not raw:
+        xf = F.silu(xf * sc[:, None, None, :] + sh[:, None, None, :]).to(dt).float()
+    ref = F.conv2d(xf.cpu().permute(0, 3, 1, 2), w.to(dt).float(), bias.cpu(), padding=1).permute(0, 2, 3, 1)
+    ref = ref + bb.cpu()[:, None, None, :]
+    sk = None
+    if skip is not None:
+        s1, s2 = skip
+        sa = rnd("sw.sa" + tag, (B, H, W, s1), 1.1).to(DEV, dt)
+        sb = rnd("sw.sb" + tag, (B, H, W, s2), 0.8).to(DEV, dt) if s2 else None
+        sw = rnd(f"sw.sw{s1 + s2}", (CO, s1 + s2, 1, 1), 1.0 / math.sqrt(s1 + s2))
+        sxf = torch.cat([sa.float(), sb.float()], -1) if s2 else sa.float()
+        ref = ref + F.conv2d(sxf.cpu().permute(0, 3, 1, 2), sw.to(dt).float(), None).permute(0, 2, 3, 1)
+        sk = (sa, sb, ops.pack_frag_weight(sw, dt).to(DEV))
+    ref = ref * 0.70710678
+    y, st = ops.conv3x3_streamed(a, ops.pack_frag_weight(w, dt).to(DEV), CO, x2=bt, gn=None if raw else (sc, sh), bias=bias,
+                                 bias_b=bb, skip=sk, out_scale=0.70710678, stats=True)
+    tol = 4e-3 if dt == torch.float16 else 8e-3
+    assert rel_rms(y.float(), ref) < tol
+    s = ops.stats_to_float(st)
+    assert torch.allclose(s[..., 0].cpu(), ref.double().sum((1, 2)), rtol=3e-3, atol=3e-3 * H * W)
+    assert torch.allclose(s[..., 1].cpu(), (ref.double() ** 2).sum((1, 2)), rtol=4e-3, atol=4e-3 * H * W)
+    # plain launch: no bias / statistics
+    y2 = ops.conv3x3_streamed(a, ops.pack_frag_weight(w, dt).to(DEV), CO, x2=bt, gn=None if raw else (sc, sh), skip=sk)
+    ref2 = (ref / 0.70710678) - bias.cpu() - bb.cpu()[:, None, None, :]
+    assert rel_rms(y2.float(), ref2) < tol
+    # the same launch twice: bit-identical (fixed summation order, integer statistics)
+    y3, st3 = ops.conv3x3_streamed(a, ops.pack_frag_weight(w, dt).to(DEV), CO, x2=bt, gn=None if raw else (sc, sh), bias=bias,
+                                   bias_b=bb, skip=sk, out_scale=0.70710678, stats=True)
+    assert torch.equal(y, y3) and torch.equal(st, st3)
+
+
+def test_sw_rejects_what_it_does_not_instantiate():
+    a = torch.zeros((1, 8, 32, 64), device=DEV, dtype=torch.float16)
+    w = ops.pack_frag_weight(torch.zeros((64, 64, 3, 3)), torch.float16).to(DEV)
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_streamed(a, w, 64)  # 64 couts: the register-weight kernel's layer
+    a2 = torch.zeros((1, 12, 32, 128), device=DEV, dtype=torch.float16)
+    w2 = ops.pack_frag_weight(torch.zeros((128, 128, 3, 3)), torch.float16).to(DEV)
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_streamed(a2, w2, 128)  # H % 8 != 0
