@@ -202,6 +202,9 @@ struct ConvArgs {
   // optional second copies of w / sw in the register-weight kernel's FRAGMENT-major order (conv3x3_rw.hip, ds_rw_frag_index):
   // one load instruction of a wave = 1 KB of contiguous memory.  Null: that kernel gathers its fragments from w / sw.
   const void* w_frag; const void* sw_frag;
+  // split mode (conv3x3_sws.hip): w_frag / sw_frag are hi / lo fragment copies (ds_sws_frag_index); ident_frag = that copy of the
+  // Cout x Cout identity matrix (taps = 1), which a residual meets as a folded skip
+  const void* ident_frag;
   // optional fused 1x1 skip convolution on the raw block input (3x3 launches only): y += sw * cat([sx, sx2])
   const void* sx; long sx_bs; int ldsx;  //   [B][M][ldsx], sCin channels (sC1 from sx when sx2 != null)
   const void* sx2; long sx2_bs; int ldsx2; int sC1; int sCin;
@@ -244,6 +247,7 @@ struct ConvArgs {
 #define DS_OPT_NO_SW 4096u       // no streamed-weight 3x3 kernel (conv3x3_sw.hip): generic tile / two-launch cat route instead (A/B)
 #define DS_OPT_NO_SW_RW 8192u    // ... only for the launches the register-weight kernel does not take (A/B: by default it also takes the
                                  // 128-cout launches with < 2 tiles of 8 x 32 per CU, where that kernel pays its weight prologue per tile)
+#define DS_OPT_NO_SWS 16384u     // no split-mode streamed-weight kernel (conv3x3_sws.hip): the generic tile in split mode instead (A/B)
 #define DS_OPT_NO_WFRAG 32u   // the engine does not hand the fragment-major weight copies to the register-weight kernel (A/B)
 unsigned ds_default_opts();
 int ds_num_cus();  // compute units of the current device (cached per device ordinal)
@@ -270,6 +274,16 @@ inline bool ds_sw_frag_shape(int taps, int Cin, int Cout) { return (Cout == 128 
 bool ds_conv_sw_supported(const ConvArgs& a);  // conv3x3_sw.hip: streamed weights, 64 .. 256 -> 128 n couts, 16-bit
 bool ds_conv_sw_eligible(const ConvArgs& a);   // ... and dispatched there
 int ds_launch_conv_sw(const ConvArgs& a, hipStream_t st);
+// conv3x3_sws.hip: the split mode's streamed-weight kernel (fp32 tensors, hi / lo bfloat16 planes).  Element (cout co, tap, input
+// channel ch) of a [Cout][taps][Cin] weight tensor, plane 0 = bf16(w), plane 1 = bf16(w - plane 0), lives at
+//   ((((ch / 32 * taps + tap) * 2 + ch % 32 / 16) * 2 + plane) * (Cout / 32) + co / 32) * 64 + (ch % 16 / 8) * 32 + co % 32) * 8 + ch % 8
+__host__ __device__ inline long ds_sws_frag_index(int co, int tap, int ch, int taps, int Cout, int plane) {
+  return ((((((long)(ch / 32) * taps + tap) * 2 + (ch % 32) / 16) * 2 + plane) * (Cout / 32) + co / 32) * 64 + ((ch % 16) / 8) * 32 + co % 32) * 8 + ch % 8;
+}
+inline bool ds_sws_frag_shape(int taps, int Cin, int Cout) { return (Cout == 64 || Cout == 128) && Cin % 64 == 0 && Cin >= 64 && Cin <= 256; }
+bool ds_conv_sws_supported(const ConvArgs& a);
+bool ds_conv_sws_eligible(const ConvArgs& a);
+int ds_launch_conv_sws(const ConvArgs& a, hipStream_t st);
 bool ds_conv_ws_eligible(const ConvArgs& a);   // conv3x3_ws.hip: weight-stationary 64 -> 64 bf16 kernel
 int ds_launch_conv_ws(const ConvArgs& a, hipStream_t st);
 bool ds_conv_thin_eligible(const ConvArgs& a);   // conv3x3_ws.hip: the 8 -> 64 first layer

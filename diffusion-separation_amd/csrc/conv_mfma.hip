@@ -958,8 +958,9 @@ int ds_conv_chunk(int taps, int dtype) {
 // Which instantiation ds_launch_conv picks (profiling label): 0/1/2 = 3x3 {8x32xBN64, 8x32xBN32, 8x8xBN64},
 // 3/4/5 = the same tiles for 1x1 / GEMM, 6 = the weight-stationary 64 -> 64 kernel (conv3x3_ws.hip), 7 = the
 // small-image kernel (conv3x3_small.hip), 8 = the register-weight kernel (conv3x3_rw.hip), 9 = the streamed-weight kernel
-// (conv3x3_sw.hip).
+// (conv3x3_sw.hip), 10 = its split-mode sibling (conv3x3_sws.hip).
 int ds_conv_config_id(const ConvArgs& a) {
+  if (ds_conv_sws_eligible(a)) return 10;
   if (ds_conv_sw_eligible(a)) return 9;
   if (ds_conv_rw_eligible(a)) return 8;
   if (ds_conv_ws_eligible(a) || ds_conv_thin_eligible(a) || ds_conv_thin_out_eligible(a)) return 6;
@@ -988,6 +989,7 @@ int ds_launch_conv(const ConvArgs& a, hipStream_t st) {
     DS_CHECK(M * mld * esz < 2147483647L, "conv: image too large for 32-bit buffer offsets");
     DS_CHECK((long)a.Cout * a.taps * a.Cin * esz < 2147483647L, "conv: weight tensor too large");
   }
+  if (ds_conv_sws_eligible(a)) return ds_launch_conv_sws(a, st);
   if (ds_conv_sw_eligible(a)) return ds_launch_conv_sw(a, st);
   if (ds_conv_rw_eligible(a)) return ds_launch_conv_rw(a, st);
   if (ds_conv_ws_eligible(a)) return ds_launch_conv_ws(a, st);

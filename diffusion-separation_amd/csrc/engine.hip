@@ -51,6 +51,9 @@ struct Module {
   // second copies of Conv_0 / Conv_1 / Conv_2 in the register-weight kernel's fragment-major order (16-bit engines, the shapes
   // that kernel takes: ds_rw_frag_shape), -1 = none
   long pf0 = -1, pf1 = -1, pf2 = -1;
+  // split engines: the copies are hi / lo plane pairs (ds_sws_frag_index); pf_id = that copy of the identity matrix, which the
+  // residual of a block without Conv_2 meets as a folded skip (conv3x3_sws.hip)
+  long pf_id = -1;
   // cat(128, 128) -> 128 blocks whose convolutions run as two 128-channel launches (res_block): fragment-major copies of the
   // two halves of Conv_0, of the first half of Conv_2, and the second half of Conv_2 packed for a stand-alone 1x1 launch
   long pf0a = -1, pf0b = -1, pf2a = -1, pk2b = -1;
@@ -145,9 +148,10 @@ struct ArchBuilder {
     }
     m.pk0 = pack(out, 9, in);
     m.pk1 = pack(out, 9, out);
-    if (ds_rw_frag_shape(9, in, out) || ds_sw_frag_shape(9, in, out)) m.pf0 = pack(out, 9, in);
-    if (ds_rw_frag_shape(9, out, out) || ds_sw_frag_shape(9, out, out)) m.pf1 = pack(out, 9, out);
-    if (m.has_conv2 && (ds_rw_frag_shape(1, in, out) || ds_sw_frag_shape(1, in, out))) m.pf2 = pack(out, 1, in);
+    if (ds_rw_frag_shape(9, in, out) || ds_sw_frag_shape(9, in, out) || ds_sws_frag_shape(9, in, out)) m.pf0 = pack(out, 9, in);
+    if (ds_rw_frag_shape(9, out, out) || ds_sw_frag_shape(9, out, out) || ds_sws_frag_shape(9, out, out)) m.pf1 = pack(out, 9, out);
+    if (m.has_conv2 && (ds_rw_frag_shape(1, in, out) || ds_sw_frag_shape(1, in, out) || ds_sws_frag_shape(1, in, out))) m.pf2 = pack(out, 1, in);
+    if (!m.has_conv2 && ds_sws_frag_shape(1, out, out)) m.pf_id = pack(out, 1, out);
     if (in == 256 && in_c1 == 128 && out == 128 && !up && !down) {
       m.pf0a = pack(out, 9, 128); m.pf0b = pack(out, 9, 128); m.pf2a = pack(out, 1, 128); m.pk2b = pack(out, 1, 128);
     }
@@ -317,6 +321,21 @@ __global__ __launch_bounds__(256) void repack_frag_kernel(const float* __restric
     dst[ds_rw_frag_index(o, tap, i, taps, O)] = f2h(src[o * so + i * si + tap * st]);
   }
 }
+// ... and the split mode's: hi = bf16(w), lo = bf16(w - hi) at ds_sws_frag_index(o, tap, i, plane); src == null: the O x O identity
+__global__ __launch_bounds__(256) void repack_frag_split_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int O, int I,
+                                                                int taps, long so, long si, long st) {
+  const long total = (long)O * taps * I;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int i = (int)(idx % I);
+    const long r = idx / I;
+    const int tap = (int)(r % taps), o = (int)(r / taps);
+    const float w = src ? src[o * so + i * si + tap * st] : (o == i ? 1.f : 0.f);
+    const uint32_t hi = pack_bf16x2(w, 0.f);
+    const uint32_t lo = pack_bf16x2(w - bf_lo(hi), 0.f);
+    dst[ds_sws_frag_index(o, tap, i, taps, O, 0)] = (bf16_t)(hi & 0xffffu);
+    dst[ds_sws_frag_index(o, tap, i, taps, O, 1)] = (bf16_t)(lo & 0xffffu);
+  }
+}
 // Fused attention block: M[c'][k] = sum_c Wk[c'][c] Wq[k][c] (NIN.W is [in][out]: Wq^T applied to h gives q) in fragment-major
 // order, and b'[c'] = sum_c Wk[c'][c] b_q[c] — fp32 sums, one rounding to the storage type (attn_fused.hip)
 __global__ __launch_bounds__(256) void attn_fold_qk_kernel(const float* __restrict__ wq, const float* __restrict__ wk,
@@ -360,6 +379,7 @@ unsigned ds_default_opts() {
     if (on("DIFFSEP_RW_BIG_HALF")) g_opts |= DS_OPT_RW_BIG_HALF;
     if (on("DIFFSEP_NO_STFT_FUSED")) g_opts |= DS_OPT_NO_STFT_FUSED;
     if (on("DIFFSEP_NO_SW")) g_opts |= DS_OPT_NO_SW;
+    if (on("DIFFSEP_NO_SWS")) g_opts |= DS_OPT_NO_SWS;
     if (on("DIFFSEP_NO_SW_RW")) g_opts |= DS_OPT_NO_SW_RW;
   });
   return g_opts;
@@ -388,6 +408,7 @@ static int opt_bit(const char* name, unsigned* bit) {
       {"rw_big_half", DS_OPT_RW_BIG_HALF},
       {"no_split256", DS_OPT_NO_SPLIT256},
       {"no_sw", DS_OPT_NO_SW},
+      {"no_sws", DS_OPT_NO_SWS},
       {"no_sw_rw", DS_OPT_NO_SW_RW}};
   for (const auto& t : tab)
     if (!strcmp(name, t.n)) { *bit = t.b; return 0; }
@@ -615,7 +636,7 @@ struct SkipConv { const Tn* x; const void* w; int chunk; const void* w_frag; }; 
 static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias, const float* bias_b, int bias_b_ld,
                 const Tn* res, float scale, Tn& y, int Cout, int taps, int B, const float* div_b,
                 hipStream_t st, const GnAff* gn = nullptr, int gn_act = 0, bool want_stats = false,
-                const SkipConv* skip = nullptr, const void* w_frag = nullptr) {
+                const SkipConv* skip = nullptr, const void* w_frag = nullptr, const void* ident_frag = nullptr) {
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.B = B; a.H = x.H; a.W = x.W; a.Cin = x.C; a.Cout = Cout; a.taps = taps; a.dtype = e->cfg.dtype; a.split = e->split;
@@ -628,8 +649,9 @@ static int conv(diffsep_engine* e, const Tn& x, const void* w, const float* bias
     a.gn_groups = gn->groups; a.gn_inv_count = gn->inv_count; a.gn_eps = 1e-6f;
   }
   a.w = w; a.w_bs = 0; a.w_chunked = weight_chunk(taps, x.C, x.p2 ? x.C1 : 0, e->cfg.dtype);
-  const bool use_frag = e->cfg.dtype == DS_BF16 && !(e->opts & DS_OPT_NO_WFRAG);
+  const bool use_frag = (e->cfg.dtype == DS_BF16 || (e->cfg.dtype == DS_F32 && e->split)) && !(e->opts & DS_OPT_NO_WFRAG);
   a.w_frag = use_frag ? w_frag : nullptr;
+  a.ident_frag = use_frag ? ident_frag : nullptr;
   a.bias = bias; a.bias_b = bias_b; a.bias_b_ld = bias_b_ld; a.bias_mode = 0; a.div_b = div_b;
   a.res = res ? res->p : nullptr; a.res_bs = res ? (long)res->H * res->W * res->ld : 0; a.ldr = res ? res->ld : 0;
   a.out_scale = scale;
@@ -712,9 +734,12 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
   // 256^2; Conv_1 + the 256-channel 1x1 skip: the first half of the skip folded as before, the second as a 1x1 launch.
   // Only from 128 rows up: at 64^2 (where nf = 64 has these blocks) the register-weight launches carry their weight prologue for
   // two tiles per block and the pair is SLOWER than the generic tile (61.5 + 50.0 against 49.3 + 42.6 us per block in the graph).
+  // Round 5, with the streamed-weight kernel (conv3x3_sw.hip; stand-alone, B = 16): Conv_0 as ONE launch 659 us at 256^2 against
+  // 269 + 318 for the pair, 155 against 77 + 89 at 128^2 — the pair stays at 256 rows; Conv_1 with the WHOLE 256-channel skip
+  // folded 438 us at 256^2 against 319 + 193 (3x3 with half of the skip + the 1x1 launch on the other half), 103 against 91 + 47 at
+  // 128^2 — one launch at every size.  Option no_sw: the route of round 4.
   if (e->cfg.dtype == DS_BF16 && mode == 0 && x.p2 && m.pf0a >= 0 && x.C1 == 128 && x.sa && x.sa2 && x.W % 32 == 0 && x.H % 8 == 0 &&
-      x.H >= 128 && (long)B * (x.H / 4) * (x.W / 32) >= ds_num_cus() &&
-      (e->opts & DS_OPT_NO_SW) &&  // (round 5: the streamed-weight kernel takes these blocks whole; the route stays for the A/B)
+      x.H >= ((e->opts & DS_OPT_NO_SW) ? 128 : 256) && (long)B * (x.H / 4) * (x.W / 32) >= ds_num_cus() &&
       !(e->opts & (DS_OPT_NO_RW | DS_OPT_NO_RW128 | DS_OPT_NO_SPLIT256 | DS_OPT_NO_WFRAG))) {
     Tn xa = x, xb = x;
     xa.C = 128; xa.p2 = nullptr; xa.C1 = 0; xa.ld2 = 0; xa.sa2 = nullptr;
@@ -732,8 +757,13 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
              PKF(e, m.pf0b)))
       return 1;
     if (gn_stats(e, h1, P(e, m.gn1_w), P(e, m.gn1_b), B, a1, st, true)) return 1;
-    Tn outp = e_tensor(e, B, Ho, Wo, m.out_ch);
     out = e_tensor(e, B, Ho, Wo, m.out_ch);
+    if (!(e->opts & DS_OPT_NO_SW) && m.pf2 >= 0) {
+      const SkipConv skw = {&x, PK(e, m.pk2), weight_chunk(9, m.in_ch, m.in_c1, e->cfg.dtype), PKF(e, m.pf2)};
+      return conv(e, h1, PK(e, m.pk1), P(e, m.conv1_b), P(e, m.conv2_b), 0, nullptr, kInvSqrt2, out, m.out_ch, 9, B, nullptr, st, &a1, 1,
+                  true, &skw, PKF(e, m.pf1));
+    }
+    Tn outp = e_tensor(e, B, Ho, Wo, m.out_ch);
     const SkipConv sk = {&xa, PK(e, m.pk2), weight_chunk(9, 128, 0, e->cfg.dtype), PKF(e, m.pf2a)};
     if (conv(e, h1, PK(e, m.pk1), P(e, m.conv1_b), P(e, m.conv2_b), 0, nullptr, 1.f, outp, m.out_ch, 9, B, nullptr, st, &a1, 1,
              false, &sk, PKF(e, m.pf1)))
@@ -776,7 +806,7 @@ static int res_block(diffsep_engine* e, const Module& m, const Tn& x, const floa
     if (conv(e, xr, PK(e, m.pk2), P(e, m.conv2_b), nullptr, 0, nullptr, 1.f, skip, m.out_ch, 1, B, nullptr, st)) return 1;
   }
   return conv(e, h1, PK(e, m.pk1), P(e, m.conv1_b), nullptr, 0, &skip, kInvSqrt2, out, m.out_ch, 9, B, nullptr, st,
-              &a1, 1, true, nullptr, PKF(e, m.pf1));
+              &a1, 1, true, nullptr, PKF(e, m.pf1), m.has_conv2 ? nullptr : PKF(e, m.pf_id));
 }
 
 // attention core shared with the unit entry point: o = softmax(q k^T C^-1/2) v
@@ -1119,6 +1149,12 @@ static int repack_weight(diffsep_engine* e, const PRef& src, long pk, int O, int
   return 0;
 }
 static int repack_frag(diffsep_engine* e, const PRef& src, long pf, int O, int I, int taps, long so, long si, long stp) {
+  if (pf >= 0 && e->cfg.dtype == DS_F32 && e->split && ds_sws_frag_shape(taps, I, O)) {  // hi / lo planes: 2 x 2 bytes per weight = one slot
+    hipLaunchKernelGGL(repack_frag_split_kernel, dim3(cdiv((long)O * taps * I, 256)), dim3(256), 0, 0, e->d_blob + src.off,
+                       (bf16_t*)((float*)(e->d_pack) + pf), O, I, taps, so, si, stp);
+    DS_LAUNCH_CHECK();
+    return 0;
+  }
   if (pf < 0 || e->cfg.dtype != DS_BF16) return 0;
   hipLaunchKernelGGL(repack_frag_kernel, dim3(cdiv((long)O * taps * I, 256)), dim3(256), 0, 0, e->d_blob + src.off,
                      (bf16_t*)(e->d_pack) + pf, O, I, taps, so, si, stp);
@@ -1138,6 +1174,11 @@ static int repack_module(diffsep_engine* e, const Module& m) {
       rc |= repack_frag(e, m.conv0_w, m.pf0, m.out_ch, m.in_ch, 9, (long)m.in_ch * 9, 9, 1);
       rc |= repack_frag(e, m.conv1_w, m.pf1, m.out_ch, m.out_ch, 9, (long)m.out_ch * 9, 9, 1);
       if (m.has_conv2) rc |= repack_frag(e, m.conv2_w, m.pf2, m.out_ch, m.in_ch, 1, m.in_ch, 1, 0);
+      if (m.pf_id >= 0 && e->cfg.dtype == DS_F32 && e->split) {
+        hipLaunchKernelGGL(repack_frag_split_kernel, dim3(cdiv((long)m.out_ch * m.out_ch, 256)), dim3(256), 0, 0, (const float*)nullptr,
+                           (bf16_t*)((float*)(e->d_pack) + m.pf_id), m.out_ch, m.out_ch, 1, 0L, 0L, 0L);
+        DS_LAUNCH_CHECK();
+      }
       if (m.pf0a >= 0) {  // the halves of a cat(128, 128) block (channel offset 128 in the second)
         PRef w0b = m.conv0_w, w2b = m.conv2_w;
         w0b.off += 128L * 9;
@@ -1783,8 +1824,9 @@ extern "C" int32_t diffsep_conv3x3_streamed(const void* x, const void* x2, int32
                                             const float* bias_b, const void* sx, const void* sx2, int32_t sC1,
                                             int32_t sCin, const void* sw_frag, void* y, int32_t B, int32_t H, int32_t W,
                                             int32_t Cin, int32_t Cout, float out_scale, int32_t dtype, int64_t* stats,
-                                            void* stream) {
+                                            const void* res, const void* ident_frag, void* stream) {
   DS_CHECK(x && w_frag && y, "conv3x3_streamed: null pointer");
+  DS_CHECK(!res || (dtype == DS_F32_SPLIT && ident_frag && !sx), "conv3x3_streamed: a residual needs the split mode, the identity copy and no skip");
   DS_CHECK(B > 0 && H > 0 && W > 0, "conv3x3_streamed: empty problem");
   DS_CHECK(!x2 || (C1 > 0 && C1 < Cin), "conv3x3_streamed: bad concat split");
   DS_CHECK(!sx || (sw_frag && sCin > 0 && (!sx2 || (sC1 > 0 && sC1 < sCin))), "conv3x3_streamed: bad skip operands");
@@ -1807,14 +1849,23 @@ extern "C" int32_t diffsep_conv3x3_streamed(const void* x, const void* x2, int32
   a.out_scale = out_scale;
   a.y = y; a.y_bs = (long)H * W * Cout; a.ldy = Cout;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.taps = 9;
-  a.dtype = dtype;
-  DS_CHECK((long)H * W * (Cin > Cout ? Cin : Cout) * 2 < 2147483647L, "conv3x3_streamed: image too large for 32-bit buffer offsets");
+  a.dtype = dtype == DS_F32_SPLIT ? DS_F32 : dtype; a.split = dtype == DS_F32_SPLIT;
+  DS_CHECK((long)H * W * (Cin > Cout ? Cin : Cout) * 4 < 2147483647L, "conv3x3_streamed: image too large for 32-bit buffer offsets");
+  if (a.split) {  // fp32 tensors, hi / lo fragment copies: conv3x3_sws.hip
+    a.res = res; a.res_bs = (long)H * W * Cout; a.ldr = Cout; a.ident_frag = ident_frag;
+    DS_CHECK(ds_conv_sws_supported(a), "conv3x3_streamed: shape outside the split kernel's instantiations (Cout = 64 / 128, Cin = 64 .. 256 "
+                                       "by 64, W % 32 == 0, H % 8 == 0; skip / residual channels 64 .. 256 by 64 behind GroupNorm; raw input: Cin <= 128)");
+    return ds_launch_conv_sws(a, (hipStream_t)stream);
+  }
   DS_CHECK(ds_conv_sw_supported(a), "conv3x3_streamed: shape outside the kernel's instantiations (16-bit, Cout = 128 / 256, Cin = 64 .. 256 "
                                     "by 64, W % 32 == 0, H % 8 == 0; a skip needs GroupNorm and Cin = 128; raw input: Cin <= 128)");
   return ds_launch_conv_sw(a, (hipStream_t)stream);
 }
 extern "C" int64_t diffsep_frag_index(int32_t cout, int32_t tap, int32_t cin, int32_t taps, int32_t Cout) {
   return ds_rw_frag_index(cout, tap, cin, taps, Cout);
+}
+extern "C" int64_t diffsep_frag_index_split(int32_t cout, int32_t tap, int32_t cin, int32_t taps, int32_t Cout, int32_t plane) {
+  return ds_sws_frag_index(cout, tap, cin, taps, Cout, plane);
 }
 
 extern "C" int32_t diffsep_conv2d_chunk(int32_t ksize, int32_t dtype) { return ds_conv_chunk(ksize == 3 ? 9 : 1, dtype); }

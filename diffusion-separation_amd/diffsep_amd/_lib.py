@@ -92,8 +92,10 @@ _SIGS = {
     "diffsep_conv2d_fused": (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F,
                                   _I, _P, _I, _P, _P, _P, _P, _I, _P]),
     "diffsep_conv2d_chunk": (_I, [_I, _I]),
-    "diffsep_conv3x3_streamed": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
+    "diffsep_conv3x3_streamed": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P,
+                                      _P, _P]),
     "diffsep_frag_index": (_L, [_I, _I, _I, _I, _I]),
+    "diffsep_frag_index_split": (_L, [_I, _I, _I, _I, _I, _I]),
     "diffsep_resblock_forward": (_I, [_I, _I, _I, _I, _I, _I, _P, _L, _P, _P, _P, _I, _I, _I, _P]),
     "diffsep_attnblock_forward": (_I, [_I, _I, _P, _L, _P, _P, _I, _I, _I, _P]),
     "diffsep_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P]),

@@ -70,9 +70,31 @@ def pack_frag_weight(w, dtype):
     return out.to(dtype)
 
 
-def conv3x3_streamed(x, w_frag, cout, x2=None, gn=None, bias=None, bias_b=None, skip=None, out_scale=1.0, stats=False, out=None):
-    """The streamed-weight 3x3 kernel as a unit (diffsep_conv3x3_streamed).  x [B,H,W,C1] (+ x2 [B,H,W,C2]) dense 16-bit;
-    gn = (scale, shift) [B,Cin] f32 -> SiLU(GroupNorm(.)) on the fly; skip = (sx, sx2 | None, sw_frag): folded 1x1 on raw channels."""
+def pack_frag_weight_split(w):
+    """OIHW float32 -> the split mode's fragment copy (diffsep_frag_index_split): bfloat16 planes hi = bf16(w), lo = bf16(w - hi);
+    element (o, tap, i, plane) at ((((i // 32 * taps + tap) * 2 + i % 32 // 16) * 2 + plane) * (O // 32) + o // 32) * 64
+    + (i % 16 // 8) * 32 + o % 32) * 8 + i % 8.  I % 32 == 0, O % 32 == 0.  Returns a bfloat16 tensor of 2 O taps I elements."""
+    O, I, kh, kw = w.shape
+    taps = kh * kw
+    assert I % 32 == 0 and O % 32 == 0
+    o, t, i = torch.meshgrid(torch.arange(O), torch.arange(taps), torch.arange(I), indexing="ij")
+    base = (((i // 32 * taps + t) * 2 + (i % 32) // 16) * 2) * (O // 32)
+    tail = (o // 32) * 64 + ((i % 16) // 8) * 32 + o % 32
+    wf = w.permute(0, 2, 3, 1).reshape(-1).float()
+    hi = wf.to(torch.bfloat16)
+    lo = (wf - hi.float()).to(torch.bfloat16)
+    out = torch.empty(2 * O * taps * I, dtype=torch.bfloat16)
+    out[((base * 64 + tail) * 8 + i % 8).reshape(-1)] = hi
+    out[(((base + O // 32) * 64 + tail) * 8 + i % 8).reshape(-1)] = lo
+    return out
+
+
+def conv3x3_streamed(x, w_frag, cout, x2=None, gn=None, bias=None, bias_b=None, skip=None, out_scale=1.0, stats=False, out=None,
+                     res=None, ident_frag=None):
+    """The streamed-weight 3x3 kernels as units (diffsep_conv3x3_streamed).  x [B,H,W,C1] (+ x2 [B,H,W,C2]) dense; 16-bit tensors:
+    conv3x3_sw.hip with pack_frag_weight copies; float32 tensors: the split mode's conv3x3_sws.hip with pack_frag_weight_split
+    copies (res + ident_frag: residual against the identity copy).  gn = (scale, shift) [B,Cin] f32 -> SiLU(GroupNorm(.)) on the
+    fly; skip = (sx, sx2 | None, sw_frag): folded 1x1 on raw channels."""
     B, H, W, C1 = x.shape
     Cin = C1 + (x2.shape[-1] if x2 is not None else 0)
     y = torch.zeros((B, H, W, cout), dtype=x.dtype, device=x.device) if out is None else out
@@ -85,9 +107,11 @@ def conv3x3_streamed(x, w_frag, cout, x2=None, gn=None, bias=None, bias_b=None, 
     sx, sx2, swf = skip if skip is not None else (None, None, None)
     sC1 = sx.shape[-1] if sx is not None else 0
     sCin = sC1 + (sx2.shape[-1] if sx2 is not None else 0)
-    check(_L(x).diffsep_conv3x3_streamed(_ptr(x), _ptr(x2), C1, _ptr(sc), _ptr(sh), _ptr(w_frag), _ptr(bias), _ptr(bias_b),
-                                         _ptr(sx), _ptr(sx2), sC1, sCin, _ptr(swf), _ptr(y), B, H, W, Cin, cout, out_scale,
-                                         _dt(x), _ptr(st), _stream_ptr()), _L(x))
+    split = x.dtype == torch.float32
+    L = lib("bf16") if split else _L(x)
+    check(L.diffsep_conv3x3_streamed(_ptr(x), _ptr(x2), C1, _ptr(sc), _ptr(sh), _ptr(w_frag), _ptr(bias), _ptr(bias_b),
+                                     _ptr(sx), _ptr(sx2), sC1, sCin, _ptr(swf), _ptr(y), B, H, W, Cin, cout, out_scale,
+                                     F32_SPLIT if split else _dt(x), _ptr(st), _ptr(res), _ptr(ident_frag), _stream_ptr()), L)
     return (y, st) if stats is not False else y
 
 

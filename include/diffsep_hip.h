@@ -290,12 +290,19 @@ int32_t diffsep_conv2d_chunk(int32_t ksize, int32_t dtype);
  * y [B][H][W][Cout] = (conv + bias + bias_b[b]) * out_scale; `stats` as in diffsep_conv2d_fused.  w_frag / sw_frag: the
  * [Cout][3 x 3][Cin] / [Cout][sCin] weights in FRAGMENT-major order — element (cout, tap, cin) at diffsep_frag_index(cout, tap,
  * cin, taps, Cout): one k-step (64-channel chunk, tap, 16-channel block) of all couts is contiguous, cout group by cout group,
- * so that a wave's 1 KB load instruction is one MFMA B-operand. */
+ * so that a wave's 1 KB load instruction is one MFMA B-operand.
+ * dtype = DIFFSEP_F32_SPLIT: the split mode's sibling (csrc/conv3x3_sws.hip; sdes/__init__.py:166-188 runs on it in the head of a
+ * hybrid run): fp32 tensors, Cout = 64 / 128, every product as three bfloat16 MFMAs on hi / lo planes; w_frag / sw_frag
+ * are then PAIRS of bfloat16 planes (hi = bf16(w), lo = bf16(w - hi)) at diffsep_frag_index_split(cout, tap, cin, taps, Cout,
+ * plane); `res` (nullable, split mode only, no skip): residual [B][H][W][Cout] added before out_scale — it rides through the
+ * matrix cores against `ident_frag`, the split copy of the Cout x Cout identity (taps = 1). */
 int32_t diffsep_conv3x3_streamed(const void* x, const void* x2, int32_t C1, const float* gn_scale, const float* gn_shift,
                                  const void* w_frag, const float* bias, const float* bias_b, const void* sx, const void* sx2,
                                  int32_t sC1, int32_t sCin, const void* sw_frag, void* y, int32_t B, int32_t H, int32_t W,
-                                 int32_t Cin, int32_t Cout, float out_scale, int32_t dtype, int64_t* stats, void* stream);
+                                 int32_t Cin, int32_t Cout, float out_scale, int32_t dtype, int64_t* stats, const void* res,
+                                 const void* ident_frag, void* stream);
 int64_t diffsep_frag_index(int32_t cout, int32_t tap, int32_t cin, int32_t taps, int32_t Cout);
+int64_t diffsep_frag_index_split(int32_t cout, int32_t tap, int32_t cin, int32_t taps, int32_t Cout, int32_t plane);
 /* `stats` (nullable): channel-sum accumulators of the OUTPUT for the next GroupNorm, [B][Cout][2] int64 fixed point
  * (sum * 2^24, sum of squares * 2^16; exact to 6e-8 / 1.5e-5 per tile, no overflow while the per-image sum of
  * squares of a channel stays below 1.4e14).  Every block ADDS its tile's totals with integer atomics (associative:

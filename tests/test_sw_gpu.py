@@ -36,6 +36,15 @@ def test_frag_index_matches_the_library():
         for (o, t, i) in [(0, 0, 0), (5, taps - 1, 17), (O - 1, taps // 2, I - 1), (33, 0, 70 % I), (97, taps - 1, 63)]:
             k = L.diffsep_frag_index(o, t, i, taps, O)
             assert p[k] == w.reshape(O, I, taps)[o, i, t]
+        # the split mode's copy: plane 0 = bf16(w), plane 1 = bf16(w - plane 0)
+        w2 = (w + 0.37) / 1024.0
+        ps = ops.pack_frag_weight_split(w2).float()
+        for (o, t, i) in [(0, 0, 0), (5, taps - 1, 17), (O - 1, taps // 2, I - 1), (33, 0, 70 % I), (97, taps - 1, 63)]:
+            k0 = L.diffsep_frag_index_split(o, t, i, taps, O, 0)
+            k1 = L.diffsep_frag_index_split(o, t, i, taps, O, 1)
+            v = w2.reshape(O, I, taps)[o, i, t]
+            hi = v.to(torch.bfloat16).float()
+            assert ps[k0] == hi and ps[k1] == (v - hi).to(torch.bfloat16).float()
 
 
 # (B, H, W): one tile per block; several tiles per block and image borders inside a block's range; one row of tiles; wide
@@ -112,3 +121,62 @@ def test_sw_rejects_what_it_does_not_instantiate():
     w2 = ops.pack_frag_weight(torch.zeros((128, 128, 3, 3)), torch.float16).to(DEV)
     with pytest.raises(RuntimeError):
         ops.conv3x3_streamed(a2, w2, 128)  # H % 8 != 0
+
+
+# ------------------------------------------------------------------------------------------------ split mode (conv3x3_sws.hip)
+# (C1, C2, raw input?, skip channels (first, second) | "res", Cout)
+SPLIT_CASES = [
+    (64, 0, True, None, 64), (128, 0, True, None, 128),
+    (64, 0, False, None, 64), (64, 64, False, None, 64), (128, 0, False, None, 64), (128, 64, False, None, 64),
+    (128, 128, False, None, 128), (128, 64, False, None, 128), (128, 0, False, None, 128),
+    (64, 0, False, "res", 64), (64, 0, False, (64, 0), 64), (64, 0, False, (64, 64), 64), (64, 0, False, (128, 64), 64),
+    (128, 0, False, "res", 128), (128, 0, False, (64, 0), 128), (128, 0, False, (128, 0), 128), (128, 0, False, (128, 64), 128),
+    (128, 0, False, (128, 128), 128),
+]
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 8, 32), (3, 64, 96), (20, 64, 64), (5, 24, 32)])
+@pytest.mark.parametrize("C1,C2,raw,skip,CO", SPLIT_CASES)
+def test_sws_split_conv3x3_matches_torch_fp32(B, H, W, C1, C2, raw, skip, CO):
+    """fp32 tensors, hi / lo bfloat16 products: 2^-17 relative per product -> 2e-5 relative RMS on the output (the generic tile in
+    split mode has the same gate in tests/test_split_gpu.py)."""
+    if B * H * W > 60000 and raw:
+        pytest.skip("large case covered by the GroupNorm variants")
+    C = C1 + C2
+    tag = f"s{B}.{H}.{C1}.{C2}"
+    a = (rnd("sws.a" + tag, (B, H, W, C1), 1.2) + 0.1).to(DEV)
+    bt = (rnd("sws.b" + tag, (B, H, W, C2), 0.9) - 0.2).to(DEV) if C2 else None
+    w = rnd(f"sws.w{C}.{CO}", (CO, C, 3, 3), 1.0 / math.sqrt(9 * C))
+    bias, bb = rnd("sws.bias", (CO,), 0.1).to(DEV), rnd(f"sws.bb{B}", (B, CO), 0.1).to(DEV)
+    sc = (1.0 + rnd(f"sws.sc{B}{C}", (B, C), 0.2)).to(DEV)
+    sh = rnd(f"sws.sh{B}{C}", (B, C), 0.2).to(DEV)
+    xf = torch.cat([a, bt], -1) if C2 else a
+    if not raw:
+        xf = F.silu(xf * sc[:, None, None, :] + sh[:, None, None, :])
+    ref = F.conv2d(xf.double().cpu().permute(0, 3, 1, 2), w.double(), bias.double().cpu(), padding=1).permute(0, 2, 3, 1)
+    ref = ref + bb.double().cpu()[:, None, None, :]
+    sk, res, ident = None, None, None
+    if skip == "res":
+        res = rnd("sws.r" + tag, (B, H, W, CO), 1.3).to(DEV)
+        ident = ops.pack_frag_weight_split(torch.eye(CO).reshape(CO, CO, 1, 1)).to(DEV)
+        ref = ref + res.double().cpu()
+    elif skip is not None:
+        s1, s2 = skip
+        sa = rnd("sws.sa" + tag, (B, H, W, s1), 1.1).to(DEV)
+        sb = rnd("sws.sb" + tag, (B, H, W, s2), 0.8).to(DEV) if s2 else None
+        sw = rnd(f"sws.sw{s1 + s2}", (CO, s1 + s2, 1, 1), 1.0 / math.sqrt(s1 + s2))
+        sxf = torch.cat([sa, sb], -1) if s2 else sa
+        ref = ref + F.conv2d(sxf.double().cpu().permute(0, 3, 1, 2), sw.double(), None).permute(0, 2, 3, 1)
+        sk = (sa, sb, ops.pack_frag_weight_split(sw).to(DEV))
+    ref = ref * 0.70710678
+    wf = ops.pack_frag_weight_split(w).to(DEV)
+    y, st = ops.conv3x3_streamed(a, wf, CO, x2=bt, gn=None if raw else (sc, sh), bias=bias, bias_b=bb, skip=sk, out_scale=0.70710678,
+                                 stats=True, res=res, ident_frag=ident)
+    r = rel_rms(y, ref)
+    assert r < 2e-5, r
+    s = ops.stats_to_float(st)
+    assert torch.allclose(s[..., 0].cpu(), ref.sum((1, 2)), rtol=1e-4, atol=1e-4 * H * W)
+    assert torch.allclose(s[..., 1].cpu(), (ref ** 2).sum((1, 2)), rtol=1e-4, atol=1e-4 * H * W)
+    y3, st3 = ops.conv3x3_streamed(a, wf, CO, x2=bt, gn=None if raw else (sc, sh), bias=bias, bias_b=bb, skip=sk, out_scale=0.70710678,
+                                   stats=True, res=res, ident_frag=ident)
+    assert torch.equal(y, y3) and torch.equal(st, st3)
