@@ -247,6 +247,8 @@ struct ConvArgs {
 #define DS_OPT_NO_SW 4096u       // no streamed-weight 3x3 kernel (conv3x3_sw.hip): generic tile / two-launch cat route instead (A/B)
 #define DS_OPT_NO_SW_RW 8192u    // ... only for the launches the register-weight kernel does not take (A/B: by default it also takes the
                                  // 128-cout launches with < 2 tiles of 8 x 32 per CU, where that kernel pays its weight prologue per tile)
+#define DS_OPT_NO_SW_ROWS4 32768u // ... not on levels with fewer 8 x 32 tiles than compute units (its 4 x 32 tile variant; A/B)
+#define DS_OPT_SW_ROWS4 65536u    // (tests, with rw_small: the 4 x 32 tile variant on every shape)
 #define DS_OPT_NO_SWS 16384u     // no split-mode streamed-weight kernel (conv3x3_sws.hip): the generic tile in split mode instead (A/B)
 #define DS_OPT_NO_WFRAG 32u   // the engine does not hand the fragment-major weight copies to the register-weight kernel (A/B)
 unsigned ds_default_opts();

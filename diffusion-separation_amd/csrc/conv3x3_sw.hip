@@ -82,15 +82,18 @@ struct SwK {
   int dbg;  // profiling builds: bit 0 = stores fall outside the tensor, bit 1 = loads do
 };
 
-constexpr int RPW = 8, RH = RPW / 2, NCG = 4, CO = 32 * NCG;  // the wave's rows (= the tile's), rows per half-phase, cout groups
 #ifndef SW_D
 #define SW_D 16  // ring depth: k-steps between a fragment's load and its MFMAs (A/B: -DSW_D=..)
 #endif
 constexpr int RING = SW_D;
 
-template <int NCH, int NSK>
+// RPW: the wave's pixel rows; NCG: cout groups of 32 per block (4: 128 couts on ONE pixel group, tile RPW x 32; 2: 64 couts,
+// 2 cout groups x 2 pixel groups, tile 2 RPW x 32 — RPW = 4 only: the halo ring of a 16-row tile does not fit the LDS)
+template <int NCH, int NSK, int RPW, int NCG>
 struct SwGeom {
-  static constexpr int TH = RPW, HH_ = TH + 2, HP = HH_ * HW_;
+  static constexpr int RH = RPW / 2, CO = 32 * NCG, PGN = 4 / NCG;
+  static_assert((RPW == 8 && NCG == 4) || RPW == 4, "instantiated tile shapes");
+  static constexpr int TH = PGN * RPW, HH_ = TH + 2, HP = HH_ * HW_;
   // 16-byte staging pieces per thread and chunk: NI passes over the tile's own pixels (a pass = NT / PPL = 32 pixels = one
   // tile row: always inside the image, no flags, no selects), then NB passes over the NBP pixels of the halo border
   static constexpr int NI = TH * TW * PPL / NT, NBP = HP - TH * TW, NB = (NBP * PPL + NT - 1) / NT;
@@ -136,10 +139,10 @@ struct SwGeom {
 
 // NCH: 64-channel chunks of the 3x3 input (one tensor or the in-place concat of two); NSK: 64-channel chunks of the folded
 // 1x1 skip; MODE: 0 raw input, 2 GroupNorm + SiLU
-template <int NCH, int NSK, int MODE>
+template <int NCH, int NSK, int MODE, int RPW, int NCG>
 __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
-  using G = SwGeom<NCH, NSK>;
-  constexpr int TH = G::TH, HP = G::HP, LDS_A = G::LDS_A, NL = G::NL, NPH = G::NPH, CIN = G::CIN;
+  using G = SwGeom<NCH, NSK, RPW, NCG>;
+  constexpr int TH = G::TH, HP = G::HP, LDS_A = G::LDS_A, NL = G::NL, NPH = G::NPH, CIN = G::CIN, RH = G::RH, CO = G::CO, PGN = G::PGN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
   float* sTab = reinterpret_cast<float*>(smem + G::OFF_TAB);
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, h = lane >> 5;
-  const int cg = wave;
+  const int cg = wave % NCG, pg = wave / NCG;
   const int b = blockIdx.x / (p.G * p.ncb), cb = (blockIdx.x / p.G) % p.ncb, part = blockIdx.x % p.G;
   const int t0 = (int)((long)part * p.tiles_per_img / p.G);
   const int nt = (int)((long)(part + 1) * p.tiles_per_img / p.G) - t0;
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
   const bool has_stats = p.stats != nullptr;
   const float osc = FOLD ? p.out_scale * -0.6931471805599453f : p.out_scale;
   // fragment base of this lane: pixel (row pg * RPW, column l32) of the halo tile, k-half h
-  const int fbase = l32 * AROW + h * 16;
+  const int fbase = (pg * RPW * HW_ + l32) * AROW + h * 16;
 
   // ---- epilogue of one tile, in the accumulator layout (no LDS): lane (pixel l32, half h) holds, per row, the cout
   // quads 8 q + 4 h .. + 3 of the wave's 32 couts.  A 16-byte load / store of a lane covers couts 16 j + 8 h .. + 7 of its
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
         auto q = __builtin_amdgcn_permlane16_swap(a[d], b2[d], false, false);
         a[d] = q[0]; b2[d] = q[1];
       }
-      const int pix = g.pix0 + r * p.W + (lane & 15);
+      const int pix = g.pix0 + (pg * RPW + r) * p.W + (lane & 15);
       const unsigned o = __umul24((unsigned)pix, (unsigned)p.ldy * 2u) + spiece;
 #ifdef SW_TIMING
       const unsigned o1 = (p.dbg & 1) ? OOB : o, o2 = (p.dbg & 1) ? OOB : o + 16u * (unsigned)p.ldy * 2u;
@@ -576,8 +579,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
     constexpr int R0 = HF * RH, ER0 = HF ? 0 : RH;
     const char* fb = sA + slot_r * LDS_A + fbase + R0 * HW_ * AROW;
     if constexpr (EPI) {  // the rows this half finishes were last written by asm MFMAs: 12 wait states before they are read
-      static_assert(RH == 4, "one guard for the half's four accumulators");
-      asm volatile("s_nop 11" : "+a"(acc[ER0]), "+a"(acc[ER0 + 1]), "+a"(acc[ER0 + 2]), "+a"(acc[ER0 + 3]));
+      if constexpr (RH == 4) asm volatile("s_nop 11" : "+a"(acc[ER0]), "+a"(acc[ER0 + 1]), "+a"(acc[ER0 + 2]), "+a"(acc[ER0 + 3]));
+      else asm volatile("s_nop 11" : "+a"(acc[ER0]), "+a"(acc[ER0 + 1]));
     }
     if constexpr (HF == 0 && C1 < NCH) act_tab(C1);
     // K order inside a 3x3 chunk: (kx, 16-channel block) groups outside, ky inside.  The RH rows of this half use the
@@ -700,7 +703,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(osa[d]), "+v"(osb[d]));
       } else {
-        const int pix = ge.pix0 + rr * p.W + (lane & 15);
+        const int pix = ge.pix0 + (pg * RPW + rr) * p.W + (lane & 15);
         const unsigned o = __umul24((unsigned)pix, (unsigned)p.ldy * 2u) + spiece;
 #ifdef SW_TIMING
         const unsigned o1 = (p.dbg & 1) ? OOB : o, o2 = (p.dbg & 1) ? OOB : o + 16u * (unsigned)p.ldy * 2u;
@@ -830,7 +833,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
     if (++tx2 == p.tiles_x) { tx2 = 0; ++ty2; }
   }
   // the second half of the last tile's rows
-  asm volatile("s_nop 11" : "+a"(acc[RH]), "+a"(acc[RH + 1]), "+a"(acc[RH + 2]), "+a"(acc[RH + 3]));
+  if constexpr (RH == 4) asm volatile("s_nop 11" : "+a"(acc[RH]), "+a"(acc[RH + 1]), "+a"(acc[RH + 2]), "+a"(acc[RH + 3]));
+  else asm volatile("s_nop 11" : "+a"(acc[RH]), "+a"(acc[RH + 1]));
 #pragma unroll
   for (int e = 0; e < RH * 2; ++e) {
     float4 t0, t1;
@@ -854,10 +858,11 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
       const int co = tid >> 1, st = tid & 1;
       const int wcg = co >> 5, c32 = co & 31, q = c32 >> 3, hh = (c32 >> 2) & 1, i = c32 & 3;
       double a = 0.0;
-      for (int l = 0; l < 32; ++l) {
-        const int t = wcg * 64 + hh * 32 + l;
-        a += (double)red[t * RED_ROW + st * 16 + 4 * q + i];
-      }
+      for (int wpg = 0; wpg < PGN; ++wpg)
+        for (int l = 0; l < 32; ++l) {
+          const int t = (wpg * NCG + wcg) * 64 + hh * 32 + l;
+          a += (double)red[t * RED_ROW + st * 16 + 4 * q + i];
+        }
       ds_stat_add(p.stats + ((long)b * p.cout + cb * CO + co) * 2 + st, (long long)llrint(a * (st ? DS_STAT_SQ_SCALE : DS_STAT_SUM_SCALE)));
     }
   }
@@ -865,9 +870,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
   RT_FLUSH
 }
 
-template <int NCH, int NSK, int MODE>
+template <int NCH, int NSK, int MODE, int RPW, int NCG>
 int sw_launch(const SwK& k0, const ConvArgs& a, hipStream_t st) {
-  using G = SwGeom<NCH, NSK>;
+  using G = SwGeom<NCH, NSK, RPW, NCG>;
   SwK k = k0;
   const int tiles = (a.H / G::TH) * (a.W / TW);
   int g = ds_num_cus() / (a.B * k.ncb);
@@ -879,41 +884,71 @@ int sw_launch(const SwK& k0, const ConvArgs& a, hipStream_t st) {
   k.G = g;
   k.tiles_x = a.W / TW;
   k.tiles_per_img = tiles;
-  auto kern = conv3x3_sw_kernel<NCH, NSK, MODE>;
+  auto kern = conv3x3_sw_kernel<NCH, NSK, MODE, RPW, NCG>;
   DS_FUNC_LDS_ONCE(kern, G::LDS_TOTAL);
   hipLaunchKernelGGL(kern, dim3(a.B * k.ncb * k.G), dim3(NT), G::LDS_TOTAL, st, k);
   DS_LAUNCH_CHECK();
   {
     static char name[64] = {0};
-    if (!name[0]) snprintf(name, sizeof(name), "conv3x3_sw_kernel<%d,%d,%d>", NCH, NSK, MODE);
+    if (!name[0]) snprintf(name, sizeof(name), "conv3x3_sw_kernel<%d,%d,%d,%d,%d>", NCH, NSK, MODE, RPW, NCG);
     ds_set_last_conv_kernel(name);
   }
   return 0;
 }
 
+// the (input chunks, skip chunks, mode) sets instantiated per tile shape
+bool sw_shape(int cout, int nch, int nsk, int mode) {
+  if (cout == 64) return nch == 3 && nsk == 0 && mode == 2;  // (cat(128, 64) -> 64 of the 128^2 up path: the one 64-cout layer the
+                                                               // register-weight kernel does not hold)
+  if (mode == 0) return nsk == 0 && (nch == 1 || nch == 2);
+  if (nsk == 0) return nch >= 1 && nch <= 4;
+  return nch == 2 && nsk >= 1 && nsk <= 4;
+}
+template <int RPW>
+int sw_dispatch128(const SwK& k, const ConvArgs& a, int nch, int nsk, int mode, hipStream_t st) {
+#define SW_CASE(NCH_, NSK_, MODE_) if (nch == NCH_ && nsk == NSK_ && mode == MODE_) return sw_launch<NCH_, NSK_, MODE_, RPW, 4>(k, a, st)
+  SW_CASE(1, 0, 0); SW_CASE(2, 0, 0);
+  SW_CASE(1, 0, 2); SW_CASE(2, 0, 2); SW_CASE(3, 0, 2); SW_CASE(4, 0, 2);
+  SW_CASE(2, 1, 2); SW_CASE(2, 2, 2); SW_CASE(2, 3, 2); SW_CASE(2, 4, 2);
+#undef SW_CASE
+  return -1;
+}
+// rows per wave of a 128-cout launch: 8 x 32 tiles where every compute unit gets one, 4 x 32 tiles on smaller levels (nf = 64 at
+// 32^2, B = 16: 128 blocks; half the stream reuse, but twice the blocks), 0 = neither
+int sw_rpw(const ConvArgs& a) {
+  const bool h8 = a.H % 8 == 0;
+  const long t4 = (long)a.B * (a.H / 4) * (a.W / TW) * (a.Cout / 128);
+  if (h8 && !(a.opts & DS_OPT_SW_ROWS4) && (t4 >= 2L * ds_num_cus() || (a.opts & DS_OPT_RW_SMALL))) return 8;
+  return (2 * t4 >= ds_num_cus() || (a.opts & DS_OPT_RW_SMALL)) ? 4 : 0;
+}
+
 }  // namespace
 
-// The layers this kernel can take: 16-bit 3x3, Cout a multiple of 128, Cin = 64 .. 256 in 64-channel chunks (one tensor or the
-// in-place concat of two, split on a chunk boundary), input raw or GroupNorm + SiLU, optional folded 1x1 skip on 64 .. 256 raw
-// channels, whole 8 x 32 tiles, fragment-major weight copies at hand.  (A residual stays with the other kernels.)
+// The layers this kernel can take: 16-bit 3x3, Cout = 128 / 256 (Cin = 64 .. 256 in 64-channel chunks: one tensor or the in-place
+// concat of two, split on a chunk boundary; input raw or GroupNorm + SiLU; optional folded 1x1 skip on 64 .. 256 raw channels, or
+// a residual against the identity copy ConvArgs.ident_frag) or Cout = 64 with Cin = 192; whole tiles; fragment-major weight
+// copies at hand.
 bool ds_conv_sw_supported(const ConvArgs& a) {
-  if (!(a.dtype == DS_BF16 && a.taps == 9 && a.Cout % CO == 0 && a.Cout <= 256 && a.Cin % KC == 0 && a.Cin >= KC && a.Cin <= 4 * KC &&
-        a.w_frag && a.w_bs == 0 && a.bias_mode == 0 && !a.div_b && !a.res && a.W % TW == 0 && a.H % RPW == 0 && a.H >= RPW &&
+  if (!(a.dtype == DS_BF16 && a.taps == 9 && (a.Cout == 64 || a.Cout == 128 || a.Cout == 256) && a.Cin % KC == 0 && a.Cin >= KC &&
+        a.Cin <= 4 * KC && a.w_frag && a.w_bs == 0 && a.bias_mode == 0 && !a.div_b && a.W % TW == 0 && a.H % 4 == 0 && a.H >= 4 &&
         a.ldy >= a.Cout && a.ldy % 8 == 0))
     return false;
+  if (a.Cout == 64 && a.H % 8 != 0) return false;
   if (a.x2 ? !(a.C1 % KC == 0 && a.C1 > 0 && a.C1 < a.Cin && a.ldx % 8 == 0 && a.ldx2 % 8 == 0) : a.ldx % 8 != 0) return false;
   const bool gn = a.gn_scale || a.gn_acc1;
   if (gn && !a.gn_act) return false;  // (affine without SiLU does not occur in front of a 3x3 convolution)
   if (a.gn_acc1 && !(a.gn_groups > 0 && a.Cin % a.gn_groups == 0 && a.Cin / a.gn_groups <= 8 && (!a.x2 || a.gn_acc2))) return false;
+  int nsk = 0;
   if (a.sx) {
-    if (!(a.sw && a.sw_frag && a.sCin % KC == 0 && a.sCin >= KC && a.sCin <= 4 * KC && a.ldsx % 8 == 0 &&
+    if (!(a.sw && a.sw_frag && !a.res && a.sCin % KC == 0 && a.sCin >= KC && a.sCin <= 4 * KC && a.ldsx % 8 == 0 &&
           (!a.sx2 || (a.sC1 % KC == 0 && a.sC1 > 0 && a.sC1 < a.sCin && a.ldsx2 % 8 == 0))))
       return false;
-    if (!gn || a.Cin != 2 * KC) return false;  // (instantiated: the second convolution of a 128-channel block with its folded skip)
-  } else if (!gn && a.Cin > 2 * KC) {
-    return false;  // (instantiated raw: 64 / 128 input channels — the first convolution behind a resampling)
+    nsk = a.sCin / KC;
+  } else if (a.res) {
+    if (!(a.ident_frag && a.Cout == 128 && a.ldr >= a.Cout && a.ldr % 8 == 0)) return false;
+    nsk = a.Cout / KC;
   }
-  return true;
+  return sw_shape(a.Cout, a.Cin / KC, nsk, gn ? 2 : 0);
 }
 // ... and the launches it is given: what neither the register-weight kernel nor (small images) the small-image kernel holds, on
 // levels with at least one 8 x 32 tile per compute unit and cout block — and the register-weight kernel's own 128-cout launches
@@ -921,8 +956,10 @@ bool ds_conv_sw_supported(const ConvArgs& a) {
 // B = 16: 26.6 against 28.0 us, with a folded 64 / 128-channel skip 28.4 / 29.1 against 38 us; option no_sw_rw for the A/B)
 bool ds_conv_sw_eligible(const ConvArgs& a) {
   if ((a.opts & DS_OPT_NO_SW) || !ds_conv_sw_supported(a)) return false;
-  const long tiles = (long)a.B * (a.H / RPW) * (a.W / TW) * (a.Cout / CO);
-  if (tiles < ds_num_cus() && !(a.opts & DS_OPT_RW_SMALL)) return false;
+  if (a.Cout == 64) return (long)a.B * (a.H / 8) * (a.W / TW) >= ds_num_cus() || (a.opts & DS_OPT_RW_SMALL);
+  const int rpw = sw_rpw(a);
+  if (rpw == 0 || (rpw == 4 && (a.opts & DS_OPT_NO_SW_ROWS4))) return false;
+  const long tiles = (long)a.B * (a.H / 8) * (a.W / TW) * (a.Cout / 128);
   if (ds_conv_rw_eligible(a)) return !(a.opts & DS_OPT_NO_SW_RW) && tiles < 2L * ds_num_cus();
   return true;
 }
@@ -932,7 +969,7 @@ int ds_launch_conv_sw(const ConvArgs& a, hipStream_t st) {
   k.x = reinterpret_cast<const bf16_t*>(a.x); k.x_bs = a.x_bs; k.ldx = a.ldx; k.C1 = a.x2 ? a.C1 : a.Cin;
   k.x2 = reinterpret_cast<const bf16_t*>(a.x2); k.x2_bs = a.x2_bs; k.ldx2 = a.x2 ? a.ldx2 : a.ldx;
   k.wfrag = reinterpret_cast<const bf16_t*>(a.w_frag);
-  k.swfrag = a.sx ? reinterpret_cast<const bf16_t*>(a.sw_frag) : nullptr;
+  k.swfrag = nullptr;
   k.frag_step = (unsigned)(a.Cout / 32) * 1024u;
   k.gn_scale = a.gn_scale; k.gn_shift = a.gn_shift;
   k.gn_acc1 = a.gn_acc1; k.gn_acc2 = a.gn_acc2; k.gn_gamma = a.gn_gamma; k.gn_beta = a.gn_beta;
@@ -941,28 +978,36 @@ int ds_launch_conv_sw(const ConvArgs& a, hipStream_t st) {
   k.out_scale = a.out_scale;
   k.y = reinterpret_cast<bf16_t*>(a.y); k.y_bs = a.y_bs; k.ldy = a.ldy;
   k.stats = a.stats_acc;
-  k.sx = reinterpret_cast<const bf16_t*>(a.sx); k.sx_bs = a.sx_bs; k.ldsx = a.ldsx; k.sC1 = a.sx2 ? a.sC1 : a.sCin;
-  k.sx2 = reinterpret_cast<const bf16_t*>(a.sx2); k.sx2_bs = a.sx2_bs; k.ldsx2 = a.sx2 ? a.ldsx2 : a.ldsx;
-  k.H = a.H; k.W = a.W; k.G = 0; k.ncb = a.Cout / CO; k.cout = a.Cout; k.tiles_x = 0; k.tiles_per_img = 0;
+  k.sx = nullptr; k.sx_bs = 0; k.ldsx = 0; k.sC1 = 0; k.sx2 = nullptr; k.sx2_bs = 0; k.ldsx2 = 0;
+  int nsk = 0;
+  if (a.sx) {
+    k.sx = reinterpret_cast<const bf16_t*>(a.sx); k.sx_bs = a.sx_bs; k.ldsx = a.ldsx; k.sC1 = a.sx2 ? a.sC1 : a.sCin;
+    k.sx2 = reinterpret_cast<const bf16_t*>(a.sx2); k.sx2_bs = a.sx2_bs; k.ldsx2 = a.sx2 ? a.ldsx2 : a.ldsx;
+    k.swfrag = reinterpret_cast<const bf16_t*>(a.sw_frag);
+    nsk = a.sCin / KC;
+  } else if (a.res) {  // the residual [B][H][W][Cout] as a folded skip against the identity matrix (exact in the fp32 accumulators)
+    k.sx = reinterpret_cast<const bf16_t*>(a.res); k.sx_bs = a.res_bs; k.ldsx = a.ldr; k.sC1 = a.Cout; k.ldsx2 = a.ldr;
+    k.swfrag = reinterpret_cast<const bf16_t*>(a.ident_frag);
+    nsk = a.Cout / KC;
+  }
+  k.H = a.H; k.W = a.W; k.G = 0; k.cout = a.Cout; k.tiles_x = 0; k.tiles_per_img = 0;
 #ifdef SW_TIMING  // (profiling builds only: stores / loads outside the tensors)
   k.dbg = getenv("DIFFSEP_SW_DBG") ? atoi(getenv("DIFFSEP_SW_DBG")) : 0;
 #else
   k.dbg = 0;
 #endif
   const int mode = ((a.gn_scale || a.gn_acc1) && a.gn_act) ? 2 : 0;
-  const int nch = a.Cin / KC, nsk = a.sx ? a.sCin / KC : 0;
-  if (mode == 0) {
-    if (nch == 1) return sw_launch<1, 0, 0>(k, a, st);
-    return sw_launch<2, 0, 0>(k, a, st);
+  const int nch = a.Cin / KC;
+  int rc = -1;
+  if (a.Cout == 64) {
+    k.ncb = 1;
+    if (nch == 3 && nsk == 0 && mode == 2) rc = sw_launch<3, 0, 2, 4, 2>(k, a, st);
+  } else {
+    k.ncb = a.Cout / 128;
+    const int rpw = sw_rpw(a);
+    // (the unit entry point reaches here whatever the dispatch rule says: 8-row tiles whenever the image has them)
+    rc = (rpw == 8 || (rpw == 0 && a.H % 8 == 0 && !(a.opts & DS_OPT_SW_ROWS4))) ? sw_dispatch128<8>(k, a, nch, nsk, mode, st) : sw_dispatch128<4>(k, a, nch, nsk, mode, st);
   }
-  if (nsk == 0) {
-    if (nch == 1) return sw_launch<1, 0, 2>(k, a, st);
-    if (nch == 2) return sw_launch<2, 0, 2>(k, a, st);
-    if (nch == 3) return sw_launch<3, 0, 2>(k, a, st);
-    return sw_launch<4, 0, 2>(k, a, st);
-  }
-  if (nsk == 1) return sw_launch<2, 1, 2>(k, a, st);
-  if (nsk == 2) return sw_launch<2, 2, 2>(k, a, st);
-  if (nsk == 3) return sw_launch<2, 3, 2>(k, a, st);
-  return sw_launch<2, 4, 2>(k, a, st);
+  DS_CHECK(rc >= 0, "conv3x3_sw: shape outside the instantiated set");
+  return rc;
 }

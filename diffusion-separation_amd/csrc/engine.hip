@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void repack_frag_kernel(const float* __restric
     const int i = (int)(idx % I);
     const long r = idx / I;
     const int tap = (int)(r % taps), o = (int)(r / taps);
-    dst[ds_rw_frag_index(o, tap, i, taps, O)] = f2h(src[o * so + i * si + tap * st]);
+    dst[ds_rw_frag_index(o, tap, i, taps, O)] = f2h(src ? src[o * so + i * si + tap * st] : (o == i ? 1.f : 0.f));  // (null: the identity)
   }
 }
 // ... and the split mode's: hi = bf16(w), lo = bf16(w - hi) at ds_sws_frag_index(o, tap, i, plane); src == null: the O x O identity
@@ -380,6 +380,7 @@ unsigned ds_default_opts() {
     if (on("DIFFSEP_NO_STFT_FUSED")) g_opts |= DS_OPT_NO_STFT_FUSED;
     if (on("DIFFSEP_NO_SW")) g_opts |= DS_OPT_NO_SW;
     if (on("DIFFSEP_NO_SWS")) g_opts |= DS_OPT_NO_SWS;
+    if (on("DIFFSEP_NO_SW_ROWS4")) g_opts |= DS_OPT_NO_SW_ROWS4;
     if (on("DIFFSEP_NO_SW_RW")) g_opts |= DS_OPT_NO_SW_RW;
   });
   return g_opts;
@@ -409,6 +410,8 @@ static int opt_bit(const char* name, unsigned* bit) {
       {"no_split256", DS_OPT_NO_SPLIT256},
       {"no_sw", DS_OPT_NO_SW},
       {"no_sws", DS_OPT_NO_SWS},
+      {"no_sw_rows4", DS_OPT_NO_SW_ROWS4},
+      {"sw_rows4", DS_OPT_SW_ROWS4},
       {"no_sw_rw", DS_OPT_NO_SW_RW}};
   for (const auto& t : tab)
     if (!strcmp(name, t.n)) { *bit = t.b; return 0; }
@@ -1174,6 +1177,11 @@ static int repack_module(diffsep_engine* e, const Module& m) {
       rc |= repack_frag(e, m.conv0_w, m.pf0, m.out_ch, m.in_ch, 9, (long)m.in_ch * 9, 9, 1);
       rc |= repack_frag(e, m.conv1_w, m.pf1, m.out_ch, m.out_ch, 9, (long)m.out_ch * 9, 9, 1);
       if (m.has_conv2) rc |= repack_frag(e, m.conv2_w, m.pf2, m.out_ch, m.in_ch, 1, m.in_ch, 1, 0);
+      if (m.pf_id >= 0 && e->cfg.dtype == DS_BF16) {
+        hipLaunchKernelGGL(repack_frag_kernel, dim3(cdiv((long)m.out_ch * m.out_ch, 256)), dim3(256), 0, 0, (const float*)nullptr,
+                           (bf16_t*)(e->d_pack) + m.pf_id, m.out_ch, m.out_ch, 1, 0L, 0L, 0L);
+        DS_LAUNCH_CHECK();
+      }
       if (m.pf_id >= 0 && e->cfg.dtype == DS_F32 && e->split) {
         hipLaunchKernelGGL(repack_frag_split_kernel, dim3(cdiv((long)m.out_ch * m.out_ch, 256)), dim3(256), 0, 0, (const float*)nullptr,
                            (bf16_t*)((float*)(e->d_pack) + m.pf_id), m.out_ch, m.out_ch, 1, 0L, 0L, 0L);
@@ -1826,7 +1834,7 @@ extern "C" int32_t diffsep_conv3x3_streamed(const void* x, const void* x2, int32
                                             int32_t Cin, int32_t Cout, float out_scale, int32_t dtype, int64_t* stats,
                                             const void* res, const void* ident_frag, void* stream) {
   DS_CHECK(x && w_frag && y, "conv3x3_streamed: null pointer");
-  DS_CHECK(!res || (dtype == DS_F32_SPLIT && ident_frag && !sx), "conv3x3_streamed: a residual needs the split mode, the identity copy and no skip");
+  DS_CHECK(!res || (ident_frag && !sx), "conv3x3_streamed: a residual needs the identity copy and no skip");
   DS_CHECK(B > 0 && H > 0 && W > 0, "conv3x3_streamed: empty problem");
   DS_CHECK(!x2 || (C1 > 0 && C1 < Cin), "conv3x3_streamed: bad concat split");
   DS_CHECK(!sx || (sw_frag && sCin > 0 && (!sx2 || (sC1 > 0 && sC1 < sCin))), "conv3x3_streamed: bad skip operands");
@@ -1851,14 +1859,14 @@ extern "C" int32_t diffsep_conv3x3_streamed(const void* x, const void* x2, int32
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.taps = 9;
   a.dtype = dtype == DS_F32_SPLIT ? DS_F32 : dtype; a.split = dtype == DS_F32_SPLIT;
   DS_CHECK((long)H * W * (Cin > Cout ? Cin : Cout) * 4 < 2147483647L, "conv3x3_streamed: image too large for 32-bit buffer offsets");
+  a.res = res; a.res_bs = (long)H * W * Cout; a.ldr = Cout; a.ident_frag = ident_frag;
   if (a.split) {  // fp32 tensors, hi / lo fragment copies: conv3x3_sws.hip
-    a.res = res; a.res_bs = (long)H * W * Cout; a.ldr = Cout; a.ident_frag = ident_frag;
     DS_CHECK(ds_conv_sws_supported(a), "conv3x3_streamed: shape outside the split kernel's instantiations (Cout = 64 / 128, Cin = 64 .. 256 "
                                        "by 64, W % 32 == 0, H % 8 == 0; skip / residual channels 64 .. 256 by 64 behind GroupNorm; raw input: Cin <= 128)");
     return ds_launch_conv_sws(a, (hipStream_t)stream);
   }
   DS_CHECK(ds_conv_sw_supported(a), "conv3x3_streamed: shape outside the kernel's instantiations (16-bit, Cout = 128 / 256, Cin = 64 .. 256 "
-                                    "by 64, W % 32 == 0, H % 8 == 0; a skip needs GroupNorm and Cin = 128; raw input: Cin <= 128)");
+                                    "by 64, W % 32 == 0, H % 4 == 0; a skip needs GroupNorm and Cin = 128; raw input: Cin <= 128; Cout = 64: Cin = 192)");
   return ds_launch_conv_sw(a, (hipStream_t)stream);
 }
 extern "C" int64_t diffsep_frag_index(int32_t cout, int32_t tap, int32_t cin, int32_t taps, int32_t Cout) {

@@ -294,8 +294,10 @@ int32_t diffsep_conv2d_chunk(int32_t ksize, int32_t dtype);
  * dtype = DIFFSEP_F32_SPLIT: the split mode's sibling (csrc/conv3x3_sws.hip; sdes/__init__.py:166-188 runs on it in the head of a
  * hybrid run): fp32 tensors, Cout = 64 / 128, every product as three bfloat16 MFMAs on hi / lo planes; w_frag / sw_frag
  * are then PAIRS of bfloat16 planes (hi = bf16(w), lo = bf16(w - hi)) at diffsep_frag_index_split(cout, tap, cin, taps, Cout,
- * plane); `res` (nullable, split mode only, no skip): residual [B][H][W][Cout] added before out_scale — it rides through the
- * matrix cores against `ident_frag`, the split copy of the Cout x Cout identity (taps = 1). */
+ * plane).  `res` (nullable, no skip beside it; 16-bit: Cout = 128): residual [B][H][W][Cout] added before out_scale — it rides
+ * through the matrix cores against `ident_frag`, the fragment copy (of that mode) of the Cout x Cout identity (taps = 1).
+ * 16-bit tile shapes: 8 x 32 pixels x 128 couts, 4 x 32 x 128 where H % 8 != 0 (and, in the engine, on levels with fewer 8-row
+ * tiles than compute units), 8 x 32 x 64 for the one 64-cout layer the register-weight kernel does not hold (Cin = 192). */
 int32_t diffsep_conv3x3_streamed(const void* x, const void* x2, int32_t C1, const float* gn_scale, const float* gn_shift,
                                  const void* w_frag, const float* bias, const float* bias_b, const void* sx, const void* sx2,
                                  int32_t sC1, int32_t sCin, const void* sw_frag, void* y, int32_t B, int32_t H, int32_t W,

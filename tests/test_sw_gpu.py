@@ -48,7 +48,7 @@ def test_frag_index_matches_the_library():
 
 
 # (B, H, W): one tile per block; several tiles per block and image borders inside a block's range; one row of tiles; wide
-SHAPES = [(2, 8, 32), (3, 64, 96), (40, 64, 64), (1, 128, 256), (5, 24, 32)]
+SHAPES = [(2, 8, 32), (3, 64, 96), (40, 64, 64), (1, 128, 256), (5, 24, 32), (3, 12, 64)]  # (H = 12: the 4 x 32 tile variant)
 # (C1, C2, raw input?, skip channels (first, second), Cout)
 CASES = [
     (64, 0, True, None, 128),        # 64 -> 128 behind a down-sampling (raw input)
@@ -61,6 +61,8 @@ CASES = [
     (128, 0, False, (128, 64), 128),   # Conv_1 + folded skip on cat(128, 64)
     (128, 0, False, (128, 128), 128),  # Conv_1 + folded skip on cat(128, 128)
     (128, 128, False, None, 256),    # two cout blocks
+    (128, 0, False, "res", 128),     # Conv_1 + residual (against the identity copy)
+    (128, 64, False, None, 64),      # cat(128, 64) -> 64: two cout groups x two pixel groups
 ]
 
 
@@ -85,8 +87,14 @@ def test_sw_conv3x3_matches_torch(dt, B, H, W, C1, C2, raw, skip, CO):
         xf = F.silu(xf * sc[:, None, None, :] + sh[:, None, None, :]).to(dt).float()
     ref = F.conv2d(xf.cpu().permute(0, 3, 1, 2), w.to(dt).float(), bias.cpu(), padding=1).permute(0, 2, 3, 1)
     ref = ref + bb.cpu()[:, None, None, :]
-    sk = None
-    if skip is not None:
+    sk, res, ident = None, None, None
+    if CO == 64 and H % 8 != 0:
+        pytest.skip("64 couts: 8-row tiles only")
+    if skip == "res":
+        res = rnd("sw.r" + tag, (B, H, W, CO), 1.3).to(DEV, dt)
+        ident = ops.pack_frag_weight(torch.eye(CO).reshape(CO, CO, 1, 1), dt).to(DEV)
+        ref = ref + res.float().cpu()
+    elif skip is not None:
         s1, s2 = skip
         sa = rnd("sw.sa" + tag, (B, H, W, s1), 1.1).to(DEV, dt)
         sb = rnd("sw.sb" + tag, (B, H, W, s2), 0.8).to(DEV, dt) if s2 else None
@@ -96,31 +104,44 @@ def test_sw_conv3x3_matches_torch(dt, B, H, W, C1, C2, raw, skip, CO):
         sk = (sa, sb, ops.pack_frag_weight(sw, dt).to(DEV))
     ref = ref * 0.70710678
     y, st = ops.conv3x3_streamed(a, ops.pack_frag_weight(w, dt).to(DEV), CO, x2=bt, gn=None if raw else (sc, sh), bias=bias,
-                                 bias_b=bb, skip=sk, out_scale=0.70710678, stats=True)
+                                 bias_b=bb, skip=sk, out_scale=0.70710678, stats=True, res=res, ident_frag=ident)
     tol = 4e-3 if dt == torch.float16 else 8e-3
     assert rel_rms(y.float(), ref) < tol
     s = ops.stats_to_float(st)
     assert torch.allclose(s[..., 0].cpu(), ref.double().sum((1, 2)), rtol=3e-3, atol=3e-3 * H * W)
     assert torch.allclose(s[..., 1].cpu(), (ref.double() ** 2).sum((1, 2)), rtol=4e-3, atol=4e-3 * H * W)
     # plain launch: no bias / statistics
-    y2 = ops.conv3x3_streamed(a, ops.pack_frag_weight(w, dt).to(DEV), CO, x2=bt, gn=None if raw else (sc, sh), skip=sk)
+    y2 = ops.conv3x3_streamed(a, ops.pack_frag_weight(w, dt).to(DEV), CO, x2=bt, gn=None if raw else (sc, sh), skip=sk, res=res,
+                              ident_frag=ident)
     ref2 = (ref / 0.70710678) - bias.cpu() - bb.cpu()[:, None, None, :]
     assert rel_rms(y2.float(), ref2) < tol
     # the same launch twice: bit-identical (fixed summation order, integer statistics)
     y3, st3 = ops.conv3x3_streamed(a, ops.pack_frag_weight(w, dt).to(DEV), CO, x2=bt, gn=None if raw else (sc, sh), bias=bias,
-                                   bias_b=bb, skip=sk, out_scale=0.70710678, stats=True)
+                                   bias_b=bb, skip=sk, out_scale=0.70710678, stats=True, res=res, ident_frag=ident)
     assert torch.equal(y, y3) and torch.equal(st, st3)
+
+
+def test_sw_four_row_tiles_on_every_shape():
+    """the 4 x 32 tile variant (the engine's choice below one 8-row tile per compute unit) forced on shapes the 8-row variant takes"""
+    L = _lib.lib("f16")
+    _lib.check(L.diffsep_set_option(b"sw_rows4", 1), L)
+    try:
+        for (B, H, W) in [(3, 64, 96), (2, 32, 32)]:
+            for case in [(128, 128, False, None, 128), (128, 0, False, (128, 128), 128), (128, 0, False, "res", 128), (64, 0, True, None, 128)]:
+                test_sw_conv3x3_matches_torch(torch.float16, B, H, W, *case)
+    finally:
+        _lib.check(L.diffsep_set_option(b"sw_rows4", 0), L)
 
 
 def test_sw_rejects_what_it_does_not_instantiate():
     a = torch.zeros((1, 8, 32, 64), device=DEV, dtype=torch.float16)
     w = ops.pack_frag_weight(torch.zeros((64, 64, 3, 3)), torch.float16).to(DEV)
     with pytest.raises(RuntimeError):
-        ops.conv3x3_streamed(a, w, 64)  # 64 couts: the register-weight kernel's layer
-    a2 = torch.zeros((1, 12, 32, 128), device=DEV, dtype=torch.float16)
+        ops.conv3x3_streamed(a, w, 64)  # 64 -> 64: the register-weight kernel's layer
+    a2 = torch.zeros((1, 10, 32, 128), device=DEV, dtype=torch.float16)
     w2 = ops.pack_frag_weight(torch.zeros((128, 128, 3, 3)), torch.float16).to(DEV)
     with pytest.raises(RuntimeError):
-        ops.conv3x3_streamed(a2, w2, 128)  # H % 8 != 0
+        ops.conv3x3_streamed(a2, w2, 128)  # H % 4 != 0
 
 
 # ------------------------------------------------------------------------------------------------ split mode (conv3x3_sws.hip)
