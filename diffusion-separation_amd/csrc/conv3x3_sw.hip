@@ -158,49 +158,58 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
 
   // ---- tables: GroupNorm scale / shift of image b, bias.  The operands are LOADED here, ahead of the first chunk's loads and
   // the first weight fragments (loads return in order), and turned into the LDS tables after those have been issued
-  static_assert(CIN <= NT && CO <= NT, "one table entry per thread");
-  constexpr int CPG_MAX = 8;  // channels per GroupNorm group: min(C / 4, 32) groups -> 4 (C <= 128) or 8 (C = 256)
-  long long t_s[CPG_MAX], t_q[CPG_MAX];
-  float t_gam = 1.f, t_bet = 0.f, t_sc = 1.f, t_sh = 0.f, t_bias = 0.f;
+  static_assert(CIN <= 2 * NT && CO <= NT, "at most two table entries per thread");
+  constexpr int TE = (CIN + NT - 1) / NT;       // table entries per thread (2: the 512-channel inputs of nf = 128)
+  constexpr int CPG_MAX = CIN > 256 ? 16 : 8;   // channels per GroupNorm group: min(C / 4, 32) groups -> 4 (C <= 128), 8 (256), 16 (512)
+  long long t_s[TE][CPG_MAX], t_q[TE][CPG_MAX];
+  float t_gam[TE], t_bet[TE], t_sc[TE], t_sh[TE], t_bias = 0.f;
 #pragma unroll
-  for (int j = 0; j < CPG_MAX; ++j) { t_s[j] = 0; t_q[j] = 0; }
-  if (tid < CIN) {
-    const int c = tid;
-    if (p.gn_acc1) {  // statistics straight from the producers' channel-sum accumulators
-      const int C1 = p.C1, C2 = CIN - C1;
-      const int cpg = CIN / p.gn_groups, g0 = (c / cpg) * cpg;
+  for (int e = 0; e < TE; ++e) {
+    t_gam[e] = 1.f; t_bet[e] = 0.f; t_sc[e] = 1.f; t_sh[e] = 0.f;
 #pragma unroll
-      for (int j = 0; j < CPG_MAX; ++j) {
-        if (j < cpg) {
-          const int cc = g0 + j;
-          const long long* src = cc < C1 ? p.gn_acc1 + ((long)b * C1 + cc) * 2 : p.gn_acc2 + ((long)b * C2 + (cc - C1)) * 2;
-          t_s[j] = src[0];
-          t_q[j] = src[1];
+    for (int j = 0; j < CPG_MAX; ++j) { t_s[e][j] = 0; t_q[e][j] = 0; }
+    const int c = tid + e * NT;
+    if (c < CIN) {
+      if (p.gn_acc1) {  // statistics straight from the producers' channel-sum accumulators
+        const int C1 = p.C1, C2 = CIN - C1;
+        const int cpg = CIN / p.gn_groups, g0 = (c / cpg) * cpg;
+#pragma unroll
+        for (int j = 0; j < CPG_MAX; ++j) {
+          if (j < cpg) {
+            const int cc = g0 + j;
+            const long long* src = cc < C1 ? p.gn_acc1 + ((long)b * C1 + cc) * 2 : p.gn_acc2 + ((long)b * C2 + (cc - C1)) * 2;
+            t_s[e][j] = src[0];
+            t_q[e][j] = src[1];
+          }
         }
+        t_gam[e] = p.gn_gamma ? p.gn_gamma[c] : 1.f;
+        t_bet[e] = p.gn_beta ? p.gn_beta[c] : 0.f;
+      } else if (p.gn_scale) {
+        t_sc[e] = p.gn_scale[(long)b * CIN + c];
+        t_sh[e] = p.gn_shift[(long)b * CIN + c];
       }
-      t_gam = p.gn_gamma ? p.gn_gamma[c] : 1.f;
-      t_bet = p.gn_beta ? p.gn_beta[c] : 0.f;
-    } else if (p.gn_scale) {
-      t_sc = p.gn_scale[(long)b * CIN + c];
-      t_sh = p.gn_shift[(long)b * CIN + c];
     }
   }
   if (tid < CO) t_bias = (p.bias ? p.bias[cb * CO + tid] : 0.f) + (p.bias_b ? p.bias_b[(long)b * p.bias_b_ld + cb * CO + tid] : 0.f);
   auto build_tables = [&]() __attribute__((always_inline)) {
-    if (tid < CIN) {
-      float sc = t_sc, sh = t_sh;
-      if (p.gn_acc1) {
-        long long t_ssum = 0, t_ssq = 0;
 #pragma unroll
-        for (int j = 0; j < CPG_MAX; ++j) { t_ssum += t_s[j]; t_ssq += t_q[j]; }
-        const double mean = (double)t_ssum * (1.0 / DS_STAT_SUM_SCALE) * (double)p.gn_inv_count;
-        double var = (double)t_ssq * (1.0 / DS_STAT_SQ_SCALE) * (double)p.gn_inv_count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        sc = (float)(1.0 / sqrt(var + (double)p.gn_eps)) * t_gam;
-        sh = t_bet - (float)mean * sc;
+    for (int e = 0; e < TE; ++e) {
+      const int c = tid + e * NT;
+      if (c < CIN) {
+        float sc = t_sc[e], sh = t_sh[e];
+        if (p.gn_acc1) {
+          long long t_ssum = 0, t_ssq = 0;
+#pragma unroll
+          for (int j = 0; j < CPG_MAX; ++j) { t_ssum += t_s[e][j]; t_ssq += t_q[e][j]; }
+          const double mean = (double)t_ssum * (1.0 / DS_STAT_SUM_SCALE) * (double)p.gn_inv_count;
+          double var = (double)t_ssq * (1.0 / DS_STAT_SQ_SCALE) * (double)p.gn_inv_count - mean * mean;
+          if (var < 0.0) var = 0.0;
+          sc = (float)(1.0 / sqrt(var + (double)p.gn_eps)) * t_gam[e];
+          sh = t_bet[e] - (float)mean * sc;
+        }
+        sTab[c] = sc;
+        sTab[CIN + c] = sh;
       }
-      sTab[tid] = sc;
-      sTab[CIN + tid] = sh;
     }
     if (tid < CO) sTab[2 * CIN + tid] = t_bias * p.out_scale;
   };
@@ -901,15 +910,17 @@ bool sw_shape(int cout, int nch, int nsk, int mode) {
   if (cout == 64) return nch == 3 && nsk == 0 && mode == 2;  // (cat(128, 64) -> 64 of the 128^2 up path: the one 64-cout layer the
                                                                // register-weight kernel does not hold)
   if (mode == 0) return nsk == 0 && (nch == 1 || nch == 2);
-  if (nsk == 0) return nch >= 1 && nch <= 4;
-  return nch == 2 && nsk >= 1 && nsk <= 4;
+  if (nsk == 0) return (nch >= 1 && nch <= 4) || nch == 6 || nch == 8;
+  if (nch == 2) return (nsk >= 1 && nsk <= 4) || nsk == 6;
+  return nch == 4 && (nsk == 2 || nsk == 4 || nsk == 6 || nsk == 8);  // (nf = 128: the 256-channel blocks)
 }
 template <int RPW>
 int sw_dispatch128(const SwK& k, const ConvArgs& a, int nch, int nsk, int mode, hipStream_t st) {
 #define SW_CASE(NCH_, NSK_, MODE_) if (nch == NCH_ && nsk == NSK_ && mode == MODE_) return sw_launch<NCH_, NSK_, MODE_, RPW, 4>(k, a, st)
   SW_CASE(1, 0, 0); SW_CASE(2, 0, 0);
-  SW_CASE(1, 0, 2); SW_CASE(2, 0, 2); SW_CASE(3, 0, 2); SW_CASE(4, 0, 2);
-  SW_CASE(2, 1, 2); SW_CASE(2, 2, 2); SW_CASE(2, 3, 2); SW_CASE(2, 4, 2);
+  SW_CASE(1, 0, 2); SW_CASE(2, 0, 2); SW_CASE(3, 0, 2); SW_CASE(4, 0, 2); SW_CASE(6, 0, 2); SW_CASE(8, 0, 2);
+  SW_CASE(2, 1, 2); SW_CASE(2, 2, 2); SW_CASE(2, 3, 2); SW_CASE(2, 4, 2); SW_CASE(2, 6, 2);
+  SW_CASE(4, 2, 2); SW_CASE(4, 4, 2); SW_CASE(4, 6, 2); SW_CASE(4, 8, 2);
 #undef SW_CASE
   return -1;
 }
@@ -924,28 +935,29 @@ int sw_rpw(const ConvArgs& a) {
 
 }  // namespace
 
-// The layers this kernel can take: 16-bit 3x3, Cout = 128 / 256 (Cin = 64 .. 256 in 64-channel chunks: one tensor or the in-place
-// concat of two, split on a chunk boundary; input raw or GroupNorm + SiLU; optional folded 1x1 skip on 64 .. 256 raw channels, or
+// The layers this kernel can take: 16-bit 3x3, Cout = 128 / 256 (Cin = 64 .. 512 in 64-channel chunks: one tensor or the in-place
+// concat of two, split on a chunk boundary; input raw or GroupNorm + SiLU; optional folded 1x1 skip on 64 .. 512 raw channels, or
 // a residual against the identity copy ConvArgs.ident_frag) or Cout = 64 with Cin = 192; whole tiles; fragment-major weight
 // copies at hand.
 bool ds_conv_sw_supported(const ConvArgs& a) {
   if (!(a.dtype == DS_BF16 && a.taps == 9 && (a.Cout == 64 || a.Cout == 128 || a.Cout == 256) && a.Cin % KC == 0 && a.Cin >= KC &&
-        a.Cin <= 4 * KC && a.w_frag && a.w_bs == 0 && a.bias_mode == 0 && !a.div_b && a.W % TW == 0 && a.H % 4 == 0 && a.H >= 4 &&
+        a.Cin <= 8 * KC && a.w_frag && a.w_bs == 0 && a.bias_mode == 0 && !a.div_b && a.W % TW == 0 && a.H % 4 == 0 && a.H >= 4 &&
         a.ldy >= a.Cout && a.ldy % 8 == 0))
     return false;
   if (a.Cout == 64 && a.H % 8 != 0) return false;
   if (a.x2 ? !(a.C1 % KC == 0 && a.C1 > 0 && a.C1 < a.Cin && a.ldx % 8 == 0 && a.ldx2 % 8 == 0) : a.ldx % 8 != 0) return false;
   const bool gn = a.gn_scale || a.gn_acc1;
   if (gn && !a.gn_act) return false;  // (affine without SiLU does not occur in front of a 3x3 convolution)
-  if (a.gn_acc1 && !(a.gn_groups > 0 && a.Cin % a.gn_groups == 0 && a.Cin / a.gn_groups <= 8 && (!a.x2 || a.gn_acc2))) return false;
+  if (a.gn_acc1 && !(a.gn_groups > 0 && a.Cin % a.gn_groups == 0 && a.Cin / a.gn_groups <= (a.Cin > 256 ? 16 : 8) && (!a.x2 || a.gn_acc2)))
+    return false;
   int nsk = 0;
   if (a.sx) {
-    if (!(a.sw && a.sw_frag && !a.res && a.sCin % KC == 0 && a.sCin >= KC && a.sCin <= 4 * KC && a.ldsx % 8 == 0 &&
+    if (!(a.sw && a.sw_frag && !a.res && a.sCin % KC == 0 && a.sCin >= KC && a.sCin <= 8 * KC && a.ldsx % 8 == 0 &&
           (!a.sx2 || (a.sC1 % KC == 0 && a.sC1 > 0 && a.sC1 < a.sCin && a.ldsx2 % 8 == 0))))
       return false;
     nsk = a.sCin / KC;
   } else if (a.res) {
-    if (!(a.ident_frag && a.Cout == 128 && a.ldr >= a.Cout && a.ldr % 8 == 0)) return false;
+    if (!(a.ident_frag && a.Cout >= 128 && a.ldr >= a.Cout && a.ldr % 8 == 0)) return false;
     nsk = a.Cout / KC;
   }
   return sw_shape(a.Cout, a.Cin / KC, nsk, gn ? 2 : 0);

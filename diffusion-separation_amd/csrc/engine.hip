@@ -151,7 +151,7 @@ struct ArchBuilder {
     if (ds_rw_frag_shape(9, in, out) || ds_sw_frag_shape(9, in, out) || ds_sws_frag_shape(9, in, out)) m.pf0 = pack(out, 9, in);
     if (ds_rw_frag_shape(9, out, out) || ds_sw_frag_shape(9, out, out) || ds_sws_frag_shape(9, out, out)) m.pf1 = pack(out, 9, out);
     if (m.has_conv2 && (ds_rw_frag_shape(1, in, out) || ds_sw_frag_shape(1, in, out) || ds_sws_frag_shape(1, in, out))) m.pf2 = pack(out, 1, in);
-    if (!m.has_conv2 && ds_sws_frag_shape(1, out, out)) m.pf_id = pack(out, 1, out);
+    if (!m.has_conv2 && (ds_sws_frag_shape(1, out, out) || ds_sw_frag_shape(1, out, out))) m.pf_id = pack(out, 1, out);
     if (in == 256 && in_c1 == 128 && out == 128 && !up && !down) {
       m.pf0a = pack(out, 9, 128); m.pf0b = pack(out, 9, 128); m.pf2a = pack(out, 1, 128); m.pk2b = pack(out, 1, 128);
     }

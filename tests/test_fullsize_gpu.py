@@ -203,9 +203,12 @@ def test_nf128_sampler_precision_gates_vs_fp32_engine():
     got["split"] = si_sdr(sep, ref)
     for k, s in got.items():
         print(f"\n[nf128 N30 {k} vs fp32 engine] SI-SDR mean {float(s.mean()):.2f} min {float(s.min()):.2f} dB")
-    # gates: a few dB under the measurement (f16 36.0 / 35.4, bf16 19.4 / 17.9, hybrid (bf16 + split head) 43.9 / 42.7, hybrid_f16 62.5 / 61.6, split 77.7 / 77.0 dB
+    # gates: a few dB under the measurement (f16 36.0 / 35.4 in round 4, bf16 19.4 / 17.9, hybrid (bf16 + split head) 43.9 / 42.7, hybrid_f16 62.5 / 61.6, split 77.7 / 77.0 dB
     # mean / min)
-    assert float(got["f16"].mean()) > 33.0 and float(got["f16"].min()) > 32.0
+    # (f16 alone is NOT the mode shipped at this width — "auto" = hybrid, gated below.  Round 5: 33.8 / 30.9 dB since the 128- and
+    # 256-cout layers of the <= 128-row levels run on the streamed-weight kernel, whose GroupNorm + SiLU is packed half precision
+    # like the register-weight kernel's; the generic tile they left activated in fp32)
+    assert float(got["f16"].mean()) > 31.0 and float(got["f16"].min()) > 28.5
     assert float(got["bf16"].mean()) > 13.0 and float(got["bf16"].min()) > 11.0  # (16.6 - 19.4 / 14.3 - 17.9 dB depending on which kernels run: not a usable mode at this width)
     assert float(got["hybrid"].mean()) > 40.0 and float(got["hybrid"].min()) > 39.0
     assert float(got["hybrid_f16"].mean()) > 56.0 and float(got["hybrid_f16"].min()) > 55.0

@@ -63,6 +63,9 @@ CASES = [
     (128, 128, False, None, 256),    # two cout blocks
     (128, 0, False, "res", 128),     # Conv_1 + residual (against the identity copy)
     (128, 64, False, None, 64),      # cat(128, 64) -> 64: two cout groups x two pixel groups
+    # nf = 128: 256-channel blocks (two cout blocks; 512 input channels: two table entries per thread, 16 channels per GroupNorm group)
+    (256, 256, False, None, 256), (256, 128, False, None, 128), (256, 0, False, (256, 256), 256), (256, 0, False, (256, 128), 256),
+    (256, 0, False, "res", 256), (128, 0, False, (256, 128), 128),
 ]
 
 
@@ -74,6 +77,8 @@ def test_sw_conv3x3_matches_torch(dt, B, H, W, C1, C2, raw, skip, CO):
         pytest.skip("bfloat16 build: two shapes")
     if B * H * W > 200000 and (raw or CO == 256):
         pytest.skip("large case covered by the GroupNorm variants")
+    if (C1 + C2 > 256 or C1 == 256) and (B, H, W) not in ((2, 8, 32), (3, 64, 96), (3, 12, 64)):
+        pytest.skip("nf = 128 shapes: three image sizes")
     C = C1 + C2
     tag = f"{B}.{H}.{C1}.{C2}"
     a = (rnd("sw.a" + tag, (B, H, W, C1), 1.2) + 0.1).to(DEV, dt)
