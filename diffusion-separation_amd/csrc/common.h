@@ -282,7 +282,7 @@ int ds_launch_conv_sw(const ConvArgs& a, hipStream_t st);
 __host__ __device__ inline long ds_sws_frag_index(int co, int tap, int ch, int taps, int Cout, int plane) {
   return ((((((long)(ch / 32) * taps + tap) * 2 + (ch % 32) / 16) * 2 + plane) * (Cout / 32) + co / 32) * 64 + ((ch % 16) / 8) * 32 + co % 32) * 8 + ch % 8;
 }
-inline bool ds_sws_frag_shape(int taps, int Cin, int Cout) { return (Cout == 64 || Cout == 128) && Cin % 64 == 0 && Cin >= 64 && Cin <= 256; }
+inline bool ds_sws_frag_shape(int taps, int Cin, int Cout) { return (Cout == 64 || Cout == 128 || Cout == 256) && Cin % 64 == 0 && Cin >= 64 && Cin <= 256; }
 bool ds_conv_sws_supported(const ConvArgs& a);
 bool ds_conv_sws_eligible(const ConvArgs& a);
 int ds_launch_conv_sws(const ConvArgs& a, hipStream_t st);

@@ -268,7 +268,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
     TileG g;
     const int y0 = ty * TH, x0 = tx * TW;
     g.edge = (y0 == 0 ? 1u : 0u) | (y0 + TH == p.H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + TW == p.W ? 8u : 0u);
-    g.pix0 = valid ? y0 * p.W + x0 : 0x3fffff;
+    // (no tile: the first pixel PAST the image — every offset pixel x pitch is then >= the tensor's size, and stays below 2^32 for
+    // every pitch; a constant like 0x3fffff times a 1 KB pitch plus a tile offset WRAPS into the tensor)
+    g.pix0 = valid ? y0 * p.W + x0 : M;
     return g;
   };
   auto tile_geom = [&](int i) {

@@ -265,7 +265,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sws_kernel(SwsK p) {
     TileG g;
     const int y0 = ty * TH, x0 = tx * TW;
     g.edge = (y0 == 0 ? 1u : 0u) | (y0 + TH == p.H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + TW == p.W ? 8u : 0u);
-    g.pix0 = valid ? y0 * p.W + x0 : 0x3fffff;
+    // (no tile: the first pixel PAST the image — every offset pixel x pitch is then >= the tensor's size, and stays below 2^32 for
+    // every pitch; a constant like 0x3fffff times a 1 KB pitch plus a tile offset WRAPS into the tensor)
+    g.pix0 = valid ? y0 * p.W + x0 : M;
     return g;
   };
   auto tile_geom = [&](int i) {
@@ -553,7 +555,7 @@ int sws_launch(const SwsK& k0, const ConvArgs& a, hipStream_t st) {
 template <int NCG>
 int sws_dispatch(const SwsK& k, const ConvArgs& a, int nch, int nsk, int mode, hipStream_t st) {
 #define SWS_CASE(NCH_, NSK_, MODE_) if (nch == NCH_ && nsk == NSK_ && mode == MODE_) return sws_launch<NCH_, NSK_, MODE_, NCG>(k, a, st)
-  SWS_CASE(2, 0, 0); SWS_CASE(4, 0, 0);                                        // raw input (behind a resampling)
+  SWS_CASE(2, 0, 0); SWS_CASE(4, 0, 0); SWS_CASE(8, 0, 0);                     // raw input (behind a resampling)
   SWS_CASE(2, 0, 2); SWS_CASE(4, 0, 2); SWS_CASE(6, 0, 2); SWS_CASE(8, 0, 2);  // Conv_0 of plain blocks (one tensor or a concat)
   SWS_CASE(2, 2, 2); SWS_CASE(2, 4, 2); SWS_CASE(2, 6, 2);                      // 64 -> 64 + residual / skip on 64, 128, 192 raw channels
   SWS_CASE(4, 2, 2); SWS_CASE(4, 4, 2); SWS_CASE(4, 6, 2); SWS_CASE(4, 8, 2);  // 128 -> 128 + residual / skip on 64 .. 256 raw channels
@@ -563,12 +565,12 @@ int sws_dispatch(const SwsK& k, const ConvArgs& a, int nch, int nsk, int mode, h
 
 }  // namespace
 
-// The launches this kernel takes: fp32 tensors in split mode, 3x3, 64 or 128 couts, input channels and skip channels in the
+// The launches this kernel takes: fp32 tensors in split mode, 3x3, 64 / 128 / 256 couts, input channels and skip channels in the
 // instantiated set (sws_dispatch), whole tiles (W % 32 == 0, H % 8 == 0), fragment-major hi / lo weight copies at hand; a residual
 // needs the identity copy (ConvArgs.ident_frag).
 static bool sws_shape(int Cout, int nch, int nsk, int mode) {
-  if (!(Cout == 64 || Cout == 128)) return false;  // (wider layers: Cin = 512 is not instantiated either — the generic tile keeps them)
-  if (mode == 0) return nsk == 0 && (nch == 2 || nch == 4);
+  if (!(Cout == 64 || Cout == 128 || Cout == 256)) return false;  // (256: two cout blocks of 128)
+  if (mode == 0) return nsk == 0 && (nch == 2 || nch == 4 || nch == 8);
   if (nsk == 0) return nch == 2 || nch == 4 || nch == 6 || nch == 8;
   if (nch == 2) return nsk == 2 || nsk == 4 || nsk == 6;
   if (nch == 4) return nsk == 2 || nsk == 4 || nsk == 6 || nsk == 8;
@@ -576,7 +578,7 @@ static bool sws_shape(int Cout, int nch, int nsk, int mode) {
 }
 bool ds_conv_sws_supported(const ConvArgs& a) {
   if (!(a.dtype == DS_F32 && a.split && a.taps == 9 && a.Cin % KC == 0 && a.w_frag && a.w_bs == 0 && a.bias_mode == 0 && !a.div_b &&
-        a.W % TW == 0 && a.H % 8 == 0 && a.H >= 8 && a.ldy >= a.Cout && a.ldy % 4 == 0 && a.Cout <= 128))
+        a.W % TW == 0 && a.H % 8 == 0 && a.H >= 8 && a.ldy >= a.Cout && a.ldy % 4 == 0 && a.Cout <= 256))
     return false;
   if (a.x2 ? !(a.C1 % KC == 0 && a.C1 > 0 && a.C1 < a.Cin && a.ldx % 4 == 0 && a.ldx2 % 4 == 0) : a.ldx % 4 != 0) return false;
   const bool gn = a.gn_scale || a.gn_acc1;
@@ -589,7 +591,7 @@ bool ds_conv_sws_supported(const ConvArgs& a) {
       return false;
     nsk = a.sCin / KC;
   } else if (a.res) {
-    if (!(a.ident_frag && a.ldr >= a.Cout && a.ldr % 4 == 0 && a.Cout <= 128)) return false;
+    if (!(a.ident_frag && a.ldr >= a.Cout && a.ldr % 4 == 0)) return false;
     nsk = a.Cout / KC;
   }
   return sws_shape(a.Cout, a.Cin / KC, nsk, gn ? 2 : 0);

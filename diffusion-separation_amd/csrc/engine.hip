@@ -1861,7 +1861,7 @@ extern "C" int32_t diffsep_conv3x3_streamed(const void* x, const void* x2, int32
   DS_CHECK((long)H * W * (Cin > Cout ? Cin : Cout) * 4 < 2147483647L, "conv3x3_streamed: image too large for 32-bit buffer offsets");
   a.res = res; a.res_bs = (long)H * W * Cout; a.ldr = Cout; a.ident_frag = ident_frag;
   if (a.split) {  // fp32 tensors, hi / lo fragment copies: conv3x3_sws.hip
-    DS_CHECK(ds_conv_sws_supported(a), "conv3x3_streamed: shape outside the split kernel's instantiations (Cout = 64 / 128, Cin = 64 .. 256 "
+    DS_CHECK(ds_conv_sws_supported(a), "conv3x3_streamed: shape outside the split kernel's instantiations (Cout = 64 / 128 / 256, Cin = 64 .. 256 "
                                        "by 64, W % 32 == 0, H % 8 == 0; skip / residual channels 64 .. 256 by 64 behind GroupNorm; raw input: Cin <= 128)");
     return ds_launch_conv_sws(a, (hipStream_t)stream);
   }

@@ -292,7 +292,7 @@ int32_t diffsep_conv2d_chunk(int32_t ksize, int32_t dtype);
  * cin, taps, Cout): one k-step (64-channel chunk, tap, 16-channel block) of all couts is contiguous, cout group by cout group,
  * so that a wave's 1 KB load instruction is one MFMA B-operand.
  * dtype = DIFFSEP_F32_SPLIT: the split mode's sibling (csrc/conv3x3_sws.hip; sdes/__init__.py:166-188 runs on it in the head of a
- * hybrid run): fp32 tensors, Cout = 64 / 128, every product as three bfloat16 MFMAs on hi / lo planes; w_frag / sw_frag
+ * hybrid run): fp32 tensors, Cout = 64 / 128 / 256, every product as three bfloat16 MFMAs on hi / lo planes; w_frag / sw_frag
  * are then PAIRS of bfloat16 planes (hi = bf16(w), lo = bf16(w - hi)) at diffsep_frag_index_split(cout, tap, cin, taps, Cout,
  * plane).  `res` (nullable, no skip beside it; 16-bit: Cout = 128): residual [B][H][W][Cout] added before out_scale — it rides
  * through the matrix cores against `ident_frag`, the fragment copy (of that mode) of the Cout x Cout identity (taps = 1).

@@ -157,7 +157,7 @@ SPLIT_CASES = [
     (128, 128, False, None, 128), (128, 64, False, None, 128), (128, 0, False, None, 128),
     (64, 0, False, "res", 64), (64, 0, False, (64, 0), 64), (64, 0, False, (64, 64), 64), (64, 0, False, (128, 64), 64),
     (128, 0, False, "res", 128), (128, 0, False, (64, 0), 128), (128, 0, False, (128, 0), 128), (128, 0, False, (128, 64), 128),
-    (128, 0, False, (128, 128), 128),
+    (128, 0, False, (128, 128), 128), (128, 128, False, None, 256), (128, 128, True, None, 256),
 ]
 
 

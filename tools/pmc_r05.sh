@@ -17,7 +17,7 @@ DT=$DT python - "$OUT" "$CMD" <<'PY'
 import csv, glob, json, os, re, sys
 out, cmd = sys.argv[1], sys.argv[2]
 def short(k):
-    m = re.search(r"((?:conv3x3_rw|conv3x3_ws1|conv_mfma|conv3x3_small|conv3x3_thin_in|conv3x3_thin_out|attn_fused)_kernel(?:<[^>]*>)?)", k)
+    m = re.search(r"((?:conv3x3_rw|conv3x3_sws|conv3x3_sw|conv3x3_ws1|conv_mfma|conv3x3_small|conv3x3_thin_in|conv3x3_thin_out|attn_fused)_kernel(?:<[^>]*>)?)", k)
     return m.group(1).replace("unsigned short", os.environ.get("DT", "bf16")).replace("float", "f32").replace(" ", "") if m else None
 res, dur = {}, {}
 for p in ("p1", "p2"):

@@ -16,7 +16,7 @@ OUT=$OUT DT=$DT python - <<'PY'
 import csv, glob, json, os, re
 out, dt = os.environ["OUT"], os.environ["DT"]
 def short(k):
-    m = re.search(r"((?:conv3x3_rw|conv3x3_ws1|conv_mfma|conv3x3_small|conv3x3_thin_in|conv3x3_thin_out|attn_fused)_kernel(?:<[^>]*>)?)", k)
+    m = re.search(r"((?:conv3x3_rw|conv3x3_sws|conv3x3_sw|conv3x3_ws1|conv_mfma|conv3x3_small|conv3x3_thin_in|conv3x3_thin_out|attn_fused)_kernel(?:<[^>]*>)?)", k)
     return m.group(1).replace("unsigned short", dt if dt in ("f16", "bf16") else "bf16").replace("float", "f32").replace(" ", "") if m else None
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
