@@ -206,3 +206,50 @@ def test_sws_split_conv3x3_matches_torch_fp32(B, H, W, C1, C2, raw, skip, CO):
     y3, st3 = ops.conv3x3_streamed(a, wf, CO, x2=bt, gn=None if raw else (sc, sh), bias=bias, bias_b=bb, skip=sk, out_scale=0.70710678,
                                    stats=True, res=res, ident_frag=ident)
     assert torch.equal(y, y3) and torch.equal(st, st3)
+
+
+# ------------------------------------------------------------------------------------------------ the engine's dispatch
+def _score_with_kernels(eng, xt, t, mn):
+    eng.set_graph(False)
+    eng.profile_begin()
+    y = eng.score(xt, t, mn)
+    eng.profile_end()
+    return y, {r["kernel"] for r in eng.profile_records()}
+
+
+@pytest.mark.parametrize("mode", ["f16", "split"])
+def test_engine_dispatches_the_streamed_kernels_and_matches_the_oracle(mode):
+    """nf = 64 at the bench's batch (B = 16 x 4 s): the 64- / 32-row levels and cat(128, 64) -> 64 run on conv3x3_sw.hip (8-row,
+    4-row and 64-cout variants) in the half-precision engine, every >= 32-row 3x3 layer with >= 64 couts on conv3x3_sws.hip in the
+    split engine; the options no_sw / no_sws restore the dispatch of before; both against the CPU oracle (one evaluation)."""
+    import diffsep_oracle as O
+    from diffsep_amd.engine import Engine, pack_state_dict, param_table
+    dt = _lib.F16 if mode == "f16" else _lib.F32_SPLIT
+    cfg = _lib.model_config(nf=64, num_sources=2, dtype=dt)
+    sd = synth.synth_state_dict([(n, s) for n, s, _ in param_table(cfg)], 7)
+    eng = Engine(cfg, pack_state_dict(cfg, sd))
+    B, T = 16, 32000
+    mix = torch.from_numpy(synth.synth_batch(B, T=T)[0])
+    mn, _, _ = O.normalize_batch(mix)
+    ocfg = O.default_config(64, 2)
+    xt = O.prior_sampling(ocfg, mn, rnd("swe.z", (B, 2, T)))
+    t = torch.full((B,), 0.5)
+    torch.set_num_threads(min(torch.get_num_threads(), 16))
+    ref = O.score_forward(O.to_torch(sd), ocfg, xt[:2], t[:2], mn[:2])  # (two utterances of the batch on the CPU)
+    y, ks = _score_with_kernels(eng, xt.to(DEV), t.to(DEV), mn.to(DEV))
+    name, opt = ("conv3x3_sw_kernel", "no_sw") if mode == "f16" else ("conv3x3_sws_kernel", "no_sws")
+    mine = sorted(k for k in ks if k.startswith(name + "<"))
+    print(f"\n[{mode}] streamed instantiations in one evaluation: {mine}")
+    if mode == "f16":
+        assert "conv3x3_sw_kernel<4,0,2,8,4>" in mine and "conv3x3_sw_kernel<4,0,2,4,4>" in mine and "conv3x3_sw_kernel<3,0,2,4,2>" in mine
+        assert "conv3x3_sw_kernel<2,2,2,8,4>" in mine  # (Conv_1 + residual of the 64-row level: the identity copy)
+    else:
+        assert "conv3x3_sws_kernel<4,0,2,2>" in mine and "conv3x3_sws_kernel<8,0,2,4>" in mine and "conv3x3_sws_kernel<2,2,2,2>" in mine
+    eng.set_option(opt, 1)
+    y0, ks0 = _score_with_kernels(eng, xt.to(DEV), t.to(DEV), mn.to(DEV))
+    eng.set_option(opt, 0)
+    assert not any(k.startswith(name + "<") for k in ks0)
+    tol = 8e-3 if mode == "f16" else 1e-4  # (a whole evaluation: ~150 layers of 2^-17 products)
+    r, r0 = rel_rms(y[:2], ref), rel_rms(y0[:2], ref)
+    print(f"[{mode}] one evaluation vs the CPU oracle: streamed {r:.3e}, option {opt} {r0:.3e}")
+    assert r < tol and r0 < tol and not torch.equal(y, y0)
