@@ -313,19 +313,19 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
   // every input of the launch is activated (no raw skip / residual chunk shares the accumulators): the activation may
   // leave a constant factor to the epilogue
   constexpr bool FOLD = MODE == 2 && NSK == 0;
-  // Round 5.  (i) RW_ACT_PK (half-precision build): GroupNorm affine + SiLU in PACKED half precision — per dword (two channels)
+  // Round 5.  (i) SW_ACT_PK (half-precision build): GroupNorm affine + SiLU in PACKED half precision — per dword (two channels)
   // v_pk_fma_f16, 2 x v_exp_f16, v_pk_add_f16, 2 x v_rcp_f16, v_pk_mul_f16 = 7 instructions (8 without FOLD) instead of 11
   // (2 fma_mix, 2 exp, 2 add, 2 rcp, 2 mul, cvt_pk); the upper halves go through SDWA forms of the transcendentals, no
-  // unpack / pack.  What it costs in rounding is gated by tests/test_engine_gpu.py against the CPU oracle (-DRW_ACT_F32
-  // restores the fp32 arithmetic for the A/B).  (ii) RW_PIPE: a unit runs in THREE stages, one unit apart (affine + exp |
+  // unpack / pack.  What it costs in rounding is gated by tests/test_engine_gpu.py against the CPU oracle (-DSW_ACT_F32
+  // restores the fp32 arithmetic for the A/B).  (ii) SW_PIPE: a unit runs in THREE stages, one unit apart (affine + exp |
   // 1 + e, rcp | multiply, write, re-issue): the single in-order wave no longer issues a transcendental's consumer straight
   // behind it (a k-step carries 0.6 units: inside one unit every instruction depends on the previous one).
-#if defined(DS_HALF_F16) && !defined(RW_ACT_F32)
+#if defined(DS_HALF_F16) && !defined(SW_ACT_F32)
   constexpr bool ACT_PK = true;
 #else
   constexpr bool ACT_PK = false;
 #endif
-#ifdef RW_NO_PIPE
+#ifdef SW_NO_PIPE
   constexpr int PIPE_LAG = 0;
 #else
   constexpr int PIPE_LAG = 2;
@@ -432,13 +432,13 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
         so.z = ok ? so.z : 0u;
         so.w = ok ? so.w : 0u;
       }
-#ifdef RW_ABL_NOLDSW
+#ifdef SW_ABL_NOLDSW
       asm volatile("" :: "v"(so));
 #else
       if (P1 < NCH || k < NI)  // (border pieces of a skip chunk: nothing was loaded, nothing is read)
         *reinterpret_cast<u32x4_t*>(sA + sl * LDS_A + (k < NI ? ldi0 + k * HW_ * AROW : dstb[k < NI ? 0 : k - NI])) = so;
 #endif
-#ifdef RW_ABL_NOLOAD
+#ifdef SW_ABL_NOLOAD
       pa[k][0] += rel;
 #else
       issue_one(P2_, g2, k, rel);
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
     v[4] = fmaf(acc[r][8 * j + 4], osc, t1.x); v[5] = fmaf(acc[r][8 * j + 5], osc, t1.y);
     v[6] = fmaf(acc[r][8 * j + 6], osc, t1.z); v[7] = fmaf(acc[r][8 * j + 7], osc, t1.w);
     // (always taken: a branch here would cut the half-phase's instruction stream into separately scheduled pieces)
-#ifndef RW_ABL_NOSTATS
+#ifndef SW_ABL_NOSTATS
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       ssum[8 * j + e] += v[e];
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
 #else
       const unsigned o1 = o, o2 = o + 16u * (unsigned)p.ldy * 2u;
 #endif
-#ifdef RW_ABL_NOSTORE
+#ifdef SW_ABL_NOSTORE
       asm volatile("" :: "v"(a), "v"(b2), "v"(o1), "v"(o2));
 #else
       __builtin_amdgcn_raw_buffer_store_b128(a, ry, o1, 0, 0);    // pixels 0 .. 15 of the row
@@ -564,11 +564,11 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
   //     lumps; spread evenly over the phase's gaps, a gap of an epilogue half counting W_E / W_N of another one;
   //   * epilogue lumps (EPI halves): per row 20 lumps — per half row (j) 4 x {2 fma + pack | the pair's statistics}, the
   //     permlane32 swap; then the permlane16 regrouping and the two stores — spread evenly over the half's gaps.
-#ifndef RW_W_E
-#define RW_W_E 2
-#define RW_W_N 5
+#ifndef SW_W_E
+#define SW_W_E 2
+#define SW_W_N 5
 #endif
-  constexpr int W_E = RW_W_E, W_N = RW_W_N;  // capacity of a gap for unit lumps: epilogue half / other half (A/B: -DRW_W_E=.. -DRW_W_N=..)
+  constexpr int W_E = SW_W_E, W_N = SW_W_N;  // capacity of a gap for unit lumps: epilogue half / other half (A/B: -DSW_W_E=.. -DSW_W_N=..)
   float et[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // the two cout pairs in flight through the epilogue lumps
   u32x4_t osa = {0, 0, 0, 0}, osb = {0, 0, 0, 0};  // the row's two store pieces after the regrouping
   auto half = [&](auto P_, auto HF_, auto EPI_, int slot_r, const TileG& ge, const TileG& g1, const TileG& g2) __attribute__((always_inline)) {
@@ -607,8 +607,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
     u32x4_t rf[2][RFN];
 #pragma unroll
     for (int j = 0; j < RFN; ++j) rf[0][j] = ldg(0, j);
-#define RW_FRAG(ks, r) rf[((ks) / SUB) & 1][(r) + (CONV ? (ks) % SUB : 0)]
-#define RW_FRAG_LAST(ks) rf[((ks) / SUB) & 1][RFN - 1]
+#define SW_FRAG(ks, r) rf[((ks) / SUB) & 1][(r) + (CONV ? (ks) % SUB : 0)]
+#define SW_FRAG_LAST(ks) rf[((ks) / SUB) & 1][RFN - 1]
     constexpr int SP0 = G::pos0(P) + HF * NK;  // stream position of this half's first k-step
     // relative pixel index of the border pieces that complete in a k-step, read (registers or LDS table) one k-step ahead
     int rels[2][NL];
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
         } else if constexpr (ACT1) {
           if (u1 >= 0) unit_s01(std::integral_constant<int, C1>{}, -1, u1);
         }
-#ifndef RW_ABL_NOSTAGE
+#ifndef SW_ABL_NOSTAGE
         if (s2) {
           const int rel = ((u2 & 3) == 3 && (u2 >> 2) >= NI) ? rels[par][u2 >> 2] : 0;
           if constexpr (ACT1 && ACT_PK) unit_fin(std::integral_constant<int, C1>{}, std::integral_constant<int, C2>{}, g1, g2, slot_r ^ 1, u2, rel);
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
             else asm volatile(DS_CVT_PK_H_ASM " %0, %1, %2" : "=v"(osb[q]) : "v"(et[q & 1][0]), "v"(et[q & 1][1]));
           }
         } else {
-#ifndef RW_ABL_NOSTATS
+#ifndef SW_ABL_NOSTATS
           const int e0 = 8 * j + 2 * pr;
           asm volatile("v_add_f32 %0, %0, %1" : "+v"(ssum[e0]) : "v"(et[pr & 1][0]));
           asm volatile("v_add_f32 %0, %0, %1" : "+v"(ssum[e0 + 1]) : "v"(et[pr & 1][1]));
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
 #else
         const unsigned o1 = o, o2 = o + 16u * (unsigned)p.ldy * 2u;
 #endif
-#ifdef RW_ABL_NOSTORE
+#ifdef SW_ABL_NOSTORE
         asm volatile("" :: "v"(osa), "v"(osb), "v"(o1), "v"(o2));
 #else
         __builtin_amdgcn_raw_buffer_store_b128(osa, ry, o1, 0, 0);   // pixels 0 .. 15 of the row
@@ -733,12 +733,12 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
       if (ks + 1 < NK) fetch_rels(ks + 1, (ks + 1) & 1);
-      // RW_DEP: the k-step's LAST pixel fragment rides along as an unused operand of every MFMA of the k-step: the
+      // SW_DEP: the k-step's LAST pixel fragment rides along as an unused operand of every MFMA of the k-step: the
       // compiler then waits ONCE per k-step (for the newest fragment) instead of once per MFMA
-#ifdef RW_NO_DEP
-#define RW_DEP
+#ifdef SW_NO_DEP
+#define SW_DEP
 #else
-#define RW_DEP , "v"(RW_FRAG_LAST(ks))
+#define SW_DEP , "v"(SW_FRAG_LAST(ks))
 #endif
 #pragma unroll
       for (int r = 0; r < RH; ++r) {
@@ -746,8 +746,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
         // of the register file) and the accumulators are "a" operands; pixel fragments and everything the VALU touches live
         // in the architectural half.  What the compiler does not know about an asm MFMA: the 12 wait states between its
         // result and a read of it — the guard at the start of every epilogue half.
-        if (P == 0 && ks == 0) asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, 0" : "=a"(acc[R0 + r]) : "a"(ring[(SP0 + ks) % RING]), "v"(RW_FRAG(ks, r)) RW_DEP);
-        else asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, %0" : "+a"(acc[R0 + r]) : "a"(ring[(SP0 + ks) % RING]), "v"(RW_FRAG(ks, r)) RW_DEP);
+        if (P == 0 && ks == 0) asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, 0" : "=a"(acc[R0 + r]) : "a"(ring[(SP0 + ks) % RING]), "v"(SW_FRAG(ks, r)) SW_DEP);
+        else asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, %0" : "+a"(acc[R0 + r]) : "a"(ring[(SP0 + ks) % RING]), "v"(SW_FRAG(ks, r)) SW_DEP);
         // ---- the gap behind this MFMA
         {  // the next group's fragments, one per MFMA slot of this group
           const int g = ks / SUB, q = (ks % SUB) * RH + r;
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
         const int gh = ks * RH + r, gp = HF * NGH + gh;
 #pragma unroll
         for (int L = lub(gp); L < lub(gp + 1); ++L) unit_lump(L, ks & 1);
-#ifndef RW_ABL_NOEPI
+#ifndef SW_ABL_NOEPI
         if constexpr (EPI) {
 #pragma unroll
           for (int LE = gh * NLE / NGH; LE < (gh + 1) * NLE / NGH; ++LE) epi_lump(LE);
@@ -818,11 +818,6 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
     auto run = [&](auto self, auto P_) __attribute__((always_inline)) {
       constexpr int P = decltype(P_)::value;
       sync_lds();
-#ifdef RW_SKEW
-      if (wave == 1) __builtin_amdgcn_s_sleep(RW_SKEW);
-      if (wave == 2) __builtin_amdgcn_s_sleep(2 * RW_SKEW);
-      if (wave == 3) __builtin_amdgcn_s_sleep(3 * RW_SKEW);
-#endif
       RT_MARK(1)
       const int slot_r = ph & 1;
       half(P_, std::integral_constant<int, 0>{}, std::integral_constant<bool, P == 0>{}, slot_r, gp, ((P + 1) / NPH == 0 ? gc : gn), ((P + 2) / NPH == 0 ? gc : ((P + 2) / NPH == 1 ? gn : gnn)));

@@ -1,6 +1,6 @@
 // conv3x3_sws.hip — 3x3 convolution of the SPLIT mode (fp32 tensors, every product as three bfloat16 MFMAs on hi / lo halves:
-// hi x hi + hi x lo + lo x hi, fp32 accumulation, 2^-17 relative product error) with STREAMED weights, for the 64- and 128-cout
-// layers of the >= 32-row levels; gfx950.  The split engine is the head of every hybrid run (pl_model dtype "hybrid": what "auto"
+// hi x hi + hi x lo + lo x hi, fp32 accumulation, 2^-17 relative product error) with STREAMED weights, for the 64- / 128- / 256-cout
+// layers (<= 256 input channels) of the >= 32-row levels; gfx950.  The split engine is the head of every hybrid run (pl_model dtype "hybrid": what "auto"
 // ships above nf = 64) and the overflow net of the half-precision engine; until round 5 all of its >= 32-row layers ran on the
 // generic tile (conv_mfma.hip, SP = 1) at ~0.27 of what the three-MFMA product allows.
 // Reference: layers.py:141-156 (ddpm_conv3x3), layerspp.py:291-323 (ResnetBlockBigGANpp), ncsnpp.py:409-417 (the concat).
