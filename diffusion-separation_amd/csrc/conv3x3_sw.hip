@@ -1,7 +1,7 @@
-// conv3x3_sw.hip — 3x3 convolution with STREAMED weights for the 16-bit 128-cout layers whose weights no register file holds:
-// Cin = 192 / 256 (the cat(128, 64) / cat(128, 128) blocks: nf = 64 at 64^2, nf = 128 at 256^2 / 128^2), folded 1x1 skips on up to
-// 256 raw channels, and the 64 -> 128 / 128 -> 128 layers of levels with one or two tiles per compute unit, where the
-// register-weight kernel (conv3x3_rw.hip) pays a 295 KB weight prologue per block; gfx950, bfloat16 or (-DDS_HALF_F16) fp16 storage.
+// conv3x3_sw.hip — 3x3 convolution with STREAMED weights for the 16-bit layers whose weights no register file holds — Cin = 192 ..
+// 512 (the cat blocks: nf = 64 at 64^2, nf = 128 from 128^2 down), folded 1x1 skips on up to 512 raw channels, 256 couts — and for
+// the 64 -> 128 / 128 -> 128 layers of levels with one or two tiles per compute unit, where the register-weight kernel
+// (conv3x3_rw.hip) pays a 295 KB weight prologue per block; gfx950, bfloat16 or (-DDS_HALF_F16) fp16 storage.
 // Reference: layers.py:141-156 (ddpm_conv3x3), layerspp.py:291-323 (ResnetBlockBigGANpp), ncsnpp.py:409-417 (the concat).
 //
 // The staging pipeline, the hand-placed MFMA gaps and the in-register epilogue are those of conv3x3_rw.hip (read its header first).
@@ -17,8 +17,12 @@
 //     compiler keeps a loaded value that crosses a loop boundary in the architectural half and copies it over);
 //   * chunk order of a tile: first 3x3 chunk, the skip chunks, the other 3x3 chunks — the first and the last phase are
 //     long ones (each carries the epilogue of half a tile under its MFMAs).
-// Any number of 64-channel chunks (NCH <= 4 instantiated, NSK <= 4); the block's 128 couts may be one of several cout blocks
-// of a wider layer (Cout = 128 ncb: the fragment-major copy keeps the layer's Cout / 32 groups side by side).
+//   * tile shapes (RPW rows per wave, NCG cout groups per block): 8 x 32 pixels x 128 couts (RPW = 8, NCG = 4: the description above);
+//     4 x 32 x 128 (RPW = 4) where a level has fewer 8-row tiles than compute units or H % 8 != 0; 8 x 32 x 64 (RPW = 4, NCG = 2:
+//     two cout groups x two pixel groups) for the one 64-cout layer the register-weight kernel does not hold.
+// Any number of 64-channel chunks (instantiated: sw_shape below); the block's 128 couts may be one of several cout blocks of a
+// wider layer (Cout = 128 ncb: the fragment-major copy keeps the layer's Cout / 32 groups side by side); a residual rides as
+// skip chunks against an identity copy (exact in the fp32 accumulators).
 #include <stdlib.h>
 
 #include <type_traits>
