@@ -17,6 +17,7 @@
 //     compiler keeps a loaded value that crosses a loop boundary in the architectural half and copies it over);
 //   * chunk order of a tile: first 3x3 chunk, the skip chunks, the other 3x3 chunks — the first and the last phase are
 //     long ones (each carries the epilogue of half a tile under its MFMAs).
+//     Only those two run as half-phases; the phases between them walk (and stream) their k-steps once, on all 8 rows per fragment;
 //   * tile shapes (RPW rows per wave, NCG cout groups per block): 8 x 32 pixels x 128 couts (RPW = 8, NCG = 4: the description above);
 //     4 x 32 x 128 (RPW = 4) where a level has fewer 8-row tiles than compute units or H % 8 != 0; 8 x 32 x 64 (RPW = 4, NCG = 2:
 //     two cout groups x two pixel groups) for the one 64-cout layer the register-weight kernel does not hold.
@@ -120,8 +121,17 @@ struct SwGeom {
   }
   static constexpr int nk_of(int P) { return chunk_of(P) < NCH ? KSC : NKB; }
   // ---- the weight stream of one tile: position s = (phase, half, k-step of the half) in program order
-  static constexpr int S = 2 * NKS;
-  static constexpr int pos0(int P) { int s = 0; for (int q = 0; q < P; ++q) s += 2 * nk_of(q); return s; }
+  // (the first and the last phase run as two half-phases of 4 rows — the epilogue of the other half rides under each — and walk
+  // their chunk's k-steps twice; the phases in between have no epilogue to carry and run all 8 rows per fragment: SW_NO_FULL
+  // builds them as halves too, for the A/B)
+#ifdef SW_NO_FULL
+  static constexpr bool mid(int P) { return false; }
+#else
+  static constexpr bool mid(int P) { return P > 0 && P < NPH - 1; }
+#endif
+  static constexpr int len_of(int P) { return (mid(P) ? 1 : 2) * nk_of(P); }
+  static constexpr int pos0(int P) { int s = 0; for (int q = 0; q < P; ++q) s += len_of(q); return s; }
+  static constexpr int S = pos0(NPH);
   // k-step ks of a 3x3 chunk in the loop's order ((kx, block) groups outside, ky inside) -> (tap, block) order of the copies
   static constexpr int widx(bool conv, int ks) {
     if (!conv) return ks;
@@ -131,7 +141,7 @@ struct SwGeom {
   // fragment of stream position s: k-step index into wfrag (>= 0) or, for a skip chunk, -1 - index into swfrag
   static constexpr int frag_of(int s) {
     int P = 0;
-    while (s >= 2 * nk_of(P)) { s -= 2 * nk_of(P); ++P; }
+    while (s >= len_of(P)) { s -= len_of(P); ++P; }
     const int nk = nk_of(P), ks = s % nk, c = chunk_of(P);
     return c < NCH ? c * KSC + widx(true, ks) : -1 - ((c - NCH) * NKB + ks);
   }
@@ -576,8 +586,11 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
   float et[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // the two cout pairs in flight through the epilogue lumps
   u32x4_t osa = {0, 0, 0, 0}, osb = {0, 0, 0, 0};  // the row's two store pieces after the regrouping
   auto half = [&](auto P_, auto HF_, auto EPI_, int slot_r, const TileG& ge, const TileG& g1, const TileG& g2) __attribute__((always_inline)) {
-    constexpr int P = decltype(P_)::value, HF = decltype(HF_)::value;
+    constexpr int P = decltype(P_)::value, HF = decltype(HF_)::value;  // HF = 2: all RPW rows in one pass (a phase without epilogue)
     constexpr bool EPI = decltype(EPI_)::value;
+    constexpr bool FULL = HF == 2;
+    static_assert(!(FULL && EPI), "an epilogue half runs under the MFMAs of the OTHER half's rows");
+    constexpr int RR = FULL ? RPW : RH;          // rows of this pass
     constexpr int C = G::chunk_of(P);
     constexpr bool CONV = C < NCH;
     constexpr int NK = CONV ? KSC : NKB;
@@ -591,19 +604,20 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
     // first unit lump of phase gap GP in [0, 2 NGH]
     auto lub = [](int GP) constexpr { return NLU * (GP <= NGH ? GP * w0 : NGH * w0 + (GP - NGH) * w1) / CAP; };
     constexpr int NLE = RH * 22;  // epilogue lumps of an EPI half
-    constexpr int R0 = HF * RH, ER0 = HF ? 0 : RH;
+    constexpr int R0 = FULL ? 0 : HF * RH, ER0 = HF ? 0 : RH;
+    constexpr int GP0 = FULL ? 0 : HF * NGH;     // first gap of this pass in the phase's gap numbering [0, 2 NGH)
     const char* fb = sA + slot_r * LDS_A + fbase + R0 * HW_ * AROW;
     if constexpr (EPI) {  // the rows this half finishes were last written by asm MFMAs: 12 wait states before they are read
       if constexpr (RH == 4) asm volatile("s_nop 11" : "+a"(acc[ER0]), "+a"(acc[ER0 + 1]), "+a"(acc[ER0 + 2]), "+a"(acc[ER0 + 3]));
       else asm volatile("s_nop 11" : "+a"(acc[ER0]), "+a"(acc[ER0 + 1]));
     }
-    if constexpr (HF == 0 && C1 < NCH) act_tab(C1);
+    if constexpr ((HF == 0 || FULL) && C1 < NCH) act_tab(C1);
     // K order inside a 3x3 chunk: (kx, 16-channel block) groups outside, ky inside.  The RH rows of this half use the
     // pixel fragments of input rows R0 .. R0 + RH + 1 at the group's (kx, block): each is read ONCE per group and serves up
     // to three k-steps (ky) — RH + 2 fragment reads per 3 RH MFMAs instead of 3 RH, and one wait per group.  (A skip
     // chunk has one k-step per group: the centre tap.)
-    constexpr int SUB = CONV ? 3 : 1, RFN = CONV ? RH + 2 : RH, NG = NK / SUB;
-    static_assert(SUB * RH >= RFN, "the next group's fragments are read in the MFMA slots of the current one");
+    constexpr int SUB = CONV ? 3 : 1, RFN = CONV ? RR + 2 : RR, NG = NK / SUB;
+    static_assert(SUB * RR >= RFN, "the next group's fragments are read in the MFMA slots of the current one");
     auto ldg = [&](int g, int j) __attribute__((always_inline)) {  // fragment j of group g = kx * NKB + block
       const int dx = CONV ? g / NKB : 1, kb = g % NKB, row = CONV ? j : j + 1;
       return *reinterpret_cast<const u32x4_t*>(fb + (row * HW_ + dx) * AROW + kb * 32);
@@ -613,13 +627,13 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
     for (int j = 0; j < RFN; ++j) rf[0][j] = ldg(0, j);
 #define SW_FRAG(ks, r) rf[((ks) / SUB) & 1][(r) + (CONV ? (ks) % SUB : 0)]
 #define SW_FRAG_LAST(ks) rf[((ks) / SUB) & 1][RFN - 1]
-    constexpr int SP0 = G::pos0(P) + HF * NK;  // stream position of this half's first k-step
+    constexpr int SP0 = G::pos0(P) + (FULL ? 0 : HF * NK);  // stream position of this pass's first k-step
     // relative pixel index of the border pieces that complete in a k-step, read (registers or LDS table) one k-step ahead
     int rels[2][NL];
     auto fetch_rels = [&](int ks, int par) __attribute__((always_inline)) {  // for the unit lumps of k-step ks of this half
-      const int gp0 = HF * NGH + ks * RH;
+      const int gp0 = GP0 + ks * RR;
 #pragma unroll
-      for (int L = lub(gp0); L < lub(gp0 + RH); ++L) {
+      for (int L = lub(gp0); L < lub(gp0 + RR); ++L) {
         const int u = (L >> 1) - LAG;
         if ((L & 1) && u >= 0 && u < NU && (u & 3) == 3 && (u >> 2) >= NI)
           rels[par][u >> 2] = REL_REGS ? relreg[(u >> 2) - NI] : sDesc[((u >> 2) - NI) * NT + tid];
@@ -745,7 +759,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
 #define SW_DEP , "v"(SW_FRAG_LAST(ks))
 #endif
 #pragma unroll
-      for (int r = 0; r < RH; ++r) {
+      for (int r = 0; r < RR; ++r) {
         // Inline asm: the weight fragment (ring, loaded by the compiler's own buffer_load straight into the accumulator half
         // of the register file) and the accumulators are "a" operands; pixel fragments and everything the VALU touches live
         // in the architectural half.  What the compiler does not know about an asm MFMA: the 12 wait states between its
@@ -754,10 +768,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
         else asm volatile(DS_MFMA_H32_ASM " %0, %1, %2, %0" : "+a"(acc[R0 + r]) : "a"(ring[(SP0 + ks) % RING]), "v"(SW_FRAG(ks, r)) SW_DEP);
         // ---- the gap behind this MFMA
         {  // the next group's fragments, one per MFMA slot of this group
-          const int g = ks / SUB, q = (ks % SUB) * RH + r;
+          const int g = ks / SUB, q = (ks % SUB) * RR + r;
           if (q < RFN && g + 1 < NG) rf[(g + 1) & 1][q] = ldg(g + 1, q);
         }
-        const int gh = ks * RH + r, gp = HF * NGH + gh;
+        const int gh = ks * RR + r, gp = GP0 + gh;
 #pragma unroll
         for (int L = lub(gp); L < lub(gp + 1); ++L) unit_lump(L, ks & 1);
 #ifndef SW_ABL_NOEPI
@@ -824,6 +838,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
       sync_lds();
       RT_MARK(1)
       const int slot_r = ph & 1;
+      if constexpr (G::mid(P)) {
+        half(P_, std::integral_constant<int, 2>{}, std::false_type{}, slot_r, gp, ((P + 1) / NPH == 0 ? gc : gn), ((P + 2) / NPH == 0 ? gc : ((P + 2) / NPH == 1 ? gn : gnn)));
+      } else {
       half(P_, std::integral_constant<int, 0>{}, std::integral_constant<bool, P == 0>{}, slot_r, gp, ((P + 1) / NPH == 0 ? gc : gn), ((P + 2) / NPH == 0 ? gc : ((P + 2) / NPH == 1 ? gn : gnn)));
       if constexpr (P == 0) {
         if (i == 0) {  // (the first tile has no predecessor: what that epilogue summed up was not an output)
@@ -832,6 +849,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_sw_kernel(SwK p) {
         }
       }
       half(P_, std::integral_constant<int, 1>{}, std::integral_constant<bool, P == NPH - 1>{}, slot_r, gc, ((P + 1) / NPH == 0 ? gc : gn), ((P + 2) / NPH == 0 ? gc : ((P + 2) / NPH == 1 ? gn : gnn)));
+      }
       ++ph;
       RT_MARK(G::chunk_of(P) < NCH ? 2 : 3)
       if constexpr (P + 1 < NPH) self(self, std::integral_constant<int, P + 1>{});
