@@ -957,11 +957,11 @@ int ds_conv_chunk(int taps, int dtype) {
 
 // Which instantiation ds_launch_conv picks (profiling label): 0/1/2 = 3x3 {8x32xBN64, 8x32xBN32, 8x8xBN64},
 // 3/4/5 = the same tiles for 1x1 / GEMM, 6 = the weight-stationary 64 -> 64 kernel (conv3x3_ws.hip), 7 = the
-// small-image kernel (conv3x3_small.hip), 8 = the register-weight kernel (conv3x3_rw.hip), 9 = the streamed-weight kernel
-// (conv3x3_sw.hip), 10 = its split-mode sibling (conv3x3_sws.hip).
+// small-image kernel (conv3x3_small.hip), 8 = the register-weight kernel (conv3x3_rw.hip), 10 = the streamed-weight kernel
+// (conv3x3_sw.hip), 11 = its split-mode sibling (conv3x3_sws.hip).  (9 = the fused attention block, launched by engine.hip.)
 int ds_conv_config_id(const ConvArgs& a) {
-  if (ds_conv_sws_eligible(a)) return 10;
-  if (ds_conv_sw_eligible(a)) return 9;
+  if (ds_conv_sws_eligible(a)) return 11;
+  if (ds_conv_sw_eligible(a)) return 10;
   if (ds_conv_rw_eligible(a)) return 8;
   if (ds_conv_ws_eligible(a) || ds_conv_thin_eligible(a) || ds_conv_thin_out_eligible(a)) return 6;
   if (ds_conv_small_eligible(a)) return 7;

@@ -79,7 +79,15 @@ static int rup8(int c) { return (c + 7) & ~7; }
 
 struct ArchBuilder {
   Arch& A;
-  explicit ArchBuilder(Arch& a) : A(a) {}
+  // which fragment-major weight copies get a slot in the pack buffer: bit 0 = the shapes of the 16-bit kernels (conv3x3_rw / _sw,
+  // the fused attention block), bit 1 = the shapes of the split-precision kernel (conv3x3_sws).  An exact-fp32 engine reads none
+  // of them (0); the unit entry points build their one-module engines with every copy (3).
+  int frag;
+  explicit ArchBuilder(Arch& a, int frag_mask = 3) : A(a), frag(frag_mask) {}
+  bool frag_wanted(int taps, int cin, int cout) const {
+    return ((frag & 1) && (ds_rw_frag_shape(taps, cin, cout) || ds_sw_frag_shape(taps, cin, cout))) ||
+           ((frag & 2) && ds_sws_frag_shape(taps, cin, cout));
+  }
   PRef add(const std::string& name, std::initializer_list<int64_t> shp) {
     ParamInfo p;
     p.name = name;
@@ -148,11 +156,12 @@ struct ArchBuilder {
     }
     m.pk0 = pack(out, 9, in);
     m.pk1 = pack(out, 9, out);
-    if (ds_rw_frag_shape(9, in, out) || ds_sw_frag_shape(9, in, out) || ds_sws_frag_shape(9, in, out)) m.pf0 = pack(out, 9, in);
-    if (ds_rw_frag_shape(9, out, out) || ds_sw_frag_shape(9, out, out) || ds_sws_frag_shape(9, out, out)) m.pf1 = pack(out, 9, out);
-    if (m.has_conv2 && (ds_rw_frag_shape(1, in, out) || ds_sw_frag_shape(1, in, out) || ds_sws_frag_shape(1, in, out))) m.pf2 = pack(out, 1, in);
-    if (!m.has_conv2 && (ds_sws_frag_shape(1, out, out) || ds_sw_frag_shape(1, out, out))) m.pf_id = pack(out, 1, out);
-    if (in == 256 && in_c1 == 128 && out == 128 && !up && !down) {
+    if (frag_wanted(9, in, out)) m.pf0 = pack(out, 9, in);
+    if (frag_wanted(9, out, out)) m.pf1 = pack(out, 9, out);
+    if (m.has_conv2 && frag_wanted(1, in, out)) m.pf2 = pack(out, 1, in);
+    if (!m.has_conv2 && (((frag & 2) && ds_sws_frag_shape(1, out, out)) || ((frag & 1) && ds_sw_frag_shape(1, out, out))))
+      m.pf_id = pack(out, 1, out);
+    if ((frag & 1) && in == 256 && in_c1 == 128 && out == 128 && !up && !down) {
       m.pf0a = pack(out, 9, 128); m.pf0b = pack(out, 9, 128); m.pf2a = pack(out, 1, 128); m.pk2b = pack(out, 1, 128);
     }
     m.temb_off = A.dense_total;
@@ -168,7 +177,7 @@ struct ArchBuilder {
       m.nin_w[i] = add(p + "NIN_" + std::to_string(i) + ".W", {c, c});
       m.nin_b[i] = add(p + "NIN_" + std::to_string(i) + ".b", {c});
       m.pk_nin[i] = pack(c, 1, c);
-      if (c == 128 && i != 1) m.pf_nin[i] = pack(c, 1, c);
+      if ((frag & 1) && c == 128 && i != 1) m.pf_nin[i] = pack(c, 1, c);
     }
     if (c == 128) { m.ab_off = A.attn_bias_total; A.attn_bias_total += c; }
     A.mods.push_back(m);
@@ -183,7 +192,7 @@ struct ArchBuilder {
   }
 };
 
-static int build_arch(const diffsep_model_config& c, Arch& A) {
+static int build_arch(const diffsep_model_config& c, Arch& A, int frag_mask = 3) {
   DS_CHECK(c.nf >= 8 && c.nf % 8 == 0, "config: nf must be a positive multiple of 8");
   DS_CHECK(c.num_sources >= 1 && c.num_sources <= 3, "config: num_sources must be 1..3");
   DS_CHECK(c.n_levels >= 1 && c.n_levels <= 8, "config: n_levels must be 1..8");
@@ -196,7 +205,7 @@ static int build_arch(const diffsep_model_config& c, Arch& A) {
   A.cpad_in = rup8(channels);
   A.cpad_out = rup8(A.chan_out);
   const int image_size = c.n_fft / 2 + 1;
-  ArchBuilder b(A);
+  ArchBuilder b(A, frag_mask);
   // state_dict order: output_layer is registered before all_modules (ncsnpp.py:104-105 vs :308)
   A.out_w = b.add("output_layer.weight", {A.chan_out, channels, 1, 1});
   A.out_b = b.add("output_layer.bias", {A.chan_out});
@@ -514,7 +523,7 @@ struct diffsep_engine {
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
 };
-#define DS_NCLS 10
+#define DS_NCLS 12
 static hipEvent_t prof_event(diffsep_engine* e) {
   if (!e->ev_pool.empty()) { hipEvent_t v = e->ev_pool.back(); e->ev_pool.pop_back(); return v; }
   hipEvent_t v = nullptr;
@@ -1094,6 +1103,7 @@ static int ensure_plan(diffsep_engine* e, int B, long T, hipStream_t st) {
     DS_HIP(hipStreamSynchronize(st));
     drop_graph(e);  // their addresses die with the old arena (nothing is in flight after the synchronisation)
     if (e->arena) DS_HIP(hipFree(e->arena));
+    e->tracked.clear();  // (track_tensors: those pointers were into the old arena)
     e->arena = nullptr;
     e->cap = 0;
     // (hipFree / hipMalloc synchronise the whole device: grow with headroom so that a stream of utterances of
@@ -1230,7 +1240,8 @@ extern "C" int32_t diffsep_engine_create(const diffsep_model_config* cfg, const 
   diffsep_engine* e = new diffsep_engine();
   e->cfg = *cfg;
   if (cfg->dtype == DS_F32_SPLIT) { e->cfg.dtype = DS_F32; e->split = 1; }  // storage and every non-MFMA kernel: plain fp32
-  if (build_arch(e->cfg, e->arch)) { delete e; return 1; }
+  // fragment-major weight copies only for the kernels this engine can dispatch to (an exact-fp32 engine: none)
+  if (build_arch(e->cfg, e->arch, e->cfg.dtype == DS_BF16 ? 1 : (e->split ? 2 : 0))) { delete e; return 1; }
   const Arch& A = e->arch;
   if (n_floats != A.total) {
     ds_set_error("engine_create: weight blob has " + std::to_string(n_floats) + " floats, expected " +
@@ -1346,6 +1357,11 @@ extern "C" int32_t diffsep_engine_set_option(diffsep_engine* e, const char* name
     e->ablate = (unsigned)value;
   } else if (!strcmp(name, "dbg_alloc")) {
     e->dbg_alloc = value != 0;
+    return 0;  // (a log switch: no launch decision depends on it)
+  } else if (!strcmp(name, "no_stft_fused")) {
+    // stft.hip reads the PROCESS default (ds_default_opts): an engine-level value would be accepted and do nothing
+    ds_set_error("engine_set_option: 'no_stft_fused' is a process-level option (diffsep_set_option / DIFFSEP_NO_STFT_FUSED)");
+    return 1;
   } else if (!strcmp(name, "track_tensors")) {
     e->track_tensors = value != 0;
     e->tracked.clear();

@@ -118,7 +118,8 @@ class Engine:
         return int(self._L.diffsep_engine_get_option(self._h, str(name).encode()))
 
     CONV_CLASSES = ("conv3x3_8x32xN64", "conv3x3_8x32xN32", "conv3x3_8x8xN64", "gemm1x1_256xN64", "gemm1x1_256xN32",
-                    "gemm1x1_64xN64", "conv3x3_ws_64to64", "conv3x3_small_16couts", "conv3x3_rw_regweights", "attention_fused")
+                    "gemm1x1_64xN64", "conv3x3_ws_64to64", "conv3x3_small_16couts", "conv3x3_rw_regweights", "attention_fused",
+                    "conv3x3_sw_streamed", "conv3x3_sws_split")
 
     def profile_begin(self):
         check(self._L.diffsep_engine_profile_begin(self._h), self._L)

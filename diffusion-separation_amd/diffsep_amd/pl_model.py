@@ -103,7 +103,8 @@ class DiffSepModel:
                                             init_seed=init_seed, **sm)
         self.tail_model, self.head_steps = None, 0
         if dtype == "hybrid":
-            self.tail_model = ScoreModelNCSNpp(dtype="split", device=device, init_seed=init_seed, lib_kind="f16", **sm)
+            # the split-precision head engine: the SAME parameters as score_model in another mode (a twin holds no weights)
+            self.tail_model = self.score_model.twin("split", lib_kind="f16")
             self.head_steps = HYBRID_HEAD_STEPS if head_steps is None else int(head_steps)
         sd = dict(cfg_get(config, "model.sde"))
         target = str(sd.pop("_target_", "sdes.sdes.MixSDE"))
@@ -144,10 +145,12 @@ class DiffSepModel:
         return model
 
     def to(self, device):
-        self.score_model.to(device)
-        if self.tail_model is not None:
-            self.tail_model.to(device)
-        # (the fallback's score model is the tail model or a twin that follows score_model's device and weights)
+        """The device the engines live on.  The parameters stay host tensors (the engine holds the only device copy of the
+        weights, repacked): this is not nn.Module.to — score_model.to(device) is, and the engines follow that as well."""
+        if device != self.score_model.device:
+            self.score_model.device = device
+            self.score_model.weights_changed()
+        # (tail_model and the fallback's score model are twins: they follow score_model's device and weights)
         return self
 
     def has_fallback(self):
@@ -155,12 +158,10 @@ class DiffSepModel:
         return self.dtype in ("f16", "fp16", "hybrid")
 
     def load_state_dict(self, state, strict=True):
-        """Weights in the reference's score_model key layout ('backbone.all_modules....'), into every engine of the model.
-        The overflow fallback follows: a split twin re-reads its parent's weights (ScoreModelNCSNpp.twin), and the cached
-        fallback object is dropped."""
+        """Weights in the reference's score_model key layout ('backbone.all_modules....').  Every engine of the model follows:
+        the hybrid head engine and the overflow fallback are twins of score_model (ScoreModelNCSNpp.twin), rebuilt from its
+        parameters at their next use; the cached fallback object is dropped."""
         self.score_model.load_state_dict(state, strict=strict)
-        if self.tail_model is not None:
-            self.tail_model.load_state_dict(state, strict=strict)
         self._fallback = None
         return self
 

@@ -1,21 +1,121 @@
-"""ScoreModelNCSNpp with the reference constructor and forward contract
-(models/score_models.py:10-138), backed by the HIP engine: forward(xt, time_cond, mix) runs
-STFT -> NCSN++ -> iSTFT entirely in libdiffsep_hip.so.
+"""ScoreModelNCSNpp with the reference constructor and forward contract (models/score_models.py:10-138), backed by the HIP
+engine: forward(xt, time_cond, mix) runs STFT -> NCSN++ -> iSTFT entirely in libdiffsep_hip.so.
 
-A drop-in for hydra configs: `_target_: diffsep_amd.score_models.ScoreModelNCSNpp` accepts the same
-kwargs as `models.score_models.ScoreModelNCSNpp`; weights arrive through load_state_dict() with the
-reference's key layout (backbone.all_modules.{i}...., backbone.output_layer.*).
+It is a torch.nn.Module with the reference's parameter tree — `backbone.all_modules.{i}....`, `backbone.output_layer.*`
+as nn.Parameters in the reference's registration order, `stft.window` / `stft_inv.window` as buffers — so that the
+reference's own LightningModule can hold it: `_target_: diffsep_amd.score_models.ScoreModelNCSNpp` in
+config/model/default.yaml:15 makes `DiffSepModel.__init__` (pl_model.py:105) build this class, `self.parameters()` feeds
+torch_ema (pl_model.py:142), `load_from_checkpoint` loads a reference checkpoint strictly (separate.py:44), and the EMA
+swap of `.eval()` (pl_model.py:655-660) writes into these tensors.  The parameters are the ONLY copy of the weights on the
+Python side; an engine holds its own repacked copy on the device, and every use of an engine first asks whether the
+tensors still hold what that copy was packed from (_poll_weights): if not, the engine is rebuilt from the new weights.
 """
+import zlib
+
 import numpy as np
 import torch
+from torch import nn
 
 from . import _lib, synth
-from .engine import Engine, pack_state_dict, param_table
+from .engine import Engine, param_table
+
+_DTYPES = {"bf16": _lib.BF16, "f16": _lib.F16, "fp16": _lib.F16, "f32": _lib.F32, "fp32": _lib.F32, "split": _lib.F32_SPLIT}
+
+try:  # (64-bit, ~10 GB/s; the image has it — zlib's crc32 otherwise)
+    import xxhash
+
+    def _digest(buf):
+        return xxhash.xxh3_64_intdigest(buf)
+except Exception:  # pragma: no cover
+    def _digest(buf):
+        return zlib.crc32(buf)
 
 
-class ScoreModelNCSNpp:
+class _Node(nn.Module):
+    """One level of the reference's module tree (NCSNpp, its all_modules list, a ResnetBlockBigGANpp, a Conv2d ...): holds
+    parameters and child nodes under the reference's names, nothing else."""
+
+
+class _StftBuffers(nn.Module):
+    """`stft.window` / `stft_inv.window`: torchaudio's Spectrogram / InverseSpectrogram keep their Hann window as a
+    persistent buffer (models/score_models.py:29-30), so a reference checkpoint carries both keys.  They load into this
+    buffer; a state dict WITHOUT them loads too (the window is a constant of the configuration: periodic Hann(n_fft), which
+    is what the engine's STFT kernels use)."""
+
+    def __init__(self, n_fft):
+        super().__init__()
+        self.register_buffer("window", torch.hann_window(n_fft))
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        n = len(missing_keys)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+        del missing_keys[n:]
+
+
+class _EngineSlot:
+    """One engine (a precision mode in one build of the library) over the weights of a ScoreModelNCSNpp.  engine() returns
+    it, (re)built whenever the owner's weights or device are not the ones the current engine was packed from."""
+
+    def __init__(self, owner, cfg, lib_kind):
+        self.owner, self.cfg, self.lib_kind = owner, cfg, lib_kind
+        self._engine, self._key = None, None
+        self.builds = 0
+
+    def engine(self):
+        own = self.owner
+        blob = own._poll_weights()
+        key = (own._fingerprint, str(own.engine_device()))
+        if self._engine is None or key != self._key:
+            self.close()
+            self._engine = own._engine_factory(self.cfg, own.packed_blob() if blob is None else blob,
+                                               device=own.engine_device(), lib_kind=self.lib_kind)
+            self._key = key
+            self.builds += 1
+        return self._engine
+
+    def close(self):
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+
+
+class ScoreModelTwin:
+    """The same weights in another precision mode (ScoreModelNCSNpp.twin): a score function and an engine of its own, no
+    parameters of its own — weights, device, load_state_dict() and to() are the owner's."""
+
+    def __init__(self, owner, dtype, lib_kind=None):
+        cfg = _lib.ModelConfig.from_buffer_copy(owner.cfg)
+        cfg.dtype = _DTYPES[dtype]
+        self.owner, self.cfg, self.lib_kind = owner, cfg, lib_kind
+        self._slot = _EngineSlot(owner, cfg, lib_kind)
+        self.num_sources = owner.num_sources
+
+    def engine(self):
+        return self._slot.engine()
+
+    def forward(self, xt, time_cond, mix):
+        return self.engine().score(xt, time_cond, mix)
+
+    __call__ = forward
+
+    def load_state_dict(self, state, strict=True):
+        return self.owner.load_state_dict(state, strict=strict)
+
+    def state_dict(self):
+        return self.owner.state_dict()
+
+    def to(self, *args, **kwargs):
+        self.owner.to(*args, **kwargs)
+        return self
+
+    def eval(self):
+        return self
+
+
+class ScoreModelNCSNpp(nn.Module):
     def __init__(self, num_sources, stft_args, backbone_args, transform="exponent", spec_abs_exponent=0.5,
                  spec_factor=3.0, spec_trans_learnable=False, dtype="f16", device=None, init_seed=0, lib_kind=None):
+        super().__init__()
         if transform != "exponent":
             raise NotImplementedError("only transform='exponent' runs on the accelerated path")
         if spec_trans_learnable:
@@ -49,87 +149,126 @@ class ScoreModelNCSNpp:
             nf=ba.get("nf", 128), num_sources=num_sources, ch_mult=tuple(ba.get("ch_mult", (1, 1, 2, 2, 2, 2, 2))),
             num_res_blocks=ba.get("num_res_blocks", 2), attn_resolution=tuple(ba.get("attn_resolutions", (16,)))[0],
             n_fft=stft_args["n_fft"], hop=stft_args["hop_length"], spec_abs_exponent=abs(spec_abs_exponent),
-            spec_factor=spec_factor, dtype={"bf16": _lib.BF16, "f16": _lib.F16, "fp16": _lib.F16, "f32": _lib.F32, "fp32": _lib.F32, "split": _lib.F32_SPLIT}[dtype])
-        self.device = device
+            spec_factor=spec_factor, dtype=_DTYPES[dtype])
+        self.device = device      # where the engine lives while the parameters are host tensors (None: the current device)
         self.lib_kind = lib_kind  # (Engine: which build of the library; None = by dtype)
-        self._engine = None
-        self._parent, self._version, self._built_version = None, 0, 0  # (twin(): weights / device follow the parent)
-        # random init like the reference constructor (no checkpoint yet): synthetic variance-scaling weights
-        self._state = synth.synth_state_dict([(n, s) for n, s, _ in param_table(self.cfg)], init_seed)
 
-    def twin(self, dtype, lib_kind=None):
-        """The same model in another precision mode; its engine is created on first use.  The twin FOLLOWS this model: it
-        reads the weights and the device of its parent whenever it (re)creates its engine, and a later load_state_dict() /
-        to() on the parent drops the twin's engine (a twin built once from a copy of __dict__ kept the weights and device
-        of the moment it was made: an overflow fallback on stale weights returns finite but wrong samples)."""
-        t = object.__new__(ScoreModelNCSNpp)
-        t.__dict__.update(self.__dict__)
-        t.cfg = _lib.ModelConfig.from_buffer_copy(self.cfg)
-        t.cfg.dtype = {"bf16": _lib.BF16, "f16": _lib.F16, "f32": _lib.F32, "split": _lib.F32_SPLIT}[dtype]
-        t.lib_kind, t._engine, t._parent, t._built_version = lib_kind, None, self, -1
-        return t
+        # ---- the reference's parameter tree, random init like the reference constructor: no
+        # checkpoint yet, synthetic variance-scaling weights.  requires_grad as in the reference — everything but the frozen
+        # Fourier projection (layerspp.py:35-37) — because torch_ema shadows exactly the parameters that require a gradient
+        # (a reference checkpoint's `ema` holds one tensor fewer than there are parameters) and refuses a state of another
+        # length.  The forward is not differentiable: this is an inference engine.
+        self._table = param_table(self.cfg)
+        off = 0
+        for _, shape, o in self._table:  # (packed_blob concatenates: the blob is the parameters in table order, no gaps)
+            assert o == off, "parameter table offsets are not contiguous"
+            off += int(np.prod(shape))
+        state = synth.synth_state_dict([(n, s) for n, s, _ in self._table], init_seed)
+        self.backbone = _Node()
+        plist = []
+        for name, _, _ in self._table:
+            node, parts = self.backbone, name.split(".")
+            for p in parts[:-1]:
+                if not hasattr(node, p):
+                    node.add_module(p, _Node())
+                node = getattr(node, p)
+            par = nn.Parameter(torch.from_numpy(state[name]), requires_grad=not name.endswith("all_modules.0.W"))
+            node.register_parameter(parts[-1], par)
+            plist.append((name, parts))
+        self.stft = _StftBuffers(stft_args["n_fft"])
+        self.stft_inv = _StftBuffers(stft_args["n_fft"])
+        self._paths = plist
 
-    def _sync_with_parent(self):
-        """twin only: adopt the parent's current weights / device; drop an engine built from older ones"""
-        par = self._parent
-        if par is None or self._built_version == par._version:
-            return
-        if self._engine is not None:
-            self._engine.close()
-            self._engine = None
-        self._state, self.device, self._built_version = par._state, par.device, par._version
+        # ---- engine bookkeeping (plain attributes: none of this is module state)
+        self._maybe_changed, self._versions, self._fingerprint, self._plist = True, None, None, None
+        self._engine_factory = Engine
+        self._slot = _EngineSlot(self, self.cfg, lib_kind)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.weights_changed())
 
     # ---- weights ---------------------------------------------------------------------------
     def param_names(self):
-        return ["backbone." + n for n, _, _ in param_table(self.cfg)]
+        return ["backbone." + n for n, _, _ in self._table]
 
-    def load_state_dict(self, state, strict=True):
-        """Keys as in the reference ('backbone.all_modules.3.weight', ...); STFT window buffers are ignored."""
-        new = {}
-        for n, shape, _ in param_table(self.cfg):
-            k = "backbone." + n
-            if k not in state:
-                if strict:
-                    raise KeyError(f"missing key '{k}'")
-                new[n] = self._state[n]
-                continue
-            v = state[k]
-            v = v.detach().cpu().float().numpy() if isinstance(v, torch.Tensor) else np.asarray(v, np.float32)
-            if tuple(v.shape) != shape:
-                raise ValueError(f"size mismatch for '{k}': {tuple(v.shape)} vs {shape}")
-            new[n] = v
-        self._state = new
-        self._version += 1
-        self._parent = None  # (a twin that gets its own weights stops following its parent)
-        if self._engine is not None:
-            self._engine.close()
-            self._engine = None
+    def _params_in_table_order(self):
+        out = []
+        for _, parts in self._paths:
+            node = self.backbone
+            for p in parts:
+                node = getattr(node, p)
+            out.append(node)
+        return out
+
+    def weights_changed(self):
+        """Tell the model that its parameters MAY hold new values: the next use of an engine compares their content with
+        what that engine was packed from.  Called by everything that can change them behind torch's version counters —
+        load_state_dict (post hook: also when a PARENT module loads), train() / eval() (the reference swaps the EMA
+        weights in right after, through `param.data.copy_`, pl_model.py:655-666), to() / half() / ... (_apply).  In-place
+        writes on the parameters themselves (optimiser steps, `p.copy_`) are seen through `Tensor._version`; call this
+        after writing through `.data` by hand."""
+        self._maybe_changed, self._plist = True, None
+
+    def packed_blob(self):
+        """float32 numpy array: the parameters in the engine's order (diffsep_param_info), as they are NOW"""
+        ps = self._plist = self._params_in_table_order()
+        for (name, shape, _), p in zip(self._table, ps):
+            if tuple(p.shape) != shape:
+                raise ValueError(f"parameter 'backbone.{name}' has shape {tuple(p.shape)}, expected {shape}")
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1).float() for p in ps])
+        return np.ascontiguousarray(flat.cpu().numpy())
+
+    def _poll_weights(self):
+        """None when nothing can have changed since the last poll; otherwise re-reads the parameters, updates
+        ._fingerprint and returns the packed blob (for the caller that has to rebuild an engine from it)."""
+        if self._plist is None:
+            self._plist = self._params_in_table_order()
+        versions = sum(p._version for p in self._plist)
+        if not self._maybe_changed and versions == self._versions and self._fingerprint is not None:
+            return None
+        w = self.stft.window
+        if w.shape != (self.cfg.n_fft,) or not torch.allclose(w.float().cpu(), torch.hann_window(self.cfg.n_fft), atol=1e-6):
+            raise NotImplementedError("stft.window is not the periodic Hann window the engine's STFT kernels implement")
+        blob = self.packed_blob()
+        self._fingerprint = _digest(blob.view(np.uint8))
+        self._maybe_changed, self._versions = False, versions
+        return blob
+
+    def load_state_dict(self, state, strict=True, assign=False):
+        """nn.Module.load_state_dict with the reference's keys ('backbone.all_modules.3.weight', ..., 'stft.window');
+        numpy arrays are accepted as values, the two window buffers may be absent.  Strict like torch: a missing /
+        unexpected key or a shape mismatch raises RuntimeError."""
+        state = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))) for k, v in state.items()}
+        return super().load_state_dict(state, strict=strict)
+
+    def train(self, mode=True):
+        super().train(mode)
+        self.weights_changed()
         return self
 
-    def state_dict(self):
-        return {"backbone." + n: torch.from_numpy(np.array(v)) for n, v in self._state.items()}
+    def _apply(self, fn, *args, **kwargs):
+        res = super()._apply(fn, *args, **kwargs)
+        self.weights_changed()
+        return res
 
-    def to(self, device):
-        if device != self.device:
-            self.device = device
-            self._version += 1
-            if self._engine is not None:  # (the engine is bound to one device: re-created there on next use)
-                self._engine.close()
-                self._engine = None
-        return self
+    def engine_device(self):
+        """The device of the parameters when they live on a GPU (the reference moves the model with .to(device),
+        separate.py:47); for host parameters the `device` constructor argument, else the current device."""
+        p = self.backbone.output_layer.weight
+        if p.is_cuda:
+            return p.device
+        return self.device
 
-    def eval(self):
-        return self
+    # ---- engines ---------------------------------------------------------------------------
+    def twin(self, dtype, lib_kind=None):
+        """The same model in another precision mode: a ScoreModelTwin whose engine is created on first use and FOLLOWS this
+        model — it is rebuilt when the weights or the device of this model are no longer the ones it was built from (a twin
+        on stale weights would return finite but wrong samples as an overflow fallback)."""
+        return ScoreModelTwin(self, dtype, lib_kind)
 
     def engine(self):
-        """The device-resident engine (created lazily on the current / configured device)."""
-        self._sync_with_parent()
-        if self._engine is None:
-            self._engine = Engine(self.cfg, pack_state_dict(self.cfg, self._state), device=self.device, lib_kind=self.lib_kind)
-        return self._engine
+        """The device-resident engine: created lazily, rebuilt when the parameters or their device changed."""
+        return self._slot.engine()
 
     # ---- reference forward ---------------------------------------------------------------
     def forward(self, xt, time_cond, mix):
         return self.engine().score(xt, time_cond, mix)
-
-    __call__ = forward

@@ -33,7 +33,12 @@ def _timesteps(sde, eps, schedule, device):
 
 
 def _engine_of(score_fn):
+    """The engine behind a score function: an engine-backed model (diffsep_amd's DiffSepModel / ScoreModelNCSNpp), or the
+    REFERENCE's DiffSepModel holding a diffsep_amd ScoreModelNCSNpp as .score_model — its forward is nothing but
+    `self.score_model(xt, time, mix)` (pl_model.py:407-409), so the fused sampler computes the same thing."""
     eng = getattr(score_fn, "engine", None)
+    if eng is None:
+        eng = getattr(getattr(score_fn, "score_model", None), "engine", None)
     return eng() if callable(eng) else eng
 
 

@@ -203,15 +203,16 @@ int32_t diffsep_engine_set_option(diffsep_engine* e, const char* name, int64_t v
 int64_t diffsep_engine_get_option(const diffsep_engine* e, const char* name);
 
 /* Measurement hook (bench.py): between begin and end every MFMA conv/GEMM launch of the engine is
- * bracketed by HIP events on its launch stream (graph replay bypassed).  Outputs are 10-entry arrays
+ * bracketed by HIP events on its launch stream (graph replay bypassed).  Outputs are 12-entry arrays
  * indexed by kernel class: 3x3 {8x32 tile x 64 cout, 8x32 x 32, 8x8 x 64}, then the same
  * tiles for 1x1 / GEMM, the weight-stationary 64 -> 64 3x3 kernel, the small-image 3x3 kernel, the register-weight
- * 3x3 kernel (conv3x3_rw.hip), the fused attention block (attn_fused.hip) — TEN entries: summed algorithmic flops, summed milliseconds, launch counts and (bytes, nullable)
+ * 3x3 kernel (conv3x3_rw.hip), the fused attention block (attn_fused.hip), the streamed-weight 3x3 kernel (conv3x3_sw.hip) and
+ * its split-precision sibling (conv3x3_sws.hip) — TWELVE entries: summed algorithmic flops, summed milliseconds, launch counts and (bytes, nullable)
  * summed algorithmic HBM bytes = every operand read once + the output written once. */
-#define DIFFSEP_NUM_KERNEL_CLASSES 10
+#define DIFFSEP_NUM_KERNEL_CLASSES 12
 int32_t diffsep_engine_profile_begin(diffsep_engine* e);
 /* Writes DIFFSEP_NUM_KERNEL_CLASSES entries per array — the caller's buffers must hold that many (ABI note: the count was 9
- * until round 3; a caller compiled against an older header must use the _n form below or be rebuilt). */
+ * until round 3 and 10 until round 5; a caller compiled against an older header must use the _n form below or be rebuilt). */
 int32_t diffsep_engine_profile_end(diffsep_engine* e, double* flops, double* ms, int64_t* launches, double* bytes);
 /* The same with the capacity of the caller's arrays stated: writes min(n_classes, DIFFSEP_NUM_KERNEL_CLASSES) entries per
  * array and never more; *n_written (nullable) receives that number. */

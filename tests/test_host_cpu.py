@@ -67,13 +67,18 @@ def test_checkpoint_loader_applies_ema(tmp_path):
     torch.save({"state_dict": sd, "hyper_parameters": {"config": cfg}, "ema": {"shadow_params": shadow}},
                tmp_path / "m.ckpt")
     m2 = DiffSepModel.load_from_checkpoint(tmp_path / "m.ckpt")
-    st = m2.score_model._state
+    st = {k[len("backbone."):]: v.numpy() for k, v in m2.score_model.state_dict().items() if k.startswith("backbone.")}
     assert np.array_equal(st["all_modules.0.W"], raw["all_modules.0.W"])  # frozen Fourier weights: no EMA
     assert np.array_equal(st["all_modules.3.weight"], ema["all_modules.3.weight"])
     assert np.array_equal(st["output_layer.bias"], ema["output_layer.bias"])
+    # what an engine would be created from = the packed EMA weights
+    from diffsep_amd.engine import pack_state_dict
+    want = dict(ema)
+    want["all_modules.0.W"] = raw["all_modules.0.W"]
+    assert np.array_equal(m2.score_model.packed_blob(), pack_state_dict(m2.score_model.cfg, want))
     m3 = DiffSepModel.load_from_checkpoint(tmp_path / "m.ckpt", use_ema=False)
-    assert np.array_equal(m3.score_model._state["all_modules.3.weight"], raw["all_modules.3.weight"])
-    with pytest.raises(KeyError):
+    assert np.array_equal(m3.score_model.state_dict()["backbone.all_modules.3.weight"].numpy(), raw["all_modules.3.weight"])
+    with pytest.raises(RuntimeError):  # (strict, like torch: the reference's load_from_checkpoint is)
         m.score_model.load_state_dict({})
 
 
@@ -350,30 +355,59 @@ def test_overflow_fallback_follows_weights_and_device():
     assert getattr(m, "_fallback", None) is None
     fb = m.fallback_model()
     tw = fb.score_model
-    assert tw._parent is m.score_model and tw.cfg.dtype != m.score_model.cfg.dtype
-    tw._sync_with_parent()
-    assert tw._state is m.score_model._state
-    # new weights on the parent (directly on the score model, as a user of the reference API would): the twin follows
-    sd = {k: v + 1.0 for k, v in m.score_model.state_dict().items()}
+    assert tw.owner is m.score_model and tw.cfg.dtype != m.score_model.cfg.dtype
+
+    # engines are device objects: a recording stand-in shows what each one WOULD be created from
+    built = []
+
+    class FakeEngine:
+        def __init__(self, cfg, blob, device=None, lib_kind=None):
+            self.blob, self.device, self.dtype, self.lib_kind = blob.copy(), device, cfg.dtype, lib_kind
+            built.append(self)
+
+        def close(self):
+            pass
+
+    from diffsep_amd.engine import pack_state_dict
+    m.score_model._engine_factory = FakeEngine
+    e0, t0 = m.score_model.engine(), tw.engine()
+    assert e0 is m.score_model.engine() and t0 is tw.engine() and len(built) == 2   # (unchanged weights: nothing rebuilt)
+    np.testing.assert_array_equal(e0.blob, t0.blob)
+    # new weights on the parent (directly on the score model, as a user of the reference API would): both engines follow
+    sd = {k: v + 1.0 for k, v in m.score_model.state_dict().items() if k.startswith("backbone.")}
     m.score_model.load_state_dict(sd)
-    assert tw._state is not m.score_model._state          # (not yet: adopted when the twin next builds its engine)
-    tw._sync_with_parent()
-    assert tw._state is m.score_model._state and tw._built_version == m.score_model._version
-    k0 = next(iter(tw._state))
-    np.testing.assert_array_equal(tw._state[k0], sd["backbone." + k0].numpy())
+    t1 = tw.engine()
+    assert t1 is not t0 and len(built) == 3
+    np.testing.assert_array_equal(t1.blob, pack_state_dict(tw.cfg, {k[len("backbone."):]: v for k, v in sd.items()}))
+    assert m.score_model.engine() is not e0 and len(built) == 4
+    # the same values loaded again: the content decides, nothing is rebuilt
+    m.score_model.load_state_dict(sd)
+    assert tw.engine() is t1 and len(built) == 4
+    # a write through .data (what torch_ema.copy_to does — invisible to Tensor._version) after eval() / train()
+    m.score_model.eval()
+    with torch.no_grad():
+        m.score_model.backbone.output_layer.bias.data.copy_(torch.full((4,), 0.25))
+    t2 = tw.engine()
+    assert t2 is not t1 and np.all(t2.blob[24:28] == 0.25)
+    # an in-place write on the parameter itself (optimiser step, p.copy_) is seen without any hook
+    with torch.no_grad():
+        m.score_model.backbone.output_layer.bias.add_(1.0)
+    assert np.all(tw.engine().blob[24:28] == 1.25)
     # ... and the device
     m.to("cuda:1")
-    tw._sync_with_parent()
-    assert tw.device == "cuda:1"
+    assert tw.engine().device == "cuda:1" and m.score_model.engine().device == "cuda:1"
     # DiffSepModel.load_state_dict drops the cached fallback object as well
     m.load_state_dict(sd)
-    assert m._fallback is None and m.fallback_model().score_model._parent is m.score_model
-    # a hybrid model's fallback is its own split head engine, loaded by DiffSepModel.load_state_dict
+    assert m._fallback is None and m.fallback_model().score_model.owner is m.score_model
+    # a hybrid model's head engine and fallback are one twin of its score model: one set of parameters
     h = DiffSepModel(default_config(nf=16), dtype="hybrid")
-    sdh = {k: v * 0.5 for k, v in h.score_model.state_dict().items()}
+    h.score_model._engine_factory = FakeEngine
+    sdh = {k: v * 0.5 for k, v in h.score_model.state_dict().items() if k.startswith("backbone.")}
     h.load_state_dict(sdh)
-    assert h.fallback_model().score_model is h.tail_model
-    np.testing.assert_array_equal(h.tail_model._state[k0], sdh["backbone." + k0].numpy())
+    assert h.fallback_model().score_model is h.tail_model and h.tail_model.owner is h.score_model
+    np.testing.assert_array_equal(h.tail_model.engine().blob,
+                                  pack_state_dict(h.tail_model.cfg, {k[len("backbone."):]: v for k, v in sdh.items()}))
+    assert h.tail_model.engine().lib_kind == "f16" and h.tail_model.engine().dtype != h.score_model.engine().dtype
 
 
 def test_bench_eight_ranks_weak_and_strong_gloo():
