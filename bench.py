@@ -53,8 +53,11 @@ GFLOP_PER_NFE = {64: 133.83, 128: 532.89}  # SURVEY.md §8d, per utterance at W=
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "split": 2500.0 / 3}  # MI355X_MICROARCH.md: dense MFMA peaks (split: 3 bf16 MFMAs per product)
 HBM_PEAK_BPS = 8.0e12                          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
-def cpu_baseline(nf, T, budget_s=12.0, max_nfe=12):
-    """Time the oracle's score evaluation (the 99 % of the path) on the host cores."""
+def cpu_baseline(nf, T, N, corrector_steps):
+    """The CPU oracle (this repo's torch-fp32 restatement of the reference path, validated against the imported reference in the
+    build container) separating ONE utterance end to end on the host cores: normalize_batch -> the full PC sampler (N reverse
+    steps x (corrector + predictor) = N (corrector_steps + 1) network evaluations on injected noise) -> scale_output, exactly the
+    work of one row of a GPU step.  Returns (seconds for the utterance, network evaluations, seconds of one evaluation, threads)."""
     import diffsep_oracle as O
     from diffsep_amd import synth
     torch.set_grad_enabled(False)
@@ -66,7 +69,7 @@ def cpu_baseline(nf, T, budget_s=12.0, max_nfe=12):
     t = torch.tensor([0.5])
     O.score_forward(p, cfg, xt, t, mix_norm)  # warm-up (oneDNN primitive creation)
     # torch's default (= all hardware threads) is not the fastest setting on many-core hosts for these
-    # small convolutions: try a few thread counts briefly and keep the best one for the timed sample.
+    # small convolutions: try a few thread counts briefly and keep the best one for the timed run.
     ncpu = torch.get_num_threads()
     best, best_t = ncpu, None
     for nt in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
@@ -78,12 +81,12 @@ def cpu_baseline(nf, T, budget_s=12.0, max_nfe=12):
         if best_t is None or d < best_t:
             best, best_t = nt, d
     torch.set_num_threads(best)
-    n, t0 = 0, time.perf_counter()
-    while n < max_nfe and (time.perf_counter() - t0 < budget_s or n < 2):
-        O.score_forward(p, cfg, xt, t, mix_norm)
-        n += 1
-    dt = (time.perf_counter() - t0) / n
-    return dt, n
+    draws = [torch.from_numpy(synth.synth_noise(f"cpu.z{i}", (1, 2, T))) for i in range(1 + N * (corrector_steps + 1))]
+    t0 = time.perf_counter()
+    out, nfe = O.separate(p, cfg, mix, draws, N=N, corrector_steps=corrector_steps, snr=0.5, eps=0.03, denoise=True)
+    dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(out).all())
+    return dt, int(nfe), best_t, best
 
 
 def run_strong(args, engs, ops, on_stream, sync, fence, dist, world, rank, dev, sde, dry):
@@ -310,7 +313,8 @@ def main():
                   file=sys.stderr, flush=True)
             K = max(1, k_fit)
         engs += [Engine(cfg, blob) for _ in range(K - 1)]
-        # Throughput mode for several engines on one GPU (round 5): a register-weight convolution whose blocks would get <= 4 tiles
+        # Throughput mode for several engines on one GPU (round 5; what evaluate / separate --streams K > 1 set through
+        # DiffSepModel.set_throughput_mode, same bits: tests/test_round6_gpu.py): a register-weight convolution whose blocks would get <= 4 tiles
         # (the 128-row level at B = 16: a 295 KB weight prologue per 4 tiles) runs on a QUARTER of the CUs with four times the tiles
         # per block; the other batches' kernels take the rest of the chip.  Same box, interleaved: 80.9 -> 82.9 utt/s with four batches
         # in flight, 260 -> 300 ms for one batch alone — so it is an option of the multi-stream callers, not a default of the engine.
@@ -493,7 +497,8 @@ def main():
         except Exception:
             traffic = traffic_source = None
         try:
-            pmc_file = "r05_pmc_mfma_util.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_pmc_mfma_util.json")) else "r04_pmc_mfma_util.json"
+            pmc_file = next(f_ for f_ in ("r06_pmc_mfma_util.json", "r05_pmc_mfma_util.json", "r04_pmc_mfma_util.json")
+                            if os.path.exists(os.path.join(ROOT, "profiles", f_)))
             pu = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             for k_, v_ in pu.get("kernels", {}).items():
                 if k_.split(" grid ")[0] == kname and pu.get("dtype") == args.dtype:
@@ -501,7 +506,7 @@ def main():
                                 "mfma_busy_per_wave_cycle": v_.get("mfma_busy_per_wave_cycle"),
                                 "valu_per_mfma": v_.get("valu_per_mfma"), "lds_per_mfma": v_.get("lds_per_mfma"),
                                 "lds_bank_conflict_cycles_per_lds_inst": v_.get("lds_bank_conflict_cycles_per_lds_inst"),
-                                "source": "profiles/%s = output of `COMMIT=%s bash tools/pmc_r05.sh` (two rocprofv3 "
+                                "source": "profiles/%s = output of `COMMIT=%s bash tools/pmc_util.sh` (two rocprofv3 "
                                           "--kernel-trace --pmc passes around the N = 4, one-in-flight, eager variant of this command; a "
                                           "separate, committed run)" % (pmc_file, pu.get("commit"))}
         except Exception:
@@ -513,6 +518,30 @@ def main():
         else:
             roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4)}
+        # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary (profiles/rNN_*_kernel_stats.md):
+        # `frac` above comes from the HIP-event pass of THIS run (one batch alone, eager launches); the profile is a separate run of
+        # the bench command under the tracer — the two must tell the same story
+        roof["frac_rocprof"] = roof["frac_rocprof_source"] = None
+        try:
+            import re as _re
+            for cand in ("r06_bench_%s_alone_kernel_stats.md" % args.dtype, "r06_bench_%s_kernel_stats.md" % args.dtype,
+                         "r05_bench_%s_kernel_stats.md" % args.dtype):
+                pth = os.path.join(ROOT, "profiles", cand)
+                if not os.path.exists(pth) or args.nf != 64 or B != 16:
+                    continue
+                for line in open(pth):
+                    m_ = _re.match(r"\| `(.+?)` \| (\d+) \| ([\d.]+) \| ([\d.]+) \|", line)
+                    if m_ and m_.group(1) == kname:
+                        avg_us = float(m_.group(4))
+                        fr = (by / max(n, 1) / (avg_us * 1e-6) / HBM_PEAK_BPS) if roof["bound"] == "hbm" else \
+                             (fl / max(n, 1) / (avg_us * 1e-6) / 1e12 / peak)
+                        roof["frac_rocprof"] = round(fr, 4)
+                        roof["frac_rocprof_source"] = "profiles/%s: %s calls, avg %.2f us" % (cand, m_.group(2), avg_us)
+                        break
+                if roof["frac_rocprof"] is not None:
+                    break
+        except Exception:
+            pass
         roof.update({"traffic": traffic, "traffic_source": traffic_source, "pmc": pmc_util, "launches": n, "avg_launch_us": round(ms / max(n, 1) * 1e3, 2),
                 "flops_per_launch": fl / max(n, 1), "algorithmic_bytes_per_launch": by / max(n, 1),
                 "hbm_floor_us": round(hbm_floor_us, 2), "mfma_floor_us": round(mfma_floor_us, 2),
@@ -785,12 +814,21 @@ def main():
             res["value_parity_grade"] = round(ok[best], 4)
             res["parity_grade_mode"] = best
         res.update(extra_json)
+        # BASELINE.json configs[1] says bf16 literally; `value` is the shipped default (f16: the same kernels and tensor width on IEEE
+        # half precision, the finer significand).  The literal-config number is reported at top level too.
+        res["config_dtype_literal"] = "bf16"
+        if args.dtype == "bf16":
+            res["value_bf16"] = res["value"]
+        elif "bf16_mode" in res:
+            res["value_bf16"] = res["bf16_mode"]["utt_per_s"]
         if not args.no_cpu_baseline and world == 1 and not dry:
-            t_nfe, n = cpu_baseline(args.nf, T)
-            res["cpu_baseline"] = {"value": round(1.0 / (t_nfe * nfe), 5), "unit": "utterances/s",
-                                   "cores": torch.get_num_threads(), "kind": "port",
-                                   "sample": "%d score evaluations (STFT->NCSN++ nf=%d->iSTFT) of the fp32 torch-CPU oracle at "
-                                             "B=1, T=%d: %.3f s each; x%d NFE per utterance" % (n, args.nf, T, t_nfe, nfe)}
+            t_utt, n_cpu, t_nfe, cores = cpu_baseline(args.nf, T, args.N, args.corrector_steps)
+            res["cpu_baseline"] = {"value": round(1.0 / t_utt, 5), "unit": "utterances/s", "cores": cores, "kind": "port",
+                                   "sample_kind": "full_run",
+                                   "sample": "ONE utterance (B=1, T=%d) end to end through the fp32 torch-CPU oracle: normalize_batch, the "
+                                             "full PC sampler (N=%d, %d corrector step: %d network evaluations STFT->NCSN++ nf=%d->iSTFT "
+                                             "on injected noise), scale_output: %.2f s (one evaluation alone: %.3f s)"
+                                             % (T, args.N, args.corrector_steps, n_cpu, args.nf, t_utt, t_nfe)}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -272,7 +272,9 @@ inline bool ds_rw_frag_shape(int taps, int Cin, int Cout) {  // the weight shape
 bool ds_conv_rw_eligible(const ConvArgs& a);   // conv3x3_rw.hip: register-resident weights, 64 / 128 -> 64 bf16, >= 32-row images
 int ds_launch_conv_rw(const ConvArgs& a, hipStream_t st);
 // the weight shapes conv3x3_sw.hip streams (fragment-major copies of 3x3 weights and folded 1x1 skips)
-inline bool ds_sw_frag_shape(int taps, int Cin, int Cout) { return (Cout == 128 || Cout == 256) && Cin % 64 == 0 && Cin >= 64 && Cin <= 512; }
+// (Cout 64 too: ds_conv_sw_supported takes e.g. the 192 -> 64 layer of the 128-row level, which is no register-weight shape; until
+// round 6 those copies existed only because the split kernel's shape test below happened to cover them)
+inline bool ds_sw_frag_shape(int taps, int Cin, int Cout) { return (Cout == 64 || Cout == 128 || Cout == 256) && Cin % 64 == 0 && Cin >= 64 && Cin <= 512; }
 bool ds_conv_sw_supported(const ConvArgs& a);  // conv3x3_sw.hip: streamed weights, 64 .. 256 -> 128 n couts, 16-bit
 bool ds_conv_sw_eligible(const ConvArgs& a);   // ... and dispatched there
 int ds_launch_conv_sw(const ConvArgs& a, hipStream_t st);

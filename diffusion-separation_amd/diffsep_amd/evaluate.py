@@ -1,8 +1,21 @@
-"""evaluate.py — the sampler + timing part of the reference's evaluate.py / evaluate_mp.py
-(evaluate.py:322-443, evaluate_mp.py:154-326,495-528) on the HIP engine, one rank per GPU.
+"""evaluate.py — the reference's evaluate.py / evaluate_mp.py (evaluate.py:164-443, evaluate_mp.py:154-326,495-528) on the
+HIP engine, one rank per GPU.  The reference's command line runs verbatim:
 
-    python -m diffsep_amd.evaluate --synthetic 32 --synthetic-weights 64 -o out/            (1 GPU)
+    python -m diffsep_amd.evaluate exp/default/2022-xx/checkpoints/epoch-979.ckpt --test -s log -d 1 --save-n 10 -o results
+    python -m diffsep_amd.evaluate --synthetic 32 --synthetic-weights 64 -o out/            (no data set / checkpoint at hand)
     python -m torch.distributed.run --nproc-per-node 8 -m diffsep_amd.evaluate ...          (8 GPUs)
+
+Reference flags (evaluate.py:168-226), same names, defaults and meaning: ckpt (or `__no_proc__`: score the unprocessed
+mixture, :245-262), -o/--output_dir, --enhance, -d/--device, -w/--dl-workers, --tag, -l/--limit, --save-n, --val, --test
+(one of the two is required unless an extension below names the data), -N, --snr, --corrector-steps, --denoise (argparse
+`type=bool` as in the reference: every non-empty value is True), --pesq-mode, --stoi-no-extended, -s/--schedule.  The data
+sets come from `<ckpt>/../../hparams.yaml` -> datamodule.{val,test}.dataset like evaluate.py:264-288 (or --dataset-dir).
+Output tree (evaluate.py:306-323,436-443): `<output_dir>/<exp>_<ckpt>_<tag_inf>/` (or `<tag>_<tag_inf>`), tag_inf =
+`N-.._snr-.._corrstep-.._denoise-.._schedule-..`, holding `<split>.json`, `<split>_summary.json` and
+`wav/<split>/NNN_{mix,enh0,enh1,tgt0,tgt1}.wav` (scaled to peak 0.95 together, estimates in the permutation that matches
+the targets) for the first --save-n utterances (default: all).  Not produced: `fig/` (matplotlib spectrogram plots of the
+intermediate states) and the PESQ field (ITU-T P.862 C code, third-party `pesq`; null, named under `not_computed`).  STOI /
+ESTOI is computed (diffsep_amd.metrics.stoi) on loader threads.
 
 Utterances are sharded over ranks in contiguous ranges (evaluate_mp.py:495-503); each rank separates its
 share, records {batch_idx, si_sdr, si_sir, si_sar, pesq, stoi, nfe, runtime, len_s} per utterance (evaluate.py:394-405;
@@ -85,9 +98,73 @@ def plan_batches(indices, lengths, width_of, batch):
     return out
 
 
-def main(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("ckpt", nargs="?", default=None)
+def _hparams_datasets(args, fs_model, splits):
+    """evaluate.py:264-288: the data sets named by the experiment's hparams.yaml (two levels above the checkpoint)."""
+    import yaml
+    hp = Path(args.ckpt).parents[1] / "hparams.yaml"
+    if not hp.exists():
+        raise SystemExit(f"{hp} not found: the reference reads the data set from it (evaluate.py:265-267); pass --dataset-dir "
+                         "ROOT or --synthetic N instead")
+    with open(hp, "r") as f:
+        config = yaml.safe_load(f)["config"]
+    out = {}
+    if args.enhance:
+        kw = dict(config["datamodule"]["test"]["dataset"])
+        kw.pop("_target_", None)
+        out["test"] = datasets.NoisyDataset(**kw)
+        return out
+    for split in splits:
+        kw = dict(config["datamodule"][split]["dataset"])
+        kw.pop("_target_", None)
+        if not Path(kw["path"]).exists():
+            kw["path"] = "./data/wsj0_mix"
+        out[split] = datasets.WSJ0_mix(**kw)
+    return out
+
+
+def save_samples(mix, est, tgt, wav_out_dir, idx, fs):
+    """evaluate.py:70-101: mixture, estimates (already in the targets' order) and targets, scaled TOGETHER to peak 0.95, as
+    32-bit float wav (what torchaudio.save writes for a float tensor).  Every source is written (the reference's fixed five
+    files are these for two sources)."""
+    allw = torch.cat((mix, est, tgt), dim=0).clone()
+    allw *= 0.95 / allw.abs().max().clamp(min=1e-30)
+    S = est.shape[0]
+    wav_out_dir.mkdir(parents=True, exist_ok=True)
+    wavio.save(wav_out_dir / f"{idx:03d}_mix.wav", allw[0:1], fs, bits=32)
+    for k in range(S):
+        wavio.save(wav_out_dir / f"{idx:03d}_enh{k}.wav", allw[1 + k:2 + k], fs, bits=32)
+    for k in range(tgt.shape[0]):
+        wavio.save(wav_out_dir / f"{idx:03d}_tgt{k}.wav", allw[1 + S + k:2 + S + k], fs, bits=32)
+
+
+def build_parser():
+    ap = argparse.ArgumentParser(description="Run evaluation on validation or test dataset")
+    # ---- the reference's arguments (evaluate.py:168-226)
+    ap.add_argument("ckpt", nargs="?", default=None, type=Path, help="Path to checkpoint to use ('__no_proc__': score the mixture)")
+    ap.add_argument("-o", "--output_dir", "--output-dir", dest="output_dir", type=Path, default=Path("results"), help="The output folder")
+    ap.add_argument("--enhance", default=False, action="store_true",
+                    help="Compute evaluation metrics for speech enhancement (evaluate.py:173-176,268-271): PriorMixSDE model, "
+                         "metrics on the first source (clean speech) only")
+    ap.add_argument("-d", "--device", default=0, help="Device to use (default: cuda:0); under torchrun LOCAL_RANK decides")
+    ap.add_argument("-w", "--dl-workers", type=int, default=None,
+                    help="Number of loader / STOI worker threads (default min(os.cpu_count(), 16))")
+    ap.add_argument("--tag", type=str, default=None,
+                    help="A tag name for the experiment. If not provided, the experiment and checkpoints name are used.")
+    ap.add_argument("-l", "--limit", type=int, default=None, help="Limit the number of samples to process")
+    ap.add_argument("--save-n", type=int, default=None, help="Save a limited number of output samples (default: save all)")
+    ap.add_argument("--val", action="store_true", help="Run on validation dataset")
+    ap.add_argument("--test", action="store_true", help="Run on test dataset")
+    ap.add_argument("-N", type=int, default=None, help="Number of steps")
+    ap.add_argument("--snr", type=float, default=None, help="Step size of corrector")
+    ap.add_argument("--corrector-steps", type=int, default=None, help="Number of corrector steps")
+    ap.add_argument("--denoise", type=bool, default=True, help="Use denoising in solver")
+    ap.add_argument("--pesq-mode", type=str, choices=["nb", "wb"], default="nb",
+                    help="Mode for PESQ 'wb' or 'nb' (accepted; PESQ is not computed: see not_computed in the summary)")
+    ap.add_argument("--stoi-no-extended", action="store_true", help="Disable extended mode for STOI")
+    ap.add_argument("-s", "--schedule", type=str, default=None, help="Pick a different schedule for the inference")
+    # ---- extensions
+    ap.add_argument("--split", default=None, choices=["train", "val", "test", "libri2mix_test"],
+                    help="with --dataset-dir: the split folder (default test); --val / --test select it the reference's way")
     ap.add_argument("--synthetic-weights", type=int, default=0, metavar="NF")
     ap.add_argument("--dataset-dir", type=str, default=None)
     ap.add_argument("--synthetic", type=int, default=0, help="number of synthetic mixtures")
@@ -95,19 +172,15 @@ def main(argv=None):
     ap.add_argument("--samples-max", type=int, default=None,
                     help="--synthetic: utterance lengths spread over [--samples, --samples-max] instead of one length")
     ap.add_argument("--n-speakers", type=int, default=2)
-    ap.add_argument("-l", "--limit", type=int, default=None)
-    ap.add_argument("-s", "--split", default="test", choices=["train", "val", "test", "libri2mix_test"])
     ap.add_argument("--cut", default="max", choices=["min", "max"])
-    ap.add_argument("-N", type=int, default=None)
-    ap.add_argument("--snr", type=float, default=None)
-    ap.add_argument("--corrector-steps", type=int, default=None)
-    ap.add_argument("--schedule", type=str, default=None)
     ap.add_argument("--dtype", default="auto", choices=["auto", "f16", "bf16", "f32", "split", "hybrid"],
                     help="auto (default): f16 for backbones up to nf = 64, hybrid for wider ones; f16: 16-bit tensors in IEEE half precision, 50 dB from the fp32 result after 60 network "
                          "evaluations; bf16: the same kernels on bfloat16 tensors (32 dB); split / f32: fp32 tensors (bf16x3 / "
                          "exact fp32 matrix products); hybrid: f16 with the first reverse steps on a split engine")
-    ap.add_argument("-o", "--output-dir", type=Path, default=Path("results"))
-    ap.add_argument("--save-wav", action="store_true")
+    ap.add_argument("--flat-output", action="store_true",
+                    help="write <split>.json / <split>_summary.json / wav/ directly into --output_dir instead of the reference's "
+                         "<output_dir>/<exp>_<ckpt>_<tag_inf>/ folder")
+    ap.add_argument("--no-stoi", action="store_true", help="skip STOI (host-side, ~0.1 s per utterance and source on one core)")
     ap.add_argument("--seed", type=int, default=0, help="torch.manual_seed before the first utterance: the i-th "
                                                          "utterance gets the i-th draw as its device RNG seed")
     ap.add_argument("--balance", action="store_true",
@@ -121,10 +194,24 @@ def main(argv=None):
                          "depend on K.  'runtime' of an utterance is its batch's latency / batch size.")
     ap.add_argument("--fp32-steps", type=int, default=None,
                     help="with --dtype hybrid: the first K reverse steps run on the fp32 engine (default: pl_model.HYBRID_HEAD_STEPS)")
-    ap.add_argument("--enhance", action="store_true",
-                    help="speech enhancement (evaluate.py:173-176,268-271): PriorMixSDE model, metrics on the first "
-                         "source (clean speech) only")
+    return ap
+
+
+def main(argv=None):
+    """Returns the folder the results were written to (rank 0; the reference's naming, evaluate.py:306-323)."""
+    ap = build_parser()
     args = ap.parse_args(argv)
+    splits = [s for s, on in (("val", args.val), ("test", args.test)) if on]
+    if not splits:
+        if args.split is not None or args.synthetic or args.dataset_dir:
+            splits = [args.split or "test"]  # (extensions that name the data themselves)
+        else:
+            ap.error("No action requested, add --val or --test")
+    if args.enhance:
+        splits = ["test"] if not args.dataset_dir or args.split is None else [args.split]  # (evaluate.py:268-271: the test set)
+    no_proc = str(args.ckpt) == "__no_proc__"
+    if args.ckpt is None and not args.synthetic_weights and not no_proc:
+        ap.error("a checkpoint (or --synthetic-weights NF) is required")
     if args.streams > 1:
         # HIP maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, one of which the null stream holds:
         # with the default, two of four worker streams share a queue (measured 10.7 instead of 18.5 utt/s).  Read
@@ -133,67 +220,133 @@ def main(argv=None):
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "LOCAL_RANK" in os.environ:
+        local = int(os.environ["LOCAL_RANK"])
+    else:  # -d 1 / -d cuda:1 (evaluate.py:177-179)
+        d = str(args.device)
+        local = int(d.split(":")[1]) if ":" in d else (int(d) if d.isdigit() else 0)
     if not torch.cuda.is_available():
         raise SystemExit("No GPU visible: this build has no CPU path")
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    def make_model():
+    n_workers = max(2, min(os.cpu_count() or 2, 16) if args.dl_workers is None else args.dl_workers)
+
+    K = max(1, args.streams)
+    models, model = [], None
+    if not no_proc:
         if args.synthetic_weights or args.ckpt is None:
             cfg = (enhancement_config(nf=args.synthetic_weights or 128) if args.enhance
                    else default_config(nf=args.synthetic_weights or 64, n_speakers=args.n_speakers))
-            return DiffSepModel(cfg, dtype=args.dtype, head_steps=args.fp32_steps)
-        return DiffSepModel.load_from_checkpoint(args.ckpt, dtype=args.dtype, head_steps=args.fp32_steps)
-
-    K = max(1, args.streams)
-    models = [make_model() for _ in range(K)]  # one engine (weights copy + workspace) per stream
-    for m in models:
-        # engines are created BEFORE the worker streams: HIP hands out hardware queues in stream-creation order, and
-        # engines created lazily in between left the workers sharing queues (measured 7.0 instead of 17 utt/s, K=4)
-        m.score_model.engine()
-        if m.tail_engine() is not None:
-            m.tail_engine()
-    model = models[0]
-    eng0 = model.score_model.engine()
-    fs = cfg_get(model.config, "model.fs", 8000)
-    N = cfg_get(model.config, "model.sampler.N", 30) if args.N is None else args.N
-    cs = cfg_get(model.config, "model.sampler.corrector_steps", 1) if args.corrector_steps is None else args.corrector_steps
-    snr = cfg_get(model.config, "model.sampler.snr", 0.5) if args.snr is None else args.snr
+            model = DiffSepModel(cfg, dtype=args.dtype, head_steps=args.fp32_steps)
+        else:
+            model = DiffSepModel.load_from_checkpoint(args.ckpt, dtype=args.dtype, head_steps=args.fp32_steps)
+        model.eval()
+        # one engine (weights repacked on the device + workspace) per stream over ONE set of parameters
+        models = [model] + [model.replica() for _ in range(K - 1)]
+        for m in models:
+            if K > 1:
+                m.set_throughput_mode(True)
+            # engines are created BEFORE the worker streams: HIP hands out hardware queues in stream-creation order, and
+            # engines created lazily in between left the workers sharing queues (measured 7.0 instead of 17 utt/s, K=4)
+            m.score_model.engine()
+            if m.tail_engine() is not None:
+                m.tail_engine()
+    fs_model = cfg_get(model.config, "model.fs", 8000) if model is not None else None
+    N = cs = snr = None
+    if model is not None:
+        N = cfg_get(model.config, "model.sampler.N", 30) if args.N is None else args.N
+        cs = cfg_get(model.config, "model.sampler.corrector_steps", 1) if args.corrector_steps is None else args.corrector_steps
+        snr = cfg_get(model.config, "model.sampler.snr", 0.5) if args.snr is None else args.snr
+    denoise = args.denoise
     n_src = 1 if args.enhance else None  # (evaluate.py:268-271)
 
-    n, get, lengths = load_dataset(args, fs)
+    # ---- the output folder (evaluate.py:257-262,306-323)
+    if args.flat_output:
+        output_dir = args.output_dir
+    elif no_proc:
+        output_dir = args.output_dir / ("mix" if args.tag is None else args.tag)
+    else:
+        tag_inf = f"N-{N}_snr-{snr}_corrstep-{cs}_denoise-{denoise}_schedule-{args.schedule}"
+        if args.tag is not None:
+            output_dir = args.output_dir / f"{args.tag}_{tag_inf}"
+        elif args.ckpt is not None and not args.synthetic_weights:
+            output_dir = args.output_dir / f"{Path(args.ckpt).absolute().parents[1].name}_{Path(args.ckpt).stem}_{tag_inf}"
+        else:
+            output_dir = args.output_dir / f"synthetic-nf{args.synthetic_weights}_random-init_{tag_inf}"
+    if rank == 0:
+        output_dir.mkdir(exist_ok=True, parents=True)
+        print(f"Created output folder {output_dir}")
+
+    # ---- the data sets, one per split (evaluate.py:245-288)
+    from_hparams = None
+    if not (args.synthetic or args.dataset_dir):
+        if no_proc:  # evaluate.py:247-255
+            from_hparams = {s: datasets.WSJ0_mix(path="data/wsj0_mix", n_spkr=2, cut="max", split=s) for s in splits}
+        else:
+            from_hparams = _hparams_datasets(args, fs_model, splits)
+
+    streams = [torch.cuda.Stream() for _ in range(K)]
+    from concurrent.futures import ThreadPoolExecutor
+    # the reference's DataLoader has worker processes; here loader threads read / synthesise and pad the next batches while the
+    # GPU separates the current ones (wav decoding and numpy release the GIL), and score STOI of the finished ones
+    loader = ThreadPoolExecutor(max_workers=n_workers)
+    for split in splits:
+        if from_hparams is not None:
+            ds = from_hparams[split]
+            n_ = len(ds) if args.limit is None else min(len(ds), args.limit)
+            data = (n_, (lambda i, ds=ds: tuple(t[..., : ds.num_samples(i)] for t in ds[i])), [ds.num_samples(i) for i in range(n_)])
+            fs = ds.fs
+        else:
+            args_split = argparse.Namespace(**{**vars(args), "split": split})
+            fs = fs_model if fs_model is not None else 8000
+            data = load_dataset(args_split, fs)
+        run_split(args, split, data, fs, models, streams, loader, output_dir, world, rank, N, cs, snr, denoise, n_src, no_proc)
+    loader.shutdown()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return output_dir
+
+
+def run_split(args, split, data, fs, models, streams, loader, output_dir, world, rank, N, cs, snr, denoise, n_src, no_proc):
+    n, get, lengths = data
+    K = len(streams)
+    model = models[0] if models else None
+    if rank == 0:
+        print(f"Processing {split}: {n} samples")
+    if no_proc:
+        width_of = lambda T: 64 * ((1 + (T + 382) // 128 + 63) // 64)
+        bucket = lambda W: 128 * W - 383
+    else:
+        eng0 = model.score_model.engine()
+        width_of, bucket = eng0.padded_frames, eng0.bucket_length
     # the reference's contiguous ranges (evaluate_mp.py:495-503), or sorted by length and dealt round-robin
     mine = rank_indices(n, world, rank, lengths, args.balance)
-    batches = plan_batches(mine, lengths, eng0.padded_frames, max(1, args.batch))
-    if batches:  # workspace for the largest call now: growing it later would stall every stream
+    batches = plan_batches(mine, lengths, width_of, max(1, args.batch))
+    if batches and not no_proc:  # workspace for the largest call now: growing it later would stall every stream
         bmax = max(len(g) for g in batches)
-        tmax = eng0.bucket_length(eng0.padded_frames(max(lengths[i] for i in mine)))
+        tmax = bucket(width_of(max(lengths[i] for i in mine)))
         for m in models:
             m.score_model.engine().reserve(bmax, tmax)
             if m.tail_engine() is not None:
                 m.tail_engine().reserve(bmax, tmax)
-    streams = [torch.cuda.Stream() for _ in range(K)]
     # utterance i of the data set gets the i-th draw of a generator seeded with --seed as its device RNG seed: the
     # records do not depend on the number of streams, of ranks, or on how the utterances are batched or dealt
     seeds = torch.randint(0, 2 ** 62, (max(n, 1),), generator=torch.Generator().manual_seed(args.seed)).tolist()
     records = []
     fallbacks = []  # batches repeated on the split-precision engine after non-finite f16 samples
     pending = [None] * K  # per worker: the batch whose sampler is running on its stream
+    stoi_jobs = []  # (record, future of the per-source STOI list)
 
     def host_stage(group):
         """load and pad one batch on the host (runs on a loader thread, ahead of the GPU): mix / tgt + lengths"""
         items = [get(i) for i in group]
         # padded to the longest length of the batch's width bucket: one workspace plan / captured graph per (B, W)
-        mix, tgt, lens = datasets.pad_batch(items, side="right",
-                                            to=eng0.bucket_length(eng0.padded_frames(max(lengths[i] for i in group))))
+        mix, tgt, lens = datasets.pad_batch(items, side="right", to=bucket(width_of(max(lengths[i] for i in group))))
         return mix.contiguous(), tgt.contiguous(), lens
 
-    # the reference's DataLoader has worker processes; here two loader threads read / synthesise and pad the next batches
-    # while the GPU separates the current ones (wav decoding and numpy release the GIL)
-    from concurrent.futures import ThreadPoolExecutor
-    loader = ThreadPoolExecutor(max_workers=2)
     ahead = {}
 
     def prefetch(j):
@@ -208,6 +361,8 @@ def main(argv=None):
         # allocated on THIS thread: the loader threads make no HIP runtime call
         mix = mix.pin_memory().to("cuda", non_blocking=True)
         tgt = tgt.pin_memory().to("cuda", non_blocking=True)
+        if no_proc:  # (evaluate.py:349-355: the raw mixture against the raw targets)
+            return mix, mix, tgt, lens
         mix_n, tgt_n = torch.zeros_like(mix), torch.zeros_like(tgt)
         for b, L in enumerate(lens):  # every utterance is normalised over ITS samples (pl_model.py:81-88)
             (m_b, t_b), *_ = models[w].normalize_batch((mix[b:b + 1, :, :L], tgt[b:b + 1, :, :L]))
@@ -216,8 +371,11 @@ def main(argv=None):
 
     def launch(group, w, j=None):
         mix, mix_n, tgt_n, lens = stage(group, w, j)
+        if no_proc:
+            est = mix_n.expand(-1, tgt_n.shape[1], -1).contiguous()  # x_result = broadcast_to(mix, target.shape)
+            return (group, lens, tgt_n, est, 0, None, (mix, mix_n, None))
         sampler = models[w].get_pc_sampler("reverse_diffusion", "ald2", mix_n, N=N, corrector_steps=cs, snr=snr,
-                                           denoise=True, intermediate=False, schedule=args.schedule,
+                                           denoise=denoise, intermediate=False, schedule=args.schedule,
                                            lengths=lens, seeds=[seeds[i] for i in group], check_finite=False)
         if K == 1:
             torch.cuda.synchronize()
@@ -225,6 +383,9 @@ def main(argv=None):
         est, nfe, *_ = sampler()  # enqueues the whole sampler on the worker's stream
         # (every tensor the asynchronous sampler reads stays referenced until the worker's stream has drained)
         return (group, lens, tgt_n, est, nfe, t0, (mix, mix_n, sampler))
+
+    def stoi_of(tgt_rows, est_rows):
+        return [metrics.stoi(t_, e_, fs, extended=not args.stoi_no_extended) for t_, e_ in zip(tgt_rows, est_rows)]
 
     def finish(w):
         if pending[w] is None:
@@ -236,27 +397,37 @@ def main(argv=None):
         # (DiffSepModel.rerun_if_nonfinite — the one place that decides; raises if that is non-finite too)
         def rerun(fb):
             with torch.cuda.stream(streams[w]):
-                r = fb.get_pc_sampler("reverse_diffusion", "ald2", _alive[1], N=N, corrector_steps=cs, snr=snr, denoise=True,
+                r = fb.get_pc_sampler("reverse_diffusion", "ald2", _alive[1], N=N, corrector_steps=cs, snr=snr, denoise=denoise,
                                       intermediate=False, schedule=args.schedule, lengths=lens,
                                       seeds=[seeds[i] for i in group], check_finite=False)()
             streams[w].synchronize()
             fallbacks.append(list(group))
             return r
-        est, nfe, *_ = models[w].rerun_if_nonfinite((est, nfe), rerun, what=f"utterances {group[:3]}...")
-        runtime = (time.perf_counter() - t0) / len(group)
+        if not no_proc:
+            est, nfe, *_ = models[w].rerun_if_nonfinite((est, nfe), rerun, what=f"utterances {group[:3]}...")
+        runtime = 0.0 if t0 is None else (time.perf_counter() - t0) / len(group)
         with torch.cuda.stream(streams[w]):
             mets = compute_metrics(est, tgt_n, n_src)
+        need_host = (not args.no_stoi) or args.save_n is None or any(i < args.save_n for i in group)
+        est_h = tgt_h = mix_h = None
+        if need_host:
+            with torch.cuda.stream(streams[w]):
+                est_h, tgt_h, mix_h = est.cpu(), tgt_n.cpu(), _alive[1].cpu()
         for b, i in enumerate(group):
-            records.append({"batch_idx": i, **mets[b], "pesq": None, "stoi": None, "nfe": int(nfe),
-                            "runtime": runtime, "len_s": lens[b] / fs})
-            if args.save_wav:
-                d = args.output_dir / "wav"
-                d.mkdir(parents=True, exist_ok=True)
-                for k in range(est.shape[1]):
-                    wavio.save(d / f"{i:05d}_s{k}.wav", est[b, k:k + 1, :lens[b]].cpu() * 0.1, fs, bits=32)
+            rec = {"batch_idx": i, **mets[b], "pesq": None, "stoi": None, "nfe": int(nfe), "runtime": runtime,
+                   "len_s": lens[b] / fs}
+            records.append(rec)
+            perm = mets[b]["perm"]
+            k_src = len(perm) if n_src is None else n_src
+            if need_host:
+                est_b = est_h[b, perm, :lens[b]]  # "fix the permutation" (evaluate.py:392): estimates in the targets' order
+                if not args.no_stoi:
+                    stoi_jobs.append((rec, loader.submit(stoi_of, tgt_h[b, :k_src, :lens[b]].numpy(), est_b[:k_src].numpy())))
+                if args.save_n is None or i < args.save_n:  # (evaluate.py:341; figures are not produced)
+                    save_samples(mix_h[b, :, :lens[b]], est_b, tgt_h[b, :, :lens[b]], output_dir / "wav" / split, i, fs)
 
     # warm every worker up on the first batch's shape (workspace plan, graph capture) outside the timed region
-    if batches:
+    if batches and not no_proc:
         for w in range(K):
             with torch.cuda.stream(streams[w]):
                 launch(batches[0], w)
@@ -275,26 +446,26 @@ def main(argv=None):
         finish(w)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t_all
-    loader.shutdown()
+    for rec, fut in stoi_jobs:
+        rec["stoi"] = fut.result()
     allrec = gather_objects(records)
     if rank == 0:
         flat = sorted([r for part in allrec for r in part], key=lambda r: r["batch_idx"])
-        args.output_dir.mkdir(parents=True, exist_ok=True)
-        with open(args.output_dir / f"{args.split}.json", "w") as f:
+        with open(output_dir / f"{split}.json", "w") as f:
             json.dump(flat, f, indent=2)
         summary = datasets.summarize([{k: v for k, v in r.items() if k not in ("batch_idx", "perm")} for r in flat])
         tot_rt = sum(r["runtime"] for r in flat)
         summary.update({"rtf": tot_rt / max(sum(r["len_s"] for r in flat), 1e-9), "world_size": world,
-                        "streams": K, "batch": args.batch, "engine_calls_rank0": len(batches), "dtype": model.dtype,
+                        "streams": K, "batch": args.batch, "engine_calls_rank0": len(batches),
+                        "dtype": model.dtype if model is not None else None,
                         "utt_per_s_rank0": len(mine) / max(wall, 1e-9), "split_fallback_batches_rank0": len(fallbacks),
-                        # metrics this build does not compute (third-party C code, out of scope: DESIGN.md section 7)
-                        "not_computed": ["pesq", "stoi"]})
-        with open(args.output_dir / f"{args.split}_summary.json", "w") as f:
+                        # PESQ is ITU-T P.862 reference C code behind the third-party `pesq` package: not restated here
+                        # (DESIGN.md section 7); STOI / ESTOI is diffsep_amd.metrics.stoi (published algorithm, restated)
+                        "not_computed": ["pesq"] + (["stoi"] if args.no_stoi else []),
+                        "stoi_extended": not args.stoi_no_extended, "pesq_mode": args.pesq_mode})
+        with open(output_dir / f"{split}_summary.json", "w") as f:
             json.dump(summary, f, indent=2)
         print(json.dumps(summary))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -153,6 +153,26 @@ class DiffSepModel:
         # (tail_model and the fallback's score model are twins: they follow score_model's device and weights)
         return self
 
+    def replica(self):
+        """Another DiffSepModel over the SAME parameters with engines of its own (twins of score_model): what a caller that
+        keeps several batches in flight on one GPU uses — one engine (weights repacked on the device + workspace) per HIP
+        stream, one set of host parameters.  load_state_dict() / to() on this model reach every replica."""
+        r = object.__new__(DiffSepModel)
+        r.__dict__.update(self.__dict__)
+        r.score_model = self.score_model.twin(self.score_model.cfg.dtype, self.score_model.lib_kind)
+        r.tail_model = self.score_model.twin("split", lib_kind="f16") if self.tail_model is not None else None
+        r._fallback, r.fallback_batches = None, 0
+        return r
+
+    def set_throughput_mode(self, on=True):
+        """For callers with SEVERAL batches in flight on one GPU (evaluate / separate --streams K > 1, bench.py): engine option
+        rw_quarter — a register-weight convolution whose blocks would get <= 4 tiles runs on a quarter of the CUs with four
+        times the tiles per block, and the other batches' kernels take the rest of the chip (+2.5 % throughput at K = 4;
+        one batch alone is 15 % slower in this mode, which is why it is not the engine's default).  The results are the
+        same bits (tests/test_round6_gpu.py)."""
+        self.score_model.set_engine_option("rw_quarter", int(bool(on)))
+        return self
+
     def has_fallback(self):
         """Whether this mode has an overflow fallback at all — from the mode alone, without constructing it."""
         return self.dtype in ("f16", "fp16", "hybrid")

@@ -60,6 +60,7 @@ class _EngineSlot:
         self.owner, self.cfg, self.lib_kind = owner, cfg, lib_kind
         self._engine, self._key = None, None
         self.builds = 0
+        self.options = {}  # engine options (Engine.set_option) that every engine of this slot gets, rebuilt ones included
 
     def engine(self):
         own = self.owner
@@ -71,7 +72,14 @@ class _EngineSlot:
                                                device=own.engine_device(), lib_kind=self.lib_kind)
             self._key = key
             self.builds += 1
+            for name, value in self.options.items():
+                self._engine.set_option(name, value)
         return self._engine
+
+    def set_option(self, name, value):
+        self.options[name] = value
+        if self._engine is not None:
+            self._engine.set_option(name, value)
 
     def close(self):
         if self._engine is not None:
@@ -85,13 +93,19 @@ class ScoreModelTwin:
 
     def __init__(self, owner, dtype, lib_kind=None):
         cfg = _lib.ModelConfig.from_buffer_copy(owner.cfg)
-        cfg.dtype = _DTYPES[dtype]
+        cfg.dtype = dtype if isinstance(dtype, int) else _DTYPES[dtype]
         self.owner, self.cfg, self.lib_kind = owner, cfg, lib_kind
         self._slot = _EngineSlot(owner, cfg, lib_kind)
         self.num_sources = owner.num_sources
 
     def engine(self):
         return self._slot.engine()
+
+    def set_engine_option(self, name, value):
+        self._slot.set_option(name, value)
+
+    def twin(self, dtype, lib_kind=None):
+        return self.owner.twin(dtype, lib_kind)
 
     def forward(self, xt, time_cond, mix):
         return self.engine().score(xt, time_cond, mix)
@@ -268,6 +282,10 @@ class ScoreModelNCSNpp(nn.Module):
     def engine(self):
         """The device-resident engine: created lazily, rebuilt when the parameters or their device changed."""
         return self._slot.engine()
+
+    def set_engine_option(self, name, value):
+        """Engine.set_option on this model's engine, now and after every rebuild"""
+        self._slot.set_option(name, value)
 
     # ---- reference forward ---------------------------------------------------------------
     def forward(self, xt, time_cond, mix):

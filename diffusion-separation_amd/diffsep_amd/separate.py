@@ -112,8 +112,11 @@ def main(argv=None):
         raise SystemExit("No GPU visible: this build has no CPU path (the reference falls back to CPU here)")
     torch.cuda.set_device(torch.device(args.device))
     model, kw = get_model(args)
-    models = [model] + [get_model(args)[0] for _ in range(K - 1)]
+    # one engine (weights repacked on the device + workspace) per stream over ONE set of parameters
+    models = [model] + [model.replica() for _ in range(K - 1)]
     for m in models:
+        if K > 1:
+            m.set_throughput_mode(True)  # (several batches in flight: pl_model.DiffSepModel.set_throughput_mode)
         m.score_model.engine()  # engines before streams (hardware queues are handed out in creation order)
         if m.tail_engine() is not None:
             m.tail_engine()

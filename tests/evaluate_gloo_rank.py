@@ -59,6 +59,15 @@ class _Model:
     def tail_engine(self):
         return None
 
+    def eval(self):
+        return self
+
+    def replica(self):
+        return _Model(dtype=self.dtype)
+
+    def set_throughput_mode(self, on=True):
+        return self
+
     def fallback_model(self):
         return None if self.dtype == "split" else _Model(dtype="split")
 

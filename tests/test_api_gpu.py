@@ -137,7 +137,7 @@ def test_evaluate_cli_writes_reference_style_results(tmp_path):
     # evaluate.py counterpart: sampler + synced timing + SI-SDR, json records {batch_idx, si_sdr, nfe, runtime, len_s}
     import json
     from diffsep_amd import evaluate as ev
-    ev.main(["--synthetic", "3", "--samples", "4000", "--synthetic-weights", "16", "-N", "2", "--dtype", "f32", "-o",
+    ev.main(["--synthetic", "3", "--samples", "4000", "--synthetic-weights", "16", "-N", "2", "--dtype", "f32", "--flat-output", "-o",
              str(tmp_path / "sep")])
     rec = json.load(open(tmp_path / "sep" / "test.json"))
     assert [r["batch_idx"] for r in rec] == [0, 1, 2]
@@ -149,7 +149,7 @@ def test_evaluate_cli_writes_reference_style_results(tmp_path):
     # --enhance: PriorMixSDE model (nr.yaml); both channels (speech, noise) are scored with the best permutation and
     # the first n_src = 1 entry is kept (evaluate.py:105-127,268-271)
     ev.main(["--synthetic", "2", "--samples", "4000", "--synthetic-weights", "16", "-N", "2", "--dtype", "f32",
-             "--enhance", "-o", str(tmp_path / "enh")])
+             "--enhance", "--flat-output", "-o", str(tmp_path / "enh")])
     rec = json.load(open(tmp_path / "enh" / "test.json"))
     assert len(rec) == 2 and all(np.asarray(r["si_sdr"]).shape == (1, 1) and len(r["perm"]) == 2 for r in rec)
     assert all(abs(r["si_sir"][0][0]) < 99.0 for r in rec)  # a real interference term (one channel alone would clamp)
@@ -163,7 +163,7 @@ def test_evaluate_streams_do_not_change_results(tmp_path):
     recs = []
     for k in (1, 3):
         ev.main(["--synthetic", "7", "--samples", "6000", "--synthetic-weights", "16", "-N", "2", "--streams", str(k),
-                 "-o", str(tmp_path / f"k{k}")])
+                 "--flat-output", "-o", str(tmp_path / f"k{k}")])
         recs.append(json.load(open(tmp_path / f"k{k}" / "test.json")))
         summ = json.load(open(tmp_path / f"k{k}" / "test_summary.json"))
         assert summ["streams"] == k and summ["number"] == 7 and summ["utt_per_s_rank0"] > 0
@@ -187,7 +187,7 @@ def test_evaluate_streams_on_files_of_different_length(tmp_path):
     assert wavio.info(root / "mix" / "u1.wav") == (8000, 3000 + 517 * 3)
     recs = []
     for k in (1, 3):
-        ev.main(["--dataset-dir", str(root), "--synthetic-weights", "16", "-N", "2", "--streams", str(k), "-o",
+        ev.main(["--dataset-dir", str(root), "--synthetic-weights", "16", "-N", "2", "--streams", str(k), "--flat-output", "-o",
                  str(tmp_path / f"k{k}")])
         recs.append(json.load(open(tmp_path / f"k{k}" / "test.json")))
     strip = lambda r: {k: v for k, v in r.items() if k != "runtime"}
@@ -208,7 +208,7 @@ def test_evaluate_cli_on_wsj0_mix_tree(tmp_path):
         for k in range(2):
             wavio.save(base / f"s{k + 1}" / f"u{i}.wav", torch.from_numpy(tgt[k:k + 1]) * 0.5, 8000)
     ev.main(["--dataset-dir", str(tmp_path / "wsj"), "--cut", "min", "--split", "test", "--synthetic-weights", "16",
-             "-N", "2", "--dtype", "f32", "-o", str(tmp_path / "out")])
+             "-N", "2", "--dtype", "f32", "--flat-output", "-o", str(tmp_path / "out")])
     rec = json.load(open(tmp_path / "out" / "test.json"))
     assert [abs(r["len_s"] - t) < 1e-9 for r, t in zip(rec, (0.5, 0.375))] == [True, True]
     assert json.load(open(tmp_path / "out" / "test_summary.json"))["number"] == 2

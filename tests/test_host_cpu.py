@@ -291,7 +291,7 @@ def test_evaluate_cli_two_ranks_balanced_gloo(tmp_path):
         for r in range(world):
             e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world)) if world > 1 else env
             procs.append(subprocess.Popen([sys.executable, os.path.join(here, "evaluate_gloo_rank.py")] + argv + extra +
-                                          ["-o", str(out)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+                                          ["--flat-output", "-o", str(out)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
         outs = [p.communicate(timeout=240) for p in procs]
         assert all(p.returncode == 0 for p in procs), [o[1][-800:] for o in outs]
         calls = [eval([l for l in o[0].splitlines() if l.startswith("CALLS")][0].split(" ", 2)[2]) for o in outs]

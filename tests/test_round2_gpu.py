@@ -454,7 +454,7 @@ def test_evaluate_batched_equals_one_utterance_at_a_time(tmp_path):
             wavio.save(root / f"s{k + 1}" / f"u{i:02d}.wav", torch.from_numpy(tgt[k:k + 1]), 8000)
     recs = {}
     for tag, extra in (("one", ["--batch", "1", "--streams", "1"]), ("bat", ["--batch", "16", "--streams", "2"])):
-        ev.main(["--dataset-dir", str(root), "--synthetic-weights", "16", "-N", "2", "--dtype", "f32", "-o",
+        ev.main(["--dataset-dir", str(root), "--synthetic-weights", "16", "-N", "2", "--dtype", "f32", "--flat-output", "-o",
                  str(tmp_path / tag)] + extra)
         recs[tag] = json.load(open(tmp_path / tag / "test.json"))
         summ = json.load(open(tmp_path / tag / "test_summary.json"))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 counters of every MFMA kernel inside the real sampler (one batch at a time, eager launches, N = 4 reverse steps:
+# Counters of every MFMA kernel inside the real sampler (one batch at a time, eager launches, N = 4 reverse steps:
 # rocprofv3 --pmc on the full 60-evaluation run crashed in round 2): MFMA utilisation, the effective shader clock
 # (GRBM_GUI_ACTIVE / 8 XCDs / kernel duration from the same pass's kernel trace), instructions per MFMA, wave states.
 # Two --pmc passes (SQ slots), kernel-trace only.  Run via gpurun; writes $OUT/summary.json.
@@ -69,7 +69,7 @@ for k, c in res.items():
     summ[k] = o
 summ = dict(sorted(summ.items(), key=lambda kv: -kv[1].get("gui_active_cycles", 0) * kv[1]["launches"]))
 doc = {"commit": os.environ.get("COMMIT", "unrecorded"), "dtype": os.environ.get("DT", "bf16"),
-       "command": "rocprofv3 --kernel-trace --pmc <8 counters> -- " + cmd + "  (two passes, tools/pmc_r03.sh)",
+       "command": "rocprofv3 --kernel-trace --pmc <8 counters> -- " + cmd + "  (two passes, tools/pmc_util.sh)",
        "note": "GRBM_GUI_ACTIVE is summed over the 8 XCDs; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs): per "
                "shader CYCLE, whatever the clock; shader_clock_ghz = GRBM_GUI_ACTIVE / 8 / kernel duration of the same dispatches (both only for dispatches >= 50 us); "
                "mfma_busy_per_wave_cycle = SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_WAVE_CYCLES); "
