@@ -314,7 +314,7 @@ def main():
             K = max(1, k_fit)
         engs += [Engine(cfg, blob) for _ in range(K - 1)]
         # Throughput mode for several engines on one GPU (round 5; what evaluate / separate --streams K > 1 set through
-        # DiffSepModel.set_throughput_mode, same bits: tests/test_round6_gpu.py): a register-weight convolution whose blocks would get <= 4 tiles
+        # DiffSepModel.set_throughput_mode; same arithmetic, other grouping of the GroupNorm partial sums: tests/test_round6_gpu.py): a register-weight convolution whose blocks would get <= 4 tiles
         # (the 128-row level at B = 16: a 295 KB weight prologue per 4 tiles) runs on a QUARTER of the CUs with four times the tiles
         # per block; the other batches' kernels take the rest of the chip.  Same box, interleaved: 80.9 -> 82.9 utt/s with four batches
         # in flight, 260 -> 300 ms for one batch alone — so it is an option of the multi-stream callers, not a default of the engine.
@@ -531,7 +531,7 @@ def main():
                     continue
                 for line in open(pth):
                     m_ = _re.match(r"\| `(.+?)` \| (\d+) \| ([\d.]+) \| ([\d.]+) \|", line)
-                    if m_ and m_.group(1) == kname:
+                    if m_ and m_.group(1).replace(" ", "") == kname.replace(" ", ""):
                         avg_us = float(m_.group(4))
                         fr = (by / max(n, 1) / (avg_us * 1e-6) / HBM_PEAK_BPS) if roof["bound"] == "hbm" else \
                              (fl / max(n, 1) / (avg_us * 1e-6) / 1e12 / peak)
