@@ -595,7 +595,10 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void istft_fused_kernel(const
       for (int e = 0; e < 16; ++e) acc[ns][c][e] = 0.f;
   const uint4* bhi = dfrag + ((size_t)(4 * wave) * 64 + lane);  // (k-step major, see stft_fused_kernel)
   const uint4* blo = bhi + (size_t)16 * 32 * 64;
-  constexpr int DEPTH = 3;
+#ifndef SI_DEPTH
+#define SI_DEPTH 3  // k-steps of B fragments in flight per wave (tools/istft_ab.sh: -DSI_DEPTH=...)
+#endif
+  constexpr int DEPTH = SI_DEPTH;
   uint4 bf[DEPTH][4][2];
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
@@ -714,7 +717,11 @@ int ds_launch_istft(const void* x, float* out, int B, int S, long T, int n_fft, 
                        S, T, F, W, Cpad, exponent, factor, ow, ob, tdiv, ow_cin, dfrag, tab, nseg);                                       \
   }
     const int em = exponent == 0.5f ? 0 : (exponent == 1.0f ? 1 : 2);
+#ifdef SI_NS1  // (A/B: one source per block, two blocks per CU)
+    if (false) {}
+#else
     if (S == 2) { if (em == 0) ISK(2, 0) else if (em == 1) ISK(2, 1) else ISK(2, 2) }
+#endif
     else { if (em == 0) ISK(1, 0) else if (em == 1) ISK(1, 1) else ISK(1, 2) }
 #undef ISK
     DS_LAUNCH_CHECK();

@@ -1,9 +1,8 @@
 """Correctors (reference sdes/correctors.py): registry names 'ald2' and 'none' on the accelerated path."""
 import abc
 
-import torch
-
 from .. import ops
+from . import noise
 from ..registry import Registry
 from .sdes import MixSDE
 
@@ -34,7 +33,7 @@ class AnnealedLangevinDynamics2(Corrector):
         smix = self.sde.sigma_mix(args[0]) if args else None
         for _ in range(self.n_steps):
             score = self.score_fn(x, t, *args)
-            z = torch.randn_like(x)
+            z = noise.randn_like(x)
             x, x_mean = ops.sde_corrector_update(self.sde.engine_config(), self.snr, x.contiguous(), t.contiguous(),
                                                  score, z, smix)
         return x, x_mean
@@ -54,7 +53,7 @@ class AnnealedLangevinDynamics(Corrector):
         x_mean = x
         for _ in range(self.n_steps):
             score = self.score_fn(x, t, *args)
-            z = torch.randn_like(x)
+            z = noise.randn_like(x)
             x, x_mean = ops.sde_corrector_update(self.sde.engine_config(), self.snr, x.contiguous(), t.contiguous(),
                                                  score, z, None, variant=1)
         return x, x_mean
@@ -68,13 +67,17 @@ class LangevinCorrector(Corrector):
         x_mean = x
         for _ in range(self.n_steps):
             score = self.score_fn(x, t, *args)
-            z = torch.randn_like(x)
+            z = noise.randn_like(x)
             x, x_mean = ops.sde_langevin_update(self.snr, x.contiguous(), score, z)
         return x, x_mean
 
 
 @CorrectorRegistry.register("none")
 class NoneCorrector(Corrector):
+    """sdes/correctors.py:131-141.  The reference's update_fn returns the 1-tuple `(x,)`, which its own sampler loop
+    (`xt, xt_mean = corrector.update_fn(...)`, sdes/__init__.py:179) cannot unpack: corrector "none" raises there.  The mirror returns
+    the pair the loop needs."""
+
     def __init__(self, *args, **kwargs):
         self.snr, self.n_steps = 0, 0
 

@@ -2,9 +2,8 @@
 `update_fn(x, t, *args) -> (x, x_mean)`; the update itself is one fused HIP kernel."""
 import abc
 
-import torch
-
 from .. import ops
+from . import noise
 from ..registry import Registry
 
 PredictorRegistry = Registry("Predictor")
@@ -31,7 +30,7 @@ class ReverseDiffusionPredictor(Predictor):
 
     def update_fn(self, x, t, *args, **kwargs):
         score = self.score_fn(x, t, *args)
-        z = torch.randn_like(x)
+        z = noise.randn_like(x)
         smix = self.sde.sigma_mix(args[0]) if args else None
         return ops.sde_predictor_update(self.sde.engine_config(), self.sde.N, x.contiguous(), t.contiguous(), score, z,
                                         smix)

@@ -12,6 +12,7 @@ import warnings
 import torch
 
 from .. import _lib, ops
+from . import noise
 from ..registry import Registry
 
 SDERegistry = Registry("SDE")
@@ -160,11 +161,11 @@ class MixSDE(SDE):
         return ops.sde_mult_std(std, x.contiguous())
 
     def prior_sampling(self, shape, y):
-        """x_T = 0.5 y + L(T) z   (sdes/sdes.py:334-346); z from torch's generator like the reference."""
+        """x_T = 0.5 y + L(T) z   (sdes/sdes.py:334-346); z: sdes/noise.py (device generator, seeded by torch's)."""
         if tuple(shape) != tuple(y.shape):
             warnings.warn(f"Target shape {tuple(shape)} does not match shape of y {tuple(y.shape)}! Ignoring target shape.")
         B, _, T = y.shape
-        z = torch.randn((B, self.ndim, T), dtype=y.dtype, device=y.device)
+        z = noise.randn((B, self.ndim, T), y)
         return ops.sde_prior(self.engine_config(), y.contiguous(), z, self.sigma_mix(y))
 
 

@@ -279,10 +279,14 @@ class Injected:
             return z
         torch.randn_like = lambda x, **k: nxt().to(x.device)
         torch.randn = lambda *a, **k: nxt().to(k.get("device", "cpu"))
+        from diffsep_amd.sdes import noise  # (the mirror classes draw through sdes/noise.py, user-written ones through torch)
+        self.o3 = noise.set_source(lambda shape, like: nxt().to(like.device))
         return self
 
     def __exit__(self, *a):
         torch.randn_like, torch.randn = self.o1, self.o2
+        from diffsep_amd.sdes import noise
+        noise.set_source(self.o3)
 
 
 def test_user_written_predictor_and_corrector_run_on_the_mirror(golden):
