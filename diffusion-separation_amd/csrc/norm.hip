@@ -473,8 +473,11 @@ __global__ __launch_bounds__(256) void gn_fir_down_strip_kernel(const bf16_t* __
 //     output rows (taps 1/8, 3/8 into the newer, 3/8, 1/8 into the older, which is then complete: one 16-byte store).
 // One barrier per input row (two row buffers).  Same arithmetic as the kernels above up to one storage rounding of the
 // activated value in front of the filter and fp32 summation order.
+#ifndef FD_MINW
+#define FD_MINW 1  // (tools/fir_ab.sh: minimum waves per SIMD the register allocation must leave room for)
+#endif
 template <int RS>
-__global__ __launch_bounds__(256) void gn_fir_down_tiled_kernel(const bf16_t* __restrict__ x, int ldx,
+__global__ __launch_bounds__(256, FD_MINW) void gn_fir_down_tiled_kernel(const bf16_t* __restrict__ x, int ldx,
                                                                 const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, int C,
                                                                 bf16_t* __restrict__ y, int ldy, bf16_t* __restrict__ xr,
@@ -607,8 +610,11 @@ __global__ __launch_bounds__(256) void gn_fir_down_tiled_kernel(const bf16_t* __
 // LDS.  Same arithmetic as the kernels above (horizontal taps first, then vertical, fp32 FMAs; zeros outside the image).
 // 91 -> 57 us at 256^2, 46 -> 27 us at 128^2.  (The FIR-down mode of this design measured slower than the 2 x 2-block
 // kernel: profiles/experiments/gn_resample_tiled_down_r02.hip.txt.)
+#ifndef UP_MINW
+#define UP_MINW 1
+#endif
 template <typename T>
-__global__ __launch_bounds__(256) void gn_resample_up_tiled_kernel(const T* __restrict__ x, int ldx,
+__global__ __launch_bounds__(256, UP_MINW) void gn_resample_up_tiled_kernel(const T* __restrict__ x, int ldx,
                                                                    const float* __restrict__ scale,
                                                                    const float* __restrict__ shift, int C,
                                                                    T* __restrict__ y, int ldy, T* __restrict__ xr,
@@ -751,7 +757,10 @@ static int gn_apply_typed(const void* x, int ldx, const float* scale, const floa
         (long)B * H * W * C >= (1l << 21)) {
       const int Ho_ = H / 2, tiles_x = W / 32, ncgb = C / 64;
       // strips of RS output rows: as long as the strips still give every CU ~2 blocks
-      int rs = 16;
+#ifndef FD_RS_MAX
+#define FD_RS_MAX 8  // (16: 99.9 -> 97.0 us at 256^2 C = 64 and 68.7 -> 62.3 at 128^2 C = 128 incl. the statistics passes; tools/fir_ab.sh)
+#endif
+      int rs = FD_RS_MAX;
       while (rs > 4 && (long)B * tiles_x * cdiv(Ho_, rs) * ncgb < 2 * ds_num_cus()) rs >>= 1;
       const int strips = cdiv(Ho_, rs);
       const unsigned nblk = (unsigned)((long)B * tiles_x * strips * ncgb);

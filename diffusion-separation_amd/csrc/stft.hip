@@ -198,8 +198,14 @@ extern "C" int diffsep_st_debug_read(unsigned long long* out, int reset) {
 #define ST_MARK(i)
 #endif
 constexpr int SF_PITCH = 272, SF_ROWS = 35, SF_CH = SF_ROWS * SF_PITCH, SF_NS = 32 * 128 + 382;
+// (waves per block: 8 — one 32-row DFT tile per wave — measured the same as 4, tools/istft_ab.sh: 32.7 vs 33.2 us: unlike the inverse
+// kernel's, this product phase is within 1.4x of its MFMA time and the staging / epilogue phases are short)
+#ifndef SF_NW
+#define SF_NW 4
+#endif
+constexpr int SF_NT = 64 * SF_NW, SF_RT = 8 / SF_NW;  // threads per block; 32-row tiles of the block's half of the DFT per wave
 template <int NC>
-__global__ __launch_bounds__(256) void stft_fused_kernel(const float* __restrict__ xt, const float* __restrict__ mix,
+__global__ __launch_bounds__(SF_NT) void stft_fused_kernel(const float* __restrict__ xt, const float* __restrict__ mix,
                                                          bf16_t* __restrict__ y, long Tlen, int F, int W, float expo,
                                                          float factor, int shift, const uint4* __restrict__ dfrag) {
   extern __shared__ __attribute__((aligned(16))) char sm[];  // [part][channel][SF_CH]
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(256) void stft_fused_kernel(const float* __restrict
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = j < 2 * NC ? pv : 0.f;
-    for (int i = tid; i < 128 * 32; i += 256) {
+    for (int i = tid; i < 128 * 32; i += SF_NT) {
       const int kb = rh * 128 + (i >> 5), f = f0 + (i & 31);
       store8<bf16_t>(y + (((long)b * 256 + kb) * W + f) * 8, o);
     }
@@ -227,13 +233,13 @@ __global__ __launch_bounds__(256) void stft_fused_kernel(const float* __restrict
   constexpr int SF_NSP = (SF_NS + 7) & ~7;
   // (loads first, nine iterations at a time: one load -> convert -> LDS store per iteration is a chain of 27 memory latencies,
   // 60 of the first version's 72 us)
-  constexpr int NPAIR = NC * (SF_NSP / 2), NIT = (NPAIR + 255) / 256, GRP = 9;
+  constexpr int NPAIR = NC * (SF_NSP / 2), NIT = (NPAIR + SF_NT - 1) / SF_NT, GRP = 9;
 #pragma unroll
   for (int base = 0; base < NIT; base += GRP) {
     float v0[GRP], v1[GRP];
 #pragma unroll
     for (int u = 0; u < GRP; ++u) {
-      const int idx = tid + (base + u) * 256;
+      const int idx = tid + (base + u) * SF_NT;
       v0[u] = 0.f; v1[u] = 0.f;
       if (base + u < NIT && idx < NPAIR) {
         const int c = idx / (SF_NSP / 2), j = 2 * (idx - c * (SF_NSP / 2));
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(256) void stft_fused_kernel(const float* __restrict
     }
 #pragma unroll
     for (int u = 0; u < GRP; ++u) {
-      const int idx = tid + (base + u) * 256;
+      const int idx = tid + (base + u) * SF_NT;
       if (base + u < NIT && idx < NPAIR) {
         const int c = idx / (SF_NSP / 2), j = 2 * (idx - c * (SF_NSP / 2));
         const bf16_t h0 = f2bf(v0[u]), h1 = f2bf(v1[u]);
@@ -258,25 +264,26 @@ __global__ __launch_bounds__(256) void stft_fused_kernel(const float* __restrict
   }
   __syncthreads();
   ST_MARK(0)
-  // ---- 32 frames x 64 DFT rows per wave (row tiles rt0, rt0 + 1), NC channels
-  f32x16 acc[2][NC];
+  // ---- 32 frames x 32 RT DFT rows per wave (row tiles rt0 .. rt0 + RT - 1), NC channels
+  constexpr int RT = SF_RT;
+  f32x16 acc[RT][NC];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < RT; ++t)
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[t][c][e] = 0.f;
-  const int rt0 = rh * 8 + 2 * wave;
+  const int rt0 = rh * 8 + RT * wave;
   // (k-step major: the 32 KB all waves of all blocks read for one k-step are CONTIGUOUS.  Tile-major, the same k-step of the 16
   // tiles sat 32 KB apart — on a quarter of the L2 channels: 2.5k cycles per k-step for 768 cycles of MFMAs)
   const uint4* ahi = dfrag + ((size_t)rt0 * 64 + lane);
   const uint4* alo = ahi + (size_t)16 * 32 * 64;
   constexpr int DEPTH = 3;  // A fragments in flight: DEPTH k-steps (L2 latency ~ 2 k-steps of 18 MFMAs)
-  uint4 a[DEPTH][2][2];
+  uint4 a[DEPTH][RT][2];
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) { a[d][t][0] = ahi[((size_t)d * 16 + t) * 64]; a[d][t][1] = alo[((size_t)d * 16 + t) * 64]; }
+    for (int t = 0; t < RT; ++t) { a[d][t][0] = ahi[((size_t)d * 16 + t) * 64]; a[d][t][1] = alo[((size_t)d * 16 + t) * 64]; }
   const char* bbase = sm + SF_PITCH * l32 + 16 * h;
 #pragma unroll
   for (int ks = 0; ks < 32; ++ks) {
@@ -288,12 +295,12 @@ __global__ __launch_bounds__(256) void stft_fused_kernel(const float* __restrict
       bh[c] = *reinterpret_cast<const uint4*>(bbase + c * SF_CH + boff);
       bl[c] = *reinterpret_cast<const uint4*>(bbase + (NC + c) * SF_CH + boff);
     }
-    uint4 ah[2], al[2];
+    uint4 ah[RT], al[RT];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) { ah[t] = a[ks % DEPTH][t][0]; al[t] = a[ks % DEPTH][t][1]; }
+    for (int t = 0; t < RT; ++t) { ah[t] = a[ks % DEPTH][t][0]; al[t] = a[ks % DEPTH][t][1]; }
     if (ks + DEPTH < 32) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < RT; ++t) {
         a[ks % DEPTH][t][0] = ahi[((size_t)(ks + DEPTH) * 16 + t) * 64];
         a[ks % DEPTH][t][1] = alo[((size_t)(ks + DEPTH) * 16 + t) * 64];
       }
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(256) void stft_fused_kernel(const float* __restrict
     // (product-major order — consecutive MFMAs on different accumulators — measured no faster here and slower in the inverse
     // kernel: the phase waits for the fragment stream, not for accumulator dependencies)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         acc[t][c] = mfma_bf32(ah[t], bh[c], acc[t][c]);
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(256) void stft_fused_kernel(const float* __restrict
   auto epilogue = [&](auto MODE_) __attribute__((always_inline)) {
     constexpr int MODE = decltype(MODE_)::value;  // 0: e = 0.5, 1: e = 1, 2: general
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -377,7 +384,7 @@ int ds_launch_stft_pack(const float* xt, const float* mix, void* y, int B, int S
   {                                                                                                                          \
     constexpr int LDS_ = 2 * NC_ * SF_CH;                                                                                    \
     DS_FUNC_LDS_ONCE((stft_fused_kernel<NC_>), LDS_);                                                                        \
-    hipLaunchKernelGGL((stft_fused_kernel<NC_>), dim3(nblk), dim3(256), LDS_, st, xt, mix, (bf16_t*)y, T, F, W, exponent, factor, shift, dfrag); \
+    hipLaunchKernelGGL((stft_fused_kernel<NC_>), dim3(nblk), dim3(SF_NT), LDS_, st, xt, mix, (bf16_t*)y, T, F, W, exponent, factor, shift, dfrag); \
   }
     if (S == 1) SFK(2) else if (S == 2) SFK(3) else SFK(4)
 #undef SFK
@@ -507,8 +514,16 @@ constexpr int SI_PITCH = 1040, SI_U = 32 * SI_PITCH, SI_SEG = 29 * 128;
 // serves both; 1 otherwise)
 // EM: 0 exponent 0.5, 1 exponent 1, 2 general — a TEMPLATE parameter: with a run-time case inside the pixel loop the compiler
 // speculated the inlined powf of the general case for every pixel (200 instead of ~60 instructions)
+// Waves per block.  The kernel is a chain of latency-bound phases (U prologue: global loads -> decompression -> LDS; products: the DFT
+// fragment stream out of L2; overlap-add; envelope + stores) on ONE block per CU (133 KB of LDS), so what hides the latencies is more
+// waves of the same block: 4 / 8 / 16 waves = 54.2 / 42.2 / 32.7 us per launch (B = 16, same bits; tools/istft_ab.sh, round 6).  16
+// waves: one 32-tap column tile per wave, four waves share a copy of the overlap-add segment (their 128 taps = every residue once).
+#ifndef SI_NW
+#define SI_NW 16
+#endif
+constexpr int SI_NT = 64 * SI_NW, SI_CT = 16 / SI_NW;  // threads per block; 32-tap column tiles per wave
 template <int NS, int EM>
-__global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void istft_fused_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int S,
+__global__ __launch_bounds__(SI_NT, NS == 1 ? 2 : 1) void istft_fused_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int S,
                                                              long Tlen, int F, int W, int ld, float expo, float factor,
                                                              const float* __restrict__ ow, const float* __restrict__ ob,
                                                              const float* __restrict__ tdiv, int ow_cin,
@@ -537,22 +552,23 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void istft_fused_kernel(const
       bim[ns] = ow ? ob[S + s] : 0.f;
     }
     const float inv_td = ow ? 1.0f / tdiv[b] : 1.f;
-    // thread -> frame r = tid & 31 (fixed), bins (tid >> 5) + 8 it; eight loads in flight per pass (one load -> LDS store per
+    // thread -> frame r = tid & 31 (fixed), bins (tid >> 5) + BG it; eight loads in flight per pass (one load -> LDS store per
     // iteration was a chain of 32 memory latencies)
+    constexpr int BG = SI_NT / 32;  // bin groups of the block
     const int r = tid & 31, f = fA + r;
     const bool fok = f >= 0 && f < F;
     char* u = sm + r * SI_PITCH;
 #pragma unroll
-    for (int base = 0; base < 32; base += 8) {
+    for (int base = 0; base < 256 / BG; base += 8) {
       uint4 raw[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int kb = (tid >> 5) + 8 * (base + q);
+        const int kb = (tid >> 5) + BG * (base + q);
         raw[q] = fok ? *reinterpret_cast<const uint4*>(x + (((long)b * 256 + kb) * W + f) * ld) : make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int kb = (tid >> 5) + 8 * (base + q);
+        const int kb = (tid >> 5) + BG * (base + q);
         float v[8];
         v[0] = h_lo(raw[q].x); v[1] = h_hi(raw[q].x); v[2] = h_lo(raw[q].y); v[3] = h_hi(raw[q].y);
         v[4] = h_lo(raw[q].z); v[5] = h_hi(raw[q].z); v[6] = h_lo(raw[q].w); v[7] = h_hi(raw[q].w);
@@ -585,25 +601,26 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void istft_fused_kernel(const
   }
   __syncthreads();
   ST_MARK(4)
-  // ---- frames[r][n]: 32 frames x 128 taps per wave (column tiles 4 wave .. + 3)
-  f32x16 acc[NS][4];
+  // ---- frames[r][n]: 32 frames x 32 SI_CT taps per wave (column tiles SI_CT wave .. + SI_CT - 1)
+  constexpr int CT = SI_CT;
+  f32x16 acc[NS][CT];
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns)
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[ns][c][e] = 0.f;
-  const uint4* bhi = dfrag + ((size_t)(4 * wave) * 64 + lane);  // (k-step major, see stft_fused_kernel)
+  const uint4* bhi = dfrag + ((size_t)(CT * wave) * 64 + lane);  // (k-step major, see stft_fused_kernel)
   const uint4* blo = bhi + (size_t)16 * 32 * 64;
 #ifndef SI_DEPTH
 #define SI_DEPTH 3  // k-steps of B fragments in flight per wave (tools/istft_ab.sh: -DSI_DEPTH=...)
 #endif
   constexpr int DEPTH = SI_DEPTH;
-  uint4 bf[DEPTH][4][2];
+  uint4 bf[DEPTH][CT][2];
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { bf[d][c][0] = bhi[((size_t)d * 16 + c) * 64]; bf[d][c][1] = blo[((size_t)d * 16 + c) * 64]; }
+    for (int c = 0; c < CT; ++c) { bf[d][c][0] = bhi[((size_t)d * 16 + c) * 64]; bf[d][c][1] = blo[((size_t)d * 16 + c) * 64]; }
   const char* abase = sm + SI_PITCH * l32 + 16 * h;
 #pragma unroll
   for (int ks = 0; ks < 32; ++ks) {
@@ -613,18 +630,18 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void istft_fused_kernel(const
       ah[ns] = *reinterpret_cast<const uint4*>(abase + ns * SRC + 32 * ks);
       al[ns] = *reinterpret_cast<const uint4*>(abase + ns * SRC + SI_U + 32 * ks);
     }
-    uint4 bh_[4], bl_[4];
+    uint4 bh_[CT], bl_[CT];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { bh_[c] = bf[ks % DEPTH][c][0]; bl_[c] = bf[ks % DEPTH][c][1]; }
+    for (int c = 0; c < CT; ++c) { bh_[c] = bf[ks % DEPTH][c][0]; bl_[c] = bf[ks % DEPTH][c][1]; }
     if (ks + DEPTH < 32) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int c = 0; c < CT; ++c) {
         bf[ks % DEPTH][c][0] = bhi[((size_t)(ks + DEPTH) * 16 + c) * 64];
         bf[ks % DEPTH][c][1] = blo[((size_t)(ks + DEPTH) * 16 + c) * 64];
       }
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) {
         acc[ns][c] = mfma_bf32(ah[ns], bh_[c], acc[ns][c]);
@@ -642,13 +659,14 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void istft_fused_kernel(const
   // (the squared window for the envelope, beside the four copies: the envelope loop below read it from global memory in a chain
   // of 15 x 4 dependent loads per thread — most of the first version's 100 us)
   float* w2 = reinterpret_cast<float*>(sm) + 4 * SI_SEG;
-  for (int i = tid; i < 512; i += 256) { const float w = i < 510 ? tab[2 * 510 + i] : 0.f; w2[i] = w * w; }
+  for (int i = tid; i < 512; i += SI_NT) { const float w = i < 510 ? tab[2 * 510 + i] : 0.f; w2[i] = w * w; }
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
-    float* mine = reinterpret_cast<float*>(sm + ns * SRC) + wave * SI_SEG;
+    // copy j holds taps 128 j .. 128 j + 127 (every residue once: one contribution per sample) = the waves 4 j / CT ... of the block
+    float* mine = reinterpret_cast<float*>(sm + ns * SRC) + (wave * CT / 4) * SI_SEG;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int n = 32 * (4 * wave + c) + l32;
+    for (int c = 0; c < CT; ++c) {
+      const int n = 32 * (CT * wave + c) + l32;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int r = 8 * (e >> 2) + 4 * h + (e & 3);
@@ -660,7 +678,7 @@ __global__ __launch_bounds__(256, NS == 1 ? 2 : 1) void istft_fused_kernel(const
   __syncthreads();
   ST_MARK(6)
   // ---- out[b, s, t] = ola / sum_f w^2[t + 255 - 128 f]   (torch.istft, center = True; zeros beyond 128 (F - 1): adjust_length)
-  for (int i = tid; i < SI_SEG; i += 256) {
+  for (int i = tid; i < SI_SEG; i += SI_NT) {
     const long t = 128L * g0 + i;
     if (t >= Tlen) break;
     if (t < 128L * (F - 1)) {
@@ -713,7 +731,7 @@ int ds_launch_istft(const void* x, float* out, int B, int S, long T, int n_fft, 
 #define ISK(NS_, EM_)                                                                                                                     \
   {                                                                                                                                          \
     DS_FUNC_LDS_ONCE((istft_fused_kernel<NS_, EM_>), NS_ * LDS1);                                                                            \
-    hipLaunchKernelGGL((istft_fused_kernel<NS_, EM_>), dim3((unsigned)(B * (S / NS_) * nseg)), dim3(256), NS_ * LDS1, st, (const bf16_t*)x, out, \
+    hipLaunchKernelGGL((istft_fused_kernel<NS_, EM_>), dim3((unsigned)(B * (S / NS_) * nseg)), dim3(SI_NT), NS_ * LDS1, st, (const bf16_t*)x, out, \
                        S, T, F, W, Cpad, exponent, factor, ow, ob, tdiv, ow_cin, dfrag, tab, nseg);                                       \
   }
     const int em = exponent == 0.5f ? 0 : (exponent == 1.0f ? 1 : 2);
