@@ -31,6 +31,10 @@ except Exception:  # pragma: no cover
         return zlib.crc32(buf)
 
 
+def _loaded(module, incompatible_keys):
+    module.weights_changed()
+
+
 class _Node(nn.Module):
     """One level of the reference's module tree (NCSNpp, its all_modules list, a ResnetBlockBigGANpp, a Conv2d ...): holds
     parameters and child nodes under the reference's names, nothing else."""
@@ -80,6 +84,13 @@ class _EngineSlot:
         self.options[name] = value
         if self._engine is not None:
             self._engine.set_option(name, value)
+
+    # copy.deepcopy / pickle of the owning module (torch.save(model), Lightning utilities): an engine is a device object of THIS
+    # process — the copy gets an empty slot and builds its own engine from its own parameters on first use
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_engine"], st["_key"], st["builds"] = None, None, 0
+        return st
 
     def close(self):
         if self._engine is not None:
@@ -197,7 +208,7 @@ class ScoreModelNCSNpp(nn.Module):
         self._maybe_changed, self._versions, self._fingerprint, self._plist = True, None, None, None
         self._engine_factory = Engine
         self._slot = _EngineSlot(self, self.cfg, lib_kind)
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module.weights_changed())
+        self.register_load_state_dict_post_hook(_loaded)  # (fires when a PARENT module's load_state_dict reaches this one, too)
 
     # ---- weights ---------------------------------------------------------------------------
     def param_names(self):
@@ -240,7 +251,8 @@ class ScoreModelNCSNpp(nn.Module):
         if not self._maybe_changed and versions == self._versions and self._fingerprint is not None:
             return None
         w = self.stft.window
-        if w.shape != (self.cfg.n_fft,) or not torch.allclose(w.float().cpu(), torch.hann_window(self.cfg.n_fft), atol=1e-6):
+        tol = 1e-6 if w.dtype in (torch.float32, torch.float64) else 4e-3  # (model.half() / .bfloat16() round the buffer too)
+        if w.shape != (self.cfg.n_fft,) or not torch.allclose(w.float().cpu(), torch.hann_window(self.cfg.n_fft), atol=tol):
             raise NotImplementedError("stft.window is not the periodic Hann window the engine's STFT kernels implement")
         blob = self.packed_blob()
         self._fingerprint = _digest(blob.view(np.uint8))

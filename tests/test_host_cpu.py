@@ -437,3 +437,44 @@ def test_bench_eight_ranks_weak_and_strong_gloo():
         else:
             assert res["scaling"] == "weak" and res["config"]["sharding"] == "utterances/8"
             assert len(res["rank_elapsed_s_per_step"]) == 8
+
+
+class _RecordingEngine:  # (module level: picklable)
+    def __init__(self, cfg, blob, device=None, lib_kind=None):
+        self.blob = blob.copy()
+
+    def close(self):
+        pass
+
+    def set_option(self, name, value):
+        pass
+
+
+def test_score_model_module_survives_deepcopy_pickle_and_half():
+    # what PyTorch / Lightning utilities do to a module that the reference's LightningModule holds: copy.deepcopy, torch.save of the
+    # whole module, .half().  An engine is a device object of this process: copies get an empty slot and build their own engine from
+    # their own parameters.
+    import copy
+    import io
+    from diffsep_amd.score_models import ScoreModelNCSNpp
+    m = ScoreModelNCSNpp(2, dict(n_fft=510, hop_length=128, center=True, pad_mode="constant"), dict(nf=16))
+    m._engine_factory = _RecordingEngine
+    b0 = m.engine().blob.copy()
+    m2 = copy.deepcopy(m)
+    assert m2._slot._engine is None and m2._slot.owner is m2 and m2.twin("split").owner is m2
+    np.testing.assert_array_equal(m2.engine().blob, b0)
+    with torch.no_grad():
+        m2.backbone.output_layer.bias.add_(1.0)
+    assert np.all(m2.engine().blob[24:28] == b0[24:28] + 1.0)
+    np.testing.assert_array_equal(m.engine().blob, b0)           # (the original is untouched)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert m3._slot._engine is None
+    np.testing.assert_array_equal(m3.engine().blob, b0)
+    m.half()                                                     # parameters AND the window buffers are rounded; the engine follows
+    b1 = m.engine().blob
+    assert b1.dtype == np.float32 and 0 < float(np.abs(b1 - b0).max()) < 2e-2
+    sd = m.state_dict()
+    assert sd["stft.window"].dtype == torch.float16 and len(sd) == 647 + 2
