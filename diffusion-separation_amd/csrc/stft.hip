@@ -380,9 +380,12 @@ int ds_launch_stft_pack(const float* xt, const float* mix, void* y, int B, int S
   if (dtype == DS_BF16 && n_fft == 510 && hop == 128 && Cpad == 8 && W % 32 == 0 && !(ds_default_opts() & DS_OPT_NO_STFT_FUSED)) {
     const uint4* dfrag = reinterpret_cast<const uint4*>(tab + ds_stft_ffrag_offset(n_fft));
     const unsigned nblk = (unsigned)(2 * (W / 32) * B);
+#ifndef SF_LDS_MIN
+#define SF_LDS_MIN 0  // (tools/istft_ab.sh: -DSF_LDS_MIN=84000 keeps two blocks from sharing a CU)
+#endif
 #define SFK(NC_)                                                                                                           \
   {                                                                                                                          \
-    constexpr int LDS_ = 2 * NC_ * SF_CH;                                                                                    \
+    constexpr int LDS0_ = 2 * NC_ * SF_CH, LDS_ = LDS0_ > SF_LDS_MIN ? LDS0_ : SF_LDS_MIN;                                   \
     DS_FUNC_LDS_ONCE((stft_fused_kernel<NC_>), LDS_);                                                                        \
     hipLaunchKernelGGL((stft_fused_kernel<NC_>), dim3(nblk), dim3(SF_NT), LDS_, st, xt, mix, (bf16_t*)y, T, F, W, exponent, factor, shift, dfrag); \
   }
